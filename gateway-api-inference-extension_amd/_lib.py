@@ -1,0 +1,88 @@
+"""ctypes binding of libeppk.so (include/eppk.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+EPPK_MAX_SCORERS = 8
+EPPK_MAX_PODS = 4096
+EPPK_MAX_ADAPTERS = 128
+EPPK_MAX_BLOCKS = 256
+EPPK_NO_PICK = -1
+
+STATUS = {0: "EPPK_OK", -1: "EPPK_ERR_ARG", -2: "EPPK_ERR_LIMIT", -3: "EPPK_ERR_DEVICE",
+          -4: "EPPK_ERR_NO_SNAPSHOT", -5: "EPPK_ERR_INDEX_FULL", -6: "EPPK_ERR_NOMEM"}
+
+# every symbol include/eppk.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "eppk_abi_version", "eppk_create", "eppk_destroy", "eppk_last_error",
+    "eppk_snapshot_publish", "eppk_snapshot_info",
+    "eppk_index_clear", "eppk_index_insert", "eppk_index_insert_picks_device", "eppk_index_remove_pod",
+    "eppk_index_size",
+    "eppk_pick_batch", "eppk_pick_batch_device",
+    "eppk_hash_prompt", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
+    "eppk_profile_enable", "eppk_profile_drain", "eppk_last_algorithmic_bytes",
+]
+
+
+class EppkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class WeightedScorer(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("weight", C.c_int32)]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_pods", C.c_uint32),
+                ("max_blocks", C.c_uint32), ("max_batch", C.c_uint32), ("index_slots", C.c_uint32),
+                ("n_scorers", C.c_uint32), ("reserved", C.c_uint32),
+                ("chain", WeightedScorer * EPPK_MAX_SCORERS)]
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeppk.so")
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load libeppk.so (built in-tree by ``__graft_entry__.build()``); raise if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the pick.")
+    lib = C.CDLL(path)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    lib.eppk_abi_version.restype = u32
+    lib.eppk_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    lib.eppk_destroy.argtypes = [vp]
+    lib.eppk_destroy.restype = None
+    lib.eppk_last_error.argtypes = [vp]
+    lib.eppk_last_error.restype = C.c_char_p
+    lib.eppk_snapshot_publish.argtypes = [vp, vp, u32, u64]
+    lib.eppk_snapshot_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.eppk_index_clear.argtypes = [vp]
+    lib.eppk_index_insert.argtypes = [vp, vp, vp, u32]
+    lib.eppk_index_insert_picks_device.argtypes = [vp, vp, vp, u32, vp]
+    lib.eppk_index_remove_pod.argtypes = [vp, u32]
+    lib.eppk_index_size.argtypes = [vp, C.POINTER(u32)]
+    lib.eppk_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp]
+    lib.eppk_pick_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    lib.eppk_hash_prompt.argtypes = [vp, C.c_size_t, vp, C.c_size_t, u32, vp, u32]
+    lib.eppk_xxh64.argtypes = [vp, C.c_size_t, u64]
+    lib.eppk_xxh64.restype = u64
+    lib.eppk_subset_mask.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.c_char_p, vp]
+    lib.eppk_round_robin.argtypes = [C.POINTER(u64), u32]
+    lib.eppk_round_robin.restype = i32
+    lib.eppk_profile_enable.argtypes = [vp, C.c_int]
+    lib.eppk_profile_drain.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    lib.eppk_last_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    _LIB = lib
+    return lib

@@ -1,0 +1,617 @@
+// eppk.hip — C ABI of libeppk (include/eppk.h): context, snapshot re-layout, launches.
+//
+// The product path.  There is NO CPU fallback in this file: if HIP is unavailable every entry point
+// that needs the device fails with EPPK_ERR_DEVICE.  Nothing here includes, links or calls oracle/.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off (binary64 mul/add never fused;
+// SEMANTICS.md §2) — see __graft_entry__.build().
+#include "eppk_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/eppk.h"
+
+using namespace eppk;
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_err;
+
+struct SnapBuf {
+  double*   base = nullptr;
+  uint32_t* queue = nullptr;
+  double*   kv = nullptr;
+  void*     act_t = nullptr;
+  void*     wait_t = nullptr;
+  void*     free_t = nullptr;
+};
+
+}  // namespace
+
+struct eppk_ctx {
+  eppk_cfg cfg{};
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+
+  // geometry
+  int lw_bytes = 8;       // lane word: 2 (P<=1024), 4 (P<=2048), 8 (P<=4096)
+  int npl = 6;            // counter bit planes: 6 (B<=63) or 9 (B<=256)
+  uint32_t pwn = 0;       // per-wave prefix table entries
+  uint32_t stride = 0;    // request row stride in bytes
+  uint32_t jmax = 0;      // ceil(max_pods/64)
+
+  // chain analysis
+  bool canonical = false; // [QUEUE|KV]* ++ tail, tail ⊂ {LORA, PREFIX} each at most once
+  uint32_t n_lead = 0;
+  bool has_l = false, has_p = false, p_first = false;
+  KTail tail{};
+  KChain kchain{};
+
+  // snapshot (double buffered: a publish never overwrites the rows an in-flight pick reads)
+  SnapBuf snap[2];
+  int cur = 0;
+  bool have_snapshot = false;
+  uint32_t n_pods = 0;
+  uint32_t qmin = 0, qmax = 0;
+  uint64_t epoch = 0;
+
+  // prefix index
+  uint64_t* keys = nullptr;
+  void* bitmaps = nullptr;
+  uint32_t slots = 0, shift = 0, limit = 0;
+  unsigned long long* stats = nullptr;  // device [4]: hits, lookups, occupied keys, dropped inserts
+
+  // staging for the host-buffer entry point
+  void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
+  void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
+  void* d_tmp = nullptr; size_t d_tmp_bytes = 0;  // index insert staging
+
+  // measurement
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t ev_used = 0;
+  uint32_t last_n_reqs = 0, last_n_pods = 0;
+
+  std::string err;
+};
+
+namespace {
+
+int fail(eppk_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  else { std::lock_guard<std::mutex> g(g_err_mu); g_create_err = msg; }
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((c), EPPK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+inline double h_clamp01(double s) {
+  if (!(s >= 0.0)) return 0.0;
+  if (s > 1.0) return 1.0;
+  return s;
+}
+
+inline uint32_t pop128(const uint64_t w[2]) {
+  return (uint32_t)__builtin_popcountll(w[0]) + (uint32_t)__builtin_popcountll(w[1]);
+}
+
+// set bit j of lane word `lane` in a [rows][64] LW table
+inline void set_lane_bit(std::vector<uint8_t>& tab, int lw_bytes, size_t row, uint32_t pod) {
+  const uint32_t lane = pod & 63u, j = pod >> 6;
+  uint8_t* e = tab.data() + (row * 64u + lane) * (size_t)lw_bytes;
+  e[j >> 3] |= (uint8_t)(1u << (j & 7u));  // little-endian lane words
+}
+
+KSnap make_ksnap(const eppk_ctx* c) {
+  const SnapBuf& s = c->snap[c->cur];
+  KSnap k{};
+  k.base = s.base; k.queue = s.queue; k.kv = s.kv;
+  k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
+  k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
+  k.qmin = c->qmin; k.qmax = c->qmax;
+  return k;
+}
+
+KIndex make_kindex(const eppk_ctx* c) {
+  KIndex k{};
+  k.keys = c->keys; k.bitmaps = c->bitmaps; k.slots = c->slots; k.shift = c->shift;
+  return k;
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------
+
+template <typename LW, int NPL>
+const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first) {
+  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true>
+                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false>;
+  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false>;
+  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false>;
+}
+
+template <typename LW, int NPL>
+const void* generic_kernel_ptr(bool masked) {
+  return masked ? (const void*)pick_generic_kernel<LW, NPL, true> : (const void*)pick_generic_kernel<LW, NPL, false>;
+}
+
+template <typename LW>
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
+  if (c->npl == 6) return fast ? fast_kernel_ptr<LW, 6>(c->has_l, c->has_p, c->p_first) : generic_kernel_ptr<LW, 6>(masked);
+  return fast ? fast_kernel_ptr<LW, 9>(c->has_l, c->has_p, c->p_first) : generic_kernel_ptr<LW, 9>(masked);
+}
+
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
+  switch (c->lw_bytes) {
+    case 2: return pick_kernel_ptr<uint16_t>(c, fast, masked);
+    case 4: return pick_kernel_ptr<uint32_t>(c, fast, masked);
+    default: return pick_kernel_ptr<uint64_t>(c, fast, masked);
+  }
+}
+
+int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
+                double* d_score, hipStream_t st) {
+  const bool masked = d_mask != nullptr;
+  const bool fast = c->canonical && !masked;
+  const void* fn = pick_kernel_ptr(c, fast, masked);
+  KSnap sn = make_ksnap(c);
+  KIndex ix = make_kindex(c);
+  const uint32_t threads = 512, wpb = threads / 64;
+  size_t lds;
+  if (fast) lds = ((size_t)sn.J * 64u + 4u + (size_t)wpb * c->pwn) * 8u;
+  else lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
+  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
+  if (per_cu < 1) per_cu = 1;
+  uint32_t grid = (n_reqs + wpb - 1) / wpb;
+  const uint32_t cap = (uint32_t)c->num_cu * (uint32_t)per_cu;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+
+  unsigned long long* stats = c->prof ? c->stats : nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof) {
+    HIPCHK(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), st));
+    if (c->ev_used + 2 > c->ev.size()) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c->ev.push_back(a);
+      c->ev.push_back(b);
+    }
+    e0 = c->ev[c->ev_used];
+    e1 = c->ev[c->ev_used + 1];
+    c->ev_used += 2;
+    HIPCHK(c, hipEventRecord(e0, st));
+  }
+  const uint8_t* reqs8 = (const uint8_t*)d_reqs;
+  uint32_t stride = c->stride, pwn = c->pwn;
+  if (fast) {
+    KTail tl = c->tail;
+    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_pick, &d_score, &stats};
+    HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st));
+  } else {
+    KChain ch = c->kchain;
+    void* args[] = {&sn, &ix, &ch, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats};
+    HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st));
+  }
+  if (c->prof) HIPCHK(c, hipEventRecord(e1, st));
+  c->last_n_reqs = n_reqs;
+  c->last_n_pods = c->n_pods;
+  return EPPK_OK;
+}
+
+template <typename F>
+int by_lane_word(const eppk_ctx* c, F&& f) {
+  switch (c->lw_bytes) {
+    case 2: return f((uint16_t)0);
+    case 4: return f((uint32_t)0);
+    default: return f((uint64_t)0);
+  }
+}
+
+int ensure_tmp(eppk_ctx* c, size_t bytes) {
+  if (bytes <= c->d_tmp_bytes) return EPPK_OK;
+  if (c->d_tmp) HIPCHK(c, hipFree(c->d_tmp));
+  c->d_tmp = nullptr; c->d_tmp_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->d_tmp, bytes));
+  c->d_tmp_bytes = bytes;
+  return EPPK_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+uint32_t eppk_abi_version(void) { return EPPK_ABI_VERSION; }
+
+const char* eppk_last_error(const eppk_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> g(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_create_err;
+  return copy.c_str();
+}
+
+int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, EPPK_ERR_ARG, "eppk_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(eppk_cfg)) return fail(nullptr, EPPK_ERR_ARG, "eppk_create: struct_size mismatch");
+  if (cfg->max_pods == 0 || cfg->max_pods > EPPK_MAX_PODS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: max_pods out of range (1..4096)");
+  if (cfg->max_blocks > EPPK_MAX_BLOCKS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: max_blocks > 256");
+  if (cfg->n_scorers > EPPK_MAX_SCORERS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: n_scorers > 8");
+  if (cfg->index_slots && ((cfg->index_slots & (cfg->index_slots - 1)) || cfg->index_slots < 64u || cfg->index_slots > (1u << 30)))
+    return fail(nullptr, EPPK_ERR_ARG, "eppk_create: index_slots must be a power of two in [64, 2^30]");
+  for (uint32_t k = 0; k < cfg->n_scorers; ++k)
+    if (cfg->chain[k].kind < EPPK_SCORER_QUEUE || cfg->chain[k].kind > EPPK_SCORER_PREFIX)
+      return fail(nullptr, EPPK_ERR_ARG, "eppk_create: unknown scorer kind");
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, EPPK_ERR_DEVICE, std::string("eppk_create: no HIP device (") + hipGetErrorString(e) + "); libeppk has no CPU path");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, EPPK_ERR_ARG, "eppk_create: device ordinal out of range");
+
+  eppk_ctx* c = new (std::nothrow) eppk_ctx();
+  if (!c) return fail(nullptr, EPPK_ERR_NOMEM, "eppk_create: out of memory");
+  c->cfg = *cfg;
+  auto bail = [&](int code) { std::string m = c->err; eppk_destroy(c); fail(nullptr, code, m); return code; };
+#define CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(EPPK_ERR_DEVICE); } } while (0)
+  CHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  CHK(hipGetDeviceProperties(&prop, cfg->device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
+  c->npl = cfg->max_blocks <= 63 ? 6 : 9;
+  c->pwn = (cfg->max_blocks + 2u) & ~1u;
+  c->stride = 8u + 8u * cfg->max_blocks;
+  c->jmax = (cfg->max_pods + 63u) / 64u;
+
+  // chain analysis: leading pod-only scorers fuse into base[]
+  c->kchain.n = cfg->n_scorers;
+  for (uint32_t k = 0; k < cfg->n_scorers; ++k) { c->kchain.kind[k] = cfg->chain[k].kind; c->kchain.w[k] = (double)cfg->chain[k].weight; }
+  uint32_t lead = 0;
+  while (lead < cfg->n_scorers && (cfg->chain[lead].kind == EPPK_SCORER_QUEUE || cfg->chain[lead].kind == EPPK_SCORER_KV)) ++lead;
+  c->n_lead = lead;
+  c->canonical = true;
+  int nl = 0, np = 0;
+  for (uint32_t k = lead; k < cfg->n_scorers; ++k) {
+    if (cfg->chain[k].kind == EPPK_SCORER_LORA) { if (nl++ == 0 && np) c->p_first = true; }
+    else if (cfg->chain[k].kind == EPPK_SCORER_PREFIX) ++np;
+    else c->canonical = false;
+  }
+  if (nl > 1 || np > 1) c->canonical = false;
+  c->has_l = nl > 0; c->has_p = np > 0;
+  if (!(c->has_l && c->has_p)) c->p_first = false;
+  if (c->canonical) {
+    static const double tier_score[4] = {0.0, 0.6, 0.8, 1.0};
+    double wl = 0.0, wp = 0.0;
+    for (uint32_t k = lead; k < cfg->n_scorers; ++k) {
+      if (cfg->chain[k].kind == EPPK_SCORER_LORA) wl = (double)cfg->chain[k].weight;
+      if (cfg->chain[k].kind == EPPK_SCORER_PREFIX) wp = (double)cfg->chain[k].weight;
+    }
+    for (int t = 0; t < 4; ++t) c->tail.lw[t] = h_clamp01(tier_score[t]) * wl;
+    c->tail.wp = wp;
+  }
+
+  const size_t np64 = (size_t)c->jmax * 64u;
+  const size_t lora_bytes = (size_t)EPPK_MAX_ADAPTERS * 64u * (size_t)c->lw_bytes;
+  for (int b = 0; b < 2; ++b) {
+    CHK(hipMalloc((void**)&c->snap[b].base, np64 * 8u));
+    CHK(hipMalloc((void**)&c->snap[b].queue, np64 * 4u));
+    CHK(hipMalloc((void**)&c->snap[b].kv, np64 * 8u));
+    CHK(hipMalloc(&c->snap[b].act_t, lora_bytes));
+    CHK(hipMalloc(&c->snap[b].wait_t, lora_bytes));
+    CHK(hipMalloc(&c->snap[b].free_t, 64u * (size_t)c->lw_bytes));
+  }
+  CHK(hipMalloc((void**)&c->stats, 4 * sizeof(unsigned long long)));
+  CHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
+  if (cfg->index_slots) {
+    c->slots = cfg->index_slots;
+    uint32_t lg = 0;
+    while ((1u << lg) < c->slots) ++lg;
+    c->shift = 64u - lg;
+    c->limit = c->slots / 2u;  // load factor <= 0.5
+    CHK(hipMalloc((void**)&c->keys, (size_t)c->slots * 8u));
+    CHK(hipMalloc(&c->bitmaps, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes));
+    CHK(hipMemset(c->keys, 0, (size_t)c->slots * 8u));
+    CHK(hipMemset(c->bitmaps, 0, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes));
+  }
+  CHK(hipDeviceSynchronize());
+#undef CHK
+  *out = c;
+  return EPPK_OK;
+}
+
+void eppk_destroy(eppk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int b = 0; b < 2; ++b) {
+    (void)hipFree(c->snap[b].base); (void)hipFree(c->snap[b].queue); (void)hipFree(c->snap[b].kv);
+    (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t);
+  }
+  (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats);
+  (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
+  if (c->h_reqs) (void)hipHostFree(c->h_reqs);
+  if (c->h_mask) (void)hipHostFree(c->h_mask);
+  if (c->h_pick) (void)hipHostFree(c->h_pick);
+  if (c->h_score) (void)hipHostFree(c->h_score);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---- snapshot ------------------------------------------------------------------------------------
+
+int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) {
+  if (!c || (!rows && n_pods)) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_publish: null argument");
+  if (n_pods > c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_snapshot_publish: n_pods > max_pods");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const uint32_t J = (n_pods + 63u) / 64u;
+  const size_t np64 = (size_t)J * 64u;
+
+  // QUEUE normalisers over all pods (the unmasked candidate set)
+  uint32_t qmin = 0, qmax = 0;
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    const uint32_t q = rows[p].queue;
+    if (p == 0) { qmin = qmax = q; }
+    else { qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax; }
+  }
+
+  // fused leading pod-only terms: the same binary64 operations, in chain order (SEMANTICS.md §2)
+  std::vector<double> base(np64 ? np64 : 1, 0.0), kv(np64 ? np64 : 1, 0.0);
+  std::vector<uint32_t> queue(np64 ? np64 : 1, 0u);
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    kv[p] = rows[p].kv_util;
+    queue[p] = rows[p].queue;
+    double t = 0.0;
+    for (uint32_t k = 0; k < c->n_lead; ++k) {
+      double s;
+      if (c->cfg.chain[k].kind == EPPK_SCORER_QUEUE)
+        s = (qmax == qmin) ? 1.0 : (double)(qmax - rows[p].queue) / (double)(qmax - qmin);
+      else
+        s = 1.0 - rows[p].kv_util;
+      t = t + h_clamp01(s) * (double)c->cfg.chain[k].weight;
+    }
+    base[p] = t;
+  }
+
+  // lane-transposed LoRA sets
+  const size_t lw = (size_t)c->lw_bytes;
+  std::vector<uint8_t> act((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), wait((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), freeb(64u * lw, 0);
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    const eppk_pod_row& r = rows[p];
+    for (uint32_t a = 0; a < EPPK_MAX_ADAPTERS; ++a) {
+      if ((r.active[a >> 6] >> (a & 63u)) & 1u) set_lane_bit(act, c->lw_bytes, a, p);
+      if ((r.waiting[a >> 6] >> (a & 63u)) & 1u) set_lane_bit(wait, c->lw_bytes, a, p);
+    }
+    if (pop128(r.active) + pop128(r.waiting) < r.max_lora) set_lane_bit(freeb, c->lw_bytes, 0, p);
+  }
+
+  const int nxt = c->cur ^ 1;
+  SnapBuf& s = c->snap[nxt];
+  if (np64) {
+    HIPCHK(c, hipMemcpyAsync(s.base, base.data(), np64 * 8u, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s.kv, kv.data(), np64 * 8u, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s.queue, queue.data(), np64 * 4u, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(s.act_t, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.wait_t, wait.data(), wait.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.free_t, freeb.data(), freeb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->cur = nxt;
+  c->n_pods = n_pods; c->qmin = qmin; c->qmax = qmax; c->epoch = epoch;
+  c->have_snapshot = true;
+  return EPPK_OK;
+}
+
+int eppk_snapshot_info(const eppk_ctx* c, uint32_t* n_pods, uint64_t* epoch) {
+  if (!c) return EPPK_ERR_ARG;
+  if (!c->have_snapshot) return EPPK_ERR_NO_SNAPSHOT;
+  if (n_pods) *n_pods = c->n_pods;
+  if (epoch) *epoch = c->epoch;
+  return EPPK_OK;
+}
+
+// ---- prefix index --------------------------------------------------------------------------------
+
+int eppk_index_clear(eppk_ctx* c) {
+  if (!c) return EPPK_ERR_ARG;
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemsetAsync(c->keys, 0, (size_t)c->slots * 8u, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return EPPK_OK;
+}
+
+int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+  if (!c || ((!hashes || !pods) && n)) return fail(c, EPPK_ERR_ARG, "eppk_index_insert: null argument");
+  if (!c->slots) return fail(c, EPPK_ERR_ARG, "eppk_index_insert: context was created with index_slots = 0");
+  for (uint32_t i = 0; i < n; ++i)
+    if (pods[i] >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert: pod >= max_pods");
+  if (n == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_tmp(c, (size_t)n * 12u);
+  if (rc) return rc;
+  uint64_t* d_h = (uint64_t*)c->d_tmp;
+  uint32_t* d_p = (uint32_t*)((uint8_t*)c->d_tmp + (size_t)n * 8u);
+  unsigned long long before[4];
+  HIPCHK(c, hipMemcpyAsync(before, c->stats, sizeof before, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_h, hashes, (size_t)n * 8u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_p, pods, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream));
+  const uint32_t threads = 256, grid = (n + threads - 1) / threads;
+  rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, c->shift,
+                       c->limit, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  unsigned long long after[4];
+  HIPCHK(c, hipMemcpyAsync(after, c->stats, sizeof after, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (after[3] != before[3]) return fail(c, EPPK_ERR_INDEX_FULL, "eppk_index_insert: table at load limit, inserts dropped");
+  return rc;
+}
+
+int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, void* stream) {
+  if (!c || ((!d_reqs || !d_picks) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: null argument");
+  if (!c->slots) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: no index");
+  if (n_reqs == 0 || c->cfg.max_blocks == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const uint64_t total = (uint64_t)n_reqs * c->cfg.max_blocks;
+  const uint32_t threads = 256;
+  const uint64_t grid64 = (total + threads - 1) / threads;
+  if (grid64 > 0x7FFFFFFFull) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert_picks_device: batch too large");
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->slots,
+                       c->shift, c->limit, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  return rc;
+}
+
+int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
+  if (!c) return EPPK_ERR_ARG;
+  if (pod >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_remove_pod: pod >= max_pods");
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const uint32_t rows = c->slots + 1u, threads = 256, grid = (rows + threads - 1) / threads;
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->bitmaps, rows, pod);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+int eppk_index_size(eppk_ctx* c, uint32_t* n_entries) {
+  if (!c || !n_entries) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  unsigned long long st[4];
+  HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_entries = (uint32_t)st[2];
+  return EPPK_OK;
+}
+
+// ---- the hot path ----------------------------------------------------------------------------------
+
+int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, int32_t* d_out_pick,
+                           double* d_out_score, void* stream) {
+  if (!c || ((!d_reqs || !d_out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_device: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch_device: no snapshot published");
+  if (n_reqs == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  return launch_pick(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream ? (hipStream_t)stream : c->stream);
+}
+
+int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick, double* out_score) {
+  if (!c || ((!reqs || !out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  // validate rows on the host: never hand the kernel an out-of-range adapter / block count
+  for (uint32_t r = 0; r < n_reqs; ++r) {
+    eppk_req_hdr h;
+    std::memcpy(&h, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof h);
+    if (h.n_blocks > c->cfg.max_blocks || h.adapter < -1 || h.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
+      return fail(c, EPPK_ERR_ARG, "eppk_pick_batch: request row " + std::to_string(r) + " out of range");
+  }
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t mb = c->cfg.max_batch;
+  const size_t J = (c->n_pods + 63u) / 64u;
+  if (!c->d_reqs) {
+    HIPCHK(c, hipMalloc(&c->d_reqs, mb * c->stride));
+    HIPCHK(c, hipMalloc((void**)&c->d_pick, mb * 4u));
+    HIPCHK(c, hipMalloc((void**)&c->d_score, mb * 8u));
+    HIPCHK(c, hipHostMalloc(&c->h_reqs, mb * c->stride, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_pick, mb * 4u, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_score, mb * 8u, hipHostMallocDefault));
+  }
+  if (cand_mask && !c->d_mask) {
+    HIPCHK(c, hipMalloc((void**)&c->d_mask, mb * c->jmax * 8u));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
+  }
+  std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+  HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+  if (cand_mask && J) {
+    std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = launch_pick(c, c->d_reqs, n_reqs, (cand_mask && J) ? c->d_mask : nullptr, c->d_pick, c->d_score, c->stream);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
+  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
+  if (cand_mask && !J) for (uint32_t r = 0; r < n_reqs; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+  return EPPK_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+
+int eppk_profile_enable(eppk_ctx* c, int on) {
+  if (!c) return EPPK_ERR_ARG;
+  c->prof = on != 0;
+  c->ev_used = 0;
+  return EPPK_OK;
+}
+
+int eppk_profile_drain(eppk_ctx* c, float* ms, uint32_t cap, uint32_t* n_out) {
+  if (!c || (!ms && cap) || !n_out) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  uint32_t n = 0;
+  for (size_t i = 0; i + 1 < c->ev_used && n < cap; i += 2) {
+    HIPCHK(c, hipEventSynchronize(c->ev[i + 1]));
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+    ms[n++] = t;
+  }
+  *n_out = n;
+  c->ev_used = 0;
+  return EPPK_OK;
+}
+
+int eppk_last_algorithmic_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* probes) {
+  if (!c || !bytes) return EPPK_ERR_ARG;
+  if (!c->prof) return fail(c, EPPK_ERR_ARG, "eppk_last_algorithmic_bytes: enable profiling first");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipDeviceSynchronize());
+  unsigned long long st[4];
+  HIPCHK(c, hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
+  // SURVEY §8(d) byte model: pod rows + request rows + picks + index rows actually needed by the
+  // sequential walk (a hit reads key + pod-set row, the terminating miss reads a key).
+  const uint64_t row = 8u + 64u * (uint64_t)c->lw_bytes;
+  *bytes = (uint64_t)c->last_n_pods * sizeof(eppk_pod_row) + (uint64_t)c->last_n_reqs * ((uint64_t)c->stride + 4u) +
+           (uint64_t)st[0] * row + (uint64_t)(st[1] - st[0]) * 8u;
+  if (probes) *probes = st[1];
+  return EPPK_OK;
+}
+
+}  // extern "C"

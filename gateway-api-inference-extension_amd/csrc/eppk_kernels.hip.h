@@ -1,0 +1,507 @@
+// eppk_kernels.hip.h — gfx950 kernels of the batched endpoint pick.  (Device code only.)
+//
+// What is computed: SEMANTICS.md.  How it is laid out for CDNA4:
+//
+//   * one WAVEFRONT (64 lanes) owns one request at a time; lane l owns pods {j*64 + l}.
+//   * every per-pod bit set that a request needs (prefix-index pod sets, LoRA active/waiting sets,
+//     free-slot set, candidate mask) is stored / re-laid "lane-transposed": a row of 64 lane words
+//     (type LW = u16/u32/u64 for P <= 1024/2048/4096) where bit j of lane word l is pod j*64+l.
+//     One coalesced 64*sizeof(LW)-byte load therefore hands every lane exactly the membership bits
+//     of the pods it scores, with no cross-lane traffic.
+//   * the prefix walk adds up to n_blocks such rows into bit-sliced (vertical) counters: NPL planes
+//     of LW per lane, i.e. matched[pod] for 64 pods per lane in NPL registers.
+//   * pod-only scorers that lead the chain are fused on the host into base[p] (same binary64 ops in
+//     the same order, so bit-exact) and staged once per workgroup into LDS; the pair loop is then
+//     two binary64 adds, two LDS table look-ups, and a strict-greater running argmax.
+//   * argmax across lanes: 6-step xor-shuffle on (score desc, index asc).
+//   * no MFMA: this is integer/bit/f64-add work (north_star); the bound is HBM for index rows.
+//
+// Replaces (reference, all spec-only or Go): Scorer.Score + weighted sum + Picker.Pick
+//   docs/proposals/0845-scheduler-architecture-proposal/interfaces/interface.go:113-142,
+//   called per request through EndpointPicker.Pick, pkg/lwepp/handlers/server.go:79-82.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eppk {
+
+constexpr uint32_t kNotFound = 0xFFFFFFFFu;
+constexpr uint32_t kNoPod = 0xFFFFFFFFu;
+constexpr uint64_t kHomeMul = 0x9E3779B97F4A7C15ull;
+
+// ---- kernel argument blocks (plain structs, passed by value) --------------------------------
+
+struct KSnap {
+  const double*   base;    // [J*64] fused leading pod-only terms (fast path)
+  const uint32_t* queue;   // [J*64]
+  const double*   kv;      // [J*64]
+  const void*     act_t;   // [A][64] LW  bit j of [a][l] : adapter a active on pod j*64+l
+  const void*     wait_t;  // [A][64] LW
+  const void*     free_t;  // [64] LW     loaded < max_lora
+  uint32_t n_pods;
+  uint32_t J;              // ceil(n_pods/64)
+  uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
+};
+
+struct KIndex {
+  const uint64_t* keys;    // [slots]; 0 = empty.  hash 0 lives in the extra slot `slots`
+  const void*     bitmaps; // [slots+1][64] LW
+  uint32_t slots;          // power of two (0 = no index)
+  uint32_t shift;          // 64 - log2(slots)
+};
+
+struct KChain {            // the whole weighted chain (generic kernel)
+  uint32_t n;
+  uint32_t kind[8];
+  double   w[8];
+};
+
+struct KTail {             // the request-dependent tail after fusion (fast kernel)
+  double lw[4];            // clamp01(tier score) * w_lora, tier 0..3 = {0.0, 0.6, 0.8, 1.0}
+  double wp;               // (double) w_prefix
+};
+
+// ---- small device helpers --------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t home_slot(uint64_t h, uint32_t shift) {
+  return (uint32_t)((h * kHomeMul) >> shift);
+}
+
+__device__ __forceinline__ double clamp01(double s) {
+  if (!(s >= 0.0)) return 0.0;
+  if (s > 1.0) return 1.0;
+  return s;
+}
+
+// Look one hash up; returns its slot or kNotFound.  Linear probing; the table is never full.
+__device__ __forceinline__ uint32_t probe(const KIndex& ix, uint64_t h, bool active) {
+  if (!active || ix.slots == 0) return kNotFound;
+  if (h == 0) return ix.slots;
+  uint32_t s = home_slot(h, ix.shift);
+  const uint32_t mask = ix.slots - 1;
+  for (uint32_t n = 0; n < ix.slots; ++n) {
+    const uint64_t k = ix.keys[s];
+    if (k == h) return s;
+    if (k == 0) return kNotFound;
+    s = (s + 1) & mask;
+  }
+  return kNotFound;
+}
+
+// Bit-sliced counter: c[k] holds bit k of 8*sizeof(LW) independent counters. add a 0/1 vector.
+template <typename LW, int NPL>
+__device__ __forceinline__ void planes_add(LW (&c)[NPL], LW m) {
+  LW carry = m;
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const LW t = c[k] & carry;
+    c[k] ^= carry;
+    carry = t;
+  }
+}
+
+template <typename LW> struct lane_word;
+template <> struct lane_word<uint16_t> { static constexpr int halves = 1; static constexpr int bits = 16; };
+template <> struct lane_word<uint32_t> { static constexpr int halves = 1; static constexpr int bits = 32; };
+template <> struct lane_word<uint64_t> { static constexpr int halves = 2; static constexpr int bits = 64; };
+
+template <typename LW>
+__device__ __forceinline__ uint32_t half32(LW x, int h) {
+  if constexpr (sizeof(LW) == 8) return (uint32_t)(x >> (32 * h));
+  else return (uint32_t)x;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, off);
+  hi = __shfl_xor(hi, off);
+  return __hiloint2double(hi, lo);
+}
+
+// (score desc, index asc) argmax across the 64 lanes; every lane ends with the winner.
+__device__ __forceinline__ void wave_argmax(double& best, uint32_t& bidx) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ob = shfl_xor_f64(best, off);
+    const uint32_t oi = (uint32_t)__shfl_xor((int)bidx, off);
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The prefix walk of one request (SEMANTICS.md §3 PREFIX) into bit-sliced counters.
+// Returns the number of non-empty index rows added (= leading non-empty look-ups).
+template <typename LW, int NPL>
+__device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t* hs, uint32_t nb, int lane,
+                                                LW (&c)[NPL]) {
+  const LW* bm = (const LW*)ix.bitmaps;
+  uint32_t hits = 0;
+  bool stop = false;
+  for (uint32_t b0 = 0; b0 < nb && !stop; b0 += 64) {
+    const uint32_t i = b0 + (uint32_t)lane;
+    const bool act = i < nb;
+    const uint64_t h = act ? hs[i] : 0;
+    const uint32_t slot = probe(ix, h, act);               // all of the chunk's keys in parallel
+    const unsigned long long found = __ballot(slot != kNotFound);
+    const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
+    const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);  // leading found
+    for (uint32_t k0 = 0; k0 < m && !stop; k0 += 8) {      // 8 independent row loads in flight
+      LW w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t k = k0 + (uint32_t)u;
+        const uint32_t s = __builtin_amdgcn_readlane(slot, (k < m) ? k : 0);
+        w[u] = (k < m) ? bm[(size_t)s * 64u + (uint32_t)lane] : (LW)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t k = k0 + (uint32_t)u;
+        if (k < m && !stop) {
+          if (__ballot(w[u] != 0) == 0ull) stop = true;    // key present but pod set empty
+          else { planes_add<LW, NPL>(c, w[u]); ++hits; }
+        }
+      }
+    }
+    if (m < chunk) stop = true;                            // first absent key ends the walk
+  }
+  return hits;
+}
+
+template <int NPL>
+__device__ __forceinline__ uint32_t planes_get(const uint32_t (&c32)[NPL], uint32_t jj) {
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) cnt |= ((c32[k] >> jj) & 1u) << k;
+  return cnt;
+}
+
+// Transpose one natural-layout candidate mask row ([J] u64, bit p%64 of word p/64) into a lane word.
+template <typename LW>
+__device__ __forceinline__ LW transpose_mask(const uint64_t* row, uint32_t J, int lane) {
+  const uint64_t mine = ((uint32_t)lane < J) ? row[lane] : 0ull;
+  LW out = 0;
+  for (uint32_t j = 0; j < J; ++j) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, j);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), j);
+    const uint64_t mj = ((uint64_t)hi << 32) | lo;
+    out |= (LW)((LW)((mj >> lane) & 1ull) << j);
+  }
+  return out;
+}
+
+// Lane word with bit j set iff pod j*64+lane exists.
+template <typename LW>
+__device__ __forceinline__ LW valid_word(uint32_t n_pods, int lane) {
+  // pods owned by this lane: j < ceil((n_pods - lane)/64)
+  const uint32_t cnt = ((uint32_t)lane < n_pods) ? (n_pods - (uint32_t)lane + 63u) / 64u : 0u;
+  if (cnt >= (uint32_t)lane_word<LW>::bits) return (LW)~(LW)0;
+  return (LW)(((LW)1 << cnt) - 1);
+}
+
+// ---- FAST pick kernel --------------------------------------------------------------------------
+// Chain = [pod-only scorers fused into base] ++ tail, tail in {∅, L, P, LP, PL}; no candidate mask.
+// LDS: base[J*64] f64 | lw[4] f64 | per wave pw[pwn] f64.
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
+__global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+                                                        uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                        int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                                        unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_base = (double*)smem;
+  double* s_lw = s_base + (size_t)sn.J * 64u;
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t wib = threadIdx.x >> 6;
+  const uint32_t wpb = blockDim.x >> 6;
+  double* s_pw = s_lw + 4 + (size_t)wib * pwn;
+
+  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
+  if (threadIdx.x < 4) s_lw[threadIdx.x] = tl.lw[threadIdx.x];
+  __syncthreads();
+
+  const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
+  const LW valid = valid_word<LW>(sn.n_pods, lane);
+  unsigned long long w_hits = 0, w_lookups = 0;
+
+  const uint32_t gwave = blockIdx.x * wpb + wib;
+  const uint32_t nwaves = gridDim.x * wpb;
+  for (uint32_t r = gwave; r < n_reqs; r += nwaves) {
+    const uint8_t* row = reqs + (size_t)r * stride;
+    const int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
+
+    // prefix walk -> bit-sliced matched counts
+    LW c[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) c[k] = 0;
+    if (HAS_P) {
+      const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, c);
+      w_hits += hits;
+      w_lookups += (hits + 1u < nb) ? hits + 1u : nb;
+      // pw[cnt] = clamp01(cnt / n) * w_prefix, one division per lane per request
+      wave_lds_fence();  // previous request's readers are done
+      for (uint32_t cnt = (uint32_t)lane; cnt <= nb; cnt += 64u) {
+        const double s = nb ? (double)cnt / (double)nb : 0.0;
+        s_pw[cnt] = clamp01(s) * tl.wp;
+      }
+      wave_lds_fence();
+    }
+
+    // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 (waiting), 2: 0.8 (free slot), 3: 1.0 (active)}
+    LW thi = 0, tlo = 0;
+    if (HAS_L) {
+      LW a = 0, w = 0;
+      if (adapter >= 0) {
+        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
+        w = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
+      }
+      thi = a | freew;
+      tlo = a | ((LW)~freew & w);
+    }
+
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
+#pragma unroll
+    for (int hf = 0; hf < lane_word<LW>::halves; ++hf) {
+      const uint32_t j0 = (uint32_t)hf * 32u;
+      if (j0 >= sn.J) break;
+      const uint32_t jn = (sn.J - j0) < 32u ? (sn.J - j0) : 32u;
+      const uint32_t v32 = half32<LW>(valid, hf);
+      const uint32_t hi32 = half32<LW>(thi, hf), lo32 = half32<LW>(tlo, hf);
+      uint32_t c32[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) c32[k] = half32<LW>(c[k], hf);
+      for (uint32_t jj = 0; jj < jn; ++jj) {
+        const uint32_t p = (j0 + jj) * 64u + (uint32_t)lane;
+        double t = s_base[p];
+        double tl_term = 0.0, tp_term = 0.0;
+        if (HAS_L) tl_term = s_lw[(((hi32 >> jj) & 1u) << 1) | ((lo32 >> jj) & 1u)];
+        if (HAS_P) tp_term = s_pw[planes_get<NPL>(c32, jj)];
+        if (HAS_L && HAS_P) {
+          if (P_FIRST) { t = t + tp_term; t = t + tl_term; }
+          else { t = t + tl_term; t = t + tp_term; }
+        } else if (HAS_L) {
+          t = t + tl_term;
+        } else if (HAS_P) {
+          t = t + tp_term;
+        }
+        const bool ok = (v32 >> jj) & 1u;
+        if (ok && t > best) { best = t; bidx = p; }
+      }
+    }
+    wave_argmax(best, bidx);
+    if (lane == 0) {
+      const bool none = bidx == kNoPod;
+      out_pick[r] = none ? -1 : (int32_t)bidx;
+      if (out_score) out_score[r] = none ? 0.0 : best;
+    }
+  }
+  if (HAS_P && stats && lane == 0 && (w_hits | w_lookups)) {
+    atomicAdd(&stats[0], w_hits);
+    atomicAdd(&stats[1], w_lookups);
+  }
+}
+
+// ---- GENERIC pick kernel -----------------------------------------------------------------------
+// Any chain order (duplicates allowed), optional candidate mask; every scorer evaluated per pair in
+// chain order.  Slower; it is both the fallback for non-canonical chains / masked batches and an
+// independent on-device statement of SEMANTICS.md.
+// LDS: queue[J*64] u32 | kv[J*64] f64 | per wave pw[pwn] f64 (raw ratios cnt/n).
+template <typename LW, int NPL, bool MASKED>
+__global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, KChain ch, const uint8_t* __restrict__ reqs,
+                                                           uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                           const uint64_t* __restrict__ cand_mask,
+                                                           int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                                           unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_kv = (double*)smem;
+  uint32_t* s_q = (uint32_t*)(s_kv + (size_t)sn.J * 64u);
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t wib = threadIdx.x >> 6;
+  const uint32_t wpb = blockDim.x >> 6;
+  double* s_pw = (double*)(s_q + (size_t)sn.J * 64u) + (size_t)wib * pwn;
+
+  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_kv[i] = sn.kv[i]; s_q[i] = sn.queue[i]; }
+  __syncthreads();
+
+  bool has_q = false, has_l = false, has_p = false;
+  for (uint32_t k = 0; k < ch.n; ++k) {
+    has_q |= ch.kind[k] == 1u; has_l |= ch.kind[k] == 3u; has_p |= ch.kind[k] == 4u;
+  }
+  const LW freew = has_l ? ((const LW*)sn.free_t)[lane] : (LW)0;
+  const LW valid = valid_word<LW>(sn.n_pods, lane);
+  unsigned long long w_hits = 0, w_lookups = 0;
+
+  const uint32_t gwave = blockIdx.x * wpb + wib;
+  const uint32_t nwaves = gridDim.x * wpb;
+  for (uint32_t r = gwave; r < n_reqs; r += nwaves) {
+    const uint8_t* row = reqs + (size_t)r * stride;
+    const int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
+
+    LW cand = valid;
+    if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
+
+    LW c[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) c[k] = 0;
+    if (has_p) {
+      for (uint32_t k = 0; k < ch.n; ++k) {
+        if (ch.kind[k] != 4u) continue;   // every PREFIX entry performs (and is billed) its own walk; counts are identical
+        LW cc[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) cc[q] = 0;
+        const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, cc);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) c[q] = cc[q];
+        w_hits += hits;
+        w_lookups += (hits + 1u < nb) ? hits + 1u : nb;
+      }
+      wave_lds_fence();
+      for (uint32_t cnt = (uint32_t)lane; cnt <= nb; cnt += 64u) s_pw[cnt] = nb ? (double)cnt / (double)nb : 0.0;
+      wave_lds_fence();
+    }
+
+    LW thi = 0, tlo = 0;
+    if (has_l) {
+      LW a = 0, w = 0;
+      if (adapter >= 0) {
+        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
+        w = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
+      }
+      thi = a | freew;
+      tlo = a | ((LW)~freew & w);
+    }
+
+    // QUEUE normalisers over the request's candidates
+    uint32_t qmin = sn.qmin, qmax = sn.qmax;
+    if (MASKED && has_q) {
+      uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+      for (uint32_t j = 0; j < sn.J; ++j) {
+        if ((cand >> j) & 1) {
+          const uint32_t q = s_q[j * 64u + (uint32_t)lane];
+          mn = q < mn ? q : mn;
+          mx = q > mx ? q : mx;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t omn = (uint32_t)__shfl_xor((int)mn, off), omx = (uint32_t)__shfl_xor((int)mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+      }
+      qmin = mn; qmax = mx;
+    }
+    const double qden = (double)(qmax - qmin);
+
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
+    for (uint32_t j = 0; j < sn.J; ++j) {
+      const uint32_t p = j * 64u + (uint32_t)lane;
+      const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
+      double t = 0.0;
+      for (uint32_t k = 0; k < ch.n; ++k) {
+        double s;
+        switch (ch.kind[k]) {
+          case 1u: s = (qmax == qmin) ? 1.0 : (double)(qmax - s_q[p]) / qden; break;
+          case 2u: s = 1.0 - s_kv[p]; break;
+          case 3u: s = tier == 3u ? 1.0 : tier == 2u ? 0.8 : tier == 1u ? 0.6 : 0.0; break;
+          default: s = s_pw[cnt]; break;
+        }
+        t = t + clamp01(s) * ch.w[k];
+      }
+      const bool ok = (cand >> j) & 1;
+      if (ok && t > best) { best = t; bidx = p; }
+    }
+    wave_argmax(best, bidx);
+    if (lane == 0) {
+      const bool none = bidx == kNoPod;
+      out_pick[r] = none ? -1 : (int32_t)bidx;
+      if (out_score) out_score[r] = none ? 0.0 : best;
+    }
+  }
+  if (stats && lane == 0 && (w_hits | w_lookups)) {
+    atomicAdd(&stats[0], w_hits);
+    atomicAdd(&stats[1], w_lookups);
+  }
+}
+
+// ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
+// stats[2] = occupied keys, stats[3] = dropped inserts (table at its load limit)
+
+template <typename LW>
+__device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_t pod) {
+  const uint32_t lane = pod & 63u, j = pod >> 6;
+  if constexpr (sizeof(LW) == 8) {
+    atomicOr((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, 1ull << j);
+  } else if constexpr (sizeof(LW) == 4) {
+    atomicOr((unsigned int*)bitmaps + (size_t)slot * 64u + lane, 1u << j);
+  } else {
+    const size_t e = (size_t)slot * 64u + lane;           // u16 element index
+    atomicOr((unsigned int*)bitmaps + (e >> 1), (1u << j) << (16u * (uint32_t)(e & 1u)));
+  }
+}
+
+template <typename LW>
+__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift,
+                                                 uint32_t limit, unsigned long long* stats, uint64_t h, uint32_t pod) {
+  uint32_t slot = kNotFound;
+  if (h == 0) {
+    slot = slots;
+  } else {
+    uint32_t s = home_slot(h, shift);
+    const uint32_t mask = slots - 1;
+    for (uint32_t n = 0; n < slots; ++n) {
+      unsigned long long k = __hip_atomic_load((unsigned long long*)&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == 0ull) {
+        if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) break;
+        k = atomicCAS((unsigned long long*)&keys[s], 0ull, (unsigned long long)h);
+        if (k == 0ull) { atomicAdd(&stats[2], 1ull); slot = s; break; }
+      }
+      if (k == (unsigned long long)h) { slot = s; break; }
+      s = (s + 1) & mask;
+    }
+  }
+  if (slot == kNotFound) { atomicAdd(&stats[3], 1ull); return; }
+  bitmap_set<LW>(bitmaps, slot, pod);
+}
+
+template <typename LW>
+__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift, uint32_t limit,
+                                    unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, hashes[i], pods[i]);
+}
+
+// thread (r, i): append picks[r] to hash i of request r
+template <typename LW>
+__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift, uint32_t limit,
+                                          unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
+                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
+  if (r >= n_reqs) return;
+  const int32_t pick = picks[r];
+  const uint8_t* row = reqs + (size_t)r * stride;
+  const uint32_t nb = ((const uint32_t*)row)[1];
+  if (pick < 0 || i >= nb) return;
+  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, ((const uint64_t*)(row + 8))[i], (uint32_t)pick);
+}
+
+// clear pod's bit in every row: one thread per slot
+template <typename LW>
+__global__ void index_remove_pod_kernel(void* bitmaps, uint32_t rows, uint32_t pod) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= rows) return;
+  LW* w = (LW*)bitmaps + (size_t)s * 64u + (pod & 63u);
+  *w = (LW)(*w & (LW)~((LW)1 << (pod >> 6)));
+}
+
+}  // namespace eppk

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference picker seam, on top of the C ABI (include/eppk.h).
+
+Reference shapes mirrored (same names, argument meaning and error behaviour):
+
+* ``EndpointPicker.Pick(ctx, *PickRequest, []*Endpoint) (*PickResult, error)``
+  — pkg/lwepp/handlers/server.go:79-82; ``BatchedPicker.pick_endpoints`` is the batched form.
+* ``RoundRobinPicker`` — server.go:84-101 (pre-increment atomic counter, ``Unavailable`` on empty).
+* subset filter of ``handleRequestHeaders`` — request.go:104-133 → ``subset_mask``.
+* ``WeightedScorer{Scorer, weight int}`` / ``SchedulerProfile`` —
+  docs/proposals/0845-scheduler-architecture-proposal/interfaces/interface.go:70-79, :132-135
+  → the ``chain`` argument.
+
+Everything that scores or picks runs in libeppk's HIP kernels; this file only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import EppkError
+
+POD_DTYPE = np.dtype([("queue", "<u4"), ("running", "<u4"), ("kv_util", "<f8"), ("max_lora", "<u4"),
+                      ("flags", "<u4"), ("active", "<u8", (2,)), ("waiting", "<u8", (2,)),
+                      ("reserved", "<u8")])
+assert POD_DTYPE.itemsize == 64
+
+
+class ScorerKind(enum.IntEnum):
+    QUEUE = 1
+    KV = 2
+    LORA = 3
+    PREFIX = 4
+
+
+class Unavailable(RuntimeError):
+    """codes.Unavailable: no endpoints available (server.go:91-93, request.go:100-102)."""
+
+
+@dataclass
+class Endpoint:
+    """Identity of a candidate — pkg/lwepp/datastore/datastore.go:40-46."""
+    address: str
+    port: str
+    pod_name: str = ""
+
+
+@dataclass
+class PickResult:
+    """server.go:72-77."""
+    endpoint: str
+    fallbacks: List[str] = field(default_factory=list)
+
+
+def join_host_port(host: str, port: str) -> str:
+    """net.JoinHostPort as used at server.go:99 (IPv6 literals are bracketed)."""
+    return f"[{host}]:{port}" if (":" in host or "%" in host) else f"{host}:{port}"
+
+
+def make_req_rows(adapter: np.ndarray, n_blocks: np.ndarray, hashes: Optional[np.ndarray], max_blocks: int) -> np.ndarray:
+    """Pack request rows: [R, 1+max_blocks] u64; word 0 = adapter (i32, low half) | n_blocks << 32."""
+    adapter = np.asarray(adapter, dtype=np.int32)
+    n_blocks = np.asarray(n_blocks, dtype=np.uint32)
+    R = adapter.shape[0]
+    rows = np.zeros((R, 1 + max_blocks), dtype=np.uint64)
+    rows[:, 0] = adapter.view(np.uint32).astype(np.uint64) | (n_blocks.astype(np.uint64) << np.uint64(32))
+    if hashes is not None and max_blocks:
+        h = np.asarray(hashes, dtype=np.uint64)
+        rows[:, 1:1 + h.shape[1]] = h
+    return rows
+
+
+def subset_mask(endpoints: Sequence[Endpoint], filter_value: Optional[str]) -> Tuple[np.ndarray, int]:
+    """Candidate bitmask of one request — request.go:104-133. Returns (mask words, n_candidates)."""
+    lib = _lib.load_library()
+    n = len(endpoints)
+    addrs = (C.c_char_p * max(n, 1))(*[e.address.encode() for e in endpoints])
+    ports = (C.c_char_p * max(n, 1))(*[e.port.encode() for e in endpoints])
+    mask = np.zeros(max((n + 63) // 64, 1), dtype=np.uint64)
+    rc = lib.eppk_subset_mask(addrs, ports, n, None if filter_value is None else filter_value.encode(),
+                              mask.ctypes.data)
+    if rc < 0:
+        raise EppkError(rc, "eppk_subset_mask")
+    return mask[: (n + 63) // 64], rc
+
+
+def hash_prompt(model: bytes, prompt: bytes, block_chars: int, max_blocks: int) -> np.ndarray:
+    """Chained XXH64 block hashes of one prompt (SEMANTICS.md §4)."""
+    lib = _lib.load_library()
+    out = np.zeros(max_blocks, dtype=np.uint64)
+    n = lib.eppk_hash_prompt(model, len(model), prompt, len(prompt), block_chars, out.ctypes.data, max_blocks)
+    if n < 0:
+        raise EppkError(n, "eppk_hash_prompt")
+    return out[:n]
+
+
+class RoundRobinPicker:
+    """server.go:84-101 — the reference's picker; the shim's fail-open fallback."""
+
+    def __init__(self) -> None:
+        self._ctr = C.c_uint64(0)
+        self._lib = _lib.load_library()
+
+    def pick_index(self, n_candidates: int) -> int:
+        idx = self._lib.eppk_round_robin(C.byref(self._ctr), n_candidates)
+        if idx < 0:
+            raise Unavailable("no endpoints available")
+        return idx
+
+    def Pick(self, req, endpoints: Sequence[Endpoint]) -> PickResult:  # noqa: N802 (reference name)
+        e = endpoints[self.pick_index(len(endpoints))] if len(endpoints) else None
+        if e is None:
+            raise Unavailable("no endpoints available")
+        return PickResult(endpoint=join_host_port(e.address, e.port))
+
+
+class BatchedPicker:
+    """One SchedulerProfile (weighted scorer chain + best-score picker) bound to one GPU."""
+
+    def __init__(self, chain: Sequence[Tuple[int, int]], max_pods: int, max_blocks: int = 0, max_batch: int = 65536,
+                 index_slots: int = 0, device: int = 0) -> None:
+        self._lib = _lib.load_library()
+        cfg = _lib.Cfg()
+        cfg.struct_size = C.sizeof(_lib.Cfg)
+        cfg.device = device
+        cfg.max_pods = max_pods
+        cfg.max_blocks = max_blocks
+        cfg.max_batch = max_batch
+        cfg.index_slots = index_slots
+        cfg.n_scorers = len(chain)
+        if len(chain) > _lib.EPPK_MAX_SCORERS:
+            raise EppkError(-2, "more than 8 scorers")
+        for i, (kind, weight) in enumerate(chain):
+            cfg.chain[i].kind = int(kind)
+            cfg.chain[i].weight = int(weight)
+        self._ctx = C.c_void_p()
+        rc = self._lib.eppk_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            raise EppkError(rc, (self._lib.eppk_last_error(None) or b"").decode())
+        self.chain = [(int(k), int(w)) for k, w in chain]
+        self.max_pods, self.max_blocks, self.max_batch, self.index_slots = max_pods, max_blocks, max_batch, index_slots
+        self.device = device
+        self.n_pods = 0
+        self.row_words = 1 + max_blocks
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise EppkError(rc, f"{what}: {(self._lib.eppk_last_error(self._ctx) or b'').decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.eppk_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- snapshot / index -------------------------------------------------------------------
+    def publish(self, pods: np.ndarray, epoch: int = 0) -> None:
+        pods = np.ascontiguousarray(pods, dtype=POD_DTYPE)
+        self._check(self._lib.eppk_snapshot_publish(self._ctx, pods.ctypes.data, pods.shape[0], epoch), "snapshot_publish")
+        self.n_pods = int(pods.shape[0])
+
+    def index_clear(self) -> None:
+        self._check(self._lib.eppk_index_clear(self._ctx), "index_clear")
+
+    def index_insert(self, hashes: np.ndarray, pods: np.ndarray) -> None:
+        h = np.ascontiguousarray(hashes, dtype=np.uint64).ravel()
+        p = np.ascontiguousarray(pods, dtype=np.uint32).ravel()
+        assert h.shape == p.shape
+        self._check(self._lib.eppk_index_insert(self._ctx, h.ctypes.data, p.ctypes.data, h.shape[0]), "index_insert")
+
+    def index_remove_pod(self, pod: int) -> None:
+        self._check(self._lib.eppk_index_remove_pod(self._ctx, pod), "index_remove_pod")
+
+    def index_size(self) -> int:
+        n = C.c_uint32(0)
+        self._check(self._lib.eppk_index_size(self._ctx, C.byref(n)), "index_size")
+        return n.value
+
+    # -- the hot path -----------------------------------------------------------------------
+    def pick(self, reqs: np.ndarray, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """Host-buffer entry point. reqs: [R, 1+max_blocks] u64 rows; mask: [R, ceil(P/64)] u64 or None."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words, "request row stride mismatch"
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        mptr = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert mask.shape == (R, (self.n_pods + 63) // 64), "mask shape mismatch"
+            mptr = mask.ctypes.data
+        self._check(self._lib.eppk_pick_batch(self._ctx, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data), "pick_batch")
+        return picks, scores
+
+    def pick_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
+        """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
+        self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
+
+    def index_insert_picks_device(self, d_reqs: int, d_picks: int, n_reqs: int, stream: int = 0) -> None:
+        self._check(self._lib.eppk_index_insert_picks_device(self._ctx, d_reqs, d_picks, n_reqs, stream or None), "index_insert_picks_device")
+
+    def pick_endpoints(self, endpoints: Sequence[Endpoint], reqs: np.ndarray, mask: Optional[np.ndarray] = None) -> List[PickResult]:
+        """Batched EndpointPicker.Pick: one PickResult per request; Unavailable if any request has no candidate."""
+        if len(endpoints) != self.n_pods:
+            raise EppkError(-1, "endpoints must be the published snapshot's candidate slice")
+        picks, _ = self.pick(reqs, mask)
+        out = []
+        for p in picks:
+            if p < 0:
+                raise Unavailable("no endpoints available")
+            e = endpoints[int(p)]
+            out.append(PickResult(endpoint=join_host_port(e.address, e.port)))
+        return out
+
+    # -- measurement ------------------------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        self._check(self._lib.eppk_profile_enable(self._ctx, 1 if on else 0), "profile_enable")
+
+    def profile_drain(self, cap: int = 65536) -> np.ndarray:
+        ms = np.zeros(cap, dtype=np.float32)
+        n = C.c_uint32(0)
+        self._check(self._lib.eppk_profile_drain(self._ctx, ms.ctypes.data, cap, C.byref(n)), "profile_drain")
+        return ms[: n.value].copy()
+
+    def algorithmic_bytes(self) -> Tuple[int, int]:
+        b, p = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.eppk_last_algorithmic_bytes(self._ctx, C.byref(b), C.byref(p)), "last_algorithmic_bytes")
+        return b.value, p.value

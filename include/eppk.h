@@ -1,0 +1,202 @@
+/*
+ * eppk.h — C ABI of libeppk, the MI355X-native batched endpoint picker.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference gateway: the per-request
+ * endpoint pick.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference tree):
+ *
+ *   - the picker seam      pkg/lwepp/handlers/server.go:79-82   (EndpointPicker.Pick)
+ *   - its only call site   pkg/lwepp/handlers/request.go:141-163 (pickEndpoint)
+ *   - the scheduler shape  docs/proposals/0845-scheduler-architecture-proposal/interfaces/interface.go:55-142
+ *                          (Scheduler / SchedulerProfile / Filter / Scorer / WeightedScorer / Picker)
+ *   - scorer inputs        docs/proposals/003-model-server-protocol/README.md:28-57
+ *   - prefix chain/index   docs/proposals/0602-prefix-cache-aware-routing-proposal/README.md:99-122
+ *
+ * The reference has no FFI today (pure Go, CGO_ENABLED=0: lwepp.Dockerfile:8); INTEGRATION.md shows
+ * the cgo binding a maintainer would add on top of this header.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch / HIP types in signatures (streams travel as void*).
+ *   - every function returns EPPK_OK (0) or a negative eppk_status; nothing aborts, nothing calls back.
+ *   - the caller owns all host buffers for the duration of the call only; the library owns device memory.
+ *   - a context is bound to one GPU; calls on one context must be serialised by the caller
+ *     (the Go shim's dispatcher goroutine does that: INTEGRATION.md).  Different contexts are independent.
+ *   - arithmetic contract: SEMANTICS.md.  Picks are bit-exact against oracle/ on the same inputs.
+ */
+#ifndef EPPK_H
+#define EPPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPPK_ABI_VERSION 1u
+
+/* Limits of this build (SEMANTICS.md §limits). */
+#define EPPK_MAX_PODS      4096u /* candidate endpoints per snapshot                         */
+#define EPPK_MAX_ADAPTERS  128u  /* LoRA adapter ids 0..127 (two u64 words per pod row)      */
+#define EPPK_MAX_BLOCKS    256u  /* prefix blocks per request (upstream maxPrefixBlocksToMatch) */
+#define EPPK_MAX_SCORERS   8u    /* entries in a profile's weighted scorer chain             */
+
+#define EPPK_NO_PICK       (-1)  /* out_pick value: request had zero candidates (-> 503, fail closed) */
+#define EPPK_ADAPTER_BASE  (-1)  /* req.adapter value: request targets the base model         */
+
+typedef enum eppk_status {
+  EPPK_OK              = 0,
+  EPPK_ERR_ARG         = -1, /* null pointer / out-of-range argument / bad struct_size       */
+  EPPK_ERR_LIMIT       = -2, /* exceeds a limit given at eppk_create                         */
+  EPPK_ERR_DEVICE      = -3, /* HIP runtime error (message in eppk_last_error)               */
+  EPPK_ERR_NO_SNAPSHOT = -4, /* pick before the first eppk_snapshot_publish                  */
+  EPPK_ERR_INDEX_FULL  = -5, /* prefix table load factor exceeded; grow index_slots          */
+  EPPK_ERR_NOMEM       = -6
+} eppk_status;
+
+/* Scorer plugins of the fused chain.  Replaces Scorer.Score (interface.go:120-126);
+ * formulas in SEMANTICS.md §scorers. */
+typedef enum eppk_scorer_kind {
+  EPPK_SCORER_QUEUE  = 1, /* TotalQueuedRequests, lower is better   (003-…/README.md:30) */
+  EPPK_SCORER_KV     = 2, /* KVCacheUtilization, lower is better    (003-…/README.md:32) */
+  EPPK_SCORER_LORA   = 3, /* LoRA affinity tiers                    (003-…/README.md:46-57) */
+  EPPK_SCORER_PREFIX = 4  /* prefix-cache block-hash match ratio    (0602-…/README.md:99-112) */
+} eppk_scorer_kind;
+
+/* One WeightedScorer{Scorer, weight int} (interface.go:132-135). */
+typedef struct eppk_weighted_scorer {
+  uint32_t kind;   /* eppk_scorer_kind */
+  int32_t  weight; /* integer weight applied at profile level */
+} eppk_weighted_scorer;
+
+/* Context configuration == one SchedulerProfile (interface.go:70-79) with picker "best-score"
+ * (examples/example.yaml:14-15) and a deterministic tie-break (lowest snapshot index). */
+typedef struct eppk_cfg {
+  uint32_t struct_size;   /* = sizeof(eppk_cfg) */
+  int32_t  device;        /* HIP device ordinal */
+  uint32_t max_pods;      /* <= EPPK_MAX_PODS */
+  uint32_t max_blocks;    /* B: u64 hash slots in every request row (row stride = 8 + 8*B) */
+  uint32_t max_batch;     /* largest n_reqs for the host-buffer entry point */
+  uint32_t index_slots;   /* prefix table capacity, power of two; 0 = no prefix index */
+  uint32_t n_scorers;     /* <= EPPK_MAX_SCORERS; order fixes the fp summation order */
+  uint32_t reserved;
+  eppk_weighted_scorer chain[EPPK_MAX_SCORERS];
+} eppk_cfg;
+
+/* One candidate endpoint's metrics: the row the scorers read.  The reference's Endpoint
+ * (pkg/lwepp/datastore/datastore.go:40-46) carries identity only; these fields are the
+ * model-server-protocol gauges (003-…/README.md:28-57).  64 bytes, natural (per-pod) layout;
+ * the library re-lays it out for the device. */
+typedef struct eppk_pod_row {
+  uint32_t queue;       /* TotalQueuedRequests   */
+  uint32_t running;     /* TotalRunningRequests (carried, not scored) */
+  double   kv_util;     /* KVCacheUtilization in [0,1] */
+  uint32_t max_lora;    /* max_lora label */
+  uint32_t flags;       /* reserved, 0 */
+  uint64_t active[2];   /* running_lora_adapters as a bitset over adapter ids 0..127 */
+  uint64_t waiting[2];  /* waiting_lora_adapters bitset */
+  uint64_t reserved;
+} eppk_pod_row;
+
+#ifdef __cplusplus
+static_assert(sizeof(eppk_pod_row) == 64, "eppk_pod_row must be 64 bytes");
+#else
+_Static_assert(sizeof(eppk_pod_row) == 64, "eppk_pod_row must be 64 bytes");
+#endif
+
+/* Request row header; followed in memory by max_blocks u64 chained block hashes
+ * (hash[i] = H(block_i || LE64(hash[i-1])), 0602-…/README.md:99).  Row stride = 8 + 8*max_blocks. */
+typedef struct eppk_req_hdr {
+  int32_t  adapter;   /* adapter id 0..127, or EPPK_ADAPTER_BASE */
+  uint32_t n_blocks;  /* number of valid hashes, <= max_blocks */
+} eppk_req_hdr;
+
+typedef struct eppk_ctx eppk_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+uint32_t    eppk_abi_version(void);
+/* Create a picker bound to cfg->device.  Replaces the hard-wired `picker: &RoundRobinPicker{}`
+ * in NewStreamingServer (handlers/server.go:43-48). */
+int         eppk_create(const eppk_cfg* cfg, eppk_ctx** out);
+void        eppk_destroy(eppk_ctx* ctx);
+/* Last error text of this context (or of the last failed eppk_create when ctx == NULL). */
+const char* eppk_last_error(const eppk_ctx* ctx);
+
+/* ---- frozen pod-metrics snapshot ------------------------------------------------------------ */
+
+/* Publish a frozen snapshot of n_pods rows; row i is candidate index i (the order of the
+ * `endpoints` slice handed to Pick, handlers/server.go:90; the datastore's PodList order,
+ * datastore.go:181-193).  Takes effect for every later pick.  epoch is caller bookkeeping. */
+int eppk_snapshot_publish(eppk_ctx* ctx, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch);
+int eppk_snapshot_info(const eppk_ctx* ctx, uint32_t* n_pods, uint64_t* epoch);
+
+/* ---- approximate prefix index (0602-…/README.md:101-112), device resident ------------------- */
+
+int eppk_index_clear(eppk_ctx* ctx);
+/* "hash(chunk i): append s" for n (hash, pod) pairs. */
+int eppk_index_insert(eppk_ctx* ctx, const uint64_t* hashes, const uint32_t* pods, uint32_t n);
+/* Post-pick update on device: for every request r with picks[r] >= 0 append picks[r] to each of
+ * its n_blocks hashes.  d_reqs / d_picks are DEVICE pointers (see eppk_pick_batch_device). */
+int eppk_index_insert_picks_device(eppk_ctx* ctx, const void* d_reqs, const int32_t* d_picks,
+                                   uint32_t n_reqs, void* stream);
+/* Drop pod from every entry (endpoint deleted / cache flushed). */
+int eppk_index_remove_pod(eppk_ctx* ctx, uint32_t pod);
+/* Number of occupied slots (diagnostic; synchronises). */
+int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* Pick one endpoint for each of n_reqs requests against the published snapshot.
+ * Batched replacement for EndpointPicker.Pick (handlers/server.go:79-82) as invoked by
+ * pickEndpoint (request.go:149), evaluating Filter* -> Score* -> Picker
+ * (0845-…/README.md:68-85) for the whole batch in one kernel.
+ *   reqs      n_reqs rows of stride 8 + 8*max_blocks bytes (eppk_req_hdr + hashes)
+ *   cand_mask nullable; else [n_reqs][ceil(n_pods/64)] u64, bit p%64 of word p/64 set = pod p is a
+ *             candidate (the subset filter of request.go:104-133 as a bitmask)
+ *   out_pick  [n_reqs] candidate index, or EPPK_NO_PICK when the request has no candidates
+ *   out_score nullable; [n_reqs] weighted total of the picked endpoint (NaN-free; 0 for NO_PICK) */
+int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask,
+                    int32_t* out_pick, double* out_score);
+
+/* Same, with every buffer already resident in this device's HBM; asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the context's own stream).  No n_reqs limit. */
+int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
+                           const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
+                           void* stream);
+
+/* ---- adjacent host-side steps of the same path ---------------------------------------------- */
+
+/* Chain-hash a prompt into block hashes (0602-…/README.md:99): XXH64, seed 0,
+ * h[-1] = XXH64(model), h[i] = XXH64(prompt[i*block_chars .. (i+1)*block_chars) || LE64(h[i-1])).
+ * Only full blocks are hashed.  Returns the number of hashes written (<= max_out) or <0. */
+int eppk_hash_prompt(const uint8_t* model, size_t model_len, const uint8_t* prompt, size_t prompt_len,
+                     uint32_t block_chars, uint64_t* out, uint32_t max_out);
+uint64_t eppk_xxh64(const void* data, size_t len, uint64_t seed);
+
+/* Candidate subset filter of handleRequestHeaders (request.go:104-133) as a bitmask builder.
+ *   addrs/ports  n_pods C strings: Endpoint.Address / Endpoint.Port (datastore.go:43-44)
+ *   filter       comma-separated "ip" (all ports) or "ip:port" entries, whitespace-trimmed
+ *   out_mask     ceil(n_pods/64) u64 words
+ * Returns the number of candidates (0 = fail closed), or <0. */
+int eppk_subset_mask(const char* const* addrs, const char* const* ports, uint32_t n_pods,
+                     const char* filter, uint64_t* out_mask);
+
+/* RoundRobinPicker.Pick (handlers/server.go:90-101): idx = atomic(++*counter) % n_candidates.
+ * The fail-open fallback of the shim.  Returns the index, or EPPK_NO_PICK when n_candidates == 0. */
+int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
+
+/* When enabled, every pick launch is bracketed by HIP events on the launch stream. */
+int eppk_profile_enable(eppk_ctx* ctx, int on);
+/* Synchronise and copy out up to cap kernel durations (ms) recorded since the last drain. */
+int eppk_profile_drain(eppk_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out);
+/* Algorithmic (compulsory) bytes of the last pick launch, SURVEY §8(d) byte model; computed on
+ * device from the actual probe counts.  Synchronises. */
+int eppk_last_algorithmic_bytes(eppk_ctx* ctx, uint64_t* bytes, uint64_t* probes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPPK_H */

@@ -1,0 +1,170 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.  PARITY UNPINNED (see oracle.h): restates SEMANTICS.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def load() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    lib.orc_index_new.restype = vp
+    lib.orc_index_free.argtypes = [vp]
+    lib.orc_index_free.restype = None
+    lib.orc_index_clear.argtypes = [vp]
+    lib.orc_index_clear.restype = None
+    lib.orc_index_insert.argtypes = [vp, u64, u32]
+    lib.orc_index_insert.restype = None
+    lib.orc_index_remove_pod.argtypes = [vp, u32]
+    lib.orc_index_remove_pod.restype = None
+    lib.orc_index_size.argtypes = [vp]
+    lib.orc_index_size.restype = u64
+    lib.orc_index_lookup.argtypes = [vp, u64, vp, u32]
+    lib.orc_index_lookup.restype = u32
+    lib.orc_pick_batch.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, vp, vp, vp]
+    lib.orc_pick_batch_mt.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, vp, vp, C.c_int]
+    lib.orc_score_row.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp]
+    lib.orc_index_insert_picks.argtypes = [vp, vp, u32, u32, vp]
+    lib.orc_index_insert_picks.restype = None
+    lib.orc_xxh64.argtypes = [vp, C.c_size_t, u64]
+    lib.orc_xxh64.restype = u64
+    lib.orc_hash_prompt.argtypes = [vp, C.c_size_t, vp, C.c_size_t, u32, vp, u32]
+    lib.orc_round_robin.argtypes = [C.POINTER(u64), u32]
+    lib.orc_round_robin.restype = C.c_int32
+    lib.orc_subset_mask.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.c_char_p, vp]
+    _LIB = lib
+    return lib
+
+
+def _chain_array(chain: Sequence[Tuple[int, int]]) -> np.ndarray:
+    arr = np.zeros(len(chain), dtype=[("kind", "<u4"), ("weight", "<i4")])
+    for i, (k, w) in enumerate(chain):
+        arr[i] = (int(k), int(w))
+    return arr
+
+
+class OracleIndex:
+    def __init__(self) -> None:
+        self.lib = load()
+        self.h = C.c_void_p(self.lib.orc_index_new())
+
+    def insert(self, hashes, pods) -> None:
+        for h, p in zip(np.asarray(hashes, dtype=np.uint64).ravel().tolist(), np.asarray(pods, dtype=np.uint32).ravel().tolist()):
+            self.lib.orc_index_insert(self.h, h, p)
+
+    def remove_pod(self, pod: int) -> None:
+        self.lib.orc_index_remove_pod(self.h, pod)
+
+    def clear(self) -> None:
+        self.lib.orc_index_clear(self.h)
+
+    def size(self) -> int:
+        return int(self.lib.orc_index_size(self.h))
+
+    def lookup(self, h: int, cap: int = 4096) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.lib.orc_index_lookup(self.h, h, out.ctypes.data, cap)
+        return out[:n]
+
+    def insert_picks(self, reqs: np.ndarray, max_blocks: int, picks: np.ndarray) -> None:
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        picks = np.ascontiguousarray(picks, dtype=np.int32)
+        self.lib.orc_index_insert_picks(self.h, reqs.ctypes.data, max_blocks, reqs.shape[0], picks.ctypes.data)
+
+    def __del__(self):
+        try:
+            self.lib.orc_index_free(self.h)
+        except Exception:
+            pass
+
+
+def pick_batch(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, max_blocks: int,
+               mask: Optional[np.ndarray] = None, threads: int = 0):
+    """Sequential per-request Schedule() on the CPU. Returns (picks i32, scores f64, probes u32)."""
+    lib = load()
+    ch = _chain_array(chain)
+    pods = np.ascontiguousarray(pods)
+    assert pods.dtype.itemsize == 64
+    reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+    R = reqs.shape[0]
+    assert reqs.shape[1] == 1 + max_blocks
+    picks = np.empty(R, dtype=np.int32)
+    scores = np.empty(R, dtype=np.float64)
+    probes = np.zeros(R, dtype=np.uint32)
+    mptr = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        mptr = mask.ctypes.data
+    ih = index.h if index is not None else None
+    if threads and threads > 1:
+        rc = lib.orc_pick_batch_mt(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], ih, reqs.ctypes.data,
+                                   max_blocks, R, mptr, picks.ctypes.data, scores.ctypes.data, threads)
+    else:
+        rc = lib.orc_pick_batch(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], ih, reqs.ctypes.data,
+                                max_blocks, R, mptr, picks.ctypes.data, scores.ctypes.data, probes.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle rc={rc}")
+    return picks, scores, probes
+
+
+def score_row(chain, pods: np.ndarray, index: Optional[OracleIndex], req_row: np.ndarray, mask_row: Optional[np.ndarray] = None) -> np.ndarray:
+    lib = load()
+    ch = _chain_array(chain)
+    pods = np.ascontiguousarray(pods)
+    req_row = np.ascontiguousarray(req_row, dtype=np.uint64)
+    out = np.empty(pods.shape[0], dtype=np.float64)
+    mptr = None
+    if mask_row is not None:
+        mask_row = np.ascontiguousarray(mask_row, dtype=np.uint64)
+        mptr = mask_row.ctypes.data
+    rc = lib.orc_score_row(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], index.h if index else None,
+                           req_row.ctypes.data, mptr, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle rc={rc}")
+    return out
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return int(load().orc_xxh64(data, len(data), seed))
+
+
+def hash_prompt(model: bytes, prompt: bytes, block_chars: int, max_blocks: int) -> np.ndarray:
+    out = np.zeros(max(max_blocks, 1), dtype=np.uint64)
+    n = load().orc_hash_prompt(model, len(model), prompt, len(prompt), block_chars, out.ctypes.data, max_blocks)
+    assert n >= 0
+    return out[:n]
+
+
+def round_robin(counter: C.c_uint64, n: int) -> int:
+    return int(load().orc_round_robin(C.byref(counter), n))
+
+
+def subset_mask(addrs: Sequence[str], ports: Sequence[str], filt: Optional[str]):
+    n = len(addrs)
+    a = (C.c_char_p * max(n, 1))(*[s.encode() for s in addrs])
+    p = (C.c_char_p * max(n, 1))(*[s.encode() for s in ports])
+    mask = np.zeros(max((n + 63) // 64, 1), dtype=np.uint64)
+    rc = load().orc_subset_mask(a, p, n, None if filt is None else filt.encode(), mask.ctypes.data)
+    return mask[: (n + 63) // 64], rc

@@ -1,0 +1,532 @@
+/*
+ * oracle.c — CPU restatement of the endpoint-pick path.  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * PARITY UNPINNED for the scorer chain: restates SEMANTICS.md.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile) — binary64 multiply and add
+ * are never fused, like Go on amd64.
+ *
+ * Shape: one sequential Schedule() per request, exactly the per-request loop the batched kernel
+ * replaces (docs/proposals/0845-scheduler-architecture-proposal/README.md:68-85):
+ *     Filter* -> for each WeightedScorer: Score() then weighted accumulate -> Picker.
+ * Data structures are deliberately the naive ones (per-pod rows, hash -> sorted pod list), NOT the
+ * device layouts, so that agreement with the kernel is evidence and not a tautology.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------- */
+/* XXH64 — the published xxHash64 algorithm (SEMANTICS.md §4).  The reference names the Go module
+ * github.com/cespare/xxhash/v2 v2.3.0 only as an indirect dependency (go.mod:6), no call sites.  */
+
+static const uint64_t XP1 = 11400714785074694791ULL;
+static const uint64_t XP2 = 14029467366897019727ULL;
+static const uint64_t XP3 = 1609587929392839161ULL;
+static const uint64_t XP4 = 9650029242287828579ULL;
+static const uint64_t XP5 = 2870177450012600261ULL;
+
+static uint64_t rd64(const uint8_t* p) {
+  uint64_t v = 0;
+  for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
+  return v;
+}
+static uint32_t rd32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static uint64_t rol(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t xround(uint64_t acc, uint64_t lane) { return rol(acc + lane * XP2, 31) * XP1; }
+static uint64_t xmerge(uint64_t h, uint64_t acc) { return (h ^ xround(0, acc)) * XP1 + XP4; }
+
+uint64_t orc_xxh64(const void* data, size_t len, uint64_t seed) {
+  const uint8_t* p = (const uint8_t*)data;
+  const uint8_t* end = p + len;
+  uint64_t h;
+  if (len >= 32) {
+    uint64_t a = seed + XP1 + XP2, b = seed + XP2, c = seed, d = seed - XP1;
+    while ((size_t)(end - p) >= 32) {
+      a = xround(a, rd64(p));
+      b = xround(b, rd64(p + 8));
+      c = xround(c, rd64(p + 16));
+      d = xround(d, rd64(p + 24));
+      p += 32;
+    }
+    h = rol(a, 1) + rol(b, 7) + rol(c, 12) + rol(d, 18);
+    h = xmerge(h, a);
+    h = xmerge(h, b);
+    h = xmerge(h, c);
+    h = xmerge(h, d);
+  } else {
+    h = seed + XP5;
+  }
+  h += (uint64_t)len;
+  while ((size_t)(end - p) >= 8) {
+    h ^= xround(0, rd64(p));
+    h = rol(h, 27) * XP1 + XP4;
+    p += 8;
+  }
+  if ((size_t)(end - p) >= 4) {
+    h ^= (uint64_t)rd32(p) * XP1;
+    h = rol(h, 23) * XP2 + XP3;
+    p += 4;
+  }
+  while (p < end) {
+    h ^= (uint64_t)(*p) * XP5;
+    h = rol(h, 11) * XP1;
+    ++p;
+  }
+  h ^= h >> 33;
+  h *= XP2;
+  h ^= h >> 29;
+  h *= XP3;
+  h ^= h >> 32;
+  return h;
+}
+
+/* hash(chunk i) = hash(chunk i content + hash(chunk i-1)) — 0602-…/README.md:99 */
+int orc_hash_prompt(const uint8_t* model, size_t model_len, const uint8_t* prompt, size_t prompt_len,
+                    uint32_t block_chars, uint64_t* out, uint32_t max_out) {
+  if (block_chars == 0 || (!prompt && prompt_len) || (!model && model_len) || (!out && max_out)) return -1;
+  uint8_t* buf = (uint8_t*)malloc((size_t)block_chars + 8);
+  if (!buf) return -6;
+  uint64_t prev = orc_xxh64(model, model_len, 0);
+  uint32_t n = 0;
+  for (size_t off = 0; off + block_chars <= prompt_len && n < max_out; off += block_chars) {
+    memcpy(buf, prompt + off, block_chars);
+    for (int i = 0; i < 8; ++i) buf[block_chars + i] = (uint8_t)(prev >> (8 * i));
+    prev = orc_xxh64(buf, (size_t)block_chars + 8, 0);
+    out[n++] = prev;
+  }
+  free(buf);
+  return (int)n;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Approximate prefix index: hash -> set(pod) (0602-…/README.md:101-112).  Naive structure:     */
+/* open-addressed table of entries, each owning a sorted, growable pod list.                    */
+
+typedef struct {
+  uint64_t  hash;
+  uint32_t* pods;
+  uint32_t  n, cap;
+  int       used;
+} orc_entry;
+
+struct orc_index {
+  orc_entry* tab;
+  uint64_t   cap;  /* power of two */
+  uint64_t   used; /* entries allocated (including ones whose set became empty) */
+};
+
+static uint64_t ix_home(uint64_t h, uint64_t cap) {
+  h ^= h >> 31;
+  h *= 0x7fb5d329728ea185ULL;
+  h ^= h >> 27;
+  return h & (cap - 1);
+}
+
+orc_index* orc_index_new(void) {
+  orc_index* ix = (orc_index*)calloc(1, sizeof(*ix));
+  if (!ix) return NULL;
+  ix->cap = 1024;
+  ix->tab = (orc_entry*)calloc(ix->cap, sizeof(orc_entry));
+  if (!ix->tab) { free(ix); return NULL; }
+  return ix;
+}
+
+void orc_index_clear(orc_index* ix) {
+  if (!ix) return;
+  for (uint64_t i = 0; i < ix->cap; ++i) free(ix->tab[i].pods);
+  memset(ix->tab, 0, ix->cap * sizeof(orc_entry));
+  ix->used = 0;
+}
+
+void orc_index_free(orc_index* ix) {
+  if (!ix) return;
+  orc_index_clear(ix);
+  free(ix->tab);
+  free(ix);
+}
+
+static orc_entry* ix_find(const orc_index* ix, uint64_t hash, int for_insert) {
+  uint64_t i = ix_home(hash, ix->cap);
+  for (;;) {
+    orc_entry* e = &ix->tab[i];
+    if (!e->used) return for_insert ? e : NULL;
+    if (e->hash == hash) return e;
+    i = (i + 1) & (ix->cap - 1);
+  }
+}
+
+static void ix_grow(orc_index* ix) {
+  orc_entry* old = ix->tab;
+  uint64_t ocap = ix->cap;
+  ix->cap = ocap * 2;
+  ix->tab = (orc_entry*)calloc(ix->cap, sizeof(orc_entry));
+  for (uint64_t i = 0; i < ocap; ++i)
+    if (old[i].used) *ix_find(ix, old[i].hash, 1) = old[i];
+  free(old);
+}
+
+void orc_index_insert(orc_index* ix, uint64_t hash, uint32_t pod) {
+  if ((ix->used + 1) * 2 > ix->cap) ix_grow(ix);
+  orc_entry* e = ix_find(ix, hash, 1);
+  if (!e->used) {
+    e->used = 1;
+    e->hash = hash;
+    e->pods = NULL;
+    e->n = e->cap = 0;
+    ix->used++;
+  }
+  uint32_t lo = 0;
+  while (lo < e->n && e->pods[lo] < pod) ++lo;
+  if (lo < e->n && e->pods[lo] == pod) return; /* set semantics */
+  if (e->n == e->cap) {
+    e->cap = e->cap ? e->cap * 2 : 4;
+    e->pods = (uint32_t*)realloc(e->pods, e->cap * sizeof(uint32_t));
+  }
+  memmove(e->pods + lo + 1, e->pods + lo, (e->n - lo) * sizeof(uint32_t));
+  e->pods[lo] = pod;
+  e->n++;
+}
+
+void orc_index_remove_pod(orc_index* ix, uint32_t pod) {
+  for (uint64_t i = 0; i < ix->cap; ++i) {
+    orc_entry* e = &ix->tab[i];
+    if (!e->used) continue;
+    for (uint32_t j = 0; j < e->n; ++j)
+      if (e->pods[j] == pod) {
+        memmove(e->pods + j, e->pods + j + 1, (e->n - j - 1) * sizeof(uint32_t));
+        e->n--;
+        break;
+      }
+  }
+}
+
+uint64_t orc_index_size(const orc_index* ix) {
+  uint64_t n = 0;
+  for (uint64_t i = 0; i < ix->cap; ++i) n += (ix->tab[i].used && ix->tab[i].n > 0);
+  return n;
+}
+
+uint32_t orc_index_lookup(const orc_index* ix, uint64_t hash, uint32_t* pods, uint32_t cap) {
+  const orc_entry* e = ix ? ix_find(ix, hash, 0) : NULL;
+  if (!e) return 0;
+  for (uint32_t j = 0; j < e->n && j < cap; ++j) pods[j] = e->pods[j];
+  return e->n;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Scorers (SEMANTICS.md §3).  Each fills score[c] for the request's candidates cand[0..nc).     */
+
+static double clamp01(double s) {
+  if (!(s >= 0.0)) return 0.0;
+  if (s > 1.0) return 1.0;
+  return s;
+}
+
+static void score_queue(const eppk_pod_row* pods, const uint32_t* cand, uint32_t nc, double* score) {
+  uint32_t mn = pods[cand[0]].queue, mx = mn;
+  for (uint32_t c = 1; c < nc; ++c) {
+    uint32_t q = pods[cand[c]].queue;
+    if (q < mn) mn = q;
+    if (q > mx) mx = q;
+  }
+  for (uint32_t c = 0; c < nc; ++c) {
+    if (mx == mn) score[c] = 1.0;
+    else score[c] = (double)(mx - pods[cand[c]].queue) / (double)(mx - mn);
+  }
+}
+
+static void score_kv(const eppk_pod_row* pods, const uint32_t* cand, uint32_t nc, double* score) {
+  for (uint32_t c = 0; c < nc; ++c) score[c] = 1.0 - pods[cand[c]].kv_util;
+}
+
+static int bit128(const uint64_t w[2], int a) { return (int)((w[a >> 6] >> (a & 63)) & 1u); }
+static uint32_t pop128(const uint64_t w[2]) {
+  return (uint32_t)__builtin_popcountll(w[0]) + (uint32_t)__builtin_popcountll(w[1]);
+}
+
+static void score_lora(const eppk_pod_row* pods, const uint32_t* cand, uint32_t nc, int32_t adapter,
+                       double* score) {
+  for (uint32_t c = 0; c < nc; ++c) {
+    const eppk_pod_row* r = &pods[cand[c]];
+    int in_active = adapter >= 0 && bit128(r->active, adapter);
+    int in_waiting = adapter >= 0 && bit128(r->waiting, adapter);
+    uint32_t loaded = pop128(r->active) + pop128(r->waiting);
+    if (in_active) score[c] = 1.0;
+    else if (loaded < r->max_lora) score[c] = 0.8;
+    else if (in_waiting) score[c] = 0.6;
+    else score[c] = 0.0;
+  }
+}
+
+/* matched[] is a scratch array over ALL pods (zeroed here). Returns index lookups performed. */
+static uint32_t score_prefix(const orc_index* ix, uint32_t n_pods, const uint64_t* hashes, uint32_t n_blocks,
+                             const uint32_t* cand, uint32_t nc, uint32_t* matched, double* score) {
+  uint32_t probes = 0;
+  memset(matched, 0, (size_t)n_pods * sizeof(uint32_t));
+  for (uint32_t i = 0; i < n_blocks; ++i) {
+    ++probes;
+    const orc_entry* e = ix ? ix_find(ix, hashes[i], 0) : NULL;
+    if (!e || e->n == 0) break; /* first hash with an empty pod set ends the walk */
+    for (uint32_t j = 0; j < e->n; ++j)
+      if (e->pods[j] < n_pods) matched[e->pods[j]]++;
+  }
+  for (uint32_t c = 0; c < nc; ++c)
+    score[c] = n_blocks ? (double)matched[cand[c]] / (double)n_blocks : 0.0;
+  return probes;
+}
+
+typedef struct {
+  uint32_t* cand;
+  uint32_t* matched;
+  double*   score;
+  double*   total;
+} orc_scratch;
+
+static int scratch_init(orc_scratch* s, uint32_t n_pods) {
+  size_t n = n_pods ? n_pods : 1;
+  s->cand = (uint32_t*)malloc(n * sizeof(uint32_t));
+  s->matched = (uint32_t*)malloc(n * sizeof(uint32_t));
+  s->score = (double*)malloc(n * sizeof(double));
+  s->total = (double*)malloc(n * sizeof(double));
+  return (s->cand && s->matched && s->score && s->total) ? 0 : -6;
+}
+static void scratch_free(orc_scratch* s) {
+  free(s->cand); free(s->matched); free(s->score); free(s->total);
+}
+
+/* One scheduling cycle.  Returns 0, or -1 on an unknown scorer kind / bad row. */
+static int schedule_one(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
+                        uint32_t n_pods, const orc_index* ix, const uint8_t* req, uint32_t max_blocks,
+                        const uint64_t* mask_row, orc_scratch* s, int32_t* pick, double* pick_score,
+                        uint32_t* probes_out, uint32_t* nc_out) {
+  eppk_req_hdr hdr;
+  memcpy(&hdr, req, sizeof hdr);
+  const uint64_t* hashes = (const uint64_t*)(req + sizeof hdr);
+  if (hdr.n_blocks > max_blocks) return -1;
+  if (hdr.adapter < -1 || hdr.adapter >= (int32_t)EPPK_MAX_ADAPTERS) return -1;
+
+  /* Filter: the candidate subset (request.go:104-133 expressed as a bitmask) */
+  uint32_t nc = 0;
+  for (uint32_t p = 0; p < n_pods; ++p)
+    if (!mask_row || ((mask_row[p >> 6] >> (p & 63)) & 1u)) s->cand[nc++] = p;
+  if (nc_out) *nc_out = nc;
+  if (probes_out) *probes_out = 0;
+  if (nc == 0) { /* fail closed */
+    *pick = EPPK_NO_PICK;
+    *pick_score = 0.0;
+    return 0;
+  }
+
+  /* Score: weighted accumulation in chain order */
+  for (uint32_t c = 0; c < nc; ++c) s->total[c] = 0.0;
+  for (uint32_t k = 0; k < n_scorers; ++k) {
+    switch (chain[k].kind) {
+      case EPPK_SCORER_QUEUE: score_queue(pods, s->cand, nc, s->score); break;
+      case EPPK_SCORER_KV: score_kv(pods, s->cand, nc, s->score); break;
+      case EPPK_SCORER_LORA: score_lora(pods, s->cand, nc, hdr.adapter, s->score); break;
+      case EPPK_SCORER_PREFIX: {
+        uint32_t pr = score_prefix(ix, n_pods, hashes, hdr.n_blocks, s->cand, nc, s->matched, s->score);
+        if (probes_out) *probes_out += pr;
+        break;
+      }
+      default: return -1;
+    }
+    const double w = (double)chain[k].weight;
+    for (uint32_t c = 0; c < nc; ++c) s->total[c] = s->total[c] + clamp01(s->score[c]) * w;
+  }
+
+  /* Picker: best score, first maximum in snapshot order */
+  uint32_t best = 0;
+  for (uint32_t c = 1; c < nc; ++c)
+    if (s->total[c] > s->total[best]) best = c;
+  *pick = (int32_t)s->cand[best];
+  *pick_score = s->total[best];
+  return 0;
+}
+
+static int pick_range(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
+                      uint32_t n_pods, const orc_index* ix, const uint8_t* reqs, uint32_t max_blocks,
+                      uint32_t r0, uint32_t r1, const uint64_t* cand_mask, int32_t* out_pick,
+                      double* out_score, uint32_t* out_probes) {
+  orc_scratch s;
+  if (scratch_init(&s, n_pods)) { scratch_free(&s); return -6; }
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  const size_t mw = (n_pods + 63u) / 64u;
+  int rc = 0;
+  for (uint32_t r = r0; r < r1 && rc == 0; ++r) {
+    int32_t pick;
+    double sc;
+    uint32_t pr;
+    rc = schedule_one(chain, n_scorers, pods, n_pods, ix, reqs + stride * r, max_blocks,
+                      cand_mask ? cand_mask + mw * r : NULL, &s, &pick, &sc, &pr, NULL);
+    if (rc) break;
+    out_pick[r] = pick;
+    if (out_score) out_score[r] = sc;
+    if (out_probes) out_probes[r] = pr;
+  }
+  scratch_free(&s);
+  return rc;
+}
+
+int orc_pick_batch(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
+                   uint32_t n_pods, const orc_index* ix, const void* reqs, uint32_t max_blocks,
+                   uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick, double* out_score,
+                   uint32_t* out_probes) {
+  if ((!chain && n_scorers) || (!pods && n_pods) || (!reqs && n_reqs) || (!out_pick && n_reqs)) return -1;
+  if (n_scorers > EPPK_MAX_SCORERS) return -1;
+  return pick_range(chain, n_scorers, pods, n_pods, ix, (const uint8_t*)reqs, max_blocks, 0, n_reqs,
+                    cand_mask, out_pick, out_score, out_probes);
+}
+
+typedef struct {
+  const eppk_weighted_scorer* chain; uint32_t n_scorers;
+  const eppk_pod_row* pods; uint32_t n_pods; const orc_index* ix;
+  const uint8_t* reqs; uint32_t max_blocks, r0, r1; const uint64_t* mask;
+  int32_t* pick; double* score; int rc;
+} orc_job;
+
+static void* job_main(void* arg) {
+  orc_job* j = (orc_job*)arg;
+  j->rc = pick_range(j->chain, j->n_scorers, j->pods, j->n_pods, j->ix, j->reqs, j->max_blocks, j->r0,
+                     j->r1, j->mask, j->pick, j->score, NULL);
+  return NULL;
+}
+
+int orc_pick_batch_mt(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
+                      uint32_t n_pods, const orc_index* ix, const void* reqs, uint32_t max_blocks,
+                      uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick, double* out_score,
+                      int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if ((uint32_t)threads > n_reqs) threads = n_reqs ? (int)n_reqs : 1;
+  pthread_t tid[256];
+  orc_job job[256];
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    orc_job* j = &job[t];
+    j->chain = chain; j->n_scorers = n_scorers; j->pods = pods; j->n_pods = n_pods; j->ix = ix;
+    j->reqs = (const uint8_t*)reqs; j->max_blocks = max_blocks; j->mask = cand_mask;
+    j->pick = out_pick; j->score = out_score; j->rc = 0;
+    j->r0 = (uint32_t)((uint64_t)n_reqs * (uint64_t)t / (uint64_t)threads);
+    j->r1 = (uint32_t)((uint64_t)n_reqs * (uint64_t)(t + 1) / (uint64_t)threads);
+    if (pthread_create(&tid[t], NULL, job_main, j)) { job_main(j); tid[t] = 0; }
+  }
+  for (int t = 0; t < threads; ++t) {
+    if (tid[t]) pthread_join(tid[t], NULL);
+    if (job[t].rc) rc = job[t].rc;
+  }
+  return rc;
+}
+
+int orc_score_row(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
+                  uint32_t n_pods, const orc_index* ix, const void* req, const uint64_t* mask_row,
+                  double* out_total) {
+  orc_scratch s;
+  if (scratch_init(&s, n_pods)) { scratch_free(&s); return -6; }
+  int32_t pick; double sc; uint32_t nc = 0;
+  /* max_blocks is only a bound check here: accept the row's own n_blocks */
+  eppk_req_hdr hdr; memcpy(&hdr, req, sizeof hdr);
+  int rc = schedule_one(chain, n_scorers, pods, n_pods, ix, (const uint8_t*)req, hdr.n_blocks, mask_row,
+                        &s, &pick, &sc, NULL, &nc);
+  if (rc == 0) {
+    for (uint32_t p = 0; p < n_pods; ++p) out_total[p] = NAN;
+    for (uint32_t c = 0; c < nc; ++c) out_total[s.cand[c]] = s.total[c];
+  }
+  scratch_free(&s);
+  return rc;
+}
+
+void orc_index_insert_picks(orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
+                            const int32_t* picks) {
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  for (uint32_t r = 0; r < n_reqs; ++r) {
+    if (picks[r] < 0) continue;
+    const uint8_t* row = (const uint8_t*)reqs + stride * r;
+    eppk_req_hdr hdr; memcpy(&hdr, row, sizeof hdr);
+    const uint64_t* h = (const uint64_t*)(row + sizeof hdr);
+    for (uint32_t i = 0; i < hdr.n_blocks && i < max_blocks; ++i) orc_index_insert(ix, h[i], (uint32_t)picks[r]);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Pinned behaviour adjacent to the pick.                                                        */
+
+/* RoundRobinPicker.Pick — pkg/lwepp/handlers/server.go:90-101 */
+int32_t orc_round_robin(uint64_t* counter, uint32_t n_candidates) {
+  if (n_candidates == 0) return EPPK_NO_PICK;              /* :91-93  codes.Unavailable */
+  uint64_t index = __atomic_add_fetch(counter, 1, __ATOMIC_SEQ_CST); /* :95 atomic.AddUint64 returns the new value */
+  return (int32_t)(index % (uint64_t)n_candidates);        /* :96 */
+}
+
+static int is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+
+/* Behaviour of Go's net.SplitHostPort as used at request.go:110: returns 1 and [host,port) spans on
+ * success, 0 on any error (missing port, too many colons, bad brackets). */
+static int split_host_port(const char* s, size_t n, size_t* h0, size_t* h1, size_t* p0) {
+  size_t j = 0, k = 0;
+  long i = -1;
+  for (size_t t = 0; t < n; ++t) if (s[t] == ':') i = (long)t;
+  if (i < 0) return 0; /* missing port */
+  if (s[0] == '[') {
+    long end = -1;
+    for (size_t t = 0; t < n; ++t) if (s[t] == ']') { end = (long)t; break; }
+    if (end < 0) return 0;
+    if ((size_t)(end + 1) == n) return 0;
+    if (end + 1 != i) return 0;
+    *h0 = 1; *h1 = (size_t)end;
+    j = 1; k = (size_t)end + 1;
+  } else {
+    *h0 = 0; *h1 = (size_t)i;
+    for (size_t t = 0; t < (size_t)i; ++t) if (s[t] == ':') return 0; /* too many colons */
+  }
+  for (size_t t = j; t < n; ++t) if (s[t] == '[') return 0;
+  for (size_t t = k; t < n; ++t) if (s[t] == ']') return 0;
+  *p0 = (size_t)i + 1;
+  return 1;
+}
+
+static int span_eq(const char* a, size_t n, const char* z) { return strlen(z) == n && memcmp(a, z, n) == 0; }
+
+/* Subset filter of handleRequestHeaders — pkg/lwepp/handlers/request.go:104-133.
+ * filter == NULL: no subset filter, every pod is a candidate (:136-137).
+ * Empty-after-trim entries are dropped (the metadata path, :58-61). */
+int orc_subset_mask(const char* const* addrs, const char* const* ports, uint32_t n_pods, const char* filter,
+                    uint64_t* out_mask) {
+  if ((!addrs || !ports || !out_mask) && n_pods) return -1;
+  const uint32_t mw = (n_pods + 63u) / 64u;
+  memset(out_mask, 0, (size_t)mw * 8u);
+  int count = 0;
+  if (!filter) {
+    for (uint32_t p = 0; p < n_pods; ++p) out_mask[p >> 6] |= 1ULL << (p & 63);
+    return (int)n_pods;
+  }
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    int allowed = 0;
+    const char* s = filter;
+    while (!allowed) {
+      const char* e = strchr(s, ',');
+      size_t n = e ? (size_t)(e - s) : strlen(s);
+      const char* a = s;
+      while (n && is_space(*a)) { ++a; --n; }
+      while (n && is_space(a[n - 1])) --n;
+      if (n) {
+        size_t h0, h1, p0;
+        if (split_host_port(a, n, &h0, &h1, &p0)) {
+          /* ip:port entry allows exactly that port (:110-114, :124-127) */
+          if (span_eq(a + h0, h1 - h0, addrs[p]) && span_eq(a + p0, n - p0, ports[p])) allowed = 1;
+        } else if (span_eq(a, n, addrs[p])) {
+          allowed = 1; /* ip-only entry allows all ports (:115-117, :122-123) */
+        }
+      }
+      if (!e) break;
+      s = e + 1;
+    }
+    if (allowed) { out_mask[p >> 6] |= 1ULL << (p & 63); ++count; }
+  }
+  return count;
+}

@@ -1,0 +1,79 @@
+"""Parity tests proper: HIP path (through the C ABI) vs oracle/ on the same seeded inputs.
+
+Bar: picks identical, scores BITWISE identical (binary64), for every BASELINE.json config shape,
+with and without candidate masks, canonical and non-canonical chain orders.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q, KV, L, PF = 1, 2, 3, 4
+
+
+def run_both(pkg, orc, wl, chain=None, mask=None, max_pods=None):
+    chain = chain or wl.chain
+    with pkg.BatchedPicker(chain, max_pods=max_pods or max(wl.P, 1), max_blocks=wl.B, max_batch=max(wl.R, 1),
+                           index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        if wl.index_slots:
+            pk.index_insert(wl.index_hashes, wl.index_pods)
+        picks, scores = pk.pick(wl.reqs, mask)
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    opicks, oscores, _ = orc.pick_batch(chain, wl.pods, oix, wl.reqs, wl.B, mask)
+    return picks, scores, opicks, oscores
+
+
+def assert_same(picks, scores, opicks, oscores):
+    bad = np.nonzero(picks != opicks)[0]
+    assert bad.size == 0, f"{bad.size} picks differ, first at {bad[:5]}: gpu {picks[bad[:5]]} oracle {opicks[bad[:5]]}"
+    sb = np.nonzero(scores.view(np.uint64) != oscores.view(np.uint64))[0]
+    assert sb.size == 0, f"{sb.size} scores differ bitwise, first {sb[:5]}: {scores[sb[:5]]} vs {oscores[sb[:5]]}"
+
+
+@pytest.mark.parametrize("config,R,P", [(1, 128, 16), (2, 4096, 256), (3, 2048, 1024), (4, 2048, 2048), (5, 1024, 4096)])
+def test_config_shapes_unmasked(pkg, orc, config, R, P):
+    wl = pkg.workload.make_workload(config, R=R, P=P)
+    assert_same(*run_both(pkg, orc, wl))
+
+
+@pytest.mark.parametrize("config,R,P", [(1, 128, 16), (2, 1024, 256), (3, 1024, 1000), (4, 512, 2048), (5, 512, 4096)])
+def test_config_shapes_masked(pkg, orc, config, R, P):
+    wl = pkg.workload.make_workload(config, R=R, P=P, masked=True)
+    assert_same(*run_both(pkg, orc, wl, mask=wl.mask))
+
+
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 2047, 2048, 2049, 4095, 4096])
+def test_ragged_pod_counts(pkg, orc, P):
+    wl = pkg.workload.make_workload(5, R=192, P=P)
+    assert_same(*run_both(pkg, orc, wl))
+
+
+@pytest.mark.parametrize("chain", [
+    [(PF, 3), (L, 1)],                    # canonical, prefix first
+    [(L, 1), (PF, 3)],
+    [(PF, 3)],
+    [(L, 2)],
+    [(KV, 5)],
+    [(L, 1), (Q, 2), (PF, 3), (KV, 2)],   # non-canonical -> generic kernel
+    [(PF, 3), (Q, 1), (PF, 3)],           # duplicates
+    [(Q, -2), (KV, 3), (L, -1), (PF, 4)], # negative weights
+    [],                                   # no scorers: every total is +0.0, pick = first candidate
+])
+def test_chain_orders(pkg, orc, chain):
+    wl = pkg.workload.make_workload(3, R=512, P=777)
+    assert_same(*run_both(pkg, orc, wl, chain=chain, max_pods=1024))
+    wlm = pkg.workload.make_workload(3, R=256, P=777, masked=True)
+    assert_same(*run_both(pkg, orc, wlm, chain=chain, mask=wlm.mask, max_pods=1024))
+
+
+def test_empty_and_single_candidate_masks(pkg, orc):
+    wl = pkg.workload.make_workload(5, R=64, P=300, masked=True)
+    wl.mask[0, :] = 0                       # no candidate -> NO_PICK, score 0
+    wl.mask[1, :] = 0
+    wl.mask[1, 3] = np.uint64(1) << np.uint64(17)   # exactly pod 3*64+17
+    picks, scores, opicks, oscores = run_both(pkg, orc, wl, mask=wl.mask, max_pods=4096)
+    assert picks[0] == -1 and scores[0] == 0.0
+    assert picks[1] == 3 * 64 + 17
+    assert_same(picks, scores, opicks, oscores)
