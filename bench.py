@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — routing decisions/s of the batched endpoint pick on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch: request rows already resident in HBM ->
+fused pick kernel -> picks in HBM (+ for N>1 an RCCL all-gather of the per-rank picks).
+N=1 workload: BASELINE.json configs[4] ("64k req x 4096 pods, full scorer chain + prefix-cache"), the
+configuration the metric is quoted on; it fits one GPU.  N>1: weak scaling, every rank scores its own
+64k-request shard against the replicated snapshot + prefix index, picks are all-gathered.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by torch.distributed.run
+(one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(pkg, wl, orc, passes: int = 2):
+    """The C restatement (oracle/) timed on this box's host cores, on the SAME workload.
+
+    Single thread on a 4096-request sample (the shape of the reference's per-request loop) and all
+    cores on the whole batch.  Bounded: ~7 core-seconds per full pass at 64k x 4096."""
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    cores = os.cpu_count() or 1
+    n1 = min(wl.R, 4096)
+    t0 = time.perf_counter()
+    p1, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:n1], wl.B)
+    t1 = time.perf_counter() - t0
+    best = None
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        pm, sm, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, threads=cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert np.array_equal(p1, pm[:n1])
+    return dict(value=wl.R / best, unit="decisions/s", cores=cores, kind="port",
+                sample=f"{passes} passes of the full {wl.R} x {wl.P} batch on {cores} threads (C restatement, not Go); "
+                       f"single thread on the first {n1} requests",
+                single_thread_value=n1 / t1), pm, sm
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=5, help="BASELINE.json config number (1-based); 5 = headline")
+    ap.add_argument("--requests", type=int, default=None, help="override requests per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pick has no CPU path (libeppk fails loudly without HIP)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    # replicated snapshot + index (seed of the config), this rank's own request shard (weak scaling)
+    wl = pkg.workload.make_workload(args.config, R=args.requests, req_seed=(0x5EED0000 + args.config) ^ (0xA5A5 * rank) if rank else None)
+    R = wl.R
+    pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots, device=local_rank)
+    pk.publish(wl.pods)
+    if wl.index_slots:
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+
+    dev = torch.device("cuda", local_rank)
+    d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
+    d_pick = torch.empty(R, dtype=torch.int32, device=dev)
+    d_score = torch.empty(R, dtype=torch.float64, device=dev)
+    d_all = torch.empty(R * world, dtype=torch.int32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        pk.pick_device(d_reqs.data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_pick)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pk.profile(True)           # HIP events around every pick launch on the launch stream + probe counts
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = pk.profile_drain()
+    abytes, lookups, launches = pk.profile_bytes()
+    pk.profile(False)
+
+    picks = d_pick.cpu().numpy()
+    scores = d_score.cpu().numpy()
+    if world > 1:
+        allp = d_all.cpu().numpy()
+        assert np.array_equal(allp[rank * R:(rank + 1) * R], picks), "all-gather returned a different shard"
+
+    if rank == 0:
+        out = {
+            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if args.config == 5 and args.requests is None else f"routing decisions/sec ({wl.name})",
+            "value": world * R * args.steps / elapsed,
+            "unit": "decisions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "requests_per_gpu": R, "pods": wl.P, "adapters": wl.A, "blocks_per_request": wl.B,
+                       "chain": "queue:2,kv:2,lora:1,prefix:3" if args.config in (3, 5) else str(wl.chain),
+                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} + all-gather of picks" if world > 1 else "single GPU",
+                       "p99_step_ms": None},
+        }
+        k = np.asarray(kern_ms, dtype=np.float64)
+        per_launch_bytes = abytes / max(launches, 1)
+        avg_ms = float(k.mean()) if k.size else float("nan")
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if k.size else float("nan")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured separately with rocprofv3 --pmc
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == wl.name:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic, "kernel": "pick_fast_kernel", "kernel_avg_ms": avg_ms,
+                           "kernel_p99_ms": float(np.percentile(k, 99)) if k.size else None,
+                           "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lookups / max(launches, 1)}
+        out["config"]["p99_step_ms"] = out["roofline"]["kernel_p99_ms"]
+        if world == 1 and not args.no_cpu_baseline:
+            orc = graft.load_oracle()
+            cb, opicks, oscores = cpu_baseline(pkg, wl, orc)
+            out["cpu_baseline"] = cb
+            out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks)),
+                             "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores.view(np.uint64)))}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    pk.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,7 @@ SYMBOLS = [
     "eppk_index_size",
     "eppk_pick_batch", "eppk_pick_batch_device",
     "eppk_hash_prompt", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
-    "eppk_profile_enable", "eppk_profile_drain", "eppk_last_algorithmic_bytes",
+    "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
 
@@ -83,6 +83,6 @@ def load_library() -> C.CDLL:
     lib.eppk_round_robin.restype = i32
     lib.eppk_profile_enable.argtypes = [vp, C.c_int]
     lib.eppk_profile_drain.argtypes = [vp, vp, u32, C.POINTER(u32)]
-    lib.eppk_last_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.eppk_profile_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     _LIB = lib
     return lib

@@ -78,7 +78,8 @@ struct eppk_ctx {
   bool prof = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
-  uint32_t last_n_reqs = 0, last_n_pods = 0;
+  uint64_t fixed_bytes = 0;  // per-launch request/pod/pick bytes accumulated while profiling
+  uint32_t launches = 0;
 
   std::string err;
 };
@@ -184,7 +185,6 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   unsigned long long* stats = c->prof ? c->stats : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
-    HIPCHK(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), st));
     if (c->ev_used + 2 > c->ev.size()) {
       hipEvent_t a, b;
       HIPCHK(c, hipEventCreate(&a));
@@ -209,8 +209,10 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st));
   }
   if (c->prof) HIPCHK(c, hipEventRecord(e1, st));
-  c->last_n_reqs = n_reqs;
-  c->last_n_pods = c->n_pods;
+  if (c->prof) {
+    c->fixed_bytes += (uint64_t)c->n_pods * sizeof(eppk_pod_row) + (uint64_t)n_reqs * ((uint64_t)c->stride + 4u);
+    c->launches++;
+  }
   return EPPK_OK;
 }
 
@@ -578,8 +580,13 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
 
 int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemset(c->stats, 0, 2 * sizeof(unsigned long long)));
   c->prof = on != 0;
   c->ev_used = 0;
+  c->fixed_bytes = 0;
+  c->launches = 0;
   return EPPK_OK;
 }
 
@@ -598,19 +605,17 @@ int eppk_profile_drain(eppk_ctx* c, float* ms, uint32_t cap, uint32_t* n_out) {
   return EPPK_OK;
 }
 
-int eppk_last_algorithmic_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* probes) {
+int eppk_profile_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* lookups, uint32_t* launches) {
   if (!c || !bytes) return EPPK_ERR_ARG;
-  if (!c->prof) return fail(c, EPPK_ERR_ARG, "eppk_last_algorithmic_bytes: enable profiling first");
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
   unsigned long long st[4];
   HIPCHK(c, hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
-  // SURVEY §8(d) byte model: pod rows + request rows + picks + index rows actually needed by the
-  // sequential walk (a hit reads key + pod-set row, the terminating miss reads a key).
+  // a hit reads key + pod-set row, the terminating miss reads a key
   const uint64_t row = 8u + 64u * (uint64_t)c->lw_bytes;
-  *bytes = (uint64_t)c->last_n_pods * sizeof(eppk_pod_row) + (uint64_t)c->last_n_reqs * ((uint64_t)c->stride + 4u) +
-           (uint64_t)st[0] * row + (uint64_t)(st[1] - st[0]) * 8u;
-  if (probes) *probes = st[1];
+  *bytes = c->fixed_bytes + (uint64_t)st[0] * row + (uint64_t)(st[1] - st[0]) * 8u;
+  if (lookups) *lookups = st[1];
+  if (launches) *launches = c->launches;
   return EPPK_OK;
 }
 

@@ -238,7 +238,8 @@ class BatchedPicker:
         self._check(self._lib.eppk_profile_drain(self._ctx, ms.ctypes.data, cap, C.byref(n)), "profile_drain")
         return ms[: n.value].copy()
 
-    def algorithmic_bytes(self) -> Tuple[int, int]:
-        b, p = C.c_uint64(0), C.c_uint64(0)
-        self._check(self._lib.eppk_last_algorithmic_bytes(self._ctx, C.byref(b), C.byref(p)), "last_algorithmic_bytes")
-        return b.value, p.value
+    def profile_bytes(self) -> Tuple[int, int, int]:
+        """(algorithmic bytes, index look-ups, launches) accumulated since profile(True)."""
+        b, p, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        self._check(self._lib.eppk_profile_bytes(self._ctx, C.byref(b), C.byref(p), C.byref(n)), "profile_bytes")
+        return b.value, p.value, n.value

@@ -105,7 +105,8 @@ def _model_name(adapter: int) -> bytes:
 
 
 def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None, masked: bool = False,
-                  n_groups: int = 256, pods_per_group: int = 8, seed: Optional[int] = None) -> Workload:
+                  n_groups: int = 256, pods_per_group: int = 8, seed: Optional[int] = None,
+                  req_seed: Optional[int] = None) -> Workload:
     """Build config `config` of BASELINE.json (optionally with R / P overridden for small parity cases)."""
     c = dict(CONFIGS[config])
     if R is not None:
@@ -114,6 +115,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
         c["P"] = P
     R, P, A, B = c["R"], c["P"], c["A"], c["B"]
     seed = (0x5EED0000 + config) if seed is None else seed
+    rseed = seed if req_seed is None else req_seed   # request streams only (pods / groups / index stay on `seed`)
     lib = _lib.load_library()
 
     pods = make_pods(seed, P, A)
@@ -121,7 +123,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     # requests: Zipf(s=1) over shared "system prompt" groups; a group carries its tenant's adapter
     gw = 1.0 / np.arange(1, n_groups + 1, dtype=np.float64)
     cdf = np.cumsum(gw) / gw.sum()
-    u = (splitmix64(_sub(seed, 10), R) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    u = (splitmix64(_sub(rseed, 10), R) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
     group = np.minimum(np.searchsorted(cdf, u, side="right"), n_groups - 1).astype(np.int64)
     ga_r = splitmix64(_sub(seed, 11), n_groups)
     if A > 0:
@@ -137,7 +139,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     idx_p: List[np.ndarray] = []
     if B > 0:
         gbytes = splitmix64(_sub(seed, 12), n_groups * Bs * (BLOCK_CHARS // 8)).reshape(n_groups, -1)
-        tbytes = splitmix64(_sub(seed, 13), R * Bu * (BLOCK_CHARS // 8)).reshape(R, -1)
+        tbytes = splitmix64(_sub(rseed, 13), R * Bu * (BLOCK_CHARS // 8)).reshape(R, -1)
         out = np.zeros(B, dtype=np.uint64)
         for r in range(R):
             g = int(group[r])
@@ -170,7 +172,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     mask = None
     if masked:
         W = (P + 63) // 64
-        mask = splitmix64(_sub(seed, 15), R * max(W, 1)).reshape(R, max(W, 1))[:, :W].copy()  # ~50 % of pods
+        mask = splitmix64(_sub(rseed, 15), R * max(W, 1)).reshape(R, max(W, 1))[:, :W].copy()  # ~50 % of pods
         if P % 64 and W:
             mask[:, -1] &= np.uint64((1 << (P % 64)) - 1)
 

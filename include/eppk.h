@@ -188,13 +188,17 @@ int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
 
-/* When enabled, every pick launch is bracketed by HIP events on the launch stream. */
+/* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,
+ * every pick launch is bracketed by HIP events recorded on the launch stream and accumulates its
+ * index-probe counts on device (one atomic per wavefront). */
 int eppk_profile_enable(eppk_ctx* ctx, int on);
 /* Synchronise and copy out up to cap kernel durations (ms) recorded since the last drain. */
 int eppk_profile_drain(eppk_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out);
-/* Algorithmic (compulsory) bytes of the last pick launch, SURVEY §8(d) byte model; computed on
- * device from the actual probe counts.  Synchronises. */
-int eppk_last_algorithmic_bytes(eppk_ctx* ctx, uint64_t* bytes, uint64_t* probes);
+/* Algorithmic (compulsory) bytes of all pick launches since profiling was enabled — SURVEY §8(d)
+ * byte model, with the probe counts the sequential walk of SEMANTICS.md §3 needs (measured on
+ * device): launches * (n_pods*64 + n_reqs*(stride+4)) + hits*(8 + pod-set row) + misses*8.
+ * lookups = index look-ups of that walk; launches = pick launches counted.  Synchronises. */
+int eppk_profile_bytes(eppk_ctx* ctx, uint64_t* bytes, uint64_t* lookups, uint32_t* launches);
 
 #ifdef __cplusplus
 }
