@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,8 @@ struct SnapBuf {
   void*     act_t = nullptr;
   void*     wait_t = nullptr;
   void*     free_t = nullptr;
+  double*   topv = nullptr;   // [129][64]
+  uint32_t* topi = nullptr;   // [129][64]
 };
 
 }  // namespace
@@ -121,6 +124,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   KSnap k{};
   k.base = s.base; k.queue = s.queue; k.kv = s.kv;
   k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
+  k.topv = s.topv; k.topi = s.topi;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
   return k;
@@ -321,6 +325,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc(&c->snap[b].act_t, lora_bytes));
     CHK(hipMalloc(&c->snap[b].wait_t, lora_bytes));
     CHK(hipMalloc(&c->snap[b].free_t, 64u * (size_t)c->lw_bytes));
+    CHK(hipMalloc((void**)&c->snap[b].topv, 129u * 64u * 8u));
+    CHK(hipMalloc((void**)&c->snap[b].topi, 129u * 64u * 4u));
   }
   CHK(hipMalloc((void**)&c->stats, 4 * sizeof(unsigned long long)));
   CHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
@@ -348,6 +354,7 @@ void eppk_destroy(eppk_ctx* c) {
   for (int b = 0; b < 2; ++b) {
     (void)hipFree(c->snap[b].base); (void)hipFree(c->snap[b].queue); (void)hipFree(c->snap[b].kv);
     (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t);
+    (void)hipFree(c->snap[b].topv); (void)hipFree(c->snap[b].topi);
   }
   (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
@@ -407,6 +414,35 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
     if (pop128(r.active) + pop128(r.waiting) < r.max_lora) set_lane_bit(freeb, c->lw_bytes, 0, p);
   }
 
+  // per-adapter top-64 tables for the sparse fast path (eppk_kernels.hip.h, FAST pick kernel):
+  // T_a[p] = base[p] (+ lw[tier(a,p)]), the exact total of every pod without a prefix match.
+  std::vector<double> topv(129u * 64u, -HUGE_VAL);
+  std::vector<uint32_t> topi(129u * 64u, 0xFFFFFFFFu);
+  if (c->canonical && n_pods) {
+    std::vector<double> T(n_pods);
+    std::vector<uint32_t> order(n_pods);
+    std::vector<uint8_t> freeflag(n_pods);
+    for (uint32_t p = 0; p < n_pods; ++p) freeflag[p] = pop128(rows[p].active) + pop128(rows[p].waiting) < rows[p].max_lora;
+    const uint32_t K = n_pods < 64u ? n_pods : 64u;
+    for (uint32_t arow = 0; arow <= 128u; ++arow) {
+      if (!c->has_l && arow != 128u) continue;  // without a LoRA scorer only the base row is read
+      for (uint32_t p = 0; p < n_pods; ++p) {
+        double t = base[p];
+        if (c->has_l) {
+          const bool act = arow < 128u && ((rows[p].active[arow >> 6] >> (arow & 63u)) & 1u);
+          const bool wai = arow < 128u && ((rows[p].waiting[arow >> 6] >> (arow & 63u)) & 1u);
+          const int tier = act ? 3 : freeflag[p] ? 2 : wai ? 1 : 0;
+          t = t + c->tail.lw[tier];
+        }
+        T[p] = t;
+        order[p] = p;
+      }
+      std::partial_sort(order.begin(), order.begin() + K, order.end(),
+                        [&](uint32_t a, uint32_t b) { return T[a] > T[b] || (T[a] == T[b] && a < b); });
+      for (uint32_t k = 0; k < K; ++k) { topv[arow * 64u + k] = T[order[k]]; topi[arow * 64u + k] = order[k]; }
+    }
+  }
+
   const int nxt = c->cur ^ 1;
   SnapBuf& s = c->snap[nxt];
   if (np64) {
@@ -417,6 +453,8 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   HIPCHK(c, hipMemcpyAsync(s.act_t, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.wait_t, wait.data(), wait.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.free_t, freeb.data(), freeb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.topv, topv.data(), topv.size() * 8u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.topi, topi.data(), topi.size() * 4u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cur = nxt;
   c->n_pods = n_pods; c->qmin = qmin; c->qmax = qmax; c->epoch = epoch;

@@ -39,6 +39,8 @@ struct KSnap {
   const void*     act_t;   // [A][64] LW  bit j of [a][l] : adapter a active on pod j*64+l
   const void*     wait_t;  // [A][64] LW
   const void*     free_t;  // [64] LW     loaded < max_lora
+  const double*   topv;    // [129][64] per adapter row (128 = base model): the 64 best pods by
+  const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
@@ -205,7 +207,69 @@ __device__ __forceinline__ LW valid_word(uint32_t n_pods, int lane) {
 
 // ---- FAST pick kernel --------------------------------------------------------------------------
 // Chain = [pod-only scorers fused into base] ++ tail, tail in {∅, L, P, LP, PL}; no candidate mask.
-// LDS: base[J*64] f64 | lw[4] f64 | per wave pw[pwn] f64.
+//
+// Sparse evaluation.  Let M = {p : matched[p] > 0} for this request.  For p ∉ M the prefix term is
+// pw[0] = ±0.0, and adding ±0.0 to a value that is never −0.0 is the identity (base and base+lw are sums
+// that start from +0.0), so total[p] == T_a[p] = base[p] (+ lw[tier(a,p)]) EXACTLY — a quantity that
+// depends only on (adapter, pod).  The host therefore publishes, per adapter, the 64 best pods by
+// (T desc, p asc).  Per request the kernel
+//   1. walks the prefix index (the only HBM-heavy part) into bit-sliced counters,
+//   2. takes the first table entry that is not in M          -> best pod outside M,
+//   3. evaluates the full expression only for the pods in M  -> best pod inside M,
+//   4. merges both under (score desc, index asc).
+// If all 64 table entries are in M (a prefix cached almost everywhere) it falls back to the dense
+// scan of every pod (LDS-staged base, LDS look-up tables), which is the same arithmetic.
+// LDS: base[J*64] f64 | lw[4] f64 | per wave pw[pwn] f64 (dense fallback only).
+
+template <bool HAS_L, bool HAS_P, bool P_FIRST>
+__device__ __forceinline__ double eval_total(double base, double lterm, double pterm) {
+  double t = base;
+  if (HAS_L && HAS_P) {
+    if (P_FIRST) { t = t + pterm; t = t + lterm; }
+    else { t = t + lterm; t = t + pterm; }
+  } else if (HAS_L) {
+    t = t + lterm;
+  } else if (HAS_P) {
+    t = t + pterm;
+  }
+  return t;
+}
+
+// Dense scan of all pods of one request (per-lane running argmax); fills the wave's pw table first.
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
+__device__ __forceinline__ void dense_scan(const KSnap& sn, const KTail& tl, const double* s_base, const double* s_lw,
+                                           double* s_pw, const LW (&c)[NPL], LW thi, LW tlo, LW valid, uint32_t nb,
+                                           int lane, double& best, uint32_t& bidx) {
+  if (HAS_P) {
+    wave_lds_fence();  // previous readers of this wave's table are done
+    for (uint32_t cnt = (uint32_t)lane; cnt <= nb; cnt += 64u) {
+      const double s = nb ? (double)cnt / (double)nb : 0.0;
+      s_pw[cnt] = clamp01(s) * tl.wp;
+    }
+    wave_lds_fence();
+  }
+#pragma unroll
+  for (int hf = 0; hf < lane_word<LW>::halves; ++hf) {
+    const uint32_t j0 = (uint32_t)hf * 32u;
+    if (j0 >= sn.J) break;
+    const uint32_t jn = (sn.J - j0) < 32u ? (sn.J - j0) : 32u;
+    const uint32_t v32 = half32<LW>(valid, hf);
+    const uint32_t hi32 = half32<LW>(thi, hf), lo32 = half32<LW>(tlo, hf);
+    uint32_t c32[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) c32[k] = half32<LW>(c[k], hf);
+    for (uint32_t jj = 0; jj < jn; ++jj) {
+      const uint32_t p = (j0 + jj) * 64u + (uint32_t)lane;
+      double lterm = 0.0, pterm = 0.0;
+      if (HAS_L) lterm = s_lw[(((hi32 >> jj) & 1u) << 1) | ((lo32 >> jj) & 1u)];
+      if (HAS_P) pterm = s_pw[planes_get<NPL>(c32, jj)];
+      const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
+      const bool ok = (v32 >> jj) & 1u;
+      if (ok && t > best) { best = t; bidx = p; }
+    }
+  }
+}
+
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
 __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
@@ -234,23 +298,10 @@ __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
     const int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
     const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
 
-    // prefix walk -> bit-sliced matched counts
-    LW c[NPL];
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) c[k] = 0;
-    if (HAS_P) {
-      const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, c);
-      w_hits += hits;
-      w_lookups += (hits + 1u < nb) ? hits + 1u : nb;
-      // pw[cnt] = clamp01(cnt / n) * w_prefix, one division per lane per request
-      wave_lds_fence();  // previous request's readers are done
-      for (uint32_t cnt = (uint32_t)lane; cnt <= nb; cnt += 64u) {
-        const double s = nb ? (double)cnt / (double)nb : 0.0;
-        s_pw[cnt] = clamp01(s) * tl.wp;
-      }
-      wave_lds_fence();
-    }
-
+    // loads that do not depend on the index walk go first
+    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+    const double top_t = sn.topv[(size_t)arow * 64u + (uint32_t)lane];
+    const uint32_t top_p = sn.topi[(size_t)arow * 64u + (uint32_t)lane];
     // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 (waiting), 2: 0.8 (free slot), 3: 1.0 (active)}
     LW thi = 0, tlo = 0;
     if (HAS_L) {
@@ -263,37 +314,69 @@ __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
       tlo = a | ((LW)~freew & w);
     }
 
+    // prefix walk -> bit-sliced matched counts
+    LW c[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) c[k] = 0;
+    LW nz = 0;  // M: pods with matched > 0
+    if (HAS_P) {
+      const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, c);
+      w_hits += hits;
+      w_lookups += (hits + 1u < nb) ? hits + 1u : nb;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) nz |= c[k];
+      nz &= valid;
+    }
+
+    // best pod outside M: first table entry not in M
+    const bool has = top_p != kNoPod;
+    const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
+    LW nzq;
+    if constexpr (sizeof(LW) == 8) {
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)nz, (int)ql);
+      const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(nz >> 32), (int)ql);
+      nzq = ((uint64_t)hi << 32) | lo;
+    } else {
+      nzq = (LW)__shfl((int)(uint32_t)nz, (int)ql);
+    }
+    const unsigned long long okm = __ballot(has && !((nzq >> qj) & 1));
+    double cand_t = -__builtin_inf();
+    uint32_t cand_p = kNoPod;
+    bool dense = false;
+    if (okm) {
+      const int f = __builtin_ctzll(okm);
+      cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
+                                __builtin_amdgcn_readlane(__double2loint(top_t), f));
+      cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
+    } else {
+      dense = sn.n_pods > 64u;  // table exhausted although more pods exist
+    }
+
     double best = -__builtin_inf();
     uint32_t bidx = kNoPod;
+    if (dense) {
+      dense_scan<LW, NPL, HAS_L, HAS_P, P_FIRST>(sn, tl, s_base, s_lw, s_pw, c, thi, tlo, valid, nb, lane, best, bidx);
+      cand_t = -__builtin_inf();
+      cand_p = kNoPod;
+    } else if (HAS_P) {
+      LW rem = nz;
+      while (__any(rem != 0)) {          // each lane walks its own pods of M in ascending order
+        if (rem != 0) {
+          const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
+          rem = (LW)(rem & (LW)(rem - 1));
+          const uint32_t p = j * 64u + (uint32_t)lane;
+          uint32_t cnt = 0;
 #pragma unroll
-    for (int hf = 0; hf < lane_word<LW>::halves; ++hf) {
-      const uint32_t j0 = (uint32_t)hf * 32u;
-      if (j0 >= sn.J) break;
-      const uint32_t jn = (sn.J - j0) < 32u ? (sn.J - j0) : 32u;
-      const uint32_t v32 = half32<LW>(valid, hf);
-      const uint32_t hi32 = half32<LW>(thi, hf), lo32 = half32<LW>(tlo, hf);
-      uint32_t c32[NPL];
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) c32[k] = half32<LW>(c[k], hf);
-      for (uint32_t jj = 0; jj < jn; ++jj) {
-        const uint32_t p = (j0 + jj) * 64u + (uint32_t)lane;
-        double t = s_base[p];
-        double tl_term = 0.0, tp_term = 0.0;
-        if (HAS_L) tl_term = s_lw[(((hi32 >> jj) & 1u) << 1) | ((lo32 >> jj) & 1u)];
-        if (HAS_P) tp_term = s_pw[planes_get<NPL>(c32, jj)];
-        if (HAS_L && HAS_P) {
-          if (P_FIRST) { t = t + tp_term; t = t + tl_term; }
-          else { t = t + tl_term; t = t + tp_term; }
-        } else if (HAS_L) {
-          t = t + tl_term;
-        } else if (HAS_P) {
-          t = t + tp_term;
+          for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
+          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+          const double pterm = clamp01((double)cnt / (double)nb) * tl.wp;   // cnt > 0 implies nb > 0
+          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], HAS_L ? s_lw[tier] : 0.0, pterm);
+          if (t > best) { best = t; bidx = p; }
         }
-        const bool ok = (v32 >> jj) & 1u;
-        if (ok && t > best) { best = t; bidx = p; }
       }
     }
     wave_argmax(best, bidx);
+    if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     if (lane == 0) {
       const bool none = bidx == kNoPod;
       out_pick[r] = none ? -1 : (int32_t)bidx;

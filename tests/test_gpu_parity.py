@@ -77,3 +77,30 @@ def test_empty_and_single_candidate_masks(pkg, orc):
     assert picks[0] == -1 and scores[0] == 0.0
     assert picks[1] == 3 * 64 + 17
     assert_same(picks, scores, opicks, oscores)
+
+
+@pytest.mark.parametrize("cover", ["all", "top64", "half"])
+def test_dense_fallback_when_prefix_is_cached_everywhere(pkg, orc, cover):
+    """All 64 per-adapter table entries inside M -> the kernel must fall back to the dense scan."""
+    wl = pkg.workload.make_workload(5, R=256, P=2500)
+    rng = np.random.default_rng(7)
+    # cache the first 3 blocks of EVERY request's chain on many pods
+    if cover == "all":
+        pods = np.arange(wl.P, dtype=np.uint32)
+    elif cover == "half":
+        pods = np.arange(0, wl.P, 2, dtype=np.uint32)
+    else:
+        pods = rng.choice(wl.P, 700, replace=False).astype(np.uint32)
+    hs = np.unique(wl.reqs[:, 1:4].ravel())
+    extra_h = np.repeat(hs, pods.size)
+    extra_p = np.tile(pods, hs.size)
+    wl.index_hashes = np.concatenate([wl.index_hashes, extra_h])
+    wl.index_pods = np.concatenate([wl.index_pods, extra_p])
+    wl.index_slots = 1 << 14
+    assert_same(*run_both(pkg, orc, wl, max_pods=4096))
+
+
+def test_small_pod_counts_table_holds_every_pod(pkg, orc):
+    for P in (1, 2, 17, 64):
+        wl = pkg.workload.make_workload(3, R=128, P=P, pods_per_group=64)   # every pod is in M for most requests
+        assert_same(*run_both(pkg, orc, wl, max_pods=1024))
