@@ -70,7 +70,7 @@ struct eppk_ctx {
   uint64_t* keys = nullptr;
   void* bitmaps = nullptr;
   uint32_t slots = 0, shift = 0, limit = 0;
-  unsigned long long* stats = nullptr;  // device [4]: hits, lookups, occupied keys, dropped inserts
+  unsigned long long* stats = nullptr;  // device [4 + 2*kStatSlots]: -, -, occupied keys, dropped inserts, then per-wave {hits, lookups}
 
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
@@ -83,6 +83,8 @@ struct eppk_ctx {
   size_t ev_used = 0;
   uint64_t fixed_bytes = 0;  // per-launch request/pod/pick bytes accumulated while profiling
   uint32_t launches = 0;
+
+  const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
 
   std::string err;
 };
@@ -173,17 +175,20 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const void* fn = pick_kernel_ptr(c, fast, masked);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
-  const uint32_t threads = 512, wpb = threads / 64;
-  size_t lds;
-  if (fast) lds = ((size_t)sn.J * 64u + 4u + (size_t)wpb * c->pwn) * 8u;
-  else lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
-  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = 0;
-  HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
-  if (per_cu < 1) per_cu = 1;
+  const uint32_t threads = fast ? 256u : 512u, wpb = threads / 64;
+  size_t lds = 0;  // the fast kernel uses no LDS
+  if (!fast) lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
+  // occupancy-sized persistent grid (cached per kernel/LDS size: these are host calls on the launch path)
+  if (fn != c->occ_fn || lds != c->occ_lds) {
+    if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
+    c->occ_fn = fn; c->occ_lds = lds; c->occ_per_cu = per_cu < 1 ? 1 : per_cu;
+  }
   uint32_t grid = (n_reqs + wpb - 1) / wpb;
-  const uint32_t cap = (uint32_t)c->num_cu * (uint32_t)per_cu;
+  const uint32_t cap = (uint32_t)c->num_cu * (uint32_t)c->occ_per_cu;
   if (grid > cap) grid = cap;
+  if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
   if (grid < 1) grid = 1;
 
   unsigned long long* stats = c->prof ? c->stats : nullptr;
@@ -328,8 +333,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc((void**)&c->snap[b].topv, 129u * 64u * 8u));
     CHK(hipMalloc((void**)&c->snap[b].topi, 129u * 64u * 4u));
   }
-  CHK(hipMalloc((void**)&c->stats, 4 * sizeof(unsigned long long)));
-  CHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
+  CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
+  CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
   if (cfg->index_slots) {
     c->slots = cfg->index_slots;
     uint32_t lg = 0;
@@ -478,7 +483,7 @@ int eppk_index_clear(eppk_ctx* c) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipMemsetAsync(c->keys, 0, (size_t)c->slots * 8u, c->stream));
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
 }
@@ -620,7 +625,7 @@ int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemset(c->stats, 0, 2 * sizeof(unsigned long long)));
+  HIPCHK(c, hipMemset(c->stats + 4, 0, 2 * (size_t)kStatSlots * sizeof(unsigned long long)));
   c->prof = on != 0;
   c->ev_used = 0;
   c->fixed_bytes = 0;
@@ -647,8 +652,10 @@ int eppk_profile_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* lookups, uint32_t
   if (!c || !bytes) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
-  unsigned long long st[4];
-  HIPCHK(c, hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> slots(2 * (size_t)kStatSlots);
+  HIPCHK(c, hipMemcpy(slots.data(), c->stats + 4, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  unsigned long long st[2] = {0, 0};
+  for (size_t i = 0; i < slots.size(); i += 2) { st[0] += slots[i]; st[1] += slots[i + 1]; }
   // a hit reads key + pod-set row, the terminating miss reads a key
   const uint64_t row = 8u + 64u * (uint64_t)c->lw_bytes;
   *bytes = c->fixed_bytes + (uint64_t)st[0] * row + (uint64_t)(st[1] - st[0]) * 8u;

@@ -29,6 +29,7 @@ namespace eppk {
 constexpr uint32_t kNotFound = 0xFFFFFFFFu;
 constexpr uint32_t kNoPod = 0xFFFFFFFFu;
 constexpr uint64_t kHomeMul = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots: stats[4 + 2*wave + {0,1}]
 
 // ---- kernel argument blocks (plain structs, passed by value) --------------------------------
 
@@ -174,6 +175,90 @@ __device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t
   return hits;
 }
 
+// ---- carry-save counting ---------------------------------------------------------------------
+// Full adder on bit vectors: sum = a^b^c (v_xor3), carry = maj(a,b,c) = bfi(a^b, c, a) (v_bfi).
+template <typename LW>
+__device__ __forceinline__ void full_add(LW a, LW b, LW c, LW& sum, LW& carry) {
+  const LW x = a ^ b;
+  sum = x ^ c;
+  carry = (LW)((x & c) | ((LW)~x & a));
+}
+template <typename LW>
+__device__ __forceinline__ void half_add(LW a, LW b, LW& sum, LW& carry) {
+  sum = a ^ b;
+  carry = a & b;
+}
+
+// Add eight 0/1 vectors into the bit-sliced counters: an 8->4 carry-save tree (4 full + 3 half adders)
+// then one 4-bit ripple add into the NPL planes; ~4.5x fewer VALU ops than eight ripple adds.
+template <typename LW, int NPL>
+__device__ __forceinline__ void planes_add8(LW (&c)[NPL], const LW (&w)[8]) {
+  static_assert(NPL >= 5, "need at least 5 planes");
+  LW s1, c1, s2, c2, s3, c3, b0, c4, s5, c5, b1, c6, b2, b3;
+  full_add<LW>(w[0], w[1], w[2], s1, c1);
+  full_add<LW>(w[3], w[4], w[5], s2, c2);
+  full_add<LW>(w[6], w[7], s1, s3, c3);
+  half_add<LW>(s2, s3, b0, c4);          // ones
+  full_add<LW>(c1, c2, c3, s5, c5);      // twos
+  half_add<LW>(s5, c4, b1, c6);
+  half_add<LW>(c5, c6, b2, b3);          // fours, eights
+  LW carry, t;
+  half_add<LW>(c[0], b0, t, carry); c[0] = t;
+  full_add<LW>(c[1], b1, carry, t, carry); c[1] = t;
+  full_add<LW>(c[2], b2, carry, t, carry); c[2] = t;
+  full_add<LW>(c[3], b3, carry, t, carry); c[3] = t;
+#pragma unroll
+  for (int k = 4; k < NPL; ++k) { half_add<LW>(c[k], carry, t, carry); c[k] = t; }
+}
+
+// The prefix walk, lean form: `h0` is this lane's hash of the first 64-block chunk (prefetched),
+// all keys of a chunk are probed in parallel, rows are fetched 8 at a time and counted with the
+// carry-save tree.  nz accumulates the union of the counted rows (= pods with matched > 0).
+template <typename LW, int NPL>
+__device__ __forceinline__ uint32_t prefix_walk_csa(const KIndex& ix, const uint64_t* hs, uint64_t h0, uint32_t nb, int lane,
+                                                    LW (&c)[NPL], LW& nz) {
+  const LW* bm = (const LW*)ix.bitmaps;
+  uint32_t hits = 0;
+  bool stop = false;
+  for (uint32_t b0 = 0; b0 < nb && !stop; b0 += 64) {
+    const uint32_t i = b0 + (uint32_t)lane;
+    const bool act = i < nb;
+    const uint64_t h = (b0 == 0) ? h0 : (act ? hs[i] : 0);
+    const uint32_t slot = probe(ix, h, act);
+    const unsigned long long found = __ballot(slot != kNotFound);
+    const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
+    const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);  // leading found
+    for (uint32_t k0 = 0; k0 < m && !stop; k0 += 8) {
+      LW w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t k = k0 + (uint32_t)u;
+        const uint32_t s = __builtin_amdgcn_readlane(slot, (k < m) ? k : 0);
+        w[u] = (k < m) ? bm[(size_t)s * 64u + (uint32_t)lane] : (LW)0;
+      }
+      // rows at and after the first EMPTY row (key present, pod set empty) do not count
+      const uint32_t nrow = (m - k0) < 8u ? (m - k0) : 8u;
+      uint32_t good = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool nonempty = __ballot(w[u] != 0) != 0ull;
+        if ((uint32_t)u == good && (uint32_t)u < nrow && nonempty) ++good;
+      }
+      if (good < nrow) {
+        stop = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if ((uint32_t)u >= good) w[u] = 0;
+      }
+      planes_add8<LW, NPL>(c, w);
+      nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
+      hits += good;
+    }
+    if (m < chunk) stop = true;
+  }
+  return hits;
+}
+
 template <int NPL>
 __device__ __forceinline__ uint32_t planes_get(const uint32_t (&c32)[NPL], uint32_t jj) {
   uint32_t cnt = 0;
@@ -213,13 +298,14 @@ __device__ __forceinline__ LW valid_word(uint32_t n_pods, int lane) {
 // that start from +0.0), so total[p] == T_a[p] = base[p] (+ lw[tier(a,p)]) EXACTLY — a quantity that
 // depends only on (adapter, pod).  The host therefore publishes, per adapter, the 64 best pods by
 // (T desc, p asc).  Per request the kernel
-//   1. walks the prefix index (the only HBM-heavy part) into bit-sliced counters,
+//   1. walks the prefix index (the only HBM-heavy part) into bit-sliced counters (carry-save tree),
 //   2. takes the first table entry that is not in M          -> best pod outside M,
 //   3. evaluates the full expression only for the pods in M  -> best pod inside M,
 //   4. merges both under (score desc, index asc).
-// If all 64 table entries are in M (a prefix cached almost everywhere) it falls back to the dense
-// scan of every pod (LDS-staged base, LDS look-up tables), which is the same arithmetic.
-// LDS: base[J*64] f64 | lw[4] f64 | per wave pw[pwn] f64 (dense fallback only).
+// If all 64 table entries are in M (a prefix cached almost everywhere) step 2 becomes a scan of T_a
+// over the pods outside M (same arithmetic, base[] read from global memory).
+// No LDS and few registers: occupancy and memory-level parallelism are what this kernel lives on;
+// the next request's row is prefetched while the current one is processed.
 
 template <bool HAS_L, bool HAS_P, bool P_FIRST>
 __device__ __forceinline__ double eval_total(double base, double lterm, double pterm) {
@@ -235,68 +321,48 @@ __device__ __forceinline__ double eval_total(double base, double lterm, double p
   return t;
 }
 
-// Dense scan of all pods of one request (per-lane running argmax); fills the wave's pw table first.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
-__device__ __forceinline__ void dense_scan(const KSnap& sn, const KTail& tl, const double* s_base, const double* s_lw,
-                                           double* s_pw, const LW (&c)[NPL], LW thi, LW tlo, LW valid, uint32_t nb,
-                                           int lane, double& best, uint32_t& bidx) {
-  if (HAS_P) {
-    wave_lds_fence();  // previous readers of this wave's table are done
-    for (uint32_t cnt = (uint32_t)lane; cnt <= nb; cnt += 64u) {
-      const double s = nb ? (double)cnt / (double)nb : 0.0;
-      s_pw[cnt] = clamp01(s) * tl.wp;
-    }
-    wave_lds_fence();
-  }
-#pragma unroll
-  for (int hf = 0; hf < lane_word<LW>::halves; ++hf) {
-    const uint32_t j0 = (uint32_t)hf * 32u;
-    if (j0 >= sn.J) break;
-    const uint32_t jn = (sn.J - j0) < 32u ? (sn.J - j0) : 32u;
-    const uint32_t v32 = half32<LW>(valid, hf);
-    const uint32_t hi32 = half32<LW>(thi, hf), lo32 = half32<LW>(tlo, hf);
-    uint32_t c32[NPL];
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) c32[k] = half32<LW>(c[k], hf);
-    for (uint32_t jj = 0; jj < jn; ++jj) {
-      const uint32_t p = (j0 + jj) * 64u + (uint32_t)lane;
-      double lterm = 0.0, pterm = 0.0;
-      if (HAS_L) lterm = s_lw[(((hi32 >> jj) & 1u) << 1) | ((lo32 >> jj) & 1u)];
-      if (HAS_P) pterm = s_pw[planes_get<NPL>(c32, jj)];
-      const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
-      const bool ok = (v32 >> jj) & 1u;
-      if (ok && t > best) { best = t; bidx = p; }
-    }
-  }
+__device__ __forceinline__ double tier_term(const KTail& tl, uint32_t tier) {
+  return tier == 3u ? tl.lw[3] : tier == 2u ? tl.lw[2] : tier == 1u ? tl.lw[1] : tl.lw[0];
 }
 
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
-__global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+__global__ __launch_bounds__(256) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                         unsigned long long* __restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* s_base = (double*)smem;
-  double* s_lw = s_base + (size_t)sn.J * 64u;
+  (void)pwn;
   const int lane = (int)(threadIdx.x & 63u);
-  const uint32_t wib = threadIdx.x >> 6;
   const uint32_t wpb = blockDim.x >> 6;
-  double* s_pw = s_lw + 4 + (size_t)wib * pwn;
-
-  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
-  if (threadIdx.x < 4) s_lw[threadIdx.x] = tl.lw[threadIdx.x];
-  __syncthreads();
+  const uint32_t gwave = blockIdx.x * wpb + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * wpb;
 
   const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   unsigned long long w_hits = 0, w_lookups = 0;
 
-  const uint32_t gwave = blockIdx.x * wpb + wib;
-  const uint32_t nwaves = gridDim.x * wpb;
-  for (uint32_t r = gwave; r < n_reqs; r += nwaves) {
+  // software prefetch of the next request's header word and first 64 hashes
+  const uint32_t hwords = (stride - 8u) / 8u < 64u ? (stride - 8u) / 8u : 64u;
+  uint32_t r = gwave;
+  uint64_t nx_hdr = 0, nx_h = 0;
+  if (r < n_reqs) {
+    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)r * stride);
+    nx_hdr = row64[0];
+    nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;   // independent of the header: no wait
+  }
+  for (; r < n_reqs; r += nwaves) {
     const uint8_t* row = reqs + (size_t)r * stride;
-    const int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
-    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
+    const uint64_t hdr = nx_hdr;
+    const uint64_t h0 = nx_h;
+    const int32_t adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)hdr);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(hdr >> 32));
+    {
+      const uint32_t rn = r + nwaves;
+      if (rn < n_reqs) {
+        const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)rn * stride);
+        nx_hdr = row64[0];
+        nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
+      }
+    }
 
     // loads that do not depend on the index walk go first
     const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
@@ -314,51 +380,49 @@ __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
       tlo = a | ((LW)~freew & w);
     }
 
-    // prefix walk -> bit-sliced matched counts
+    // prefix walk -> bit-sliced matched counts; nz = M (pods with matched > 0)
     LW c[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) c[k] = 0;
-    LW nz = 0;  // M: pods with matched > 0
+    LW nz = 0;
     if (HAS_P) {
-      const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, c);
-      w_hits += hits;
-      w_lookups += (hits + 1u < nb) ? hits + 1u : nb;
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) nz |= c[k];
+      const uint32_t hits = prefix_walk_csa<LW, NPL>(ix, (const uint64_t*)(row + 8), h0, nb, lane, c, nz);
+      if (stats) { w_hits += hits; w_lookups += (hits + 1u < nb) ? hits + 1u : nb; }
       nz &= valid;
     }
+    const bool any_m = HAS_P && __any(nz != 0);
 
     // best pod outside M: first table entry not in M
     const bool has = top_p != kNoPod;
-    const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
-    LW nzq;
-    if constexpr (sizeof(LW) == 8) {
-      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)nz, (int)ql);
-      const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(nz >> 32), (int)ql);
-      nzq = ((uint64_t)hi << 32) | lo;
-    } else {
-      nzq = (LW)__shfl((int)(uint32_t)nz, (int)ql);
+    bool in_m = false;
+    if (any_m) {
+      const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
+      LW nzq;
+      if constexpr (sizeof(LW) == 8) {
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)nz, (int)ql);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(nz >> 32), (int)ql);
+        nzq = ((uint64_t)hi << 32) | lo;
+      } else {
+        nzq = (LW)__shfl((int)(uint32_t)nz, (int)ql);
+      }
+      in_m = (nzq >> qj) & 1;
     }
-    const unsigned long long okm = __ballot(has && !((nzq >> qj) & 1));
+    const unsigned long long okm = __ballot(has && !in_m);
     double cand_t = -__builtin_inf();
     uint32_t cand_p = kNoPod;
-    bool dense = false;
+    bool scan_rest = false;
     if (okm) {
       const int f = __builtin_ctzll(okm);
       cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
                                 __builtin_amdgcn_readlane(__double2loint(top_t), f));
       cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
     } else {
-      dense = sn.n_pods > 64u;  // table exhausted although more pods exist
+      scan_rest = sn.n_pods > 64u;  // table exhausted although more pods exist
     }
 
     double best = -__builtin_inf();
     uint32_t bidx = kNoPod;
-    if (dense) {
-      dense_scan<LW, NPL, HAS_L, HAS_P, P_FIRST>(sn, tl, s_base, s_lw, s_pw, c, thi, tlo, valid, nb, lane, best, bidx);
-      cand_t = -__builtin_inf();
-      cand_p = kNoPod;
-    } else if (HAS_P) {
+    if (any_m) {
       LW rem = nz;
       while (__any(rem != 0)) {          // each lane walks its own pods of M in ascending order
         if (rem != 0) {
@@ -370,12 +434,26 @@ __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
           for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
           const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
           const double pterm = clamp01((double)cnt / (double)nb) * tl.wp;   // cnt > 0 implies nb > 0
-          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], HAS_L ? s_lw[tier] : 0.0, pterm);
+          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(sn.base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
           if (t > best) { best = t; bidx = p; }
         }
       }
     }
-    wave_argmax(best, bidx);
+    if (scan_rest) {                      // rare: T_a over every pod outside M (total == T_a there)
+      const LW rest = (LW)(valid & (LW)~nz);
+      double rbest = -__builtin_inf();
+      uint32_t ridx = kNoPod;
+      for (uint32_t j = 0; j < sn.J; ++j) {
+        const uint32_t p = j * 64u + (uint32_t)lane;
+        const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+        double t = sn.base[p];
+        if (HAS_L) t = t + tier_term(tl, tier);
+        const bool ok = (rest >> j) & 1;
+        if (ok && t > rbest) { rbest = t; ridx = p; }
+      }
+      if (rbest > best || (rbest == best && ridx < bidx)) { best = rbest; bidx = ridx; }
+    }
+    if (any_m || scan_rest) wave_argmax(best, bidx);
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     if (lane == 0) {
       const bool none = bidx == kNoPod;
@@ -383,9 +461,11 @@ __global__ __launch_bounds__(512) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
       if (out_score) out_score[r] = none ? 0.0 : best;
     }
   }
-  if (HAS_P && stats && lane == 0 && (w_hits | w_lookups)) {
-    atomicAdd(&stats[0], w_hits);
-    atomicAdd(&stats[1], w_lookups);
+  // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
+  // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
+  if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
+    stats[4 + 2 * gwave] += w_hits;
+    stats[5 + 2 * gwave] += w_lookups;
   }
 }
 
@@ -510,9 +590,9 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
       if (out_score) out_score[r] = none ? 0.0 : best;
     }
   }
-  if (stats && lane == 0 && (w_hits | w_lookups)) {
-    atomicAdd(&stats[0], w_hits);
-    atomicAdd(&stats[1], w_lookups);
+  if (stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
+    stats[4 + 2 * gwave] += w_hits;
+    stats[5 + 2 * gwave] += w_lookups;
   }
 }
 
