@@ -91,13 +91,13 @@ def main() -> None:
     d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
     d_pick = torch.empty(R, dtype=torch.int32, device=dev)
     d_score = torch.empty(R, dtype=torch.float64, device=dev)
-    d_all = torch.empty(R * world, dtype=torch.int32, device=dev) if world > 1 else None
+    d_all_holder = [None]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         pk.pick_device(d_reqs.data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_pick)
+            d_all_holder[0] = pkg.distributed.all_gather_picks(d_pick, R * world, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -125,7 +125,7 @@ def main() -> None:
     picks = d_pick.cpu().numpy()
     scores = d_score.cpu().numpy()
     if world > 1:
-        allp = d_all.cpu().numpy()
+        allp = d_all_holder[0].cpu().numpy()
         assert np.array_equal(allp[rank * R:(rank + 1) * R], picks), "all-gather returned a different shard"
 
     if rank == 0:

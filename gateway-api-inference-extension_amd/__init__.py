@@ -9,11 +9,12 @@ Only the hot path lives here: ``csrc/`` holds the HIP kernels an
 * ``picker.BatchedPicker``  — batched ``EndpointPicker.Pick`` (pkg/lwepp/handlers/server.go:79-82)
 * ``picker.RoundRobinPicker`` — the reference's only picker (server.go:84-101), the fail-open fallback
 * ``picker.subset_mask``    — candidate filter of handleRequestHeaders (request.go:104-133)
+* ``distributed``           — request sharding + the all-gather of picks
 * ``workload``              — synthetic snapshot/request tables of SURVEY.md §8(d)
 
 There is no CPU implementation of the pick in this package: without ``libeppk.so`` and a HIP device
 every pick raises.
 """
-from . import _lib, picker, workload  # noqa: F401
+from . import _lib, distributed, picker, workload  # noqa: F401
 from ._lib import EppkError, lib_path, load_library  # noqa: F401
 from .picker import BatchedPicker, RoundRobinPicker, ScorerKind, subset_mask  # noqa: F401

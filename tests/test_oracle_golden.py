@@ -1,0 +1,165 @@
+"""CPU: pin the oracle (oracle/oracle.c) against the committed golden vectors (tests/golden/cases.npz).
+
+The reference holds no golden vectors for the scorer chain (parity UNPINNED); the
+vectors come from an independent numpy restatement (tests/golden/gen_golden.py) and python-xxhash.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def case_names(gold):
+    return sorted({k.split("/")[0] for k in gold.files if k.endswith("/pick")})
+
+
+def load_case(gold, name):
+    return {k.split("/", 1)[1]: gold[k] for k in gold.files if k.startswith(name + "/")}
+
+
+def rows_of(pkg, c):
+    B = int(c["B"])
+    return pkg.picker.make_req_rows(c["adapter"], c["n_blocks"], c["hashes"][:, :B] if B else None, B), B
+
+
+def test_golden_file_has_cases(gold):
+    assert len(case_names(gold)) >= 10
+
+
+def test_oracle_matches_numpy_restatement_bitwise(gold, pkg, orc):
+    for name in case_names(gold):
+        c = load_case(gold, name)
+        reqs, B = rows_of(pkg, c)
+        oix = orc.OracleIndex()
+        oix.insert(c["index_hashes"], c["index_pods"])
+        for p in c["removed"].tolist():
+            oix.remove_pod(int(p))
+        chain = [(int(k), int(w)) for k, w in c["chain"]]
+        mask = c["mask"] if c["mask"].size else None
+        picks, scores, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, mask)
+        assert np.array_equal(picks, c["pick"]), name
+        assert np.array_equal(scores.view(np.uint64), c["score"].view(np.uint64)), name
+
+
+def test_oracle_mt_equals_sequential(gold, pkg, orc):
+    c = load_case(gold, "full_masked")
+    reqs, B = rows_of(pkg, c)
+    oix = orc.OracleIndex()
+    oix.insert(c["index_hashes"], c["index_pods"])
+    chain = [(int(k), int(w)) for k, w in c["chain"]]
+    a = orc.pick_batch(chain, c["pods"], oix, reqs, B, c["mask"])
+    b = orc.pick_batch(chain, c["pods"], oix, reqs, B, c["mask"], threads=3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
+
+
+def test_xxh64_known_answers_oracle_and_library(gold, pkg, orc):
+    lib = pkg.load_library()
+    data = gold["xxh64/data"].tobytes()
+    off = 0
+    for n, e0, e2a in zip(gold["xxh64/lens"].tolist(), gold["xxh64/seed0"].tolist(), gold["xxh64/seed_2a"].tolist()):
+        m = data[off:off + n]
+        off += n
+        assert orc.xxh64(m, 0) == e0 and orc.xxh64(m, 0x2A) == e2a
+        assert lib.eppk_xxh64(m, len(m), 0) == e0 and lib.eppk_xxh64(m, len(m), 0x2A) == e2a
+    # the three values SURVEY.md §8c lists (seed 0)
+    assert orc.xxh64(b"") == 0xEF46DB3751D8E999
+    assert orc.xxh64(b"a") == 0xD24EC4F1A98C6E5B
+    assert orc.xxh64(b"abc") == 0x44BC2CF5AD770999
+
+
+def test_xxh64_against_python_xxhash_random():
+    xxhash = pytest.importorskip("xxhash")
+    import __graft_entry__ as g
+    orc = g.load_oracle()
+    lib = g.load_package().load_library()
+    rng = np.random.default_rng(1)
+    for n in list(range(0, 70)) + [127, 128, 129, 1000, 4097]:
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        seed = int(rng.integers(0, 2**63))
+        want = xxhash.xxh64(m, seed=seed).intdigest()
+        assert orc.xxh64(m, seed) == want
+        assert lib.eppk_xxh64(m, n, seed) == want
+
+
+def test_chain_hash_known_answer(gold, pkg, orc):
+    prompt = gold["chain/prompt"].tobytes()
+    want = gold["chain/expected"]
+    assert np.array_equal(orc.hash_prompt(b"m", prompt, 64, 8), want)          # only 3 full blocks in 200 bytes
+    assert np.array_equal(pkg.picker.hash_prompt(b"m", prompt, 64, 8), want)
+    assert pkg.picker.hash_prompt(b"m", prompt, 64, 2).shape[0] == 2          # max_out bounds the chain
+    assert pkg.picker.hash_prompt(b"m", prompt[:63], 64, 8).shape[0] == 0       # no full block
+    # a different model name changes every hash (LoRA-aware chains, 0602-…/README.md:121)
+    assert not np.any(pkg.picker.hash_prompt(b"n", prompt, 64, 8) == want)
+
+
+def test_hand_computed_scores(pkg, orc):
+    """Small cases computed by hand from SEMANTICS.md."""
+    Q, KV, L, PF = 1, 2, 3, 4
+    pods = np.zeros(3, dtype=pkg.picker.POD_DTYPE)
+    pods["queue"] = [0, 5, 10]
+    pods["kv_util"] = [0.5, 0.25, 1.0]
+    reqs = pkg.picker.make_req_rows(np.array([-1]), np.array([0]), None, 0)
+    # queue scores [1, .5, 0], kv scores [.5, .75, 0]; totals 2*q + 2*kv = [3, 2.5, 0]
+    picks, scores, _ = orc.pick_batch([(Q, 2), (KV, 2)], pods, None, reqs, 0)
+    assert picks[0] == 0 and scores[0] == 3.0
+    assert np.array_equal(orc.score_row([(Q, 2), (KV, 2)], pods, None, reqs[0]), [3.0, 2.5, 0.0])
+    # all queues equal -> queue score 1.0 everywhere; tie on total broken by lowest index
+    pods["queue"] = 7
+    pods["kv_util"] = 0.5
+    picks, scores, _ = orc.pick_batch([(Q, 1), (KV, 1)], pods, None, reqs, 0)
+    assert picks[0] == 0 and scores[0] == 1.5
+    # LoRA tiers: pod0 active, pod1 free slot, pod2 full + waiting, request for adapter 5
+    pods["max_lora"] = [1, 4, 1]
+    pods["active"][0, 0] = 1 << 5
+    pods["active"][2, 0] = 1 << 9
+    pods["waiting"][2, 0] = 1 << 5
+    r5 = pkg.picker.make_req_rows(np.array([5]), np.array([0]), None, 0)
+    assert np.array_equal(orc.score_row([(L, 10)], pods, None, r5[0]), [10.0, 8.0, 6.0])
+    # base-model request: in neither set -> free slot 0.8, else 0.0
+    assert np.array_equal(orc.score_row([(L, 10)], pods, None, reqs[0]), [0.0, 8.0, 0.0])
+    # prefix: 4 blocks; pod0 holds blocks 0,1,2 ; pod1 holds 0 ; pod2 holds 0,1,3 (block 3 never reached: block 2 set = {0})
+    oix = orc.OracleIndex()
+    oix.insert([11, 12, 13, 11, 11, 12, 14], [0, 0, 0, 1, 2, 2, 2])
+    rp = pkg.picker.make_req_rows(np.array([-1]), np.array([4]), np.array([[11, 12, 13, 99]], dtype=np.uint64), 4)
+    assert np.array_equal(orc.score_row([(PF, 4)], pods, oix, rp[0]), [3.0, 1.0, 2.0])
+    # interior gap: pod2 misses block 2 but the walk continues while ANY pod has the block; 14 at position 3
+    rp2 = pkg.picker.make_req_rows(np.array([-1]), np.array([4]), np.array([[11, 12, 13, 14]], dtype=np.uint64), 4)
+    assert np.array_equal(orc.score_row([(PF, 4)], pods, oix, rp2[0]), [3.0, 1.0, 3.0])
+    # clamp: kv_util > 1 -> score < 0 -> 0 ; kv_util < 0 -> score > 1 -> 1 ; NaN -> 0
+    pods["kv_util"] = [1.5, -0.5, np.nan]
+    assert np.array_equal(orc.score_row([(KV, 3)], pods, None, reqs[0]), [0.0, 3.0, 0.0])
+
+
+def test_index_semantics(orc):
+    ix = orc.OracleIndex()
+    ix.insert([5, 5, 5, 7], [3, 1, 3, 2])          # set semantics, sorted
+    assert ix.lookup(5).tolist() == [1, 3] and ix.lookup(7).tolist() == [2] and ix.lookup(9).size == 0
+    assert ix.size() == 2
+    ix.remove_pod(2)
+    assert ix.lookup(7).size == 0 and ix.size() == 1   # empty set behaves as absent
+
+
+def test_golden_vectors_regenerate_identically(tmp_path):
+    """The committed fixture is exactly what the committed script produces."""
+    pytest.importorskip("xxhash")
+    import importlib.util
+    import shutil
+    src = os.path.join(os.path.dirname(GOLD), "gen_golden.py")
+    dst = tmp_path / "gen_golden.py"
+    shutil.copy(src, dst)
+    spec = importlib.util.spec_from_file_location("gen_golden_tmp", dst)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
+    a, b = np.load(GOLD), np.load(tmp_path / "cases.npz")
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        x, y = a[k], b[k]
+        assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes(), k

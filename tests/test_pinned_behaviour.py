@@ -1,0 +1,107 @@
+"""CPU: the behaviour the reference DOES pin — round-robin picking and the subset filter — restated
+case by case from pkg/lwepp/handlers/request_test.go and checked on both the oracle and libeppk's
+host functions (through the C ABI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def eps(pkg, *pairs):
+    return [pkg.picker.Endpoint(a, p) for a, p in pairs]
+
+
+def cands(pkg, orc, endpoints, filt):
+    """Candidate addresses per the library and per the oracle (must agree)."""
+    mask, n = pkg.picker.subset_mask(endpoints, filt)
+    omask, on = orc.subset_mask([e.address for e in endpoints], [e.port for e in endpoints], filt)
+    assert n == on and np.array_equal(mask, omask)
+    sel = [e for i, e in enumerate(endpoints) if (int(mask[i >> 6]) >> (i & 63)) & 1]
+    assert len(sel) == n
+    return sel
+
+
+def test_round_robin_alternates_and_wraps(pkg, orc):
+    # request_test.go:50-88 — two pods: req1 != req2, req3 == req1
+    endpoints = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"))
+    rr = pkg.picker.RoundRobinPicker()
+    r1, r2, r3 = (rr.Pick(None, endpoints).endpoint for _ in range(3))
+    assert r1 != r2 and r3 == r1
+    # server.go:95-96 — pre-increment: the first pick on a fresh counter is index 1 % len
+    assert r1 == "10.0.0.2:8080"
+    ctr = C.c_uint64(0)
+    assert [orc.round_robin(ctr, 2) for _ in range(4)] == [1, 0, 1, 0]
+    ctr = C.c_uint64(2**64 - 1)                       # uint64 wrap-around of the counter
+    assert orc.round_robin(ctr, 3) == 0 and ctr.value == 0
+
+
+def test_round_robin_no_endpoints_is_unavailable(pkg, orc):
+    # server.go:91-93 / request_test.go:117-130
+    with pytest.raises(pkg.picker.Unavailable):
+        pkg.picker.RoundRobinPicker().Pick(None, [])
+    assert orc.round_robin(C.c_uint64(0), 0) == -1
+
+
+def test_filter_via_header_single_ip(pkg, orc):
+    # request_test.go:90-115 — header "10.0.0.2" selects exactly that pod
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"), ("10.0.0.3", "8080"))
+    assert [x.address for x in cands(pkg, orc, e, "10.0.0.2")] == ["10.0.0.2"]
+
+
+def test_filter_via_metadata_list_and_string(pkg, orc):
+    # request_test.go:132-203
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"), ("10.0.0.3", "8080"))
+    assert [x.address for x in cands(pkg, orc, e, "10.0.0.3:8080")] == ["10.0.0.3"]
+    assert [x.address for x in cands(pkg, orc, e, "10.0.0.2:8080,10.0.0.3:8080")] == ["10.0.0.2", "10.0.0.3"]
+
+
+def test_no_subset_returns_all_pods(pkg, orc):
+    # request_test.go:281-333 (no metadata / unrelated key) — filter absent
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"))
+    assert len(cands(pkg, orc, e, None)) == 2
+
+
+def test_empty_or_non_matching_subset_fails_closed(pkg, orc):
+    # request_test.go:335-369 (empty list) and :407-439 (no match): zero candidates, never fail open
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"))
+    assert cands(pkg, orc, e, "") == []
+    assert cands(pkg, orc, e, "192.168.1.1:8080") == []
+
+
+def test_whitespace_and_mixed_list_elements(pkg, orc):
+    # request_test.go:371-405 and :441-479
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.2", "8080"), ("10.0.0.3", "8080"))
+    assert [x.address for x in cands(pkg, orc, e, "  10.0.0.2:8080 ,  ,  10.0.0.3:8080  ")] == ["10.0.0.2", "10.0.0.3"]
+    assert [x.address for x in cands(pkg, orc, e, "10.0.0.2:8080, 10.0.0.3:8080")] == ["10.0.0.2", "10.0.0.3"]
+
+
+@pytest.mark.parametrize("filt,want", [
+    ("10.0.0.1:8080", [("10.0.0.1", "8080")]),                                              # specific port only
+    ("10.0.0.1", [("10.0.0.1", "8080"), ("10.0.0.1", "9090")]),                             # ip-only: all ports
+    ("10.0.0.1:8080,10.0.0.2", [("10.0.0.1", "8080"), ("10.0.0.2", "8080"), ("10.0.0.2", "9090")]),
+    ("10.0.0.1:3000", []),                                                                  # no matching port
+])
+def test_port_aware_filtering_table(pkg, orc, filt, want):
+    # request_test.go:481-551
+    e = eps(pkg, ("10.0.0.1", "8080"), ("10.0.0.1", "9090"), ("10.0.0.2", "8080"), ("10.0.0.2", "9090"))
+    assert [(x.address, x.port) for x in cands(pkg, orc, e, filt)] == want
+
+
+def test_split_host_port_edge_cases(pkg, orc):
+    # net.SplitHostPort acceptance as used at request.go:110: bracketed IPv6 parses, bare IPv6 is ip-only
+    e = eps(pkg, ("::1", "80"), ("::1", "81"), ("fe80::2", "80"))
+    assert [(x.address, x.port) for x in cands(pkg, orc, e, "[::1]:80")] == [("::1", "80")]
+    assert [(x.address, x.port) for x in cands(pkg, orc, e, "::1")] == [("::1", "80"), ("::1", "81")]
+    assert cands(pkg, orc, e, "[::1]") == [] and cands(pkg, orc, e, "[::1]x:80") == []
+
+
+def test_pick_result_endpoint_format(pkg):
+    # server.go:98-100 / server_test.go:59-121 — exact "ip:port" bytes; IPv6 is bracketed by JoinHostPort
+    assert pkg.picker.join_host_port("10.0.0.1", "8080") == "10.0.0.1:8080"
+    assert pkg.picker.join_host_port("::1", "80") == "[::1]:80"
+
+
+def test_many_pods_mask_words(pkg, orc):
+    e = [pkg.picker.Endpoint(f"10.0.{i // 256}.{i % 256}", "8000") for i in range(200)]
+    sel = cands(pkg, orc, e, "10.0.0.5,10.0.0.130:8000, 10.0.0.199:9")
+    assert [x.address for x in sel] == ["10.0.0.5", "10.0.0.130"]
