@@ -1,0 +1,301 @@
+// eppk_host.hpp — C++ host side above the C ABI, mirroring the reference's picker / scheduler interfaces
+// for this path (the reference is Go; no Go toolchain in this image, so its compiled-code host side is
+// written in C++ — the Go twin is in INTEGRATION.md).
+//
+// Mirrored reference shapes (same names, argument meaning, error behaviour):
+//   Endpoint                pkg/lwepp/datastore/datastore.go:40-46
+//   PickRequest/PickResult  pkg/lwepp/handlers/server.go:65-77
+//   EndpointPicker.Pick     pkg/lwepp/handlers/server.go:79-82    (goroutine-safe, one call per request)
+//   RoundRobinPicker        pkg/lwepp/handlers/server.go:84-101
+//   Scorer/WeightedScorer/SchedulerProfile/Picker
+//                           docs/proposals/0845-scheduler-architecture-proposal/interfaces/interface.go:70-142
+//   error codes             codes.Unavailable (server.go:91-93), codes.Internal (server.go:143-146)
+//
+// GpuPicker turns concurrent per-request Pick() calls into batches for eppk_pick_batch (one fused HIP
+// kernel per batch) and FAILS OPEN to RoundRobinPicker on any backend error (a GPU
+// picker must never take the stream down).  Nothing here scores on the CPU.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/eppk.h"
+
+namespace eppk_host {
+
+// ---- reference data shapes -------------------------------------------------------------------------
+
+struct Endpoint {  // datastore.go:40-46
+  std::string namespaced_name, pod_name, address, port;
+  std::map<std::string, std::string> labels;
+};
+
+struct PickRequest {  // server.go:65-69
+  std::map<std::string, std::vector<std::string>> headers;
+  std::string body;
+  std::string model;  // TargetModel: base model or LoRA adapter name
+};
+
+struct PickResult {  // server.go:72-77
+  std::string endpoint;  // "ip:port"
+  std::vector<std::string> fallbacks;
+};
+
+enum class Code { OK = 0, Unavailable = 14, Internal = 13 };  // grpc codes used by the reference
+struct Status {
+  Code code = Code::OK;
+  std::string message;
+  bool ok() const { return code == Code::OK; }
+};
+
+inline std::string JoinHostPort(const std::string& host, const std::string& port) {  // net.JoinHostPort, server.go:99
+  if (host.find(':') != std::string::npos || host.find('%') != std::string::npos) return "[" + host + "]:" + port;
+  return host + ":" + port;
+}
+
+class EndpointPicker {  // server.go:79-82
+ public:
+  virtual ~EndpointPicker() = default;
+  virtual Status Pick(const PickRequest& req, const std::vector<const Endpoint*>& endpoints, PickResult* out) = 0;
+};
+
+class RoundRobinPicker : public EndpointPicker {  // server.go:84-101
+ public:
+  Status Pick(const PickRequest&, const std::vector<const Endpoint*>& endpoints, PickResult* out) override {
+    const int32_t idx = eppk_round_robin(&rr_index_, (uint32_t)endpoints.size());
+    if (idx < 0) return {Code::Unavailable, "no endpoints available"};
+    out->endpoint = JoinHostPort(endpoints[(size_t)idx]->address, endpoints[(size_t)idx]->port);
+    out->fallbacks.clear();
+    return {};
+  }
+
+ private:
+  uint64_t rr_index_ = 0;
+};
+
+// ---- scheduler profile (interface.go:70-79, :132-135) ------------------------------------------------
+
+struct WeightedScorer {  // WeightedScorer{Scorer, weight int}
+  eppk_scorer_kind kind;
+  int32_t weight;
+};
+
+struct SchedulerProfile {             // filters: the candidate subset; picker: best-score, lowest index on ties
+  std::vector<WeightedScorer> scorers;  // order fixes the fp summation order (SEMANTICS.md §2)
+};
+
+// ---- backend seam: the C ABI, or a fake in CPU-only tests ---------------------------------------------
+
+class Backend {
+ public:
+  virtual ~Backend() = default;
+  virtual int Publish(const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) = 0;
+  virtual int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) = 0;
+  virtual std::string LastError() const = 0;
+};
+
+class LibEppkBackend : public Backend {  // include/eppk.h
+ public:
+  static std::unique_ptr<LibEppkBackend> Create(const eppk_cfg& cfg, std::string* err) {
+    eppk_ctx* c = nullptr;
+    if (eppk_create(&cfg, &c) != EPPK_OK) { if (err) *err = eppk_last_error(nullptr); return nullptr; }
+    return std::unique_ptr<LibEppkBackend>(new LibEppkBackend(c));
+  }
+  ~LibEppkBackend() override { eppk_destroy(ctx_); }
+  int Publish(const eppk_pod_row* rows, uint32_t n, uint64_t epoch) override { return eppk_snapshot_publish(ctx_, rows, n, epoch); }
+  int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
+    return eppk_pick_batch(ctx_, reqs, n, mask, picks, scores);
+  }
+  std::string LastError() const override { return eppk_last_error(ctx_); }
+  eppk_ctx* ctx() { return ctx_; }
+
+ private:
+  explicit LibEppkBackend(eppk_ctx* c) : ctx_(c) {}
+  eppk_ctx* ctx_;
+};
+
+// ---- GpuPicker: EndpointPicker over batched picks -------------------------------------------------------
+
+struct GpuPickerOptions {
+  uint32_t max_pods = 4096, max_blocks = 32, max_batch = 4096, block_chars = 64;
+  std::chrono::microseconds window{200};  // how long the dispatcher waits to fill a batch
+};
+
+class GpuPicker : public EndpointPicker {
+ public:
+  GpuPicker(std::unique_ptr<Backend> backend, const GpuPickerOptions& opt)
+      : be_(std::move(backend)), opt_(opt), stride_(8u + 8u * opt.max_blocks), th_([this] { Loop(); }) {}
+  ~GpuPicker() override {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_.notify_all();
+    th_.join();
+  }
+
+  // Publish the frozen snapshot: endpoints[i] is candidate index i and carries rows[i]'s gauges.
+  // adapters: LoRA adapter name -> id (0..127); any other model name is the base model.
+  Status PublishSnapshot(const std::vector<Endpoint>& endpoints, const std::vector<eppk_pod_row>& rows,
+                         const std::unordered_map<std::string, int32_t>& adapters, uint64_t epoch) {
+    if (endpoints.size() != rows.size()) return {Code::Internal, "endpoints/rows size mismatch"};
+    auto snap = std::make_shared<Snapshot>();
+    snap->endpoints = endpoints;
+    snap->adapters = adapters;
+    for (size_t i = 0; i < endpoints.size(); ++i) snap->by_addr[JoinHostPort(endpoints[i].address, endpoints[i].port)] = (uint32_t)i;
+    std::lock_guard<std::mutex> bg(be_mu_);  // serialised with the dispatcher's PickBatch (contexts are single-caller)
+    if (be_->Publish(rows.data(), (uint32_t)rows.size(), epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
+    std::lock_guard<std::mutex> g(mu_);
+    snap_ = snap;
+    return {};
+  }
+
+  // server.go:79-82 — safe to call from many threads; returns when this request's batch has been picked.
+  Status Pick(const PickRequest& req, const std::vector<const Endpoint*>& endpoints, PickResult* out) override {
+    if (endpoints.empty()) return {Code::Unavailable, "no endpoints available"};  // server.go:91-93
+    Slot slot;
+    slot.req = &req;
+    slot.cands = &endpoints;
+    std::unique_lock<std::mutex> g(mu_);
+    queue_.push_back(&slot);
+    cv_.notify_all();
+    done_cv_.wait(g, [&] { return slot.done; });
+    g.unlock();
+    if (slot.fail_open) {  // backend error: never take the stream down, fall back to the reference picker
+      fail_open_count_.fetch_add(1, std::memory_order_relaxed);
+      return rr_.Pick(req, endpoints, out);
+    }
+    if (slot.pick < 0) return {Code::Unavailable, "no endpoints available"};
+    out->endpoint = slot.endpoint;
+    out->fallbacks.clear();
+    return {};
+  }
+
+  uint64_t batches() const { return batches_.load(); }
+  uint64_t fail_opens() const { return fail_open_count_.load(); }
+  uint64_t largest_batch() const { return largest_batch_.load(); }
+
+ private:
+  struct Snapshot {
+    std::vector<Endpoint> endpoints;
+    std::unordered_map<std::string, uint32_t> by_addr;
+    std::unordered_map<std::string, int32_t> adapters;
+  };
+  struct Slot {
+    const PickRequest* req = nullptr;
+    const std::vector<const Endpoint*>* cands = nullptr;
+    bool done = false, fail_open = false;
+    int32_t pick = -1;
+    std::string endpoint;
+  };
+
+  void Loop() {
+    std::vector<Slot*> batch;
+    std::vector<uint8_t> rows;
+    std::vector<uint64_t> mask;
+    std::vector<int32_t> picks;
+    std::vector<double> scores;
+    std::unique_lock<std::mutex> g(mu_);
+    for (;;) {
+      cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
+      if (stop_ && queue_.empty()) return;
+      if (queue_.size() < opt_.max_batch && !stop_)  // give concurrent callers a moment to join the batch
+        cv_.wait_for(g, opt_.window, [&] { return stop_ || queue_.size() >= opt_.max_batch; });
+      const size_t n = queue_.size() < opt_.max_batch ? queue_.size() : opt_.max_batch;
+      batch.assign(queue_.begin(), queue_.begin() + (long)n);
+      queue_.erase(queue_.begin(), queue_.begin() + (long)n);
+      g.unlock();  // row building and the kernel run without the queue lock
+      bool failed = false;
+      {
+        // be_mu_ serialises the context (include/eppk.h: one caller per context) and pins the snapshot:
+        // the endpoint table read here is the one the device scores against.
+        std::lock_guard<std::mutex> bg(be_mu_);
+        std::shared_ptr<Snapshot> snap;
+        { std::lock_guard<std::mutex> sg(mu_); snap = snap_; }
+        failed = !snap;
+        if (!failed) {
+          const uint32_t P = (uint32_t)snap->endpoints.size(), W = (P + 63u) / 64u;
+          rows.assign(n * stride_, 0);
+          bool any_mask = false;
+          mask.assign(n * (size_t)(W ? W : 1), 0);
+          for (size_t i = 0; i < n; ++i) {
+            const PickRequest& rq = *batch[i]->req;
+            eppk_req_hdr hdr;
+            auto it = snap->adapters.find(rq.model);
+            hdr.adapter = it == snap->adapters.end() ? EPPK_ADAPTER_BASE : it->second;
+            int nb = eppk_hash_prompt((const uint8_t*)rq.model.data(), rq.model.size(), (const uint8_t*)rq.body.data(), rq.body.size(),
+                                      opt_.block_chars, (uint64_t*)(rows.data() + i * stride_ + 8), opt_.max_blocks);
+            hdr.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
+            std::memcpy(rows.data() + i * stride_, &hdr, sizeof hdr);
+            // candidate slice -> bitmask over snapshot indices (the subset filter already ran: request.go:104-133)
+            uint32_t found = 0;
+            for (const Endpoint* e : *batch[i]->cands) {
+              auto a = snap->by_addr.find(JoinHostPort(e->address, e->port));
+              if (a == snap->by_addr.end()) continue;  // candidate unknown to this snapshot: not scoreable
+              const uint64_t bit = 1ull << (a->second & 63u);
+              if (!(mask[i * W + (a->second >> 6)] & bit)) ++found;
+              mask[i * W + (a->second >> 6)] |= bit;
+            }
+            if (found != P) any_mask = true;
+          }
+          picks.resize(n);
+          scores.resize(n);
+          const int rc = be_->PickBatch(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data());
+          failed = rc != EPPK_OK;
+          if (!failed)
+            for (size_t i = 0; i < n; ++i) {
+              batch[i]->pick = picks[i];  // Slot fields other than `done` are read by the owner only after `done`
+              if (picks[i] >= 0) {
+                const Endpoint& e = snap->endpoints[(size_t)picks[i]];
+                batch[i]->endpoint = JoinHostPort(e.address, e.port);
+              }
+            }
+        }
+      }
+      g.lock();
+      for (Slot* s : batch) { s->fail_open = failed; s->done = true; }
+      batches_.fetch_add(1);
+      if (n > largest_batch_.load()) largest_batch_.store(n);
+      done_cv_.notify_all();
+    }
+  }
+
+  std::unique_ptr<Backend> be_;
+  GpuPickerOptions opt_;
+  size_t stride_;
+  RoundRobinPicker rr_;
+  std::mutex mu_;     // queue + snap_ pointer
+  std::mutex be_mu_;  // backend context + snapshot consistency; always taken BEFORE mu_
+  std::condition_variable cv_, done_cv_;
+  std::vector<Slot*> queue_;
+  std::shared_ptr<Snapshot> snap_;
+  bool stop_ = false;
+  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0};
+  std::thread th_;  // last member: started after everything above is constructed
+};
+
+inline eppk_cfg MakeCfg(const SchedulerProfile& profile, const GpuPickerOptions& opt, uint32_t index_slots, int device) {
+  eppk_cfg cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.device = device;
+  cfg.max_pods = opt.max_pods;
+  cfg.max_blocks = opt.max_blocks;
+  cfg.max_batch = opt.max_batch;
+  cfg.index_slots = index_slots;
+  cfg.n_scorers = (uint32_t)profile.scorers.size();
+  for (size_t k = 0; k < profile.scorers.size() && k < EPPK_MAX_SCORERS; ++k) {
+    cfg.chain[k].kind = (uint32_t)profile.scorers[k].kind;
+    cfg.chain[k].weight = profile.scorers[k].weight;
+  }
+  return cfg;
+}
+
+}  // namespace eppk_host

@@ -1,0 +1,223 @@
+// test_host.cpp — exercises the C++ host mirror (eppk_host.hpp).
+//   ./test_host cpu   : fake backend, no GPU — batching, concurrency, fail-open, Unavailable, masks, round robin
+//   ./test_host gpu   : real libeppk backend on device 0 — concurrent Pick() through the batcher must equal
+//                       a direct eppk_pick_batch on the same rows (oracle parity of the kernel: tests/test_gpu_parity.py)
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "eppk_host.hpp"
+
+using namespace eppk_host;
+
+#define CHECK(cond)                                                                                              \
+  do {                                                                                                           \
+    if (!(cond)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } \
+  } while (0)
+
+// Fake backend: pick = lowest candidate index whose queue gauge is minimal (enough to see masks and snapshots work).
+class FakeBackend : public Backend {
+ public:
+  int Publish(const eppk_pod_row* rows, uint32_t n, uint64_t) override { rows_.assign(rows, rows + n); return EPPK_OK; }
+  int PickBatch(const void*, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
+    calls++;
+    if (fail) return EPPK_ERR_DEVICE;
+    const uint32_t P = (uint32_t)rows_.size(), W = (P + 63u) / 64u;
+    for (uint32_t r = 0; r < n; ++r) {
+      int32_t best = -1;
+      for (uint32_t p = 0; p < P; ++p) {
+        if (mask && !((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u)) continue;
+        if (best < 0 || rows_[p].queue < rows_[(size_t)best].queue) best = (int32_t)p;
+      }
+      picks[r] = best;
+      scores[r] = 0.0;
+    }
+    return EPPK_OK;
+  }
+  std::string LastError() const override { return "fake failure"; }
+  std::vector<eppk_pod_row> rows_;
+  std::atomic<int> calls{0};
+  std::atomic<bool> fail{false};
+};
+
+static std::vector<Endpoint> make_endpoints(int n) {
+  std::vector<Endpoint> v;
+  for (int i = 0; i < n; ++i) {
+    Endpoint e;
+    e.address = "10.0.0." + std::to_string(i + 1);
+    e.port = "8080";
+    v.push_back(e);
+  }
+  return v;
+}
+
+static int run_cpu() {
+  {  // RoundRobinPicker: request_test.go:50-88 and server.go:91-96
+    auto eps = make_endpoints(2);
+    std::vector<const Endpoint*> c{&eps[0], &eps[1]};
+    RoundRobinPicker rr;
+    PickResult r1, r2, r3;
+    CHECK(rr.Pick({}, c, &r1).ok() && rr.Pick({}, c, &r2).ok() && rr.Pick({}, c, &r3).ok());
+    CHECK(r1.endpoint != r2.endpoint && r1.endpoint == r3.endpoint && r1.endpoint == "10.0.0.2:8080");
+    CHECK(rr.Pick({}, {}, &r1).code == Code::Unavailable);
+    CHECK(JoinHostPort("::1", "80") == "[::1]:80");
+  }
+  auto fake = new FakeBackend();
+  GpuPickerOptions opt;
+  opt.max_pods = 64;
+  opt.max_blocks = 4;
+  opt.max_batch = 32;
+  opt.window = std::chrono::microseconds(2000);
+  GpuPicker gp(std::unique_ptr<Backend>(fake), opt);
+  auto eps = make_endpoints(5);
+  std::vector<eppk_pod_row> rows(5);
+  std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+  const uint32_t q[5] = {9, 3, 7, 1, 5};
+  for (int i = 0; i < 5; ++i) rows[(size_t)i].queue = q[i];
+  std::vector<const Endpoint*> all;
+  for (auto& e : eps) all.push_back(&e);
+
+  // before any snapshot: fail open to round robin (never an error to the stream)
+  PickResult pr;
+  CHECK(gp.Pick({}, all, &pr).ok() && gp.fail_opens() == 1);
+  CHECK(gp.PublishSnapshot(eps, rows, {{"adapter-a", 3}}, 1).ok());
+
+  // all candidates -> min queue is pod 3; subset {0,2} -> pod 2; empty candidate slice -> Unavailable
+  CHECK(gp.Pick({}, all, &pr).ok() && pr.endpoint == "10.0.0.4:8080");
+  std::vector<const Endpoint*> sub{&eps[0], &eps[2]};
+  CHECK(gp.Pick({}, sub, &pr).ok() && pr.endpoint == "10.0.0.3:8080");
+  CHECK(gp.Pick({}, {}, &pr).code == Code::Unavailable);
+  Endpoint stranger;
+  stranger.address = "192.168.0.1";
+  stranger.port = "1";
+  std::vector<const Endpoint*> unknown{&stranger};  // candidates unknown to the snapshot: no scoreable endpoint
+  CHECK(gp.Pick({}, unknown, &pr).code == Code::Unavailable);
+
+  // concurrency: 16 threads x 200 picks are batched (fewer backend calls than picks), all correct
+  const int before = fake->calls.load();
+  std::vector<std::thread> th;
+  std::atomic<int> bad{0};
+  for (int t = 0; t < 16; ++t)
+    th.emplace_back([&, t] {
+      for (int i = 0; i < 200; ++i) {
+        PickResult r;
+        const bool use_sub = ((t + i) & 1) != 0;
+        Status s = gp.Pick({}, use_sub ? sub : all, &r);
+        if (!s.ok() || r.endpoint != (use_sub ? "10.0.0.3:8080" : "10.0.0.4:8080")) bad++;
+      }
+    });
+  for (auto& x : th) x.join();
+  CHECK(bad.load() == 0);
+  const int calls = fake->calls.load() - before;
+  CHECK(calls < 3200 && gp.largest_batch() > 1 && gp.largest_batch() <= 32);
+
+  // backend failure: every request still gets an endpoint from the round-robin fallback
+  fake->fail = true;
+  const uint64_t fo = gp.fail_opens();
+  CHECK(gp.Pick({}, all, &pr).ok() && !pr.endpoint.empty() && gp.fail_opens() == fo + 1);
+  fake->fail = false;
+  CHECK(gp.Pick({}, all, &pr).ok() && pr.endpoint == "10.0.0.4:8080");
+  std::printf("host cpu ok: %d backend calls for 3200 concurrent picks, largest batch %llu\n", calls,
+              (unsigned long long)gp.largest_batch());
+  return 0;
+}
+
+static int run_gpu() {
+  SchedulerProfile prof;
+  prof.scorers = {{EPPK_SCORER_QUEUE, 2}, {EPPK_SCORER_KV, 2}, {EPPK_SCORER_LORA, 1}, {EPPK_SCORER_PREFIX, 3}};
+  GpuPickerOptions opt;
+  opt.max_pods = 256;
+  opt.max_blocks = 8;
+  opt.max_batch = 512;
+  opt.window = std::chrono::microseconds(500);
+  eppk_cfg cfg = MakeCfg(prof, opt, 1024, 0);
+  std::string err;
+  auto be = LibEppkBackend::Create(cfg, &err);
+  if (!be) {
+    std::fprintf(stderr, "create failed: %s\n", err.c_str());
+    return 1;
+  }
+  eppk_ctx* ctx = be->ctx();
+  const int P = 200;
+  auto eps = make_endpoints(P);
+  for (int i = 0; i < P; ++i) eps[(size_t)i].address = "10.1.0." + std::to_string(i);
+  std::vector<eppk_pod_row> rows((size_t)P);
+  std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int i = 0; i < P; ++i) {
+    rows[(size_t)i].queue = (uint32_t)(rnd() % 16);
+    rows[(size_t)i].kv_util = (double)(rnd() % 1025) / 1024.0;
+    rows[(size_t)i].max_lora = 4;
+    rows[(size_t)i].active[0] = 1ull << (rnd() % 8);
+  }
+  // prompts: 6 shared system prompts; cache prompt g (for its adapter) on pods {g, g+10, g+20}
+  std::vector<std::string> sys;
+  for (int g = 0; g < 6; ++g) sys.push_back(std::string(256, (char)('a' + g)));
+  std::unordered_map<std::string, int32_t> adapters;
+  for (int a = 0; a < 8; ++a) adapters["adapter-" + std::to_string(a)] = a;
+  GpuPicker gp(std::move(be), opt);
+  CHECK(gp.PublishSnapshot(eps, rows, adapters, 1).ok());
+  for (int g = 0; g < 6; ++g) {
+    const std::string model = "adapter-" + std::to_string(g);
+    uint64_t h[8];
+    int n = eppk_hash_prompt((const uint8_t*)model.data(), model.size(), (const uint8_t*)sys[(size_t)g].data(), sys[(size_t)g].size(), 64, h, 8);
+    CHECK(n == 4);
+    for (int pod : {g, g + 10, g + 20})
+      for (int i = 0; i < n; ++i) {
+        uint32_t pp = (uint32_t)pod;
+        CHECK(eppk_index_insert(ctx, &h[i], &pp, 1) == EPPK_OK);
+      }
+  }
+  std::vector<const Endpoint*> all;
+  for (auto& e : eps) all.push_back(&e);
+
+  // direct batch = ground truth for the batcher plumbing
+  const int N = 384;
+  std::vector<PickRequest> reqs((size_t)N);
+  std::vector<uint8_t> rowsbuf((size_t)N * 72, 0);
+  for (int i = 0; i < N; ++i) {
+    const int g = i % 6;
+    PickRequest& rq = reqs[(size_t)i];
+    rq.model = (i % 5 == 0) ? "base" : "adapter-" + std::to_string(g);
+    rq.body = sys[(size_t)g] + std::string(128, (char)('0' + i % 10)) + std::to_string(i) + std::string(100, 'z');
+    eppk_req_hdr hdr;
+    auto it = adapters.find(rq.model);
+    hdr.adapter = it == adapters.end() ? -1 : it->second;
+    int nb = eppk_hash_prompt((const uint8_t*)rq.model.data(), rq.model.size(), (const uint8_t*)rq.body.data(), rq.body.size(), 64,
+                              (uint64_t*)(rowsbuf.data() + (size_t)i * 72 + 8), 8);
+    hdr.n_blocks = (uint32_t)nb;
+    std::memcpy(rowsbuf.data() + (size_t)i * 72, &hdr, 8);
+  }
+  std::vector<int32_t> want((size_t)N);
+  std::vector<double> sc((size_t)N);
+  CHECK(eppk_pick_batch(ctx, rowsbuf.data(), (uint32_t)N, nullptr, want.data(), sc.data()) == EPPK_OK);
+  int prefix_wins = 0;
+  for (int i = 0; i < N; ++i) {
+    const int g = i % 6, w = want[(size_t)i];
+    if (i % 5 != 0 && (w == g || w == g + 10 || w == g + 20)) prefix_wins++;
+  }
+
+  std::vector<std::string> got((size_t)N);
+  std::vector<std::thread> th;
+  for (int t = 0; t < 8; ++t)
+    th.emplace_back([&, t] {
+      for (int i = t; i < N; i += 8) {
+        PickResult r;
+        Status s = gp.Pick(reqs[(size_t)i], all, &r);
+        got[(size_t)i] = s.ok() ? r.endpoint : "ERR";
+      }
+    });
+  for (auto& t : th) t.join();
+  for (int i = 0; i < N; ++i) CHECK(got[(size_t)i] == JoinHostPort(eps[(size_t)want[(size_t)i]].address, "8080"));
+  CHECK(gp.fail_opens() == 0 && gp.batches() < (uint64_t)N);
+  CHECK(prefix_wins > 0);
+  std::printf("host gpu ok: %d concurrent picks in %llu batches equal the direct batch; %d picks landed on a prefix-cached pod\n", N,
+              (unsigned long long)gp.batches(), prefix_wins);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const std::string mode = argc > 1 ? argv[1] : "cpu";
+  return mode == "gpu" ? run_gpu() : run_cpu();
+}
