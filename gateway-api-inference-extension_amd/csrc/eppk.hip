@@ -341,10 +341,10 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     while ((1u << lg) < c->slots) ++lg;
     c->shift = 64u - lg;
     c->limit = c->slots / 2u;  // load factor <= 0.5
-    CHK(hipMalloc((void**)&c->keys, (size_t)c->slots * 8u));
-    CHK(hipMalloc(&c->bitmaps, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes));
-    CHK(hipMemset(c->keys, 0, (size_t)c->slots * 8u));
-    CHK(hipMemset(c->bitmaps, 0, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes));
+    CHK(hipMalloc((void**)&c->keys, ((size_t)c->slots + 2u) * 8u));
+    CHK(hipMalloc(&c->bitmaps, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes));
+    CHK(hipMemset(c->keys, 0, ((size_t)c->slots + 2u) * 8u));
+    CHK(hipMemset(c->bitmaps, 0, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes));
   }
   CHK(hipDeviceSynchronize());
 #undef CHK
@@ -481,8 +481,8 @@ int eppk_index_clear(eppk_ctx* c) {
   if (!c) return EPPK_ERR_ARG;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipMemsetAsync(c->keys, 0, (size_t)c->slots * 8u, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, ((size_t)c->slots + 1u) * 64u * (size_t)c->lw_bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->keys, 0, ((size_t)c->slots + 2u) * 8u, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
@@ -543,10 +543,10 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (pod >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_remove_pod: pod >= max_pods");
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  const uint32_t rows = c->slots + 1u, threads = 256, grid = (rows + threads - 1) / threads;
+  const uint32_t rows = c->slots + 2u, threads = 256, grid = (rows * 64u + threads - 1) / threads;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->bitmaps, rows, pod);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, pod);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());

@@ -29,6 +29,7 @@ namespace eppk {
 constexpr uint32_t kNotFound = 0xFFFFFFFFu;
 constexpr uint32_t kNoPod = 0xFFFFFFFFu;
 constexpr uint64_t kHomeMul = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t kTomb = ~0ull;           // key of a slot whose pod set became empty (never matches, never reused)
 constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots: stats[4 + 2*wave + {0,1}]
 
 // ---- kernel argument blocks (plain structs, passed by value) --------------------------------
@@ -48,8 +49,9 @@ struct KSnap {
 };
 
 struct KIndex {
-  const uint64_t* keys;    // [slots]; 0 = empty.  hash 0 lives in the extra slot `slots`
-  const void*     bitmaps; // [slots+1][64] LW
+  const uint64_t* keys;    // [slots+2]; 0 = empty, ~0 = tombstone; keys[slots], keys[slots+1] = presence of hashes 0 / ~0.
+                           // Invariant: a key that is present has a NON-EMPTY row.
+  const void*     bitmaps; // [slots+3][64] LW: rows slots / slots+1 hold hashes 0 / ~0, row slots+2 is all-zero
   uint32_t slots;          // power of two (0 = no index)
   uint32_t shift;          // 64 - log2(slots)
 };
@@ -80,7 +82,8 @@ __device__ __forceinline__ double clamp01(double s) {
 // Look one hash up; returns its slot or kNotFound.  Linear probing; the table is never full.
 __device__ __forceinline__ uint32_t probe(const KIndex& ix, uint64_t h, bool active) {
   if (!active || ix.slots == 0) return kNotFound;
-  if (h == 0) return ix.slots;
+  if (h == 0) return ix.keys[ix.slots] ? ix.slots : kNotFound;             // reserved hashes: presence words
+  if (h == kTomb) return ix.keys[ix.slots + 1u] ? ix.slots + 1u : kNotFound;
   uint32_t s = home_slot(h, ix.shift);
   const uint32_t mask = ix.slots - 1;
   for (uint32_t n = 0; n < ix.slots; ++n) {
@@ -176,12 +179,25 @@ __device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t
 }
 
 // ---- carry-save counting ---------------------------------------------------------------------
-// Full adder on bit vectors: sum = a^b^c (v_xor3), carry = maj(a,b,c) = bfi(a^b, c, a) (v_bfi).
+// Full adder on bit vectors: x = a^b, sum = x^c, carry = maj(a,b,c) = bfi(x, c, a) — 3 VALU ops per 32 bits.
+// hipcc does not form v_bfi_b32 from the C expression here (it emits and/and/or), hence the asm.
+__device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t x, uint32_t y) {  // (m & x) | (~m & y)
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(x), "v"(y));
+  return r;
+}
+template <typename LW>
+__device__ __forceinline__ LW bfi(LW m, LW x, LW y) {
+  if constexpr (sizeof(LW) == 8)
+    return ((uint64_t)bfi32((uint32_t)(m >> 32), (uint32_t)(x >> 32), (uint32_t)(y >> 32)) << 32) | bfi32((uint32_t)m, (uint32_t)x, (uint32_t)y);
+  else
+    return (LW)bfi32((uint32_t)m, (uint32_t)x, (uint32_t)y);
+}
 template <typename LW>
 __device__ __forceinline__ void full_add(LW a, LW b, LW c, LW& sum, LW& carry) {
   const LW x = a ^ b;
   sum = x ^ c;
-  carry = (LW)((x & c) | ((LW)~x & a));
+  carry = bfi<LW>(x, c, a);
 }
 template <typename LW>
 __device__ __forceinline__ void half_add(LW a, LW b, LW& sum, LW& carry) {
@@ -211,13 +227,17 @@ __device__ __forceinline__ void planes_add8(LW (&c)[NPL], const LW (&w)[8]) {
   for (int k = 4; k < NPL; ++k) { half_add<LW>(c[k], carry, t, carry); c[k] = t; }
 }
 
-// The prefix walk, lean form: `h0` is this lane's hash of the first 64-block chunk (prefetched),
-// all keys of a chunk are probed in parallel, rows are fetched 8 at a time and counted with the
-// carry-save tree.  nz accumulates the union of the counted rows (= pods with matched > 0).
+// The prefix walk, lean form.  `h0` is this lane's hash of the first 64-block chunk (prefetched); all keys of
+// a chunk are probed in parallel; rows are fetched 8 at a time, unconditionally (lanes past the last hit
+// point at the all-zero row slots+2), and counted with the carry-save tree.  Relies on the index
+// invariant "present key => non-empty row" (tombstones + presence words, index_remove_pod_kernel), so no
+// per-row emptiness test is needed.
+// nz accumulates the union of the counted rows (= pods with matched > 0).
 template <typename LW, int NPL>
 __device__ __forceinline__ uint32_t prefix_walk_csa(const KIndex& ix, const uint64_t* hs, uint64_t h0, uint32_t nb, int lane,
                                                     LW (&c)[NPL], LW& nz) {
   const LW* bm = (const LW*)ix.bitmaps;
+  const uint32_t zrow = ix.slots + 2u;
   uint32_t hits = 0;
   bool stop = false;
   for (uint32_t b0 = 0; b0 < nb && !stop; b0 += 64) {
@@ -228,32 +248,18 @@ __device__ __forceinline__ uint32_t prefix_walk_csa(const KIndex& ix, const uint
     const unsigned long long found = __ballot(slot != kNotFound);
     const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
     const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);  // leading found
-    for (uint32_t k0 = 0; k0 < m && !stop; k0 += 8) {
+    const uint32_t slot_eff = ((uint32_t)lane < m) ? slot : zrow;
+    for (uint32_t k0 = 0; k0 < m; k0 += 8) {   // k0 + 7 <= 63
       LW w[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const uint32_t k = k0 + (uint32_t)u;
-        const uint32_t s = __builtin_amdgcn_readlane(slot, (k < m) ? k : 0);
-        w[u] = (k < m) ? bm[(size_t)s * 64u + (uint32_t)lane] : (LW)0;
-      }
-      // rows at and after the first EMPTY row (key present, pod set empty) do not count
-      const uint32_t nrow = (m - k0) < 8u ? (m - k0) : 8u;
-      uint32_t good = 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool nonempty = __ballot(w[u] != 0) != 0ull;
-        if ((uint32_t)u == good && (uint32_t)u < nrow && nonempty) ++good;
-      }
-      if (good < nrow) {
-        stop = true;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if ((uint32_t)u >= good) w[u] = 0;
+        const uint32_t s = __builtin_amdgcn_readlane(slot_eff, k0 + (uint32_t)u);
+        w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
       }
       planes_add8<LW, NPL>(c, w);
       nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
-      hits += good;
     }
+    hits += m;
     if (m < chunk) stop = true;
   }
   return hits;
@@ -616,8 +622,9 @@ template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift,
                                                  uint32_t limit, unsigned long long* stats, uint64_t h, uint32_t pod) {
   uint32_t slot = kNotFound;
-  if (h == 0) {
-    slot = slots;
+  if (h == 0 || h == kTomb) {
+    slot = h == 0 ? slots : slots + 1u;
+    __hip_atomic_store((unsigned long long*)&keys[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     uint32_t s = home_slot(h, shift);
     const uint32_t mask = slots - 1;
@@ -658,13 +665,22 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
   index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, ((const uint64_t*)(row + 8))[i], (uint32_t)pick);
 }
 
-// clear pod's bit in every row: one thread per slot
+// Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
+// meets a present key with an empty pod set.  One wavefront per row (rows = slots + 2: the reserved rows too).
 template <typename LW>
-__global__ void index_remove_pod_kernel(void* bitmaps, uint32_t rows, uint32_t pod) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= rows) return;
-  LW* w = (LW*)bitmaps + (size_t)s * 64u + (pod & 63u);
-  *w = (LW)(*w & (LW)~((LW)1 << (pod >> 6)));
+__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t pod) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= slots + 2u) return;
+  LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
+  LW v = *w;
+  if (lane == (pod & 63u)) {
+    const LW nv = (LW)(v & (LW)~((LW)1 << (pod >> 6)));
+    if (nv != v) *w = nv;
+    v = nv;
+  }
+  const bool empty = __ballot(v != 0) == 0ull;
+  if (empty && lane == 0 && keys[row] != 0ull) keys[row] = row < slots ? kTomb : 0ull;  // reserved rows: clear presence
 }
 
 }  // namespace eppk

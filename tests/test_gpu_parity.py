@@ -104,3 +104,63 @@ def test_small_pod_counts_table_holds_every_pod(pkg, orc):
     for P in (1, 2, 17, 64):
         wl = pkg.workload.make_workload(3, R=128, P=P, pods_per_group=64)   # every pod is in M for most requests
         assert_same(*run_both(pkg, orc, wl, max_pods=1024))
+
+
+def test_index_remove_pod_and_reserved_hashes(pkg, orc):
+    """Tombstones (rows emptied by remove_pod behave as absent) and the reserved hashes 0 / ~0."""
+    Q, KV, L, PF = 1, 2, 3, 4
+    P, B = 130, 6
+    pods = pkg.workload.make_pods(99, P, 128)
+    rng = np.random.default_rng(3)
+    # chains built from reserved and ordinary hashes
+    H0, HF = np.uint64(0), np.uint64(0xFFFFFFFFFFFFFFFF)
+    chains = np.array([[H0, 5, 6, 7, 8, 9], [HF, H0, 11, 12, 13, 14], [21, 22, HF, 24, 25, 26], [31, H0, HF, 34, 35, 36]], dtype=np.uint64)
+    hashes = chains[rng.integers(0, 4, 200)]
+    reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, 200), np.full(200, B), hashes, B)
+    ih = np.concatenate([np.repeat(chains[g], 3) for g in range(4)])
+    ip = np.concatenate([np.tile(np.array([g, g + 64, g + 100], dtype=np.uint32), B) for g in range(4)])
+    chain = [(KV, 1), (PF, 5)]
+    with pkg.BatchedPicker(chain, max_pods=1024, max_blocks=B, max_batch=256, index_slots=256) as pk:
+        pk.publish(pods)
+        pk.index_insert(ih, ip)
+        oix = orc.OracleIndex()
+        oix.insert(ih, ip)
+        for step in range(4):
+            picks, scores = pk.pick(reqs)
+            op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert_same(picks, scores, op, osc)
+            # remove the pods of group `step` one after another: rows become empty -> keys tombstoned
+            for pod in (step, step + 64, step + 100):
+                pk.index_remove_pod(pod)
+                oix.remove_pod(pod)
+        picks, scores = pk.pick(reqs)
+        op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+        assert_same(picks, scores, op, osc)
+        # re-insert after tombstoning: the chain must be found again
+        pk.index_insert(ih[:18], ip[:18])
+        oix.insert(ih[:18], ip[:18])
+        picks, scores = pk.pick(reqs)
+        op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+        assert_same(picks, scores, op, osc)
+
+
+def test_insert_picks_post_pass_matches_oracle(pkg, orc):
+    """SEMANTICS.md §6: after a batch, index[hash[r][i]] ∪= {pick[r]} — device post-pass vs oracle, then re-pick."""
+    import torch
+    wl = pkg.workload.make_workload(3, R=512, P=600)
+    with pkg.BatchedPicker(wl.chain, max_pods=1024, max_blocks=wl.B, max_batch=wl.R, index_slots=1 << 16) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        oix = orc.OracleIndex()
+        oix.insert(wl.index_hashes, wl.index_pods)
+        d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).cuda()
+        d_pick = torch.empty(wl.R, dtype=torch.int32, device="cuda")
+        d_score = torch.empty(wl.R, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            pk.pick_device(d_reqs.data_ptr(), wl.R, None, d_pick.data_ptr(), d_score.data_ptr())
+            pk.index_insert_picks_device(d_reqs.data_ptr(), d_pick.data_ptr(), wl.R)
+            torch.cuda.synchronize()
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+            assert_same(d_pick.cpu().numpy(), d_score.cpu().numpy(), op, osc)
+            oix.insert_picks(wl.reqs, wl.B, op)
+        assert pk.index_size() == oix.size()
