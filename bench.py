@@ -60,6 +60,9 @@ def main() -> None:
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json config number (1-based); 5 = headline")
     ap.add_argument("--requests", type=int, default=None, help="override requests per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold-cache index variant)")
+    ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
+    ap.add_argument("--host-path", type=int, default=0, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H)")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +83,8 @@ def main() -> None:
 
     pkg = graft.load_package()
     # replicated snapshot + index (seed of the config), this rank's own request shard (weak scaling)
-    wl = pkg.workload.make_workload(args.config, R=args.requests, req_seed=(0x5EED0000 + args.config) ^ (0xA5A5 * rank) if rank else None)
+    wl = pkg.workload.make_workload(args.config, R=args.requests, req_seed=(0x5EED0000 + args.config) ^ (0xA5A5 * rank) if rank else None,
+                                    n_groups=args.groups, zipf_s=args.zipf)
     R = wl.R
     pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots, device=local_rank)
     pk.publish(wl.pods)
@@ -130,7 +134,7 @@ def main() -> None:
 
     if rank == 0:
         out = {
-            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if args.config == 5 and args.requests is None else f"routing decisions/sec ({wl.name})",
+            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if args.config == 5 and args.requests is None and args.groups == 256 else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf})",
             "value": world * R * args.steps / elapsed,
             "unit": "decisions/s",
             "n_gpus": world,
@@ -152,11 +156,12 @@ def main() -> None:
         avg_ms = float(k.mean()) if k.size else float("nan")
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if k.size else float("nan")
         traffic = None
+        kname = "pick_fast_kernel" if (wl.mask is None) else "pick_generic_kernel"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured separately with rocprofv3 --pmc
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == wl.name:
+                if tj.get("workload") == wl.name and args.groups == 256 and args.zipf == 1.0:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -165,6 +170,17 @@ def main() -> None:
                            "kernel_p99_ms": float(np.percentile(k, 99)) if k.size else None,
                            "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lookups / max(launches, 1)}
         out["config"]["p99_step_ms"] = out["roofline"]["kernel_p99_ms"]
+        if args.host_path and world == 1:
+            # host-observed pick latency: request rows in host memory -> pinned staging -> H2D -> kernel -> D2H (PCIe-inclusive;
+            # never `value`)
+            lat = []
+            for _ in range(args.host_path):
+                t0 = time.perf_counter()
+                pk.pick(wl.reqs)
+                lat.append(time.perf_counter() - t0)
+            lat = np.asarray(lat[2:] or lat) * 1e3
+            out["host_path"] = {"batches": int(lat.size), "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                                "decisions_per_s_p50": R / (float(np.percentile(lat, 50)) * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()
             cb, opicks, oscores = cpu_baseline(pkg, wl, orc)

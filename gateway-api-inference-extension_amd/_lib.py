@@ -43,7 +43,8 @@ class Cfg(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeppk.so")
+    # EPPK_LIB: development override used by scripts/ab.sh to A/B kernel variants
+    return os.environ.get("EPPK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeppk.so")
 
 
 _LIB = None

@@ -57,6 +57,8 @@ struct eppk_ctx {
   bool has_l = false, has_p = false, p_first = false;
   KTail tail{};
   KChain kchain{};
+  double* pterm = nullptr;  // device [(B+1)*(B+1)] exact prefix terms (fast path, max_blocks <= 64)
+  uint32_t pterm_ld = 0;
 
   // snapshot (double buffered: a publish never overwrites the rows an in-flight pick reads)
   SnapBuf snap[2];
@@ -127,6 +129,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.base = s.base; k.queue = s.queue; k.kv = s.kv;
   k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
   k.topv = s.topv; k.topi = s.topi;
+  k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
   return k;
@@ -333,6 +336,16 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc((void**)&c->snap[b].topv, 129u * 64u * 8u));
     CHK(hipMalloc((void**)&c->snap[b].topi, 129u * 64u * 4u));
   }
+  if (c->canonical && c->has_p && cfg->max_blocks >= 1 && cfg->max_blocks <= 64) {
+    // pterm[n][cnt] = clamp01((double)cnt / (double)n) * (double)w_prefix — the oracle's operations, done once here
+    const uint32_t ld = cfg->max_blocks + 1u;
+    std::vector<double> tab((size_t)ld * ld, 0.0);
+    for (uint32_t n = 1; n <= cfg->max_blocks; ++n)
+      for (uint32_t cnt = 0; cnt <= n; ++cnt) tab[(size_t)n * ld + cnt] = h_clamp01((double)cnt / (double)n) * c->tail.wp;
+    CHK(hipMalloc((void**)&c->pterm, tab.size() * 8u));
+    CHK(hipMemcpy(c->pterm, tab.data(), tab.size() * 8u, hipMemcpyHostToDevice));
+    c->pterm_ld = ld;
+  }
   CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
   CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
   if (cfg->index_slots) {
@@ -361,7 +374,7 @@ void eppk_destroy(eppk_ctx* c) {
     (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t);
     (void)hipFree(c->snap[b].topv); (void)hipFree(c->snap[b].topi);
   }
-  (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats);
+  (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);

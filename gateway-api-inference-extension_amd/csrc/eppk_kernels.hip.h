@@ -24,6 +24,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Build-time tuning knobs (A/B-tested on MI355X; defaults are the measured best — DESIGN.md §7)
+#ifndef EPPK_PIPE
+#define EPPK_PIPE 0      // 2-stage software pipeline (probe request r+1 while the rows of r are in flight): measured neutral, costs 20 VGPRs
+#endif
+#ifndef EPPK_ROWS2
+#define EPPK_ROWS2 0     // keep two 8-row batches (16 loads) in flight instead of one
+#endif
+#ifndef EPPK_PTERM_TAB
+#define EPPK_PTERM_TAB 1 // prefix term of a matched pod from the exact host-built table instead of an f64 division
+#endif
+#ifndef EPPK_MIN_WAVES
+#define EPPK_MIN_WAVES 1 // __launch_bounds__ minimum waves per SIMD for the fast kernel
+#endif
+
 namespace eppk {
 
 constexpr uint32_t kNotFound = 0xFFFFFFFFu;
@@ -43,6 +57,8 @@ struct KSnap {
   const void*     free_t;  // [64] LW     loaded < max_lora
   const double*   topv;    // [129][64] per adapter row (128 = base model): the 64 best pods by
   const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
+  const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
+  uint32_t pterm_ld;
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
@@ -227,44 +243,6 @@ __device__ __forceinline__ void planes_add8(LW (&c)[NPL], const LW (&w)[8]) {
   for (int k = 4; k < NPL; ++k) { half_add<LW>(c[k], carry, t, carry); c[k] = t; }
 }
 
-// The prefix walk, lean form.  `h0` is this lane's hash of the first 64-block chunk (prefetched); all keys of
-// a chunk are probed in parallel; rows are fetched 8 at a time, unconditionally (lanes past the last hit
-// point at the all-zero row slots+2), and counted with the carry-save tree.  Relies on the index
-// invariant "present key => non-empty row" (tombstones + presence words, index_remove_pod_kernel), so no
-// per-row emptiness test is needed.
-// nz accumulates the union of the counted rows (= pods with matched > 0).
-template <typename LW, int NPL>
-__device__ __forceinline__ uint32_t prefix_walk_csa(const KIndex& ix, const uint64_t* hs, uint64_t h0, uint32_t nb, int lane,
-                                                    LW (&c)[NPL], LW& nz) {
-  const LW* bm = (const LW*)ix.bitmaps;
-  const uint32_t zrow = ix.slots + 2u;
-  uint32_t hits = 0;
-  bool stop = false;
-  for (uint32_t b0 = 0; b0 < nb && !stop; b0 += 64) {
-    const uint32_t i = b0 + (uint32_t)lane;
-    const bool act = i < nb;
-    const uint64_t h = (b0 == 0) ? h0 : (act ? hs[i] : 0);
-    const uint32_t slot = probe(ix, h, act);
-    const unsigned long long found = __ballot(slot != kNotFound);
-    const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
-    const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);  // leading found
-    const uint32_t slot_eff = ((uint32_t)lane < m) ? slot : zrow;
-    for (uint32_t k0 = 0; k0 < m; k0 += 8) {   // k0 + 7 <= 63
-      LW w[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t s = __builtin_amdgcn_readlane(slot_eff, k0 + (uint32_t)u);
-        w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
-      }
-      planes_add8<LW, NPL>(c, w);
-      nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
-    }
-    hits += m;
-    if (m < chunk) stop = true;
-  }
-  return hits;
-}
-
 template <int NPL>
 __device__ __forceinline__ uint32_t planes_get(const uint32_t (&c32)[NPL], uint32_t jj) {
   uint32_t cnt = 0;
@@ -310,8 +288,10 @@ __device__ __forceinline__ LW valid_word(uint32_t n_pods, int lane) {
 //   4. merges both under (score desc, index asc).
 // If all 64 table entries are in M (a prefix cached almost everywhere) step 2 becomes a scan of T_a
 // over the pods outside M (same arithmetic, base[] read from global memory).
-// No LDS and few registers: occupancy and memory-level parallelism are what this kernel lives on;
-// the next request's row is prefetched while the current one is processed.
+//
+// No LDS and few registers: occupancy and memory-level parallelism are what this kernel lives on.
+// The request loop is a 2-stage software pipeline: while the rows of request r are in flight the keys
+// of request r+1 are probed, and the row of request r+2 is prefetched.
 
 template <bool HAS_L, bool HAS_P, bool P_FIRST>
 __device__ __forceinline__ double eval_total(double base, double lterm, double pterm) {
@@ -331,8 +311,27 @@ __device__ __forceinline__ double tier_term(const KTail& tl, uint32_t tier) {
   return tier == 3u ? tl.lw[3] : tier == 2u ? tl.lw[2] : tier == 1u ? tl.lw[1] : tl.lw[0];
 }
 
+// Stage 1 of a request: probe the keys of one 64-block chunk in parallel.  Returns the number m of leading
+// hits; slot_eff[lane k] = row of hit k for k < m, the all-zero row otherwise.
+__device__ __forceinline__ uint32_t probe_chunk(const KIndex& ix, uint64_t h, uint32_t nchunk, int lane, uint32_t& slot_eff) {
+  const uint32_t slot = probe(ix, h, (uint32_t)lane < nchunk);
+  const unsigned long long found = __ballot(slot != kNotFound);
+  const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);
+  slot_eff = ((uint32_t)lane < m) ? slot : ix.slots + 2u;
+  return m;
+}
+
+template <typename LW>
+__device__ __forceinline__ void load_rows8(const LW* bm, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[8]) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint32_t s = __builtin_amdgcn_readlane(slot_eff, k0 + (uint32_t)u);
+    w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
+  }
+}
+
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
-__global__ __launch_bounds__(256) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+__global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                         unsigned long long* __restrict__ stats) {
@@ -341,58 +340,115 @@ __global__ __launch_bounds__(256) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
   const uint32_t wpb = blockDim.x >> 6;
   const uint32_t gwave = blockIdx.x * wpb + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * wpb;
+  const LW* bm = (const LW*)ix.bitmaps;
 
   const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   unsigned long long w_hits = 0, w_lookups = 0;
-
-  // software prefetch of the next request's header word and first 64 hashes
   const uint32_t hwords = (stride - 8u) / 8u < 64u ? (stride - 8u) / 8u : 64u;
+
+  // ---- pipeline prologue: request r is probed, request r+nwaves is prefetched
   uint32_t r = gwave;
-  uint64_t nx_hdr = 0, nx_h = 0;
-  if (r < n_reqs) {
+  if (r >= n_reqs) return;
+  int32_t adapter;
+  uint32_t nb, m0 = 0, slot0 = 0;
+  uint64_t cur_h = 0;  // non-pipelined build: hashes of the current request
+  {
     const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)r * stride);
-    nx_hdr = row64[0];
-    nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;   // independent of the header: no wait
+    const uint64_t hdr = row64[0];
+    const uint64_t h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
+    adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)hdr);
+    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(hdr >> 32));
+    if (HAS_P && EPPK_PIPE) m0 = probe_chunk(ix, h, nb < 64u ? nb : 64u, lane, slot0);
+    cur_h = h;
   }
+  uint64_t nx_hdr = 0, nx_h = 0;
+  if (r + nwaves < n_reqs) {
+    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(r + nwaves) * stride);
+    nx_hdr = row64[0];
+    nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
+  }
+
   for (; r < n_reqs; r += nwaves) {
-    const uint8_t* row = reqs + (size_t)r * stride;
-    const uint64_t hdr = nx_hdr;
-    const uint64_t h0 = nx_h;
-    const int32_t adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)hdr);
-    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(hdr >> 32));
-    {
-      const uint32_t rn = r + nwaves;
-      if (rn < n_reqs) {
-        const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)rn * stride);
+    // ---- A. issue everything the current request needs that is already addressable
+    LW w[8];
+#if EPPK_ROWS2
+    LW w2[8];
+#endif
+    if (HAS_P && !EPPK_PIPE) m0 = probe_chunk(ix, cur_h, nb < 64u ? nb : 64u, lane, slot0);
+    if (HAS_P && m0 > 0) load_rows8<LW>(bm, slot0, 0, lane, w);
+#if EPPK_ROWS2
+    if (HAS_P && m0 > 8) load_rows8<LW>(bm, slot0, 8, lane, w2);
+#endif
+    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+    const double top_t = sn.topv[(size_t)arow * 64u + (uint32_t)lane];
+    const uint32_t top_p = sn.topi[(size_t)arow * 64u + (uint32_t)lane];
+    LW thi = 0, tlo = 0;  // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 waiting, 2: 0.8 free slot, 3: 1.0 active}
+    if (HAS_L) {
+      LW a = 0, wt = 0;
+      if (adapter >= 0) {
+        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
+        wt = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
+      }
+      thi = a | freew;
+      tlo = a | ((LW)~freew & wt);
+    }
+
+    // ---- B. stage 1 of the NEXT request (its row was prefetched one iteration ago), overlapping the loads above
+    const uint32_t rn = r + nwaves;
+    int32_t adapter_n = -1;
+    uint32_t nb_n = 0, m_n = 0, slot_n = 0;
+    if (rn < n_reqs) {
+      adapter_n = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)nx_hdr);
+      nb_n = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(nx_hdr >> 32));
+      if (HAS_P && EPPK_PIPE) m_n = probe_chunk(ix, nx_h, nb_n < 64u ? nb_n : 64u, lane, slot_n);
+      cur_h = nx_h;
+      if (rn + nwaves < n_reqs) {  // prefetch the row after next
+        const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(rn + nwaves) * stride);
         nx_hdr = row64[0];
         nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
       }
     }
 
-    // loads that do not depend on the index walk go first
-    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    const double top_t = sn.topv[(size_t)arow * 64u + (uint32_t)lane];
-    const uint32_t top_p = sn.topi[(size_t)arow * 64u + (uint32_t)lane];
-    // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 (waiting), 2: 0.8 (free slot), 3: 1.0 (active)}
-    LW thi = 0, tlo = 0;
-    if (HAS_L) {
-      LW a = 0, w = 0;
-      if (adapter >= 0) {
-        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
-        w = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
-      }
-      thi = a | freew;
-      tlo = a | ((LW)~freew & w);
-    }
-
-    // prefix walk -> bit-sliced matched counts; nz = M (pods with matched > 0)
+    // ---- C. stage 2 of the current request: count rows, evaluate, pick
     LW c[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) c[k] = 0;
-    LW nz = 0;
+    LW nz = 0;  // M: pods with matched > 0
     if (HAS_P) {
-      const uint32_t hits = prefix_walk_csa<LW, NPL>(ix, (const uint64_t*)(row + 8), h0, nb, lane, c, nz);
+      uint32_t hits = m0;
+      if (m0 > 0) {
+        planes_add8<LW, NPL>(c, w);
+        nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
+#if EPPK_ROWS2
+        if (m0 > 8) {
+          planes_add8<LW, NPL>(c, w2);
+          nz |= (LW)(w2[0] | w2[1] | w2[2] | w2[3] | w2[4] | w2[5] | w2[6] | w2[7]);
+        }
+        for (uint32_t k0 = 16; k0 < m0; k0 += 8) {
+#else
+        for (uint32_t k0 = 8; k0 < m0; k0 += 8) {
+#endif
+          load_rows8<LW>(bm, slot0, k0, lane, w);
+          planes_add8<LW, NPL>(c, w);
+          nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
+        }
+      }
+      // chunks beyond the first 64 blocks (only when every earlier key hit); not pipelined
+      uint32_t mlast = m0;
+      for (uint32_t b0 = 64; b0 < nb && mlast == 64u; b0 += 64) {
+        const uint64_t* hs = (const uint64_t*)(reqs + (size_t)r * stride + 8);
+        const uint32_t nchunk = (nb - b0) < 64u ? (nb - b0) : 64u;
+        const uint64_t h = ((uint32_t)lane < nchunk) ? hs[b0 + (uint32_t)lane] : 0ull;
+        uint32_t slotc;
+        mlast = probe_chunk(ix, h, nchunk, lane, slotc);
+        for (uint32_t k0 = 0; k0 < mlast; k0 += 8) {
+          load_rows8<LW>(bm, slotc, k0, lane, w);
+          planes_add8<LW, NPL>(c, w);
+          nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
+        }
+        hits += mlast;
+      }
       if (stats) { w_hits += hits; w_lookups += (hits + 1u < nb) ? hits + 1u : nb; }
       nz &= valid;
     }
@@ -439,7 +495,9 @@ __global__ __launch_bounds__(256) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
 #pragma unroll
           for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
           const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-          const double pterm = clamp01((double)cnt / (double)nb) * tl.wp;   // cnt > 0 implies nb > 0
+          // cnt > 0 implies nb > 0.  pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table when
+          // there is one (max_blocks <= 64), else one binary64 division here.
+          const double pterm = (EPPK_PTERM_TAB && sn.pterm) ? sn.pterm[(size_t)nb * sn.pterm_ld + cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
           const double t = eval_total<HAS_L, HAS_P, P_FIRST>(sn.base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
           if (t > best) { best = t; bidx = p; }
         }
@@ -466,6 +524,9 @@ __global__ __launch_bounds__(256) void pick_fast_kernel(KSnap sn, KIndex ix, KTa
       out_pick[r] = none ? -1 : (int32_t)bidx;
       if (out_score) out_score[r] = none ? 0.0 : best;
     }
+
+    // ---- rotate the pipeline
+    adapter = adapter_n; nb = nb_n; m0 = m_n; slot0 = slot_n;
   }
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)

@@ -106,7 +106,7 @@ def _model_name(adapter: int) -> bytes:
 
 def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None, masked: bool = False,
                   n_groups: int = 256, pods_per_group: int = 8, seed: Optional[int] = None,
-                  req_seed: Optional[int] = None) -> Workload:
+                  req_seed: Optional[int] = None, zipf_s: float = 1.0) -> Workload:
     """Build config `config` of BASELINE.json (optionally with R / P overridden for small parity cases)."""
     c = dict(CONFIGS[config])
     if R is not None:
@@ -121,7 +121,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     pods = make_pods(seed, P, A)
 
     # requests: Zipf(s=1) over shared "system prompt" groups; a group carries its tenant's adapter
-    gw = 1.0 / np.arange(1, n_groups + 1, dtype=np.float64)
+    gw = 1.0 / np.arange(1, n_groups + 1, dtype=np.float64) ** zipf_s   # zipf_s = 0 -> uniform (cold-cache variant)
     cdf = np.cumsum(gw) / gw.sum()
     u = (splitmix64(_sub(rseed, 10), R) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
     group = np.minimum(np.searchsorted(cdf, u, side="right"), n_groups - 1).astype(np.int64)
@@ -178,5 +178,5 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
 
     return Workload(name=c["name"], R=R, P=P, A=A, B=B, chain=[(int(k), int(w)) for k, w in c["chain"]], pods=pods,
                     reqs=reqs, index_hashes=index_hashes, index_pods=index_pods.astype(np.uint32), index_slots=index_slots,
-                    mask=mask, meta=dict(config=config, seed=seed, n_groups=n_groups, pods_per_group=pods_per_group,
+                    mask=mask, meta=dict(config=config, seed=seed, n_groups=n_groups, pods_per_group=pods_per_group, zipf_s=zipf_s,
                                          shared_blocks=Bs, unique_blocks=Bu))
