@@ -96,7 +96,12 @@ def main() -> None:
     d_pick = torch.empty(R, dtype=torch.int32, device=dev)
     d_score = torch.empty(R, dtype=torch.float64, device=dev)
     d_all_holder = [None]
-    stream = torch.cuda.current_stream().cuda_stream
+    # An explicit side stream: the kernel, the RCCL all-gather and the HIP-event brackets are all ordered on it.
+    # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
 
     def step():
         pk.pick_device(d_reqs.data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), stream)

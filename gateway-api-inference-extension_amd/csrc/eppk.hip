@@ -632,6 +632,25 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   return EPPK_OK;
 }
 
+// ---- on-device prompt hashing ------------------------------------------------------------------------
+
+int eppk_hash_prompts_device(eppk_ctx* c, const void* d_prompts, uint64_t prompt_stride, const uint32_t* d_prompt_len,
+                             const uint64_t* d_seed, const int32_t* d_adapter, uint32_t n_reqs, uint32_t block_chars,
+                             void* d_reqs_out, void* stream) {
+  if (!c || ((!d_prompts || !d_prompt_len || !d_seed || !d_adapter || !d_reqs_out) && n_reqs))
+    return fail(c, EPPK_ERR_ARG, "eppk_hash_prompts_device: null argument");
+  if (block_chars == 0 || (block_chars & 7u) || (prompt_stride & 7u) || ((uintptr_t)d_prompts & 7u))
+    return fail(c, EPPK_ERR_ARG, "eppk_hash_prompts_device: block_chars, prompt_stride and the prompt base must be multiples of 8 (use eppk_hash_prompt on the host otherwise)");
+  if (n_reqs == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const uint32_t threads = 64, grid = (n_reqs + threads - 1) / threads;
+  hipLaunchKernelGGL(hash_prompts_kernel, dim3(grid), dim3(threads), 0, st, (const uint8_t*)d_prompts, prompt_stride, d_prompt_len, d_seed,
+                     d_adapter, n_reqs, block_chars, c->cfg.max_blocks, (uint8_t*)d_reqs_out, c->stride);
+  HIPCHK(c, hipGetLastError());
+  return EPPK_OK;
+}
+
 // ---- measurement -----------------------------------------------------------------------------------
 
 int eppk_profile_enable(eppk_ctx* c, int on) {

@@ -663,6 +663,67 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
   }
 }
 
+// ---- on-device prompt hashing (SEMANTICS.md §4; 0602-…/README.md:99) -------------------------------------
+// One thread per request walks its prompt block by block: h[i] = XXH64(block_i || LE64(h[i-1])), seed 0, and
+// writes the complete request row {adapter, n_blocks, h[0..)}.  Blocks are 8-byte multiples (block_chars % 8
+// == 0, prompts 8-byte aligned), so every read is an aligned u64 and the XXH64 tail has no 4-/1-byte steps.
+// The chain is sequential per request and independent across requests; each lane streams its own prompt
+// (64 B per block = one sector per lane per step).  Bound: HBM read of the prompt bytes.
+namespace xxh {
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                   P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+__device__ __forceinline__ uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t round1(uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; }
+__device__ __forceinline__ uint64_t merge(uint64_t h, uint64_t acc) { return (h ^ round1(0, acc)) * P1 + P4; }
+}  // namespace xxh
+
+// XXH64(seed 0) of nw 8-byte words at `w` followed by the single word `last` (total length 8*(nw+1) bytes).
+__device__ __forceinline__ uint64_t xxh64_words_plus(const uint64_t* w, uint32_t nw, uint64_t last) {
+  using namespace xxh;
+  const uint32_t total = nw + 1u;                 // words
+  const uint64_t len = (uint64_t)total * 8u;
+  auto word = [&](uint32_t i) -> uint64_t { return i < nw ? w[i] : last; };
+  uint64_t h;
+  uint32_t i = 0;
+  if (total >= 4u) {
+    uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0ull - P1;
+    for (; i + 4u <= total; i += 4u) {
+      v1 = round1(v1, word(i));
+      v2 = round1(v2, word(i + 1));
+      v3 = round1(v3, word(i + 2));
+      v4 = round1(v4, word(i + 3));
+    }
+    h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+    h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+  } else {
+    h = P5;
+  }
+  h += len;
+  for (; i < total; ++i) h = rotl(h ^ round1(0, word(i)), 27) * P1 + P4;
+  h = (h ^ (h >> 33)) * P2;
+  h = (h ^ (h >> 29)) * P3;
+  return h ^ (h >> 32);
+}
+
+__global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_t prompt_stride, const uint32_t* __restrict__ prompt_len,
+                                    const uint64_t* __restrict__ seeds, const int32_t* __restrict__ adapters, uint32_t n_reqs,
+                                    uint32_t block_chars, uint32_t max_blocks, uint8_t* __restrict__ rows, uint32_t stride) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reqs) return;
+  const uint64_t* p = (const uint64_t*)(prompts + (size_t)r * prompt_stride);
+  const uint32_t wpb = block_chars / 8u;
+  uint32_t nblk = prompt_len[r] / block_chars;
+  if (nblk > max_blocks) nblk = max_blocks;
+  uint64_t prev = seeds[r];
+  uint64_t* out = (uint64_t*)(rows + (size_t)r * stride);
+  for (uint32_t b = 0; b < nblk; ++b) {
+    prev = xxh64_words_plus(p + (size_t)b * wpb, wpb, prev);
+    out[1 + b] = prev;
+  }
+  for (uint32_t b = nblk; b < max_blocks; ++b) out[1 + b] = 0ull;
+  out[0] = (uint64_t)(uint32_t)adapters[r] | ((uint64_t)nblk << 32);
+}
+
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
 // stats[2] = occupied keys, stats[3] = dropped inserts (table at its load limit)
 

@@ -215,6 +215,12 @@ class BatchedPicker:
     def index_insert_picks_device(self, d_reqs: int, d_picks: int, n_reqs: int, stream: int = 0) -> None:
         self._check(self._lib.eppk_index_insert_picks_device(self._ctx, d_reqs, d_picks, n_reqs, stream or None), "index_insert_picks_device")
 
+    def hash_prompts_device(self, d_prompts: int, prompt_stride: int, d_prompt_len: int, d_seed: int, d_adapter: int, n_reqs: int,
+                            block_chars: int, d_reqs_out: int, stream: int = 0) -> None:
+        """Chain-hash a batch of prompts on the device into request rows (device pointers as ints)."""
+        self._check(self._lib.eppk_hash_prompts_device(self._ctx, d_prompts, prompt_stride, d_prompt_len, d_seed, d_adapter, n_reqs,
+                                                       block_chars, d_reqs_out, stream or None), "hash_prompts_device")
+
     def pick_endpoints(self, endpoints: Sequence[Endpoint], reqs: np.ndarray, mask: Optional[np.ndarray] = None) -> List[PickResult]:
         """Batched EndpointPicker.Pick: one PickResult per request; Unavailable if any request has no candidate."""
         if len(endpoints) != self.n_pods:

@@ -160,7 +160,8 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
                     int32_t* out_pick, double* out_score);
 
 /* Same, with every buffer already resident in this device's HBM; asynchronous on `stream`
- * (a hipStream_t passed as void*; NULL = the context's own stream).  No n_reqs limit. */
+ * (a hipStream_t passed as void*; NULL = the context's own NON-BLOCKING stream, which is not ordered against the
+ * legacy default stream — callers that mix this with other GPU work pass their own stream).  No n_reqs limit. */
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
@@ -173,6 +174,19 @@ int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
 int eppk_hash_prompt(const uint8_t* model, size_t model_len, const uint8_t* prompt, size_t prompt_len,
                      uint32_t block_chars, uint64_t* out, uint32_t max_out);
 uint64_t eppk_xxh64(const void* data, size_t len, uint64_t seed);
+
+/* The same chain for a whole batch ON THE DEVICE, writing complete request rows (header + hashes) that
+ * eppk_pick_batch_device consumes — no host hashing on the critical path.
+ *   d_prompts     prompt r at d_prompts + r*prompt_stride (8-byte aligned, prompt_stride % 8 == 0)
+ *   d_prompt_len  u32[n]: bytes of prompt r (<= prompt_stride); only full blocks are hashed
+ *   d_seed        u64[n]: h[-1] of request r = eppk_xxh64(model name) (one host hash per model)
+ *   d_adapter     i32[n]: adapter id or EPPK_ADAPTER_BASE
+ *   block_chars   multiple of 8
+ *   d_reqs_out    n rows of stride 8 + 8*max_blocks
+ * All pointers are device pointers; asynchronous on `stream` (NULL = the context's stream). */
+int eppk_hash_prompts_device(eppk_ctx* ctx, const void* d_prompts, uint64_t prompt_stride, const uint32_t* d_prompt_len,
+                             const uint64_t* d_seed, const int32_t* d_adapter, uint32_t n_reqs, uint32_t block_chars,
+                             void* d_reqs_out, void* stream);
 
 /* Candidate subset filter of handleRequestHeaders (request.go:104-133) as a bitmask builder.
  *   addrs/ports  n_pods C strings: Endpoint.Address / Endpoint.Port (datastore.go:43-44)

@@ -164,3 +164,35 @@ def test_insert_picks_post_pass_matches_oracle(pkg, orc):
             assert_same(d_pick.cpu().numpy(), d_score.cpu().numpy(), op, osc)
             oix.insert_picks(wl.reqs, wl.B, op)
         assert pk.index_size() == oix.size()
+
+
+def test_device_prompt_hashing_matches_host(pkg):
+    """eppk_hash_prompts_device writes the same request rows as the host chain (SEMANTICS.md §4), bit for bit."""
+    import torch
+    rng = np.random.default_rng(11)
+    R, B, BC, stride = 300, 12, 64, 1024
+    prompts = rng.integers(0, 256, (R, stride), dtype=np.uint8)
+    lens = rng.integers(0, stride + 1, R).astype(np.uint32)
+    lens[:4] = [0, 63, 64, stride]                      # no block, just short of one, exactly one, more than max_blocks*64
+    adapters = rng.integers(-1, 128, R).astype(np.int32)
+    lib = pkg.load_library()
+    seeds = np.array([lib.eppk_xxh64(b"adapter-%d" % a, len(b"adapter-%d" % a), 0) if a >= 0 else lib.eppk_xxh64(b"base", 4, 0) for a in adapters], dtype=np.uint64)
+    want = np.zeros((R, 1 + B), dtype=np.uint64)
+    for r in range(R):
+        model = (b"adapter-%d" % adapters[r]) if adapters[r] >= 0 else b"base"
+        h = pkg.picker.hash_prompt(model, prompts[r, :lens[r]].tobytes(), BC, B)
+        want[r, 1:1 + h.size] = h
+        want[r, 0] = np.uint64(np.uint32(adapters[r])) | (np.uint64(h.size) << np.uint64(32))
+    with pkg.BatchedPicker([(2, 1)], max_pods=64, max_blocks=B, max_batch=R) as pk:
+        d_p = torch.from_numpy(prompts).cuda()
+        d_l = torch.from_numpy(lens.view(np.int32)).cuda()
+        d_s = torch.from_numpy(seeds.view(np.int64)).cuda()
+        d_a = torch.from_numpy(adapters).cuda()
+        d_rows = torch.full((R, 1 + B), -1, dtype=torch.int64, device="cuda")
+        pk.hash_prompts_device(d_p.data_ptr(), stride, d_l.data_ptr(), d_s.data_ptr(), d_a.data_ptr(), R, BC, d_rows.data_ptr())
+        torch.cuda.synchronize()
+        got = d_rows.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want)
+        # misaligned block size is rejected, not silently mis-hashed
+        with pytest.raises(pkg.EppkError):
+            pk.hash_prompts_device(d_p.data_ptr(), stride, d_l.data_ptr(), d_s.data_ptr(), d_a.data_ptr(), R, 60, d_rows.data_ptr())
