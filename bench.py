@@ -62,6 +62,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold-cache index variant)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
     ap.add_argument("--host-path", type=int, default=0, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H)")
     args = ap.parse_args()
 
@@ -76,9 +77,13 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the pick has no CPU path (libeppk fails loudly without HIP)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
@@ -93,24 +98,37 @@ def main() -> None:
 
     dev = torch.device("cuda", local_rank)
     d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
-    d_pick = torch.empty(R, dtype=torch.int32, device=dev)
+    # double-buffered picks: the RCCL all-gather of step i (comm stream) overlaps the kernel of step i+1 (compute stream)
+    d_picks = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(2)]
     d_score = torch.empty(R, dtype=torch.float64, device=dev)
-    d_all_holder = [None]
-    # An explicit side stream: the kernel, the RCCL all-gather and the HIP-event brackets are all ordered on it.
+    d_alls = [torch.empty(R * world, dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    # Explicit streams: the kernel and its HIP-event brackets are ordered on `compute`, the collective on `comm`.
     # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
-    stream = side.cuda_stream
+    compute = torch.cuda.Stream(device=dev)
+    comm = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(compute)
+    stream = compute.cuda_stream
     assert stream != 0
+    ev_kernel = [torch.cuda.Event() for _ in range(2)]   # kernel of buffer b finished
+    ev_gather = [torch.cuda.Event() for _ in range(2)]   # all-gather of buffer b finished (buffer reusable)
+    step_no = [0]
 
     def step():
-        pk.pick_device(d_reqs.data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), stream)
-        if world > 1:
-            d_all_holder[0] = pkg.distributed.all_gather_picks(d_pick, R * world, world)
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if use_dist:
+            compute.wait_event(ev_gather[b])             # the previous all-gather out of this buffer is done
+        pk.pick_device(d_reqs.data_ptr(), R, None, d_picks[b].data_ptr(), d_score.data_ptr(), stream)
+        if use_dist:
+            ev_kernel[b].record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_kernel[b])
+                dist.all_gather_into_tensor(d_alls[b], d_picks[b])
+                ev_gather[b].record(comm)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -123,7 +141,7 @@ def main() -> None:
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -131,10 +149,11 @@ def main() -> None:
     abytes, lookups, launches = pk.profile_bytes()
     pk.profile(False)
 
-    picks = d_pick.cpu().numpy()
+    last = (step_no[0] - 1) & 1
+    picks = d_picks[last].cpu().numpy()
     scores = d_score.cpu().numpy()
-    if world > 1:
-        allp = d_all_holder[0].cpu().numpy()
+    if use_dist:
+        allp = d_alls[last].cpu().numpy()
         assert np.array_equal(allp[rank * R:(rank + 1) * R], picks), "all-gather returned a different shard"
 
     if rank == 0:
@@ -153,7 +172,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": wl.name, "requests_per_gpu": R, "pods": wl.P, "adapters": wl.A, "blocks_per_request": wl.B,
                        "chain": "queue:2,kv:2,lora:1,prefix:3" if args.config in (3, 5) else str(wl.chain),
-                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} + all-gather of picks" if world > 1 else "single GPU",
+                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} per rank, RCCL all-gather of picks overlapped with the next kernel" if use_dist else "single GPU",
                        "p99_step_ms": None},
         }
         k = np.asarray(kern_ms, dtype=np.float64)
@@ -193,7 +212,7 @@ def main() -> None:
             out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks)),
                              "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores.view(np.uint64)))}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     pk.close()
