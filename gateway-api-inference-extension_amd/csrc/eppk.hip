@@ -33,6 +33,8 @@ struct SnapBuf {
   void*     act_t = nullptr;
   void*     wait_t = nullptr;
   void*     free_t = nullptr;
+  void*     qmin_t = nullptr;  // [64] LW pods at the global min / max queue depth
+  void*     qmax_t = nullptr;
   double*   topv = nullptr;   // [129][64]
   uint32_t* topi = nullptr;   // [129][64]
 };
@@ -54,6 +56,7 @@ struct eppk_ctx {
   // chain analysis
   bool canonical = false; // [QUEUE|KV]* ++ tail, tail ⊂ {LORA, PREFIX} each at most once
   uint32_t n_lead = 0;
+  bool lead_queue = false;  // a QUEUE scorer is fused into base[]
   bool has_l = false, has_p = false, p_first = false;
   KTail tail{};
   KChain kchain{};
@@ -129,6 +132,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.base = s.base; k.queue = s.queue; k.kv = s.kv;
   k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
   k.topv = s.topv; k.topi = s.topi;
+  k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
@@ -143,13 +147,13 @@ KIndex make_kindex(const eppk_ctx* c) {
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
 
-template <typename LW, int NPL>
+template <typename LW, int NPL, bool MASKED>
 const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first) {
-  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true>
-                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false>;
-  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false>;
-  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false>;
-  return (const void*)pick_fast_kernel<LW, NPL, false, false, false>;
+  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED>
+                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED>;
+  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED>;
+  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED>;
 }
 
 template <typename LW, int NPL>
@@ -157,10 +161,15 @@ const void* generic_kernel_ptr(bool masked) {
   return masked ? (const void*)pick_generic_kernel<LW, NPL, true> : (const void*)pick_generic_kernel<LW, NPL, false>;
 }
 
+template <typename LW, int NPL>
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
+  if (!fast) return generic_kernel_ptr<LW, NPL>(masked);
+  return masked ? fast_kernel_ptr<LW, NPL, true>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false>(c->has_l, c->has_p, c->p_first);
+}
+
 template <typename LW>
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
-  if (c->npl == 6) return fast ? fast_kernel_ptr<LW, 6>(c->has_l, c->has_p, c->p_first) : generic_kernel_ptr<LW, 6>(masked);
-  return fast ? fast_kernel_ptr<LW, 9>(c->has_l, c->has_p, c->p_first) : generic_kernel_ptr<LW, 9>(masked);
+  return c->npl == 6 ? pick_kernel_ptr<LW, 6>(c, fast, masked) : pick_kernel_ptr<LW, 9>(c, fast, masked);
 }
 
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
@@ -174,7 +183,7 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st) {
   const bool masked = d_mask != nullptr;
-  const bool fast = c->canonical && !masked;
+  const bool fast = c->canonical;  // masked batches use the fast kernel's MASKED instantiation
   const void* fn = pick_kernel_ptr(c, fast, masked);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
@@ -213,7 +222,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   uint32_t stride = c->stride, pwn = c->pwn;
   if (fast) {
     KTail tl = c->tail;
-    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_pick, &d_score, &stats};
+    KChain chf = c->kchain;
+    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats};
     HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st));
   } else {
     KChain ch = c->kchain;
@@ -303,6 +313,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   uint32_t lead = 0;
   while (lead < cfg->n_scorers && (cfg->chain[lead].kind == EPPK_SCORER_QUEUE || cfg->chain[lead].kind == EPPK_SCORER_KV)) ++lead;
   c->n_lead = lead;
+  for (uint32_t k = 0; k < lead; ++k) c->lead_queue |= cfg->chain[k].kind == EPPK_SCORER_QUEUE;
   c->canonical = true;
   int nl = 0, np = 0;
   for (uint32_t k = lead; k < cfg->n_scorers; ++k) {
@@ -333,6 +344,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc(&c->snap[b].act_t, lora_bytes));
     CHK(hipMalloc(&c->snap[b].wait_t, lora_bytes));
     CHK(hipMalloc(&c->snap[b].free_t, 64u * (size_t)c->lw_bytes));
+    CHK(hipMalloc(&c->snap[b].qmin_t, 64u * (size_t)c->lw_bytes));
+    CHK(hipMalloc(&c->snap[b].qmax_t, 64u * (size_t)c->lw_bytes));
     CHK(hipMalloc((void**)&c->snap[b].topv, 129u * 64u * 8u));
     CHK(hipMalloc((void**)&c->snap[b].topi, 129u * 64u * 4u));
   }
@@ -371,7 +384,7 @@ void eppk_destroy(eppk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) {
     (void)hipFree(c->snap[b].base); (void)hipFree(c->snap[b].queue); (void)hipFree(c->snap[b].kv);
-    (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t);
+    (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t); (void)hipFree(c->snap[b].qmin_t); (void)hipFree(c->snap[b].qmax_t);
     (void)hipFree(c->snap[b].topv); (void)hipFree(c->snap[b].topi);
   }
   (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
@@ -422,7 +435,7 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
 
   // lane-transposed LoRA sets
   const size_t lw = (size_t)c->lw_bytes;
-  std::vector<uint8_t> act((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), wait((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), freeb(64u * lw, 0);
+  std::vector<uint8_t> act((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), wait((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), freeb(64u * lw, 0), qminb(64u * lw, 0), qmaxb(64u * lw, 0);
   for (uint32_t p = 0; p < n_pods; ++p) {
     const eppk_pod_row& r = rows[p];
     for (uint32_t a = 0; a < EPPK_MAX_ADAPTERS; ++a) {
@@ -430,6 +443,8 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
       if ((r.waiting[a >> 6] >> (a & 63u)) & 1u) set_lane_bit(wait, c->lw_bytes, a, p);
     }
     if (pop128(r.active) + pop128(r.waiting) < r.max_lora) set_lane_bit(freeb, c->lw_bytes, 0, p);
+    if (r.queue == qmin) set_lane_bit(qminb, c->lw_bytes, 0, p);
+    if (r.queue == qmax) set_lane_bit(qmaxb, c->lw_bytes, 0, p);
   }
 
   // per-adapter top-64 tables for the sparse fast path (eppk_kernels.hip.h, FAST pick kernel):
@@ -471,6 +486,8 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   HIPCHK(c, hipMemcpyAsync(s.act_t, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.wait_t, wait.data(), wait.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.free_t, freeb.data(), freeb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.qmin_t, qminb.data(), qminb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.qmax_t, qmaxb.data(), qmaxb.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.topv, topv.data(), topv.size() * 8u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.topi, topi.data(), topi.size() * 4u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

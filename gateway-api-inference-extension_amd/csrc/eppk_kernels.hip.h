@@ -57,6 +57,9 @@ struct KSnap {
   const void*     free_t;  // [64] LW     loaded < max_lora
   const double*   topv;    // [129][64] per adapter row (128 = base model): the 64 best pods by
   const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
+  const void*     qmin_t;  // [64] LW  pods whose queue == qmin / qmax (masked fast path: are the request's
+  const void*     qmax_t;  //          QUEUE normalisers the global ones?)
+  uint32_t        lead_queue;  // the fused leading run contains a QUEUE scorer
   const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
   uint32_t pterm_ld;
   uint32_t n_pods;
@@ -330,9 +333,67 @@ __device__ __forceinline__ void load_rows8(const LW* bm, uint32_t slot_eff, uint
   }
 }
 
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST>
+// Exact evaluation of one request over its CANDIDATES ONLY, every scorer in chain order (the generic kernel's
+// arithmetic), each lane walking the set bits of its candidate word.  Used by the masked fast kernel when the
+// request's QUEUE normalisers differ from the snapshot-wide ones (so base[] / the top tables do not apply);
+// cost is proportional to the candidates per lane — small subsets (the common reason for that case) are cheap.
+template <typename LW, int NPL>
+__device__ __forceinline__ void masked_exact(const KSnap& sn, const KChain& ch, LW cand, const LW (&c)[NPL], LW thi, LW tlo,
+                                             uint32_t nb, int lane, double& best, uint32_t& bidx) {
+  bool has_q = false;
+  for (uint32_t k = 0; k < ch.n; ++k) has_q |= ch.kind[k] == 1u;
+  uint32_t qmin = 0, qmax = 0;
+  if (has_q) {
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    LW rem = cand;
+    while (__any(rem != 0)) {
+      if (rem != 0) {
+        const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
+        rem = (LW)(rem & (LW)(rem - 1));
+        const uint32_t q = sn.queue[j * 64u + (uint32_t)lane];
+        mn = q < mn ? q : mn;
+        mx = q > mx ? q : mx;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t omn = (uint32_t)__shfl_xor((int)mn, off), omx = (uint32_t)__shfl_xor((int)mx, off);
+      mn = omn < mn ? omn : mn;
+      mx = omx > mx ? omx : mx;
+    }
+    qmin = mn; qmax = mx;
+  }
+  const double qden = (double)(qmax - qmin);
+  LW rem = cand;
+  while (__any(rem != 0)) {
+    if (rem != 0) {
+      const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
+      rem = (LW)(rem & (LW)(rem - 1));
+      const uint32_t p = j * 64u + (uint32_t)lane;
+      const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
+      double t = 0.0;
+      for (uint32_t k = 0; k < ch.n; ++k) {
+        double sc;
+        switch (ch.kind[k]) {
+          case 1u: sc = (qmax == qmin) ? 1.0 : (double)(qmax - sn.queue[p]) / qden; break;
+          case 2u: sc = 1.0 - sn.kv[p]; break;
+          case 3u: sc = tier == 3u ? 1.0 : tier == 2u ? 0.8 : tier == 1u ? 0.6 : 0.0; break;
+          default: sc = nb ? (double)cnt / (double)nb : 0.0; break;
+        }
+        t = t + clamp01(sc) * ch.w[k];
+      }
+      if (t > best) { best = t; bidx = p; }
+    }
+  }
+}
+
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED>
 __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                        const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                         unsigned long long* __restrict__ stats) {
   (void)pwn;
@@ -344,6 +405,8 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
 
   const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
+  const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
+  const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
   unsigned long long w_hits = 0, w_lookups = 0;
   const uint32_t hwords = (stride - 8u) / 8u < 64u ? (stride - 8u) / 8u : 64u;
 
@@ -393,6 +456,8 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
       thi = a | freew;
       tlo = a | ((LW)~freew & wt);
     }
+    LW cand = valid;   // Filter: the request's candidate subset (request.go:104-133 as a bitmask), lane-transposed
+    if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
 
     // ---- B. stage 1 of the NEXT request (its row was prefetched one iteration ago), overlapping the loads above
     const uint32_t rn = r + nwaves;
@@ -452,72 +517,85 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
       if (stats) { w_hits += hits; w_lookups += (hits + 1u < nb) ? hits + 1u : nb; }
       nz &= valid;
     }
-    const bool any_m = HAS_P && __any(nz != 0);
-
-    // best pod outside M: first table entry not in M
-    const bool has = top_p != kNoPod;
-    bool in_m = false;
-    if (any_m) {
-      const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
-      LW nzq;
-      if constexpr (sizeof(LW) == 8) {
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)nz, (int)ql);
-        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(nz >> 32), (int)ql);
-        nzq = ((uint64_t)hi << 32) | lo;
-      } else {
-        nzq = (LW)__shfl((int)(uint32_t)nz, (int)ql);
-      }
-      in_m = (nzq >> qj) & 1;
-    }
-    const unsigned long long okm = __ballot(has && !in_m);
-    double cand_t = -__builtin_inf();
-    uint32_t cand_p = kNoPod;
-    bool scan_rest = false;
-    if (okm) {
-      const int f = __builtin_ctzll(okm);
-      cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
-                                __builtin_amdgcn_readlane(__double2loint(top_t), f));
-      cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
-    } else {
-      scan_rest = sn.n_pods > 64u;  // table exhausted although more pods exist
-    }
+    // Masked requests: base[] and the top tables embed the snapshot-wide QUEUE normalisers; they apply iff the
+    // candidates contain a pod at the global minimum and one at the global maximum queue depth.
+    bool exact = false;
+    if (MASKED && sn.lead_queue) exact = !(__any((cand & qminw) != 0) && __any((cand & qmaxw) != 0));
 
     double best = -__builtin_inf();
     uint32_t bidx = kNoPod;
-    if (any_m) {
-      LW rem = nz;
-      while (__any(rem != 0)) {          // each lane walks its own pods of M in ascending order
-        if (rem != 0) {
-          const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
-          rem = (LW)(rem & (LW)(rem - 1));
-          const uint32_t p = j * 64u + (uint32_t)lane;
-          uint32_t cnt = 0;
+    double cand_t = -__builtin_inf();
+    uint32_t cand_p = kNoPod;
+    if (MASKED && exact) {
+      if (__any(cand != 0)) {
+        masked_exact<LW, NPL>(sn, ch, cand, c, thi, tlo, nb, lane, best, bidx);
+        wave_argmax(best, bidx);
+      }
+    } else {
+      const LW mset = MASKED ? (LW)(nz & cand) : nz;         // candidates with a prefix match: evaluated in full
+      const LW okset = (LW)(cand & (LW)~nz);                 // candidates whose total is exactly T_a[p]
+      const bool any_m = HAS_P && __any(mset != 0);
+
+      // best candidate outside M: first table entry in okset
+      const bool has = top_p != kNoPod;
+      bool ok = has;
+      if (MASKED || (HAS_P && __any(nz != 0))) {
+        const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
+        LW okq;
+        if constexpr (sizeof(LW) == 8) {
+          const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)okset, (int)ql);
+          const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(okset >> 32), (int)ql);
+          okq = ((uint64_t)hi << 32) | lo;
+        } else {
+          okq = (LW)__shfl((int)(uint32_t)okset, (int)ql);
+        }
+        ok = has && ((okq >> qj) & 1);
+      }
+      const unsigned long long okm = __ballot(ok);
+      bool scan_rest = false;
+      if (okm) {
+        const int f = __builtin_ctzll(okm);
+        cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
+                                  __builtin_amdgcn_readlane(__double2loint(top_t), f));
+        cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
+      } else {
+        scan_rest = sn.n_pods > 64u && __any(okset != 0);  // table exhausted although eligible pods remain
+      }
+
+      if (any_m) {
+        LW rem = mset;
+        while (__any(rem != 0)) {          // each lane walks its own pods of M in ascending order
+          if (rem != 0) {
+            const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
+            rem = (LW)(rem & (LW)(rem - 1));
+            const uint32_t p = j * 64u + (uint32_t)lane;
+            uint32_t cnt = 0;
 #pragma unroll
-          for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
-          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-          // cnt > 0 implies nb > 0.  pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table when
-          // there is one (max_blocks <= 64), else one binary64 division here.
-          const double pterm = (EPPK_PTERM_TAB && sn.pterm) ? sn.pterm[(size_t)nb * sn.pterm_ld + cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
-          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(sn.base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
-          if (t > best) { best = t; bidx = p; }
+            for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
+            const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+            // cnt > 0 implies nb > 0.  pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table when
+            // there is one (max_blocks <= 64), else one binary64 division here.
+            const double pterm = (EPPK_PTERM_TAB && sn.pterm) ? sn.pterm[(size_t)nb * sn.pterm_ld + cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
+            const double t = eval_total<HAS_L, HAS_P, P_FIRST>(sn.base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
+            if (t > best) { best = t; bidx = p; }
+          }
         }
       }
-    }
-    if (scan_rest) {                      // rare: T_a over every pod outside M (total == T_a there)
-      const LW rest = (LW)(valid & (LW)~nz);
-      double rbest = -__builtin_inf();
-      uint32_t ridx = kNoPod;
-      for (uint32_t j = 0; j < sn.J; ++j) {
-        const uint32_t p = j * 64u + (uint32_t)lane;
-        const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-        double t = sn.base[p];
-        if (HAS_L) t = t + tier_term(tl, tier);
-        const bool ok = (rest >> j) & 1;
-        if (ok && t > rbest) { rbest = t; ridx = p; }
+      if (scan_rest) {                      // rare: T_a over every eligible pod outside M (total == T_a there)
+        double rbest = -__builtin_inf();
+        uint32_t ridx = kNoPod;
+        for (uint32_t j = 0; j < sn.J; ++j) {
+          const uint32_t p = j * 64u + (uint32_t)lane;
+          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+          double t = sn.base[p];
+          if (HAS_L) t = t + tier_term(tl, tier);
+          const bool okp = (okset >> j) & 1;
+          if (okp && t > rbest) { rbest = t; ridx = p; }
+        }
+        if (rbest > best || (rbest == best && ridx < bidx)) { best = rbest; bidx = ridx; }
       }
-      if (rbest > best || (rbest == best && ridx < bidx)) { best = rbest; bidx = ridx; }
+      if (any_m || scan_rest) wave_argmax(best, bidx);
     }
-    if (any_m || scan_rest) wave_argmax(best, bidx);
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     if (lane == 0) {
       const bool none = bidx == kNoPod;

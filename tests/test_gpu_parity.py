@@ -196,3 +196,28 @@ def test_device_prompt_hashing_matches_host(pkg):
         # misaligned block size is rejected, not silently mis-hashed
         with pytest.raises(pkg.EppkError):
             pk.hash_prompts_device(d_p.data_ptr(), stride, d_l.data_ptr(), d_s.data_ptr(), d_a.data_ptr(), R, 60, d_rows.data_ptr())
+
+
+def test_masked_fast_path_corner_cases(pkg, orc):
+    """Masked batches on the sparse kernel: (a) masks that keep the global queue extremes (tables apply),
+    (b) masks that remove every min-queue / max-queue pod (exact per-candidate evaluation, many candidates),
+    (c) masks that remove the whole top of the ranking (table exhausted -> scan of the remaining candidates)."""
+    wl = pkg.workload.make_workload(5, R=384, P=3000, masked=True)
+    P, W = wl.P, (wl.P + 63) // 64
+    q = wl.pods["queue"]
+    bits = np.zeros((wl.R, W * 64), dtype=bool)
+    rng = np.random.default_rng(5)
+    bits[:, :P] = rng.random((wl.R, P)) < 0.6
+    # (b) rows 0..127: drop all pods at the global minimum queue; rows 128..255: drop the global maximum
+    bits[:128, :P] &= (q != q.min())[None, :]
+    bits[128:256, :P] &= (q != q.max())[None, :]
+    # (c) rows 256..: drop the 300 best pods by (queue asc, kv asc) so every adapter's top-64 table is masked out
+    order = np.lexsort((wl.pods["kv_util"], q))
+    bits[256:, order[:1500]] = False
+    bits[300:310, :] = False
+    bits[300:310, 7] = True                       # single candidate
+    mask = np.packbits(bits.reshape(wl.R, W, 64), axis=2, bitorder="little").view(np.uint64).reshape(wl.R, W)
+    assert_same(*run_both(pkg, orc, wl, mask=mask, max_pods=4096))
+    # chains without a QUEUE scorer never need the exact path
+    assert_same(*run_both(pkg, orc, wl, chain=[(2, 3), (3, 2), (4, 5)], mask=mask, max_pods=4096))
+    assert_same(*run_both(pkg, orc, wl, chain=[(4, 5), (3, 2)], mask=mask, max_pods=4096))
