@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -90,6 +91,7 @@ struct eppk_ctx {
   uint32_t launches = 0;
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
+  uint32_t fast_threads = 512;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
 
   std::string err;
 };
@@ -142,6 +144,9 @@ KSnap make_ksnap(const eppk_ctx* c) {
 KIndex make_kindex(const eppk_ctx* c) {
   KIndex k{};
   k.keys = c->keys; k.bitmaps = c->bitmaps; k.slots = c->slots; k.shift = c->shift;
+  const uint64_t tb = ((uint64_t)c->slots + 3u) * 64u * (uint64_t)c->lw_bytes;
+  k.small = (c->slots && tb < (1ull << 32)) ? 1u : 0u;
+  k.table_bytes = k.small ? (uint32_t)tb : 0u;
   return k;
 }
 
@@ -187,9 +192,16 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const void* fn = pick_kernel_ptr(c, fast, masked);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
-  const uint32_t threads = fast ? 256u : 512u, wpb = threads / 64;
-  size_t lds = 0;  // the fast kernel uses no LDS
-  if (!fast) lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
+  const uint32_t threads = fast ? c->fast_threads : 512u, wpb = threads / 64;
+  // fast kernel LDS: base[J*64] f64 + the exact prefix-term table; generic: queue/kv + per-wave ratio tables
+  uint32_t pwn = c->pwn;
+  size_t lds;
+  if (fast) {
+    pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
+    lds = (size_t)sn.J * 64u * 8u + (size_t)pwn * 8u;
+  } else {
+    lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
+  }
   // occupancy-sized persistent grid (cached per kernel/LDS size: these are host calls on the launch path)
   if (fn != c->occ_fn || lds != c->occ_lds) {
     if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -219,7 +231,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     HIPCHK(c, hipEventRecord(e0, st));
   }
   const uint8_t* reqs8 = (const uint8_t*)d_reqs;
-  uint32_t stride = c->stride, pwn = c->pwn;
+  uint32_t stride = c->stride;
   if (fast) {
     KTail tl = c->tail;
     KChain chf = c->kchain;
@@ -301,6 +313,10 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
+  if (const char* ft = getenv("EPPK_FAST_THREADS")) {
+    const int v = atoi(ft);
+    if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) c->fast_threads = (uint32_t)v;
+  }
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;
@@ -364,8 +380,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (cfg->index_slots) {
     c->slots = cfg->index_slots;
     uint32_t lg = 0;
-    while ((1u << lg) < c->slots) ++lg;
-    c->shift = 64u - lg;
+    while ((1u << lg) < c->slots / 16u) ++lg;   // 16-slot buckets (eppk_kernels.hip.h: KIndex)
+    c->shift = 32u - lg;
     c->limit = c->slots / 2u;  // load factor <= 0.5
     CHK(hipMalloc((void**)&c->keys, ((size_t)c->slots + 2u) * 8u));
     CHK(hipMalloc(&c->bitmaps, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes));

@@ -24,26 +24,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Build-time tuning knobs (A/B-tested on MI355X; defaults are the measured best — DESIGN.md §7)
-#ifndef EPPK_PIPE
-#define EPPK_PIPE 0      // 2-stage software pipeline (probe request r+1 while the rows of r are in flight): measured neutral, costs 20 VGPRs
-#endif
-#ifndef EPPK_ROWS2
-#define EPPK_ROWS2 0     // keep two 8-row batches (16 loads) in flight instead of one
-#endif
-#ifndef EPPK_PTERM_TAB
-#define EPPK_PTERM_TAB 1 // prefix term of a matched pod from the exact host-built table instead of an f64 division
-#endif
+// Build-time knobs
 #ifndef EPPK_MIN_WAVES
 #define EPPK_MIN_WAVES 1 // __launch_bounds__ minimum waves per SIMD for the fast kernel
 #endif
+// EPPK_DBG_* macros below are timing experiments (ablation builds made by scripts/ab.sh); they produce WRONG results and are
+// never defined in the product build.
 
 namespace eppk {
 
 constexpr uint32_t kNotFound = 0xFFFFFFFFu;
 constexpr uint32_t kNoPod = 0xFFFFFFFFu;
-constexpr uint64_t kHomeMul = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t kHomeMul = 0x9E3779B1u;    // 2^32 / golden ratio (odd): multiplicative hashing of the folded key
 constexpr uint64_t kTomb = ~0ull;           // key of a slot whose pod set became empty (never matches, never reused)
+constexpr uint32_t kBucket = 16u;           // key slots per bucket = one 128-byte line: word 0 is the bucket header, words 1..15 hold keys
 constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots: stats[4 + 2*wave + {0,1}]
 
 // ---- kernel argument blocks (plain structs, passed by value) --------------------------------
@@ -67,12 +61,20 @@ struct KSnap {
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
 };
 
+// Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (16 u64 words =
+// one 128-byte line: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..15 = keys,
+// filled front to back, 0 = empty, ~0 = tombstone).  A look-up therefore reads ONE line and is finished unless the key is
+// absent from an overflowed bucket (~1 % of buckets at the load limit) -- no data-dependent probe chain on the hot path.
+// (With per-slot linear probing the 32 parallel look-ups of a request needed max-over-lanes dependent round trips: 3-6 at
+// load 0.5; measured 31 of 95 us per batch.)  Slot = bucket * 16 + word; the pod-set row of a key has its slot's index.
 struct KIndex {
-  const uint64_t* keys;    // [slots+2]; 0 = empty, ~0 = tombstone; keys[slots], keys[slots+1] = presence of hashes 0 / ~0.
+  const uint64_t* keys;    // [slots+2]; keys[slots], keys[slots+1] = presence of the reserved hashes 0 / ~0.
                            // Invariant: a key that is present has a NON-EMPTY row.
   const void*     bitmaps; // [slots+3][64] LW: rows slots / slots+1 hold hashes 0 / ~0, row slots+2 is all-zero
-  uint32_t slots;          // power of two (0 = no index)
-  uint32_t shift;          // 64 - log2(slots)
+  uint32_t slots;          // power of two >= 64 (0 = no index); slots / 16 buckets
+  uint32_t shift;          // 32 - log2(slots / 16)
+  uint32_t small;          // the rows table is < 4 GiB: rows are read through one buffer descriptor + SGPR offsets
+  uint32_t table_bytes;    // (slots + 3) * 64 * sizeof(LW) when small
 };
 
 struct KChain {            // the whole weighted chain (generic kernel)
@@ -88,8 +90,11 @@ struct KTail {             // the request-dependent tail after fusion (fast kern
 
 // ---- small device helpers --------------------------------------------------------------------
 
-__device__ __forceinline__ uint32_t home_slot(uint64_t h, uint32_t shift) {
-  return (uint32_t)((h * kHomeMul) >> shift);
+// Home bucket of a key: top log2(buckets) bits of a 32-bit multiplicative hash of the folded key (block hashes are XXH64
+// outputs already; the multiply only guards against structured keys).  shift = 32 - log2(buckets).
+// One v_xor + one v_mul_lo_u32 + one shift (a 64-bit multiply costs 6 VALU ops, three of them quarter rate).
+__device__ __forceinline__ uint32_t home_bucket(uint64_t h, uint32_t shift) {
+  return (((uint32_t)h ^ (uint32_t)(h >> 32)) * kHomeMul) >> shift;
 }
 
 __device__ __forceinline__ double clamp01(double s) {
@@ -98,18 +103,22 @@ __device__ __forceinline__ double clamp01(double s) {
   return s;
 }
 
-// Look one hash up; returns its slot or kNotFound.  Linear probing; the table is never full.
+// Look one hash up, one lane per key (generic kernel, long-chunk fallback); returns its slot or kNotFound.
 __device__ __forceinline__ uint32_t probe(const KIndex& ix, uint64_t h, bool active) {
   if (!active || ix.slots == 0) return kNotFound;
   if (h == 0) return ix.keys[ix.slots] ? ix.slots : kNotFound;             // reserved hashes: presence words
   if (h == kTomb) return ix.keys[ix.slots + 1u] ? ix.slots + 1u : kNotFound;
-  uint32_t s = home_slot(h, ix.shift);
-  const uint32_t mask = ix.slots - 1;
-  for (uint32_t n = 0; n < ix.slots; ++n) {
-    const uint64_t k = ix.keys[s];
-    if (k == h) return s;
-    if (k == 0) return kNotFound;
-    s = (s + 1) & mask;
+  const uint32_t bmask = (ix.slots / kBucket) - 1u;
+  uint32_t b = home_bucket(h, ix.shift);
+  for (uint32_t n = 0; n <= bmask; ++n) {
+    const uint64_t* kb = ix.keys + (size_t)b * kBucket;
+    for (uint32_t i = 1; i < kBucket; ++i) {
+      const uint64_t k = kb[i];
+      if (k == h) return b * kBucket + i;
+      if (k == 0) return kNotFound;                 // buckets fill front to back and never shrink: an empty word ends the search
+    }
+    if (!(kb[0] & 1ull)) return kNotFound;          // full but never overflowed
+    b = (b + 1) & bmask;
   }
   return kNotFound;
 }
@@ -198,60 +207,10 @@ __device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t
 }
 
 // ---- carry-save counting ---------------------------------------------------------------------
-// Full adder on bit vectors: x = a^b, sum = x^c, carry = maj(a,b,c) = bfi(x, c, a) — 3 VALU ops per 32 bits.
-// hipcc does not form v_bfi_b32 from the C expression here (it emits and/and/or), hence the asm.
-__device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t x, uint32_t y) {  // (m & x) | (~m & y)
-  uint32_t r;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(x), "v"(y));
-  return r;
-}
-template <typename LW>
-__device__ __forceinline__ LW bfi(LW m, LW x, LW y) {
-  if constexpr (sizeof(LW) == 8)
-    return ((uint64_t)bfi32((uint32_t)(m >> 32), (uint32_t)(x >> 32), (uint32_t)(y >> 32)) << 32) | bfi32((uint32_t)m, (uint32_t)x, (uint32_t)y);
-  else
-    return (LW)bfi32((uint32_t)m, (uint32_t)x, (uint32_t)y);
-}
-template <typename LW>
-__device__ __forceinline__ void full_add(LW a, LW b, LW c, LW& sum, LW& carry) {
-  const LW x = a ^ b;
-  sum = x ^ c;
-  carry = bfi<LW>(x, c, a);
-}
 template <typename LW>
 __device__ __forceinline__ void half_add(LW a, LW b, LW& sum, LW& carry) {
   sum = a ^ b;
   carry = a & b;
-}
-
-// Add eight 0/1 vectors into the bit-sliced counters: an 8->4 carry-save tree (4 full + 3 half adders)
-// then one 4-bit ripple add into the NPL planes; ~4.5x fewer VALU ops than eight ripple adds.
-template <typename LW, int NPL>
-__device__ __forceinline__ void planes_add8(LW (&c)[NPL], const LW (&w)[8]) {
-  static_assert(NPL >= 5, "need at least 5 planes");
-  LW s1, c1, s2, c2, s3, c3, b0, c4, s5, c5, b1, c6, b2, b3;
-  full_add<LW>(w[0], w[1], w[2], s1, c1);
-  full_add<LW>(w[3], w[4], w[5], s2, c2);
-  full_add<LW>(w[6], w[7], s1, s3, c3);
-  half_add<LW>(s2, s3, b0, c4);          // ones
-  full_add<LW>(c1, c2, c3, s5, c5);      // twos
-  half_add<LW>(s5, c4, b1, c6);
-  half_add<LW>(c5, c6, b2, b3);          // fours, eights
-  LW carry, t;
-  half_add<LW>(c[0], b0, t, carry); c[0] = t;
-  full_add<LW>(c[1], b1, carry, t, carry); c[1] = t;
-  full_add<LW>(c[2], b2, carry, t, carry); c[2] = t;
-  full_add<LW>(c[3], b3, carry, t, carry); c[3] = t;
-#pragma unroll
-  for (int k = 4; k < NPL; ++k) { half_add<LW>(c[k], carry, t, carry); c[k] = t; }
-}
-
-template <int NPL>
-__device__ __forceinline__ uint32_t planes_get(const uint32_t (&c32)[NPL], uint32_t jj) {
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int k = 0; k < NPL; ++k) cnt |= ((c32[k] >> jj) & 1u) << k;
-  return cnt;
 }
 
 // Transpose one natural-layout candidate mask row ([J] u64, bit p%64 of word p/64) into a lane word.
@@ -292,9 +251,10 @@ __device__ __forceinline__ LW valid_word(uint32_t n_pods, int lane) {
 // If all 64 table entries are in M (a prefix cached almost everywhere) step 2 becomes a scan of T_a
 // over the pods outside M (same arithmetic, base[] read from global memory).
 //
-// No LDS and few registers: occupancy and memory-level parallelism are what this kernel lives on.
-// The request loop is a 2-stage software pipeline: while the rows of request r are in flight the keys
-// of request r+1 are probed, and the row of request r+2 is prefetched.
+// base[] (and the exact prefix-term table) are staged once per workgroup in LDS: the evaluation of a pod of M is then
+// two LDS reads instead of two dependent L2 round trips.  All per-request addressing is scalar (the wave id is made
+// uniform with readfirstlane), the counting tree uses v_bitop3_b32 full adders (2 VALU ops per 32 pods), and the
+// argmax is a DPP max reduction; the row of the next request is prefetched while the current one is evaluated.
 
 template <bool HAS_L, bool HAS_P, bool P_FIRST>
 __device__ __forceinline__ double eval_total(double base, double lterm, double pterm) {
@@ -312,25 +272,6 @@ __device__ __forceinline__ double eval_total(double base, double lterm, double p
 
 __device__ __forceinline__ double tier_term(const KTail& tl, uint32_t tier) {
   return tier == 3u ? tl.lw[3] : tier == 2u ? tl.lw[2] : tier == 1u ? tl.lw[1] : tl.lw[0];
-}
-
-// Stage 1 of a request: probe the keys of one 64-block chunk in parallel.  Returns the number m of leading
-// hits; slot_eff[lane k] = row of hit k for k < m, the all-zero row otherwise.
-__device__ __forceinline__ uint32_t probe_chunk(const KIndex& ix, uint64_t h, uint32_t nchunk, int lane, uint32_t& slot_eff) {
-  const uint32_t slot = probe(ix, h, (uint32_t)lane < nchunk);
-  const unsigned long long found = __ballot(slot != kNotFound);
-  const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);
-  slot_eff = ((uint32_t)lane < m) ? slot : ix.slots + 2u;
-  return m;
-}
-
-template <typename LW>
-__device__ __forceinline__ void load_rows8(const LW* bm, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[8]) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t s = __builtin_amdgcn_readlane(slot_eff, k0 + (uint32_t)u);
-    w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
-  }
 }
 
 // Exact evaluation of one request over its CANDIDATES ONLY, every scorer in chain order (the generic kernel's
@@ -390,133 +331,429 @@ __device__ __forceinline__ void masked_exact(const KSnap& sn, const KChain& ch, 
   }
 }
 
+// ---- gfx950 3-input bit ops + DPP reductions ---------------------------------------------------
+// v_bitop3_b32 (new in gfx950): any 3-input boolean function in ONE VALU op.  A full adder on bit vectors is
+// then 2 ops per 32 bits (sum = a^b^c: truth table 0x96; carry = maj(a,b,c): 0xE8) instead of 3 with v_bfi.
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3_32(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+template <int TT, typename LW>
+__device__ __forceinline__ LW bitop3(LW a, LW b, LW c) {
+  if constexpr (sizeof(LW) == 8)
+    return ((uint64_t)bitop3_32<TT>((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) << 32) |
+           bitop3_32<TT>((uint32_t)a, (uint32_t)b, (uint32_t)c);
+  else
+    return (LW)bitop3_32<TT>((uint32_t)a, (uint32_t)b, (uint32_t)c);
+}
+template <typename LW>
+__device__ __forceinline__ void fa3(LW a, LW b, LW c, LW& sum, LW& carry) {
+  sum = bitop3<0x96, LW>(a, b, c);
+  carry = bitop3<0xE8, LW>(a, b, c);
+}
+
+// 16 -> 5 carry-save tree: b[k] = bit k of the per-pod number of rows (0..16) containing the pod.  11 full + 4 half adders.
+template <typename LW>
+__device__ __forceinline__ void csa16(const LW (&w)[16], LW (&b)[5]) {
+  LW s1, s2, s3, s4, s5, c1, c2, c3, c4, c5;
+  fa3<LW>(w[0], w[1], w[2], s1, c1);
+  fa3<LW>(w[3], w[4], w[5], s2, c2);
+  fa3<LW>(w[6], w[7], w[8], s3, c3);
+  fa3<LW>(w[9], w[10], w[11], s4, c4);
+  fa3<LW>(w[12], w[13], w[14], s5, c5);
+  LW t1, t2, d1, d2, d3;
+  fa3<LW>(s1, s2, s3, t1, d1);
+  fa3<LW>(s4, s5, w[15], t2, d2);
+  half_add<LW>(t1, t2, b[0], d3);                 // ones done; twos: c1..c5, d1, d2, d3
+  LW u1, u2, e1, e2, e3, e4, v1;
+  fa3<LW>(c1, c2, c3, u1, e1);
+  fa3<LW>(c4, c5, d1, u2, e2);
+  fa3<LW>(u1, u2, d2, v1, e3);
+  half_add<LW>(v1, d3, b[1], e4);                 // twos done; fours: e1..e4
+  LW x1, f1, f2;
+  fa3<LW>(e1, e2, e3, x1, f1);
+  half_add<LW>(x1, e4, b[2], f2);                 // fours done; eights: f1, f2
+  half_add<LW>(f1, f2, b[3], b[4]);
+}
+// 8 -> 4 tree (4 full + 3 half adders)
+template <typename LW>
+__device__ __forceinline__ void csa8(const LW (&w)[8], LW (&b)[4]) {
+  LW s1, c1, s2, c2, s3, c3, c4, s5, c5, c6;
+  fa3<LW>(w[0], w[1], w[2], s1, c1);
+  fa3<LW>(w[3], w[4], w[5], s2, c2);
+  fa3<LW>(w[6], w[7], s1, s3, c3);
+  half_add<LW>(s2, s3, b[0], c4);
+  fa3<LW>(c1, c2, c3, s5, c5);
+  half_add<LW>(s5, c4, b[1], c6);
+  half_add<LW>(c5, c6, b[2], b[3]);
+}
+// c += b (b is an NB-bit bit-sliced number); ripple carry.
+template <typename LW, int NPL, int NB>
+__device__ __forceinline__ void planes_addn(LW (&c)[NPL], const LW (&b)[NB]) {
+  static_assert(NPL >= NB, "planes");
+  LW carry, t;
+  half_add<LW>(c[0], b[0], t, carry); c[0] = t;
+#pragma unroll
+  for (int k = 1; k < NB; ++k) { fa3<LW>(c[k], b[k], carry, t, carry); c[k] = t; }
+#pragma unroll
+  for (int k = NB; k < NPL; ++k) { half_add<LW>(c[k], carry, t, carry); c[k] = t; }
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes outside ROW_MASK / without a source keep v
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {   // inputs are never NaN (SEMANTICS.md: clamp01 kills NaN)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max over the wavefront, returned wave-uniform.  quad xor 1, quad xor 2, half mirror, mirror (all 16 lanes of a
+// row agree), row_bcast:15 into rows 1/3, row_bcast:31 into rows 2/3; lane 63 holds the result.
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = vmax_f64(v, dpp_f64<0xB1, 0xf>(v));
+  v = vmax_f64(v, dpp_f64<0x4E, 0xf>(v));
+  v = vmax_f64(v, dpp_f64<0x141, 0xf>(v));
+  v = vmax_f64(v, dpp_f64<0x140, 0xf>(v));
+  v = vmax_f64(v, dpp_f64<0x142, 0xa>(v));
+  v = vmax_f64(v, dpp_f64<0x143, 0xc>(v));
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = dpp_min_u32<0xB1, 0xf>(v);
+  v = dpp_min_u32<0x4E, 0xf>(v);
+  v = dpp_min_u32<0x141, 0xf>(v);
+  v = dpp_min_u32<0x140, 0xf>(v);
+  v = dpp_min_u32<0x142, 0xa>(v);
+  v = dpp_min_u32<0x143, 0xc>(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// (score desc, index asc) argmax across the wavefront, wave-uniform result: f64 max by DPP, then the lowest pod index
+// among the lanes that hold it (one ballot + readlane when the maximum is unique, a u32 min reduction otherwise).
+__device__ __forceinline__ void wave_argmax_dpp(double& best, uint32_t& bidx) {
+  const double wmax = wave_max_f64(best);
+  const bool tie = best == wmax;
+  const unsigned long long tm = __ballot(tie);
+  uint32_t widx;
+  if (__builtin_popcountll(tm) == 1) widx = (uint32_t)__builtin_amdgcn_readlane((int)bidx, __builtin_ctzll(tm));
+  else widx = wave_min_u32(tie ? bidx : kNoPod);
+  best = wmax;
+  bidx = widx;
+}
+
+// ---- pair probe (fast kernel): TWO lanes per key, 32 keys per wavefront instruction group -------------------------
+// Lane l serves key l>>1; the even lane reads words 0..7 of the key's home bucket (header + 7 keys), the odd lane words
+// 8..15: four 16-byte loads per lane, every fetched 128-byte line is used completely, and the whole look-up of a request's
+// first 32 hashes is one independent gather -- no probe chain.
+constexpr uint32_t kKeysPerProbe = 32u;
+
+struct ReqRegs {            // pipeline registers of one request
+  uint64_t hdr, h;          // row header; the hash this lane pair probes (landing registers of the row prefetch)
+  uint4 kw[4];              // this lane's half of the home bucket (landing registers of the key gather)
+  uint32_t bkt;             // home bucket
+};
+
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) {   // value of the other lane of the pair
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+}
+
+// Issue the bucket loads of q.h (q.h must already be 0 in lanes without a key).
+__device__ __forceinline__ void pair_probe_issue(const KIndex& ix, ReqRegs& q, int lane) {
+  q.bkt = home_bucket(q.h, ix.shift);
+  const uint4* p = (const uint4*)(ix.keys + (size_t)q.bkt * kBucket + (size_t)(lane & 1) * 8u);
+#if defined(EPPK_DBG_KEYS_NONE)
+  q.kw[0] = q.kw[1] = q.kw[2] = q.kw[3] = make_uint4(0, 0, 0, 0);
+#else
+  q.kw[0] = p[0]; q.kw[1] = p[1]; q.kw[2] = p[2]; q.kw[3] = p[3];
+#endif
+}
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// Position (0..7) of h among this lane's 8 bucket words, 8 if absent.  Word 0 of the even lane is the header, not a key.
+__device__ __forceinline__ uint32_t match8(const uint4 (&kw)[4], uint64_t h, bool even) {
+  uint32_t pos = 8u;
+  if (u64_of(kw[3].z, kw[3].w) == h) pos = 7u;
+  if (u64_of(kw[3].x, kw[3].y) == h) pos = 6u;
+  if (u64_of(kw[2].z, kw[2].w) == h) pos = 5u;
+  if (u64_of(kw[2].x, kw[2].y) == h) pos = 4u;
+  if (u64_of(kw[1].z, kw[1].w) == h) pos = 3u;
+  if (u64_of(kw[1].x, kw[1].y) == h) pos = 2u;
+  if (u64_of(kw[0].z, kw[0].w) == h) pos = 1u;
+  if (!even && u64_of(kw[0].x, kw[0].y) == h) pos = 0u;
+  return pos;
+}
+
+// Turn the loaded buckets into the request's leading-hit count m (<= nchunk <= 32) and row map: slot_eff of lane pair k
+// = slot of hit k for k < m, the all-zero row otherwise (rows are addressed with v_readlane(slot_eff, 2k)).
+// Rare paths: reserved hashes 0 / ~0 (presence words) and keys absent from an overflowed bucket (next buckets).
+__device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const ReqRegs& q, uint32_t nchunk, int lane, uint32_t& slot_eff) {
+  const uint32_t sub = (uint32_t)lane & 1u, ki = (uint32_t)lane >> 1;
+  const bool act = ki < nchunk;
+  const uint64_t h = q.h;
+  uint32_t slot;
+#ifdef EPPK_DBG_SKIP_KEYS   // timing experiment only (wrong results): 16 pseudo-hits
+  slot = (ki < 16u && act) ? q.bkt * kBucket + 1u : kNotFound;
+#else
+  if (__any(act && (h + 1ull) <= 1ull)) {             // h == 0 or h == ~0 somewhere in the request (rare)
+    slot = probe(ix, h, act);
+  } else {
+    const uint32_t pos = match8(q.kw, h, sub == 0u);
+    uint32_t s = pos < 8u ? q.bkt * kBucket + sub * 8u + pos : kNotFound;
+    const uint32_t so = dpp_xor1(s);
+    s = so < s ? so : s;
+    uint32_t ovf = sub == 0u ? (q.kw[0].x & 1u) : 0u;  // header bit 0, seen by the even lane
+    ovf |= dpp_xor1(ovf);
+    bool pend = act && s == kNotFound && ovf != 0u;
+    if (__any(pend)) {                                 // absent from an overflowed bucket: walk the following buckets
+      const uint32_t bmask = (ix.slots / kBucket) - 1u;
+      uint32_t b = q.bkt;
+      for (uint32_t n = 0; n < bmask && __any(pend); ++n) {
+        if (pend) {
+          b = (b + 1) & bmask;
+          const uint64_t* kb = ix.keys + (size_t)b * kBucket + (size_t)sub * 8u;
+          uint32_t s2 = kNotFound;
+          for (uint32_t i = 0; i < 8u; ++i)
+            if (kb[i] == h && (sub | i) != 0u) s2 = b * kBucket + sub * 8u + i;
+          uint32_t o2 = sub == 0u ? (uint32_t)(kb[0] & 1ull) : 0u;
+          const uint32_t s2o = dpp_xor1(s2);
+          s2 = s2o < s2 ? s2o : s2;
+          o2 |= dpp_xor1(o2);
+          if (s2 != kNotFound) { s = s2; pend = false; }
+          else if (o2 == 0u) pend = false;
+        }
+      }
+    }
+    slot = act ? s : kNotFound;
+  }
+#endif
+  const unsigned long long fm = __ballot(slot != kNotFound);      // both lanes of a pair agree
+  const uint32_t m = (~fm == 0ull) ? kKeysPerProbe : (uint32_t)__builtin_ctzll(~fm) >> 1;
+  slot_eff = (ki < m) ? slot : ix.slots + 2u;
+  return m;
+}
+
+// Row loads.  A row address is wave-uniform (slot from v_readlane) plus lane * sizeof(LW).  Tables below 4 GiB are read
+// through ONE raw buffer descriptor with the row's byte offset in the instruction's SGPR offset operand: zero VALU ops and
+// zero 64-bit address arithmetic per row (buffer_load ... v_lane_off, s[rsrc], s_row_off offen).  Hit k of the request is in
+// lane pair k of slot_eff.  Larger tables take the global_load path (one v_lshl_add_u64 per row).
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <typename LW>
+__device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  if constexpr (sizeof(LW) == 8) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+  } else if constexpr (sizeof(LW) == 4) {
+    return (LW)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0);
+  } else {
+    return (LW)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0);
+  }
+}
+template <typename LW, int N>
+__device__ __forceinline__ void load_rows(const KIndex& ix, __amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
+  if (ix.small) {
+    const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
+    const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
+#ifdef EPPK_DBG_SKIP_ROWS   // timing experiment only (wrong results): no row loads, one pseudo pod per row
+      w[u] = ((uint32_t)lane == ((soff >> 9) & 63u)) ? (LW)((LW)1 << (u & 7)) : (LW)0;
+      (void)voff;
+#else
+      w[u] = buffer_load_lw<LW>(rs, voff, soff);
+#endif
+    }
+  } else {
+    const LW* bm = (const LW*)ix.bitmaps;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
+      w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
+    }
+  }
+}
+
+// rows [k0, m) of slot_eff added into non-zero counters, 16 in flight (8 for a short tail)
+template <typename LW, int NPL>
+__device__ __forceinline__ void count_more(const KIndex& ix, __amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, uint32_t m, int lane, LW (&c)[NPL]) {
+  for (; k0 + 8u < m; k0 += 16u) {
+    LW w[16], b[5];
+    load_rows<LW, 16>(ix, rs, slot_eff, k0, lane, w);
+    csa16<LW>(w, b);
+    planes_addn<LW, NPL, 5>(c, b);
+  }
+  if (k0 < m) {
+    LW w[8], b[4];
+    load_rows<LW, 8>(ix, rs, slot_eff, k0, lane, w);
+    csa8<LW>(w, b);
+    planes_addn<LW, NPL, 4>(c, b);
+  }
+}
+
+template <typename LW>
+__device__ __forceinline__ uint32_t ctz_lw(LW x) {
+  if constexpr (sizeof(LW) == 8) return (uint32_t)__builtin_ctzll((unsigned long long)x);
+  else return (uint32_t)__builtin_ctz((uint32_t)x);
+}
+
+// LDS of the fast kernel: base[J*64] f64 | pterm[(B+1)*ld] f64 (when the host built the table).
+//
+// The request loop is a 3-stage software pipeline per wavefront (unrolled twice so that the stage registers rotate by
+// renaming, not by copies -- a copy of a landing register would wait for its load):
+//   stage 0  request row of r+2      issued in iteration r   (HBM stream; a full iteration of slack)
+//   stage 1  key gather of r+1       issued in iteration r   (needs the row of r+1, prefetched in iteration r-1)
+//   stage 2  rows + tables of r, count, evaluate, pick.
+// Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
+// current request waits for is queued AHEAD of the loads that serve later requests.
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED>
-__global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+__global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                         unsigned long long* __restrict__ stats) {
-  (void)pwn;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_base = (double*)smem;
+  double* s_pterm = s_base + (size_t)sn.J * 64u;
+  const bool pterm_tab = HAS_P && sn.pterm != nullptr;
+  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
+  if (pterm_tab)
+    for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
+  __syncthreads();
+
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t wpb = blockDim.x >> 6;
-  const uint32_t gwave = blockIdx.x * wpb + (threadIdx.x >> 6);
+  // wave-uniform ids in SGPRs: every per-request address below is scalar arithmetic
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
   const uint32_t nwaves = gridDim.x * wpb;
-  const LW* bm = (const LW*)ix.bitmaps;
+  // raw buffer descriptor over the pod-set rows (gfx9 word 3: 32-bit data format); num_records = table bytes
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000);
 
   const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
   const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
   unsigned long long w_hits = 0, w_lookups = 0;
-  const uint32_t hwords = (stride - 8u) / 8u < 64u ? (stride - 8u) / 8u : 64u;
+  const uint32_t hwords = (stride - 8u) / 8u;                                       // hash words per request row
+  const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;             // ... probed by the pipelined first gather
+  // u64 word of a request row that this lane pair reads as "its" hash (always in bounds: word 0 when the row has no hashes)
+  const uint32_t ki = (uint32_t)lane >> 1;
+  const uint32_t hidx = (HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u;
+  const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
 
-  // ---- pipeline prologue: request r is probed, request r+nwaves is prefetched
-  uint32_t r = gwave;
-  if (r >= n_reqs) return;
-  int32_t adapter;
-  uint32_t nb, m0 = 0, slot0 = 0;
-  uint64_t cur_h = 0;  // non-pipelined build: hashes of the current request
-  {
-    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)r * stride);
-    const uint64_t hdr = row64[0];
-    const uint64_t h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
-    adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)hdr);
-    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(hdr >> 32));
-    if (HAS_P && EPPK_PIPE) m0 = probe_chunk(ix, h, nb < 64u ? nb : 64u, lane, slot0);
-    cur_h = h;
-  }
-  uint64_t nx_hdr = 0, nx_h = 0;
-  if (r + nwaves < n_reqs) {
-    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(r + nwaves) * stride);
-    nx_hdr = row64[0];
-    nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
-  }
+  if (gwave >= n_reqs) return;
 
-  for (; r < n_reqs; r += nwaves) {
-    // ---- A. issue everything the current request needs that is already addressable
-    LW w[8];
-#if EPPK_ROWS2
-    LW w2[8];
-#endif
-    if (HAS_P && !EPPK_PIPE) m0 = probe_chunk(ix, cur_h, nb < 64u ? nb : 64u, lane, slot0);
-    if (HAS_P && m0 > 0) load_rows8<LW>(bm, slot0, 0, lane, w);
-#if EPPK_ROWS2
-    if (HAS_P && m0 > 8) load_rows8<LW>(bm, slot0, 8, lane, w2);
-#endif
+  // Stage 0: request row (header + this lane pair's hash).  Relaxed wavefront-scope atomic loads are plain
+  // global_load_dwordx2 that the compiler neither sinks towards their first use nor hoists above earlier loads.
+  auto issue_row = [&](uint32_t rr, uint32_t r_fallback, ReqRegs& q) {
+    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(rr < n_reqs ? rr : r_fallback) * stride);
+    q.hdr = __hip_atomic_load(row64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    q.h = __hip_atomic_load(row64 + hidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  };
+  // Stage 1: home buckets of the request's first 32 hashes
+  auto issue_keys = [&](ReqRegs& q) {
+    if (use_index) {
+      q.h = (ki < hw0) ? q.h : 0ull;
+      pair_probe_issue(ix, q, lane);
+    }
+  };
+
+  // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
+  // r + 2 nwaves (into `cur`, which is free once the probe of r is finished).
+  auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
+    const int32_t adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)cur.hdr);
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(cur.hdr >> 32));
+
+    // ---- A. finish the probe of r: number of leading hits and their rows
+    uint32_t m0 = 0, slot0 = ix.slots + 2u;
+    if (use_index && nb != 0u) m0 = pair_probe_finish(ix, cur, nb < kKeysPerProbe ? nb : kKeysPerProbe, lane, slot0);
+
+    // ---- B. loads that depend on the request header only
     const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    const double top_t = sn.topv[(size_t)arow * 64u + (uint32_t)lane];
-    const uint32_t top_p = sn.topi[(size_t)arow * 64u + (uint32_t)lane];
-    LW thi = 0, tlo = 0;  // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 waiting, 2: 0.8 free slot, 3: 1.0 active}
-    if (HAS_L) {
-      LW a = 0, wt = 0;
-      if (adapter >= 0) {
-        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
-        wt = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
-      }
-      thi = a | freew;
-      tlo = a | ((LW)~freew & wt);
-    }
-    LW cand = valid;   // Filter: the request's candidate subset (request.go:104-133 as a bitmask), lane-transposed
-    if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
-
-    // ---- B. stage 1 of the NEXT request (its row was prefetched one iteration ago), overlapping the loads above
-    const uint32_t rn = r + nwaves;
-    int32_t adapter_n = -1;
-    uint32_t nb_n = 0, m_n = 0, slot_n = 0;
-    if (rn < n_reqs) {
-      adapter_n = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)nx_hdr);
-      nb_n = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(nx_hdr >> 32));
-      if (HAS_P && EPPK_PIPE) m_n = probe_chunk(ix, nx_h, nb_n < 64u ? nb_n : 64u, lane, slot_n);
-      cur_h = nx_h;
-      if (rn + nwaves < n_reqs) {  // prefetch the row after next
-        const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(rn + nwaves) * stride);
-        nx_hdr = row64[0];
-        nx_h = (HAS_P && (uint32_t)lane < hwords) ? row64[1 + lane] : 0ull;
-      }
+    const double top_t = (sn.topv + (size_t)arow * 64u)[lane];
+    const uint32_t top_p = (sn.topi + (size_t)arow * 64u)[lane];
+    LW a_w = 0, w_w = 0;
+    if (HAS_L && adapter >= 0) {
+      a_w = ((const LW*)sn.act_t + (size_t)adapter * 64u)[lane];
+      w_w = ((const LW*)sn.wait_t + (size_t)adapter * 64u)[lane];
     }
 
-    // ---- C. stage 2 of the current request: count rows, evaluate, pick
+    // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
+    LW w[16];
+    if (m0 > 8u) {
+      load_rows<LW, 16>(ix, rs, slot0, 0, lane, w);
+    } else {
+      LW t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = 0;
+      if (m0 > 0u) load_rows<LW, 8>(ix, rs, slot0, 0, lane, t);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { w[u] = t[u]; w[8 + u] = 0; }
+    }
+    issue_keys(nxt);
+    issue_row(r + 2u * nwaves, r, cur);
+    __builtin_amdgcn_sched_barrier(0);
+
     LW c[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) c[k] = 0;
-    LW nz = 0;  // M: pods with matched > 0
+    uint32_t hits = m0;
     if (HAS_P) {
-      uint32_t hits = m0;
-      if (m0 > 0) {
-        planes_add8<LW, NPL>(c, w);
-        nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
-#if EPPK_ROWS2
-        if (m0 > 8) {
-          planes_add8<LW, NPL>(c, w2);
-          nz |= (LW)(w2[0] | w2[1] | w2[2] | w2[3] | w2[4] | w2[5] | w2[6] | w2[7]);
-        }
-        for (uint32_t k0 = 16; k0 < m0; k0 += 8) {
-#else
-        for (uint32_t k0 = 8; k0 < m0; k0 += 8) {
-#endif
-          load_rows8<LW>(bm, slot0, k0, lane, w);
-          planes_add8<LW, NPL>(c, w);
-          nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
-        }
+      if (m0 > 8u) {
+        LW b[5];
+        csa16<LW>(w, b);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) c[k] = b[k];
+      } else if (m0 > 0u) {
+        LW t[8], b[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = w[u];
+        csa8<LW>(t, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = b[k];
       }
-      // chunks beyond the first 64 blocks (only when every earlier key hit); not pipelined
-      uint32_t mlast = m0;
-      for (uint32_t b0 = 64; b0 < nb && mlast == 64u; b0 += 64) {
-        const uint64_t* hs = (const uint64_t*)(reqs + (size_t)r * stride + 8);
-        const uint32_t nchunk = (nb - b0) < 64u ? (nb - b0) : 64u;
-        const uint64_t h = ((uint32_t)lane < nchunk) ? hs[b0 + (uint32_t)lane] : 0ull;
-        uint32_t slotc;
-        mlast = probe_chunk(ix, h, nchunk, lane, slotc);
-        for (uint32_t k0 = 0; k0 < mlast; k0 += 8) {
-          load_rows8<LW>(bm, slotc, k0, lane, w);
-          planes_add8<LW, NPL>(c, w);
-          nz |= (LW)(w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]);
+      if (m0 > 16u) count_more<LW, NPL>(ix, rs, slot0, 16u, m0, lane, c);
+      if (m0 == kKeysPerProbe && nb > kKeysPerProbe) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
+        uint32_t mlast = m0;
+        for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
+          const uint64_t* hs = (const uint64_t*)(reqs + (size_t)r * stride + 8);
+          const uint32_t nchunk = (nb - b0) < kKeysPerProbe ? (nb - b0) : kKeysPerProbe;
+          ReqRegs t;
+          t.hdr = 0;
+          t.h = (ki < nchunk) ? hs[b0 + ki] : 0ull;
+          pair_probe_issue(ix, t, lane);
+          uint32_t slotc;
+          mlast = pair_probe_finish(ix, t, nchunk, lane, slotc);
+          count_more<LW, NPL>(ix, rs, slotc, 0u, mlast, lane, c);
+          hits += mlast;
         }
-        hits += mlast;
       }
       if (stats) { w_hits += hits; w_lookups += (hits + 1u < nb) ? hits + 1u : nb; }
+    }
+
+#ifdef EPPK_DBG_SKIP_EVAL     // timing experiment only (wrong results): no evaluation phase
+    if (lane == 0) { out_pick[r] = (int32_t)(uint32_t)c[0] + (int32_t)hits; }
+    return;
+#endif
+    LW nz = 0;  // M: pods with matched > 0
+    if (HAS_P && hits) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) nz |= c[k];
       nz &= valid;
     }
+    // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 waiting, 2: 0.8 free slot, 3: 1.0 active}
+    LW thi = 0, tlo = 0;
+    if (HAS_L) { thi = a_w | freew; tlo = a_w | ((LW)~freew & w_w); }
+    LW cand = valid;   // Filter: the request's candidate subset (request.go:104-133 as a bitmask), lane-transposed
+    if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
+
     // Masked requests: base[] and the top tables embed the snapshot-wide QUEUE normalisers; they apply iff the
     // candidates contain a pod at the global minimum and one at the global maximum queue depth.
     bool exact = false;
@@ -529,7 +766,7 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
     if (MASKED && exact) {
       if (__any(cand != 0)) {
         masked_exact<LW, NPL>(sn, ch, cand, c, thi, tlo, nb, lane, best, bidx);
-        wave_argmax(best, bidx);
+        wave_argmax_dpp(best, bidx);
       }
     } else {
       const LW mset = MASKED ? (LW)(nz & cand) : nz;         // candidates with a prefix match: evaluated in full
@@ -539,7 +776,7 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
       // best candidate outside M: first table entry in okset
       const bool has = top_p != kNoPod;
       bool ok = has;
-      if (MASKED || (HAS_P && __any(nz != 0))) {
+      if (MASKED || (HAS_P && hits)) {
         const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
         LW okq;
         if constexpr (sizeof(LW) == 8) {
@@ -563,22 +800,20 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
       }
 
       if (any_m) {
+        const double* pt_row = s_pterm + (size_t)nb * sn.pterm_ld;   // cnt > 0 implies nb > 0
         LW rem = mset;
-        while (__any(rem != 0)) {          // each lane walks its own pods of M in ascending order
-          if (rem != 0) {
-            const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
-            rem = (LW)(rem & (LW)(rem - 1));
-            const uint32_t p = j * 64u + (uint32_t)lane;
-            uint32_t cnt = 0;
+        while (rem != 0) {                   // each lane walks its own pods of M in ascending order
+          const uint32_t j = ctz_lw<LW>(rem);
+          rem = (LW)(rem & (LW)(rem - 1));
+          const uint32_t p = j * 64u + (uint32_t)lane;
+          uint32_t cnt = 0;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
-            const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-            // cnt > 0 implies nb > 0.  pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table when
-            // there is one (max_blocks <= 64), else one binary64 division here.
-            const double pterm = (EPPK_PTERM_TAB && sn.pterm) ? sn.pterm[(size_t)nb * sn.pterm_ld + cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
-            const double t = eval_total<HAS_L, HAS_P, P_FIRST>(sn.base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
-            if (t > best) { best = t; bidx = p; }
-          }
+          for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
+          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+          // pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table (max_blocks <= 64), else one binary64 division
+          const double pterm = pterm_tab ? pt_row[cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
+          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
+          if (t > best) { best = t; bidx = p; }
         }
       }
       if (scan_rest) {                      // rare: T_a over every eligible pod outside M (total == T_a there)
@@ -587,14 +822,14 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
         for (uint32_t j = 0; j < sn.J; ++j) {
           const uint32_t p = j * 64u + (uint32_t)lane;
           const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-          double t = sn.base[p];
+          double t = s_base[p];
           if (HAS_L) t = t + tier_term(tl, tier);
           const bool okp = (okset >> j) & 1;
           if (okp && t > rbest) { rbest = t; ridx = p; }
         }
         if (rbest > best || (rbest == best && ridx < bidx)) { best = rbest; bidx = ridx; }
       }
-      if (any_m || scan_rest) wave_argmax(best, bidx);
+      if (any_m || scan_rest) wave_argmax_dpp(best, bidx);
     }
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     if (lane == 0) {
@@ -602,9 +837,21 @@ __global__ __launch_bounds__(256, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn
       out_pick[r] = none ? -1 : (int32_t)bidx;
       if (out_score) out_score[r] = none ? 0.0 : best;
     }
+  };
 
-    // ---- rotate the pipeline
-    adapter = adapter_n; nb = nb_n; m0 = m_n; slot0 = slot_n;
+  // ---- prologue: rows of the first two requests, keys of the first
+  ReqRegs qa, qb;
+  qa.kw[0] = qa.kw[1] = qa.kw[2] = qa.kw[3] = make_uint4(0, 0, 0, 0);
+  qb.kw[0] = qb.kw[1] = qb.kw[2] = qb.kw[3] = make_uint4(0, 0, 0, 0);
+  qa.bkt = qb.bkt = 0;
+  issue_row(gwave, gwave, qa);
+  issue_row(gwave + nwaves, gwave, qb);
+  issue_keys(qa);
+  // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
+  for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
+    process(r, qa, qb);
+    if (r + nwaves >= n_reqs) break;
+    process(r + nwaves, qb, qa);
   }
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
@@ -826,17 +1073,25 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     slot = h == 0 ? slots : slots + 1u;
     __hip_atomic_store((unsigned long long*)&keys[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    uint32_t s = home_slot(h, shift);
-    const uint32_t mask = slots - 1;
-    for (uint32_t n = 0; n < slots; ++n) {
-      unsigned long long k = __hip_atomic_load((unsigned long long*)&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k == 0ull) {
-        if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) break;
-        k = atomicCAS((unsigned long long*)&keys[s], 0ull, (unsigned long long)h);
-        if (k == 0ull) { atomicAdd(&stats[2], 1ull); slot = s; break; }
+    // first free word of the home bucket; a full bucket is flagged "overflowed" and the search moves to the next one
+    const uint32_t bmask = slots / kBucket - 1u;
+    uint32_t b = home_bucket(h, shift);
+    bool stop = false;
+    for (uint32_t n = 0; n <= bmask && !stop && slot == kNotFound; ++n) {
+      unsigned long long* kb = (unsigned long long*)keys + (size_t)b * kBucket;
+      for (uint32_t i = 1; i < kBucket; ++i) {
+        unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == 0ull) {
+          if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
+          k = atomicCAS(&kb[i], 0ull, (unsigned long long)h);
+          if (k == 0ull) { atomicAdd(&stats[2], 1ull); slot = b * kBucket + i; break; }
+        }
+        if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
       }
-      if (k == (unsigned long long)h) { slot = s; break; }
-      s = (s + 1) & mask;
+      if (slot == kNotFound && !stop) {
+        atomicOr(&kb[0], 1ull);
+        b = (b + 1) & bmask;
+      }
     }
   }
   if (slot == kNotFound) { atomicAdd(&stats[3], 1ull); return; }
@@ -872,6 +1127,7 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (row >= slots + 2u) return;
+  if (row < slots && (row & (kBucket - 1u)) == 0u) return;   // bucket header words are not keys (their rows are unused)
   LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
   LW v = *w;
   if (lane == (pod & 63u)) {
