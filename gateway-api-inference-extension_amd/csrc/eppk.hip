@@ -27,7 +27,9 @@ namespace {
 std::mutex g_err_mu;
 std::string g_create_err;
 
+// One device allocation per snapshot buffer; the arrays below are views into it (fast kernel: one buffer descriptor).
 struct SnapBuf {
+  uint8_t*  blob = nullptr;
   double*   base = nullptr;
   uint32_t* queue = nullptr;
   double*   kv = nullptr;
@@ -38,6 +40,10 @@ struct SnapBuf {
   void*     qmax_t = nullptr;
   double*   topv = nullptr;   // [129][64]
   uint32_t* topi = nullptr;   // [129][64]
+};
+
+struct SnapLayout {            // byte offsets inside a snapshot blob
+  size_t base = 0, queue = 0, kv = 0, act = 0, wait = 0, freew = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -66,6 +72,7 @@ struct eppk_ctx {
 
   // snapshot (double buffered: a publish never overwrites the rows an in-flight pick reads)
   SnapBuf snap[2];
+  SnapLayout lay;
   int cur = 0;
   bool have_snapshot = false;
   uint32_t n_pods = 0;
@@ -91,7 +98,7 @@ struct eppk_ctx {
   uint32_t launches = 0;
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
-  uint32_t fast_threads = 512;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
+  uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
 
   std::string err;
 };
@@ -134,6 +141,8 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.base = s.base; k.queue = s.queue; k.kv = s.kv;
   k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
   k.topv = s.topv; k.topi = s.topi;
+  k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
+  k.off_topv = (uint32_t)c->lay.topv; k.off_topi = (uint32_t)c->lay.topi; k.off_act = (uint32_t)c->lay.act; k.off_wait = (uint32_t)c->lay.wait;
   k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
@@ -198,7 +207,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   size_t lds;
   if (fast) {
     pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
-    lds = (size_t)sn.J * 64u * 8u + (size_t)pwn * 8u;
+    lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u;   // base | lw[4] | pterm
   } else {
     lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
   }
@@ -290,8 +299,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (cfg->max_pods == 0 || cfg->max_pods > EPPK_MAX_PODS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: max_pods out of range (1..4096)");
   if (cfg->max_blocks > EPPK_MAX_BLOCKS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: max_blocks > 256");
   if (cfg->n_scorers > EPPK_MAX_SCORERS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: n_scorers > 8");
-  if (cfg->index_slots && ((cfg->index_slots & (cfg->index_slots - 1)) || cfg->index_slots < 64u || cfg->index_slots > (1u << 30)))
-    return fail(nullptr, EPPK_ERR_ARG, "eppk_create: index_slots must be a power of two in [64, 2^30]");
+  if (cfg->index_slots && ((cfg->index_slots & (cfg->index_slots - 1)) || cfg->index_slots < 64u || cfg->index_slots > (1u << 28)))
+    return fail(nullptr, EPPK_ERR_ARG, "eppk_create: index_slots must be a power of two in [64, 2^28]");
   for (uint32_t k = 0; k < cfg->n_scorers; ++k)
     if (cfg->chain[k].kind < EPPK_SCORER_QUEUE || cfg->chain[k].kind > EPPK_SCORER_PREFIX)
       return fail(nullptr, EPPK_ERR_ARG, "eppk_create: unknown scorer kind");
@@ -315,7 +324,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
 
   if (const char* ft = getenv("EPPK_FAST_THREADS")) {
     const int v = atoi(ft);
-    if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) c->fast_threads = (uint32_t)v;
+    if (v >= 64 && v <= 1024 && v % 64 == 0) c->fast_threads = (uint32_t)v;
   }
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
@@ -353,19 +362,25 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
 
   const size_t np64 = (size_t)c->jmax * 64u;
   const size_t lora_bytes = (size_t)EPPK_MAX_ADAPTERS * 64u * (size_t)c->lw_bytes;
-  for (int b = 0; b < 2; ++b) {
-    CHK(hipMalloc((void**)&c->snap[b].base, np64 * 8u));
-    CHK(hipMalloc((void**)&c->snap[b].queue, np64 * 4u));
-    CHK(hipMalloc((void**)&c->snap[b].kv, np64 * 8u));
-    CHK(hipMalloc(&c->snap[b].act_t, lora_bytes));
-    CHK(hipMalloc(&c->snap[b].wait_t, lora_bytes));
-    CHK(hipMalloc(&c->snap[b].free_t, 64u * (size_t)c->lw_bytes));
-    CHK(hipMalloc(&c->snap[b].qmin_t, 64u * (size_t)c->lw_bytes));
-    CHK(hipMalloc(&c->snap[b].qmax_t, 64u * (size_t)c->lw_bytes));
-    CHK(hipMalloc((void**)&c->snap[b].topv, 129u * 64u * 8u));
-    CHK(hipMalloc((void**)&c->snap[b].topi, 129u * 64u * 4u));
+  {
+    SnapLayout& L = c->lay;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
+    L.base = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
+    L.act = take(lora_bytes); L.wait = take(lora_bytes);
+    L.freew = take(64u * (size_t)c->lw_bytes); L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
+    L.topv = take(129u * 64u * 8u); L.topi = take(129u * 64u * 4u);
+    L.bytes = off;
+    for (int b = 0; b < 2; ++b) {
+      SnapBuf& s = c->snap[b];
+      CHK(hipMalloc((void**)&s.blob, L.bytes));
+      s.base = (double*)(s.blob + L.base); s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
+      s.act_t = s.blob + L.act; s.wait_t = s.blob + L.wait; s.free_t = s.blob + L.freew;
+      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax;
+      s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
+    }
   }
-  if (c->canonical && c->has_p && cfg->max_blocks >= 1 && cfg->max_blocks <= 64) {
+  if (c->canonical && c->has_p && cfg->max_blocks >= 1 && c->npl == 6) {   // the NPL == 6 fast kernels read it unconditionally
     // pterm[n][cnt] = clamp01((double)cnt / (double)n) * (double)w_prefix — the oracle's operations, done once here
     const uint32_t ld = cfg->max_blocks + 1u;
     std::vector<double> tab((size_t)ld * ld, 0.0);
@@ -398,11 +413,7 @@ void eppk_destroy(eppk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int b = 0; b < 2; ++b) {
-    (void)hipFree(c->snap[b].base); (void)hipFree(c->snap[b].queue); (void)hipFree(c->snap[b].kv);
-    (void)hipFree(c->snap[b].act_t); (void)hipFree(c->snap[b].wait_t); (void)hipFree(c->snap[b].free_t); (void)hipFree(c->snap[b].qmin_t); (void)hipFree(c->snap[b].qmax_t);
-    (void)hipFree(c->snap[b].topv); (void)hipFree(c->snap[b].topi);
-  }
+  for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
@@ -618,7 +629,17 @@ int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch_device: no snapshot published");
   if (n_reqs == 0) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  return launch_pick(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream ? (hipStream_t)stream : c->stream);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  // the kernels address request rows with 32-bit byte offsets: split batches of 2 GiB and more
+  const uint32_t per = (uint32_t)((1ull << 31) / c->stride);
+  const size_t J = (c->n_pods + 63u) / 64u;
+  for (uint32_t r0 = 0; r0 < n_reqs; r0 += per) {
+    const uint32_t n = (n_reqs - r0 < per) ? n_reqs - r0 : per;
+    int rc = launch_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
+                         d_out_pick + r0, d_out_score ? d_out_score + r0 : nullptr, st);
+    if (rc) return rc;
+  }
+  return EPPK_OK;
 }
 
 int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick, double* out_score) {

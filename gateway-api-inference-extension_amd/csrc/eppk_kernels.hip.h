@@ -25,6 +25,15 @@
 #include <stdint.h>
 
 // Build-time knobs
+#ifndef EPPK_FAST_MAX_THREADS
+#define EPPK_FAST_MAX_THREADS 1024 // largest workgroup the fast kernel may be launched with (caps its VGPR budget at 512 * 256 / threads)
+#endif
+#ifndef EPPK_SW_PIPE
+#define EPPK_SW_PIPE 1    // 1: key gather of request r+1 issued during request r (16 landing VGPRs live across the evaluation);
+#endif                    // 0: keys gathered and consumed at the top of the request (fewer VGPRs -> more waves per SIMD)
+#ifndef EPPK_LATE_HOOK
+#define EPPK_LATE_HOOK 0
+#endif
 #ifndef EPPK_MIN_WAVES
 #define EPPK_MIN_WAVES 1 // __launch_bounds__ minimum waves per SIMD for the fast kernel
 #endif
@@ -56,6 +65,9 @@ struct KSnap {
   uint32_t        lead_queue;  // the fused leading run contains a QUEUE scorer
   const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
   uint32_t pterm_ld;
+  const uint8_t*  blob;    // all of the above live in ONE allocation: the fast kernel reads them through a single buffer
+  uint32_t blob_bytes;     // descriptor (SGPR base + 32-bit offsets: no 64-bit per-lane pointers in VGPRs)
+  uint32_t off_topv, off_topi, off_act, off_wait;   // byte offsets inside blob
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
@@ -110,8 +122,10 @@ __device__ __forceinline__ uint32_t probe(const KIndex& ix, uint64_t h, bool act
   if (h == kTomb) return ix.keys[ix.slots + 1u] ? ix.slots + 1u : kNotFound;
   const uint32_t bmask = (ix.slots / kBucket) - 1u;
   uint32_t b = home_bucket(h, ix.shift);
+#pragma unroll 1
   for (uint32_t n = 0; n <= bmask; ++n) {
     const uint64_t* kb = ix.keys + (size_t)b * kBucket;
+#pragma unroll 1
     for (uint32_t i = 1; i < kBucket; ++i) {
       const uint64_t k = kb[i];
       if (k == h) return b * kBucket + i;
@@ -400,10 +414,16 @@ __device__ __forceinline__ void planes_addn(LW (&c)[NPL], const LW (&b)[NB]) {
 }
 
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {   // lanes outside ROW_MASK / without a source keep v
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes outside ROW_MASK keep v
+  if constexpr (ROW_MASK == 0xf) {     // every lane has a source: no tied "old" operand, so no register copies
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  } else {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
 }
 __device__ __forceinline__ double vmax_f64(double a, double b) {   // inputs are never NaN (SEMANTICS.md: clamp01 kills NaN)
   double r;
@@ -423,7 +443,9 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
-  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+  uint32_t o;
+  if constexpr (ROW_MASK == 0xf) o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false);
+  else o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
   return o < v ? o : v;
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -464,14 +486,25 @@ __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) {   // value of the oth
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
 }
 
-// Issue the bucket loads of q.h (q.h must already be 0 in lanes without a key).
-__device__ __forceinline__ void pair_probe_issue(const KIndex& ix, ReqRegs& q, int lane) {
-  q.bkt = home_bucket(q.h, ix.shift);
-  const uint4* p = (const uint4*)(ix.keys + (size_t)q.bkt * kBucket + (size_t)(lane & 1) * 8u);
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+  return ((uint64_t)v.y << 32) | v.x;
+}
+// Home bucket of q.h (q.h must already be 0 in lanes without a key).
+__device__ __forceinline__ void pair_probe_prepare(const KIndex& ix, ReqRegs& q) { q.bkt = home_bucket(q.h, ix.shift); }
+// Issue the four 16-byte loads of this lane's half of the home bucket (rk = buffer descriptor of the key table).
+__device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, ReqRegs& q, int lane) {
 #if defined(EPPK_DBG_KEYS_NONE)
   q.kw[0] = q.kw[1] = q.kw[2] = q.kw[3] = make_uint4(0, 0, 0, 0);
 #else
-  q.kw[0] = p[0]; q.kw[1] = p[1]; q.kw[2] = p[2]; q.kw[3] = p[3];
+  const uint32_t voff = q.bkt * (kBucket * 8u) + ((uint32_t)lane & 1u) * 64u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(voff + 16u * (uint32_t)i), 0, 0);
+    q.kw[i] = make_uint4(v.x, v.y, v.z, v.w);
+  }
 #endif
 }
 
@@ -515,11 +548,13 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
     if (__any(pend)) {                                 // absent from an overflowed bucket: walk the following buckets
       const uint32_t bmask = (ix.slots / kBucket) - 1u;
       uint32_t b = q.bkt;
+#pragma unroll 1
       for (uint32_t n = 0; n < bmask && __any(pend); ++n) {
         if (pend) {
           b = (b + 1) & bmask;
           const uint64_t* kb = ix.keys + (size_t)b * kBucket + (size_t)sub * 8u;
           uint32_t s2 = kNotFound;
+#pragma unroll 1
           for (uint32_t i = 0; i < 8u; ++i)
             if (kb[i] == h && (sub | i) != 0u) s2 = b * kBucket + sub * 8u + i;
           uint32_t o2 = sub == 0u ? (uint32_t)(kb[0] & 1ull) : 0u;
@@ -544,7 +579,6 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
 // through ONE raw buffer descriptor with the row's byte offset in the instruction's SGPR offset operand: zero VALU ops and
 // zero 64-bit address arithmetic per row (buffer_load ... v_lane_off, s[rsrc], s_row_off offen).  Hit k of the request is in
 // lane pair k of slot_eff.  Larger tables take the global_load path (one v_lshl_add_u64 per row).
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <typename LW>
 __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
   if constexpr (sizeof(LW) == 8) {
@@ -614,16 +648,19 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED>
-__global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                         unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
-  double* s_pterm = s_base + (size_t)sn.J * 64u;
-  const bool pterm_tab = HAS_P && sn.pterm != nullptr;
+  double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
+  double* s_pterm = s_lw + 4;
+  // the exact prefix-term table exists whenever max_blocks <= 63, i.e. for every NPL == 6 instantiation (eppk.hip)
+  constexpr bool pterm_tab = HAS_P && NPL == 6;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
+  if (threadIdx.x < 4u) s_lw[threadIdx.x] = tl.lw[threadIdx.x];
   if (pterm_tab)
     for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
   __syncthreads();
@@ -632,9 +669,15 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
   const uint32_t wpb = blockDim.x >> 6;
   // wave-uniform ids in SGPRs: every per-request address below is scalar arithmetic
   const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-  const uint32_t nwaves = gridDim.x * wpb;
+  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
   // raw buffer descriptor over the pod-set rows (gfx9 word 3: 32-bit data format); num_records = table bytes
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000);
+  // ... and over the key table, the snapshot tables and the request rows: every hot-loop load is
+  // buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR row offset) -- no 64-bit per-lane pointers, no address VALU ops.
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
+  const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
 
   const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
@@ -645,44 +688,57 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
   const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;             // ... probed by the pipelined first gather
   // u64 word of a request row that this lane pair reads as "its" hash (always in bounds: word 0 when the row has no hashes)
   const uint32_t ki = (uint32_t)lane >> 1;
-  const uint32_t hidx = (HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u;
+  const uint32_t hidx8 = ((HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u) * 8u;
   const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
 
   if (gwave >= n_reqs) return;
 
-  // Stage 0: request row (header + this lane pair's hash).  Relaxed wavefront-scope atomic loads are plain
-  // global_load_dwordx2 that the compiler neither sinks towards their first use nor hoists above earlier loads.
+  // Stage 0: request row.  The header is wave-uniform: a scalar load straight into SGPRs (constant address space); the
+  // lane pair's hash is one buffer load.
   auto issue_row = [&](uint32_t rr, uint32_t r_fallback, ReqRegs& q) {
-    const uint64_t* row64 = (const uint64_t*)(reqs + (size_t)(rr < n_reqs ? rr : r_fallback) * stride);
-    q.hdr = __hip_atomic_load(row64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    q.h = __hip_atomic_load(row64 + hidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t soff = (rr < n_reqs ? rr : r_fallback) * stride;
+    q.hdr = *(const uint64_t __attribute__((address_space(4)))*)(reqs + soff);
+    q.h = buffer_load_u64(rq, hidx8, soff);
   };
   // Stage 1: home buckets of the request's first 32 hashes
-  auto issue_keys = [&](ReqRegs& q) {
+  auto prepare_keys = [&](ReqRegs& q) {
     if (use_index) {
       q.h = (ki < hw0) ? q.h : 0ull;
-      pair_probe_issue(ix, q, lane);
+      pair_probe_prepare(ix, q);
     }
+  };
+  auto issue_keys = [&](ReqRegs& q) {
+    if (use_index) pair_probe_issue(rk, q, lane);
   };
 
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
   // r + 2 nwaves (into `cur`, which is free once the probe of r is finished).
   auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
-    const int32_t adapter = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)cur.hdr);
-    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(cur.hdr >> 32));
+    const int32_t adapter = (int32_t)(uint32_t)cur.hdr;            // wave-uniform (scalar load)
+    const uint32_t nb = (uint32_t)(cur.hdr >> 32);
 
-    // ---- A. finish the probe of r: number of leading hits and their rows
+    // ---- A. finish the probe of r: number of leading hits and their rows.  The hash of r + 1 is consumed here too (its
+    // home bucket), so that the wait for its prefetch sits at the top of the iteration and not behind the row loads.
     uint32_t m0 = 0, slot0 = ix.slots + 2u;
+#if EPPK_SW_PIPE
     if (use_index && nb != 0u) m0 = pair_probe_finish(ix, cur, nb < kKeysPerProbe ? nb : kKeysPerProbe, lane, slot0);
+    prepare_keys(nxt);
+#else
+    if (use_index && nb != 0u) {
+      prepare_keys(cur);
+      issue_keys(cur);
+      m0 = pair_probe_finish(ix, cur, nb < kKeysPerProbe ? nb : kKeysPerProbe, lane, slot0);
+    }
+#endif
 
     // ---- B. loads that depend on the request header only
     const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    const double top_t = (sn.topv + (size_t)arow * 64u)[lane];
-    const uint32_t top_p = (sn.topi + (size_t)arow * 64u)[lane];
+    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, sn.off_topv + arow * 512u));
+    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(sn.off_topi + arow * 256u), 0);
     LW a_w = 0, w_w = 0;
     if (HAS_L && adapter >= 0) {
-      a_w = ((const LW*)sn.act_t + (size_t)adapter * 64u)[lane];
-      w_w = ((const LW*)sn.wait_t + (size_t)adapter * 64u)[lane];
+      a_w = buffer_load_lw<LW>(rsn, laneLW, sn.off_act + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
+      w_w = buffer_load_lw<LW>(rsn, laneLW, sn.off_wait + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
     }
 
     // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
@@ -697,9 +753,11 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
 #pragma unroll
       for (int u = 0; u < 8; ++u) { w[u] = t[u]; w[8 + u] = 0; }
     }
-    issue_keys(nxt);
+#if !EPPK_LATE_HOOK
+    if (EPPK_SW_PIPE) issue_keys(nxt);
     issue_row(r + 2u * nwaves, r, cur);
     __builtin_amdgcn_sched_barrier(0);
+#endif
 
     LW c[NPL];
 #pragma unroll
@@ -719,16 +777,23 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = b[k];
       }
+#if EPPK_LATE_HOOK   // later stages issued once the 16 landing registers of the rows are free again (lower VGPR peak)
+      __builtin_amdgcn_sched_barrier(0);
+      if (EPPK_SW_PIPE) issue_keys(nxt);
+      issue_row(r + 2u * nwaves, r, cur);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if (m0 > 16u) count_more<LW, NPL>(ix, rs, slot0, 16u, m0, lane, c);
       if (m0 == kKeysPerProbe && nb > kKeysPerProbe) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
         uint32_t mlast = m0;
         for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
-          const uint64_t* hs = (const uint64_t*)(reqs + (size_t)r * stride + 8);
           const uint32_t nchunk = (nb - b0) < kKeysPerProbe ? (nb - b0) : kKeysPerProbe;
           ReqRegs t;
           t.hdr = 0;
-          t.h = (ki < nchunk) ? hs[b0 + ki] : 0ull;
-          pair_probe_issue(ix, t, lane);
+          t.h = buffer_load_u64(rq, (1u + b0 + (ki < nchunk ? ki : 0u)) * 8u, r * stride);
+          t.h = (ki < nchunk) ? t.h : 0ull;
+          pair_probe_prepare(ix, t);
+          pair_probe_issue(rk, t, lane);
           uint32_t slotc;
           mlast = pair_probe_finish(ix, t, nchunk, lane, slotc);
           count_more<LW, NPL>(ix, rs, slotc, 0u, mlast, lane, c);
@@ -773,63 +838,70 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
       const LW okset = (LW)(cand & (LW)~nz);                 // candidates whose total is exactly T_a[p]
       const bool any_m = HAS_P && __any(mset != 0);
 
-      // best candidate outside M: first table entry in okset
-      const bool has = top_p != kNoPod;
-      bool ok = has;
-      if (MASKED || (HAS_P && hits)) {
-        const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
-        LW okq;
-        if constexpr (sizeof(LW) == 8) {
-          const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)okset, (int)ql);
-          const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(okset >> 32), (int)ql);
-          okq = ((uint64_t)hi << 32) | lo;
-        } else {
-          okq = (LW)__shfl((int)(uint32_t)okset, (int)ql);
-        }
-        ok = has && ((okq >> qj) & 1);
-      }
-      const unsigned long long okm = __ballot(ok);
-      bool scan_rest = false;
-      if (okm) {
-        const int f = __builtin_ctzll(okm);
-        cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
-                                  __builtin_amdgcn_readlane(__double2loint(top_t), f));
-        cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
-      } else {
-        scan_rest = sn.n_pods > 64u && __any(okset != 0);  // table exhausted although eligible pods remain
-      }
-
       if (any_m) {
         const double* pt_row = s_pterm + (size_t)nb * sn.pterm_ld;   // cnt > 0 implies nb > 0
+        const double nbd = (double)nb;
         LW rem = mset;
-        while (rem != 0) {                   // each lane walks its own pods of M in ascending order
+        while (rem != 0) {                   // each lane walks its own pods of M in ascending order (branch-free body)
           const uint32_t j = ctz_lw<LW>(rem);
           rem = (LW)(rem & (LW)(rem - 1));
           const uint32_t p = j * 64u + (uint32_t)lane;
           uint32_t cnt = 0;
 #pragma unroll
           for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
-          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-          // pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table (max_blocks <= 64), else one binary64 division
-          const double pterm = pterm_tab ? pt_row[cnt] : clamp01((double)cnt / (double)nb) * tl.wp;
-          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], HAS_L ? tier_term(tl, tier) : 0.0, pterm);
+          // pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table (NPL == 6), else one binary64 division
+          double pterm;
+          if constexpr (pterm_tab) pterm = pt_row[cnt];
+          else pterm = clamp01((double)cnt / nbd) * tl.wp;
+          double lterm = 0.0;
+          if (HAS_L) lterm = s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
+          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
           if (t > best) { best = t; bidx = p; }
         }
+        wave_argmax_dpp(best, bidx);
       }
-      if (scan_rest) {                      // rare: T_a over every eligible pod outside M (total == T_a there)
-        double rbest = -__builtin_inf();
-        uint32_t ridx = kNoPod;
-        for (uint32_t j = 0; j < sn.J; ++j) {
-          const uint32_t p = j * 64u + (uint32_t)lane;
-          const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
-          double t = s_base[p];
-          if (HAS_L) t = t + tier_term(tl, tier);
-          const bool okp = (okset >> j) & 1;
-          if (okp && t > rbest) { rbest = t; ridx = p; }
+
+      // Best candidate outside M: the first entry of the adapter's top table that is in okset.  No pod outside M can beat
+      // the first entry's T, so the look-up is skipped when the best pod of M already beats it.
+      const bool has = top_p != kNoPod;
+      const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), 0),
+                                           __builtin_amdgcn_readlane(__double2loint(top_t), 0));
+      if (!(any_m && best > top0)) {
+        bool ok = has;
+        if (MASKED || (HAS_P && hits)) {
+          const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
+          LW okq;
+          if constexpr (sizeof(LW) == 8) {
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)okset, (int)ql);
+            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(okset >> 32), (int)ql);
+            okq = ((uint64_t)hi << 32) | lo;
+          } else {
+            okq = (LW)__shfl((int)(uint32_t)okset, (int)ql);
+          }
+          ok = has && ((okq >> qj) & 1);
         }
-        if (rbest > best || (rbest == best && ridx < bidx)) { best = rbest; bidx = ridx; }
+        const unsigned long long okm = __ballot(ok);
+        if (okm) {
+          const int f = __builtin_ctzll(okm);
+          cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
+                                    __builtin_amdgcn_readlane(__double2loint(top_t), f));
+          cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
+        } else if (sn.n_pods > 64u && __any(okset != 0)) {
+          // rare: table exhausted although eligible pods remain -> T_a over every eligible pod outside M (total == T_a there)
+          double rbest = -__builtin_inf();
+          uint32_t ridx = kNoPod;
+          for (uint32_t j = 0; j < sn.J; ++j) {
+            const uint32_t p = j * 64u + (uint32_t)lane;
+            double t = s_base[p];
+            if (HAS_L) t = t + s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
+            const bool okp = (okset >> j) & 1;
+            if (okp && t > rbest) { rbest = t; ridx = p; }
+          }
+          wave_argmax_dpp(rbest, ridx);
+          cand_t = rbest;
+          cand_p = ridx;
+        }
       }
-      if (any_m || scan_rest) wave_argmax_dpp(best, bidx);
     }
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     if (lane == 0) {
@@ -846,7 +918,7 @@ __global__ __launch_bounds__(1024, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap s
   qa.bkt = qb.bkt = 0;
   issue_row(gwave, gwave, qa);
   issue_row(gwave + nwaves, gwave, qb);
-  issue_keys(qa);
+  if (EPPK_SW_PIPE) { prepare_keys(qa); issue_keys(qa); }
   // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
   for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
     process(r, qa, qb);
