@@ -106,13 +106,15 @@ def _model_name(adapter: int) -> bytes:
 
 def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None, masked: bool = False,
                   n_groups: int = 256, pods_per_group: int = 8, seed: Optional[int] = None,
-                  req_seed: Optional[int] = None, zipf_s: float = 1.0) -> Workload:
+                  req_seed: Optional[int] = None, zipf_s: float = 1.0, B: Optional[int] = None) -> Workload:
     """Build config `config` of BASELINE.json (optionally with R / P overridden for small parity cases)."""
     c = dict(CONFIGS[config])
     if R is not None:
         c["R"] = R
     if P is not None:
         c["P"] = P
+    if B is not None:
+        c["B"] = B
     R, P, A, B = c["R"], c["P"], c["A"], c["B"]
     seed = (0x5EED0000 + config) if seed is None else seed
     rseed = seed if req_seed is None else req_seed   # request streams only (pods / groups / index stay on `seed`)

@@ -221,3 +221,65 @@ def test_masked_fast_path_corner_cases(pkg, orc):
     # chains without a QUEUE scorer never need the exact path
     assert_same(*run_both(pkg, orc, wl, chain=[(2, 3), (3, 2), (4, 5)], mask=mask, max_pods=4096))
     assert_same(*run_both(pkg, orc, wl, chain=[(4, 5), (3, 2)], mask=mask, max_pods=4096))
+
+
+def _home_bucket(h: np.ndarray, n_buckets: int) -> np.ndarray:
+    """Home bucket of a block hash, as libeppk places it (eppk_kernels.hip.h home_bucket): top log2(buckets) bits of
+    (lo ^ hi) * 0x9E3779B1 mod 2^32.  Test-side restatement used only to BUILD colliding keys."""
+    lg = int(n_buckets).bit_length() - 1
+    f = ((h & np.uint64(0xFFFFFFFF)) ^ (h >> np.uint64(32))).astype(np.uint64)
+    return ((f * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(32 - lg)
+
+
+@pytest.mark.parametrize("chain", [[(KV, 1), (PF, 5)], [(PF, 5), (Q, 1), (KV, 1)]], ids=["fast", "generic"])
+def test_overflowed_buckets(pkg, orc, chain):
+    """More keys than a 15-key bucket holds hash to the same home bucket: the surplus lives in the following buckets and
+    look-ups (hits and misses) must walk there.  64 slots = 4 buckets, 30 keys, 24 of them with home bucket 1."""
+    P, B, slots = 200, 8, 64
+    rng = np.random.default_rng(11)
+    cand = rng.integers(1, 2**63, 200000, dtype=np.uint64)
+    hb = _home_bucket(cand, slots // 16)
+    hot = cand[hb == 1][:24]
+    cold = cand[hb == 3][:6]
+    absent = cand[hb == 1][24:40]           # never inserted; their home bucket is full and overflowed
+    assert hot.size == 24 and cold.size == 6 and absent.size == 16
+    keys = np.concatenate([hot, cold])
+    ih = np.repeat(keys, 3)
+    ip = (np.arange(ih.size, dtype=np.uint32) * 7) % P
+    pods = pkg.workload.make_pods(5, P, 128)
+    # chains: runs of present keys, broken at various depths by an absent key
+    R = 300
+    hashes = np.zeros((R, B), dtype=np.uint64)
+    for r in range(R):
+        depth = rng.integers(0, B + 1)
+        hashes[r, :depth] = rng.choice(keys, depth, replace=False) if depth else []
+        hashes[r, depth:] = rng.choice(absent, B - depth)
+    reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hashes, B)
+    with pkg.BatchedPicker(chain, max_pods=1024, max_blocks=B, max_batch=R, index_slots=slots) as pk:
+        pk.publish(pods)
+        pk.index_insert(ih, ip)
+        assert pk.index_size() == keys.size
+        picks, scores = pk.pick(reqs)
+    oix = orc.OracleIndex()
+    oix.insert(ih, ip)
+    op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+    assert_same(picks, scores, op, osc)
+
+
+def test_index_full_is_reported(pkg):
+    """The table refuses keys beyond its load limit (slots / 2) with EPPK_ERR_INDEX_FULL instead of degrading."""
+    with pkg.BatchedPicker([(PF, 1)], max_pods=64, max_blocks=4, max_batch=8, index_slots=64) as pk:
+        pk.publish(pkg.workload.make_pods(1, 64, 128))
+        h = np.arange(1, 33, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        pk.index_insert(h, np.zeros(32, dtype=np.uint32))          # exactly at the limit
+        with pytest.raises(pkg.EppkError) as ei:
+            pk.index_insert(np.array([12345], dtype=np.uint64), np.zeros(1, dtype=np.uint32))
+        assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("B,R", [(40, 256), (100, 128), (256, 64)])
+def test_long_chains_beyond_the_pipelined_gather(pkg, orc, B, R):
+    """More than 32 blocks per request: the first 32 hashes go through the pipelined gather, the rest through the
+    synchronous chunk loop (9 counter planes when B >= 64)."""
+    wl = pkg.workload.make_workload(3, R=R, P=700, B=B)
+    assert_same(*run_both(pkg, orc, wl, max_pods=1024))
