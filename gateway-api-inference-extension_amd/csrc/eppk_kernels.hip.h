@@ -535,7 +535,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
 #ifdef EPPK_DBG_SKIP_KEYS   // timing experiment only (wrong results): 16 pseudo-hits
   slot = (ki < 16u && act) ? q.bkt * kBucket + 1u : kNotFound;
 #else
-  if (__any(act && (h + 1ull) <= 1ull)) {             // h == 0 or h == ~0 somewhere in the request (rare)
+  if (__builtin_expect(__any(act && (h + 1ull) <= 1ull), 0)) {             // h == 0 or h == ~0 somewhere in the request (rare)
     slot = probe(ix, h, act);
   } else {
     const uint32_t pos = match8(q.kw, h, sub == 0u);
@@ -545,7 +545,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
     uint32_t ovf = sub == 0u ? (q.kw[0].x & 1u) : 0u;  // header bit 0, seen by the even lane
     ovf |= dpp_xor1(ovf);
     bool pend = act && s == kNotFound && ovf != 0u;
-    if (__any(pend)) {                                 // absent from an overflowed bucket: walk the following buckets
+    if (__builtin_expect(__any(pend), 0)) {            // absent from an overflowed bucket: walk the following buckets
       const uint32_t bmask = (ix.slots / kBucket) - 1u;
       uint32_t b = q.bkt;
 #pragma unroll 1
@@ -592,7 +592,7 @@ __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t
 }
 template <typename LW, int N>
 __device__ __forceinline__ void load_rows(const KIndex& ix, __amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
-  if (ix.small) {
+  if (__builtin_expect(ix.small != 0u, 1)) {
     const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
     const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
 #pragma unroll
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       __builtin_amdgcn_sched_barrier(0);
 #endif
       if (m0 > 16u) count_more<LW, NPL>(ix, rs, slot0, 16u, m0, lane, c);
-      if (m0 == kKeysPerProbe && nb > kKeysPerProbe) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
+      if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
         uint32_t mlast = m0;
         for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
           const uint32_t nchunk = (nb - b0) < kKeysPerProbe ? (nb - b0) : kKeysPerProbe;
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
                                     __builtin_amdgcn_readlane(__double2loint(top_t), f));
           cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
-        } else if (sn.n_pods > 64u && __any(okset != 0)) {
+        } else if (__builtin_expect(sn.n_pods > 64u && __any(okset != 0), 0)) {
           // rare: table exhausted although eligible pods remain -> T_a over every eligible pod outside M (total == T_a there)
           double rbest = -__builtin_inf();
           uint32_t ridx = kNoPod;
