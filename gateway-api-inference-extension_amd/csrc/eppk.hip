@@ -84,6 +84,7 @@ struct eppk_ctx {
   uint64_t* keys = nullptr;
   void* bitmaps = nullptr;
   uint32_t slots = 0, shift = 0, limit = 0;
+  size_t rows_bytes = 0, index_bytes = 0;   // rows | keys in one allocation
   unsigned long long* stats = nullptr;  // device [4 + 2*kStatSlots]: -, -, occupied keys, dropped inserts, then per-wave {hits, lookups}
 
   // staging for the host-buffer entry point
@@ -143,7 +144,6 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
   k.topv = s.topv; k.topi = s.topi;
   k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
-  k.off_topv = (uint32_t)c->lay.topv; k.off_topi = (uint32_t)c->lay.topi; k.off_act = (uint32_t)c->lay.act; k.off_wait = (uint32_t)c->lay.wait;
   k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
@@ -154,9 +154,9 @@ KSnap make_ksnap(const eppk_ctx* c) {
 KIndex make_kindex(const eppk_ctx* c) {
   KIndex k{};
   k.keys = c->keys; k.bitmaps = c->bitmaps; k.slots = c->slots; k.shift = c->shift;
-  const uint64_t tb = ((uint64_t)c->slots + 3u) * 64u * (uint64_t)c->lw_bytes;
-  k.small = (c->slots && tb < (1ull << 32)) ? 1u : 0u;
-  k.table_bytes = k.small ? (uint32_t)tb : 0u;
+  k.small = (c->slots && c->index_bytes < (1ull << 32)) ? 1u : 0u;
+  k.table_bytes = k.small ? (uint32_t)c->index_bytes : 0u;
+  k.keys_off = k.small ? (uint32_t)c->rows_bytes : 0u;
   return k;
 }
 
@@ -198,7 +198,8 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st) {
   const bool masked = d_mask != nullptr;
-  const bool fast = c->canonical;  // masked batches use the fast kernel's MASKED instantiation
+  // masked batches use the fast kernel's MASKED instantiation; an index of 4 GiB and more (32-bit buffer offsets) -> generic kernel
+  const bool fast = c->canonical && (c->slots == 0 || c->index_bytes < (1ull << 32));
   const void* fn = pick_kernel_ptr(c, fast, masked);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
@@ -367,10 +368,14 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     SnapLayout& L = c->lay;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
+    // per-adapter tables first, back to back: the fast kernel addresses them with the compile-time offsets SnapOff<LW>
+    L.topv = off; off += 129u * 64u * 8u;
+    L.topi = off; off += 129u * 64u * 4u;
+    L.act = off; off += lora_bytes;
+    L.wait = off; off += lora_bytes;
+    off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
-    L.act = take(lora_bytes); L.wait = take(lora_bytes);
     L.freew = take(64u * (size_t)c->lw_bytes); L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
-    L.topv = take(129u * 64u * 8u); L.topi = take(129u * 64u * 4u);
     L.bytes = off;
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
@@ -399,10 +404,12 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     while ((1u << lg) < c->slots / 16u) ++lg;   // 16-slot buckets (eppk_kernels.hip.h: KIndex)
     c->shift = 32u - lg;
     c->limit = c->slots / 2u;  // load factor <= 0.5
-    CHK(hipMalloc((void**)&c->keys, ((size_t)c->slots + 2u) * 8u));
-    CHK(hipMalloc(&c->bitmaps, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes));
-    CHK(hipMemset(c->keys, 0, ((size_t)c->slots + 2u) * 8u));
-    CHK(hipMemset(c->bitmaps, 0, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes));
+    // ONE allocation: pod-set rows first, the key table behind them (the fast kernel reads both through one descriptor)
+    c->rows_bytes = (((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes + 255u) & ~(size_t)255u;
+    c->index_bytes = c->rows_bytes + ((size_t)c->slots + 2u) * 8u;
+    CHK(hipMalloc(&c->bitmaps, c->index_bytes));
+    c->keys = (uint64_t*)((uint8_t*)c->bitmaps + c->rows_bytes);
+    CHK(hipMemset(c->bitmaps, 0, c->index_bytes));
   }
   CHK(hipDeviceSynchronize());
 #undef CHK
@@ -415,7 +422,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->keys); (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
@@ -539,8 +546,7 @@ int eppk_index_clear(eppk_ctx* c) {
   if (!c) return EPPK_ERR_ARG;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipMemsetAsync(c->keys, 0, ((size_t)c->slots + 2u) * 8u, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, ((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;

@@ -66,8 +66,8 @@ struct KSnap {
   const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
   uint32_t pterm_ld;
   const uint8_t*  blob;    // all of the above live in ONE allocation: the fast kernel reads them through a single buffer
-  uint32_t blob_bytes;     // descriptor (SGPR base + 32-bit offsets: no 64-bit per-lane pointers in VGPRs)
-  uint32_t off_topv, off_topi, off_act, off_wait;   // byte offsets inside blob
+  uint32_t blob_bytes;     // descriptor (SGPR base + 32-bit offsets: no 64-bit per-lane pointers in VGPRs).  topv, topi, act_t
+                           // and wait_t sit at the compile-time offsets of SnapOff<LW> (immediates, not SGPRs)
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
@@ -85,8 +85,18 @@ struct KIndex {
   const void*     bitmaps; // [slots+3][64] LW: rows slots / slots+1 hold hashes 0 / ~0, row slots+2 is all-zero
   uint32_t slots;          // power of two >= 64 (0 = no index); slots / 16 buckets
   uint32_t shift;          // 32 - log2(slots / 16)
-  uint32_t small;          // the rows table is < 4 GiB: rows are read through one buffer descriptor + SGPR offsets
-  uint32_t table_bytes;    // (slots + 3) * 64 * sizeof(LW) when small
+  uint32_t small;          // rows + keys (ONE allocation, rows first) are < 4 GiB: both are read through one buffer descriptor
+  uint32_t table_bytes;    // bytes of that allocation when small
+  uint32_t keys_off;       // byte offset of keys inside it
+};
+
+// Byte offsets of the per-adapter tables at the head of a snapshot blob (eppk.hip lays the blob out with the same constants).
+template <typename LW> struct SnapOff {
+  static constexpr uint32_t topv = 0u;                                   // f64 [129][64]
+  static constexpr uint32_t topi = 129u * 64u * 8u;                      // u32 [129][64]
+  static constexpr uint32_t act = topi + 129u * 64u * 4u;                // LW  [128][64]
+  static constexpr uint32_t wait = act + 128u * 64u * (uint32_t)sizeof(LW);
+  static constexpr uint32_t end = wait + 128u * 64u * (uint32_t)sizeof(LW);
 };
 
 struct KChain {            // the whole weighted chain (generic kernel)
@@ -495,14 +505,14 @@ __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t rs, u
 // Home bucket of q.h (q.h must already be 0 in lanes without a key).
 __device__ __forceinline__ void pair_probe_prepare(const KIndex& ix, ReqRegs& q) { q.bkt = home_bucket(q.h, ix.shift); }
 // Issue the four 16-byte loads of this lane's half of the home bucket (rk = buffer descriptor of the key table).
-__device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, ReqRegs& q, int lane) {
+__device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, uint32_t keys_off, ReqRegs& q, int lane) {
 #if defined(EPPK_DBG_KEYS_NONE)
   q.kw[0] = q.kw[1] = q.kw[2] = q.kw[3] = make_uint4(0, 0, 0, 0);
 #else
   const uint32_t voff = q.bkt * (kBucket * 8u) + ((uint32_t)lane & 1u) * 64u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(voff + 16u * (uint32_t)i), 0, 0);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(voff + 16u * (uint32_t)i), (int)keys_off, 0);
     q.kw[i] = make_uint4(v.x, v.y, v.z, v.w);
   }
 #endif
@@ -578,7 +588,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
 // Row loads.  A row address is wave-uniform (slot from v_readlane) plus lane * sizeof(LW).  Tables below 4 GiB are read
 // through ONE raw buffer descriptor with the row's byte offset in the instruction's SGPR offset operand: zero VALU ops and
 // zero 64-bit address arithmetic per row (buffer_load ... v_lane_off, s[rsrc], s_row_off offen).  Hit k of the request is in
-// lane pair k of slot_eff.  Larger tables take the global_load path (one v_lshl_add_u64 per row).
+// lane pair k of slot_eff.  (Indexes of 4 GiB and more are served by the generic kernel.)
 template <typename LW>
 __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
   if constexpr (sizeof(LW) == 8) {
@@ -591,42 +601,33 @@ __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t
   }
 }
 template <typename LW, int N>
-__device__ __forceinline__ void load_rows(const KIndex& ix, __amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
-  if (__builtin_expect(ix.small != 0u, 1)) {
-    const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
-    const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
+__device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
+  const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
+  const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
 #pragma unroll
-    for (int u = 0; u < N; ++u) {
-      const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
+  for (int u = 0; u < N; ++u) {
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
 #ifdef EPPK_DBG_SKIP_ROWS   // timing experiment only (wrong results): no row loads, one pseudo pod per row
-      w[u] = ((uint32_t)lane == ((soff >> 9) & 63u)) ? (LW)((LW)1 << (u & 7)) : (LW)0;
-      (void)voff;
+    w[u] = ((uint32_t)lane == ((soff >> 9) & 63u)) ? (LW)((LW)1 << (u & 7)) : (LW)0;
+    (void)voff;
 #else
-      w[u] = buffer_load_lw<LW>(rs, voff, soff);
+    w[u] = buffer_load_lw<LW>(rs, voff, soff);
 #endif
-    }
-  } else {
-    const LW* bm = (const LW*)ix.bitmaps;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
-      w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
-    }
   }
 }
 
 // rows [k0, m) of slot_eff added into non-zero counters, 16 in flight (8 for a short tail)
 template <typename LW, int NPL>
-__device__ __forceinline__ void count_more(const KIndex& ix, __amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, uint32_t m, int lane, LW (&c)[NPL]) {
+__device__ __forceinline__ void count_more(__amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, uint32_t m, int lane, LW (&c)[NPL]) {
   for (; k0 + 8u < m; k0 += 16u) {
     LW w[16], b[5];
-    load_rows<LW, 16>(ix, rs, slot_eff, k0, lane, w);
+    load_rows<LW, 16>(rs, slot_eff, k0, lane, w);
     csa16<LW>(w, b);
     planes_addn<LW, NPL, 5>(c, b);
   }
   if (k0 < m) {
     LW w[8], b[4];
-    load_rows<LW, 8>(ix, rs, slot_eff, k0, lane, w);
+    load_rows<LW, 8>(rs, slot_eff, k0, lane, w);
     csa8<LW>(w, b);
     planes_addn<LW, NPL, 4>(c, b);
   }
@@ -672,9 +673,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
   // raw buffer descriptor over the pod-set rows (gfx9 word 3: 32-bit data format); num_records = table bytes
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000);
-  // ... and over the key table, the snapshot tables and the request rows: every hot-loop load is
+  // (the key table lives behind the rows in the same allocation), over the snapshot tables and over the request rows: every hot-loop load is
   // buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR row offset) -- no 64-bit per-lane pointers, no address VALU ops.
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
   const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
@@ -683,13 +683,13 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
   const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
-  unsigned long long w_hits = 0, w_lookups = 0;
+  uint32_t w_hits = 0, w_lookups = 0;                                               // per wavefront and launch: < 2^32
   const uint32_t hwords = (stride - 8u) / 8u;                                       // hash words per request row
   const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;             // ... probed by the pipelined first gather
   // u64 word of a request row that this lane pair reads as "its" hash (always in bounds: word 0 when the row has no hashes)
   const uint32_t ki = (uint32_t)lane >> 1;
   const uint32_t hidx8 = ((HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u) * 8u;
-  const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
+  const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u && ix.small != 0u;   // tables of 4 GiB and more: generic kernel (eppk.hip)
 
   if (gwave >= n_reqs) return;
 
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
   };
   auto issue_keys = [&](ReqRegs& q) {
-    if (use_index) pair_probe_issue(rk, q, lane);
+    if (use_index) pair_probe_issue(rs, ix.keys_off, q, lane);
   };
 
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
@@ -733,23 +733,23 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
     // ---- B. loads that depend on the request header only
     const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, sn.off_topv + arow * 512u));
-    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(sn.off_topi + arow * 256u), 0);
+    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
+    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
     LW a_w = 0, w_w = 0;
     if (HAS_L && adapter >= 0) {
-      a_w = buffer_load_lw<LW>(rsn, laneLW, sn.off_act + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
-      w_w = buffer_load_lw<LW>(rsn, laneLW, sn.off_wait + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
+      a_w = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::act + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
+      w_w = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::wait + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
     }
 
     // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
     LW w[16];
     if (m0 > 8u) {
-      load_rows<LW, 16>(ix, rs, slot0, 0, lane, w);
+      load_rows<LW, 16>(rs, slot0, 0, lane, w);
     } else {
       LW t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = 0;
-      if (m0 > 0u) load_rows<LW, 8>(ix, rs, slot0, 0, lane, t);
+      if (m0 > 0u) load_rows<LW, 8>(rs, slot0, 0, lane, t);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { w[u] = t[u]; w[8 + u] = 0; }
     }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       issue_row(r + 2u * nwaves, r, cur);
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (m0 > 16u) count_more<LW, NPL>(ix, rs, slot0, 16u, m0, lane, c);
+      if (m0 > 16u) count_more<LW, NPL>(rs, slot0, 16u, m0, lane, c);
       if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
         uint32_t mlast = m0;
         for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
@@ -793,10 +793,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           t.h = buffer_load_u64(rq, (1u + b0 + (ki < nchunk ? ki : 0u)) * 8u, r * stride);
           t.h = (ki < nchunk) ? t.h : 0ull;
           pair_probe_prepare(ix, t);
-          pair_probe_issue(rk, t, lane);
+          pair_probe_issue(rs, ix.keys_off, t, lane);
           uint32_t slotc;
           mlast = pair_probe_finish(ix, t, nchunk, lane, slotc);
-          count_more<LW, NPL>(ix, rs, slotc, 0u, mlast, lane, c);
+          count_more<LW, NPL>(rs, slotc, 0u, mlast, lane, c);
           hits += mlast;
         }
       }
