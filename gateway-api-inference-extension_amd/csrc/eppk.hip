@@ -401,7 +401,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (cfg->index_slots) {
     c->slots = cfg->index_slots;
     uint32_t lg = 0;
-    while ((1u << lg) < c->slots / 16u) ++lg;   // 16-slot buckets (eppk_kernels.hip.h: KIndex)
+    while ((1u << lg) < c->slots / kBucket) ++lg;   // 8-word buckets (eppk_kernels.hip.h: KIndex)
     c->shift = 32u - lg;
     c->limit = c->slots / 2u;  // load factor <= 0.5
     // ONE allocation: pod-set rows first, the key table behind them (the fast kernel reads both through one descriptor)

@@ -46,7 +46,7 @@ constexpr uint32_t kNotFound = 0xFFFFFFFFu;
 constexpr uint32_t kNoPod = 0xFFFFFFFFu;
 constexpr uint32_t kHomeMul = 0x9E3779B1u;    // 2^32 / golden ratio (odd): multiplicative hashing of the folded key
 constexpr uint64_t kTomb = ~0ull;           // key of a slot whose pod set became empty (never matches, never reused)
-constexpr uint32_t kBucket = 16u;           // key slots per bucket = one 128-byte line: word 0 is the bucket header, words 1..15 hold keys
+constexpr uint32_t kBucket = 8u;            // u64 words per bucket = half a 128-byte line: word 0 is the bucket header, words 1..7 hold keys
 constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots: stats[4 + 2*wave + {0,1}]
 
 // ---- kernel argument blocks (plain structs, passed by value) --------------------------------
@@ -73,18 +73,19 @@ struct KSnap {
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
 };
 
-// Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (16 u64 words =
-// one 128-byte line: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..15 = keys,
-// filled front to back, 0 = empty, ~0 = tombstone).  A look-up therefore reads ONE line and is finished unless the key is
-// absent from an overflowed bucket (~1 % of buckets at the load limit) -- no data-dependent probe chain on the hot path.
-// (With per-slot linear probing the 32 parallel look-ups of a request needed max-over-lanes dependent round trips: 3-6 at
-// load 0.5; measured 31 of 95 us per batch.)  Slot = bucket * 16 + word; the pod-set row of a key has its slot's index.
+// Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (8 u64 words =
+// 64 bytes: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..7 = keys, filled front
+// to back, 0 = empty, ~0 = tombstone).  A look-up therefore reads ONE 64-byte bucket and is finished unless the key is
+// absent from an overflowed bucket (0.03 % of buckets at load 0.25, the recommended sizing; 2.7 % at the hard limit 0.5)
+// -- no data-dependent probe chain on the hot path.  (With per-slot linear probing the 32 parallel look-ups of a request
+// needed max-over-lanes dependent round trips: 3-6 at load 0.5; measured 31 of 95 us per batch.)
+// Slot = bucket * 8 + word; the pod-set row of a key has its slot's index (rows of header words are unused).
 struct KIndex {
   const uint64_t* keys;    // [slots+2]; keys[slots], keys[slots+1] = presence of the reserved hashes 0 / ~0.
                            // Invariant: a key that is present has a NON-EMPTY row.
   const void*     bitmaps; // [slots+3][64] LW: rows slots / slots+1 hold hashes 0 / ~0, row slots+2 is all-zero
-  uint32_t slots;          // power of two >= 64 (0 = no index); slots / 16 buckets
-  uint32_t shift;          // 32 - log2(slots / 16)
+  uint32_t slots;          // power of two >= 64 (0 = no index); slots / 8 buckets
+  uint32_t shift;          // 32 - log2(slots / 8)
   uint32_t small;          // rows + keys (ONE allocation, rows first) are < 4 GiB: both are read through one buffer descriptor
   uint32_t table_bytes;    // bytes of that allocation when small
   uint32_t keys_off;       // byte offset of keys inside it
@@ -481,14 +482,14 @@ __device__ __forceinline__ void wave_argmax_dpp(double& best, uint32_t& bidx) {
 }
 
 // ---- pair probe (fast kernel): TWO lanes per key, 32 keys per wavefront instruction group -------------------------
-// Lane l serves key l>>1; the even lane reads words 0..7 of the key's home bucket (header + 7 keys), the odd lane words
-// 8..15: four 16-byte loads per lane, every fetched 128-byte line is used completely, and the whole look-up of a request's
-// first 32 hashes is one independent gather -- no probe chain.
+// Lane l serves key l>>1; the even lane reads words 0..3 of the key's home bucket (header + 3 keys), the odd lane words
+// 4..7: two 16-byte loads per lane, and the whole look-up of a request's first 32 hashes is one independent gather --
+// no probe chain.
 constexpr uint32_t kKeysPerProbe = 32u;
 
 struct ReqRegs {            // pipeline registers of one request
   uint64_t hdr, h;          // row header; the hash this lane pair probes (landing registers of the row prefetch)
-  uint4 kw[4];              // this lane's half of the home bucket (landing registers of the key gather)
+  uint4 kw[2];              // this lane's half of the home bucket (landing registers of the key gather)
   uint32_t bkt;             // home bucket
 };
 
@@ -504,14 +505,14 @@ __device__ __forceinline__ uint64_t buffer_load_u64(__amdgpu_buffer_rsrc_t rs, u
 }
 // Home bucket of q.h (q.h must already be 0 in lanes without a key).
 __device__ __forceinline__ void pair_probe_prepare(const KIndex& ix, ReqRegs& q) { q.bkt = home_bucket(q.h, ix.shift); }
-// Issue the four 16-byte loads of this lane's half of the home bucket (rk = buffer descriptor of the key table).
+// Issue the two 16-byte loads of this lane's half of the home bucket (rk = buffer descriptor of the index allocation).
 __device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, uint32_t keys_off, ReqRegs& q, int lane) {
 #if defined(EPPK_DBG_KEYS_NONE)
-  q.kw[0] = q.kw[1] = q.kw[2] = q.kw[3] = make_uint4(0, 0, 0, 0);
+  q.kw[0] = q.kw[1] = make_uint4(0, 0, 0, 0);
 #else
-  const uint32_t voff = q.bkt * (kBucket * 8u) + ((uint32_t)lane & 1u) * 64u;
+  const uint32_t voff = q.bkt * (kBucket * 8u) + ((uint32_t)lane & 1u) * 32u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(voff + 16u * (uint32_t)i), (int)keys_off, 0);
     q.kw[i] = make_uint4(v.x, v.y, v.z, v.w);
   }
@@ -520,13 +521,9 @@ __device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, uint
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// Position (0..7) of h among this lane's 8 bucket words, 8 if absent.  Word 0 of the even lane is the header, not a key.
-__device__ __forceinline__ uint32_t match8(const uint4 (&kw)[4], uint64_t h, bool even) {
-  uint32_t pos = 8u;
-  if (u64_of(kw[3].z, kw[3].w) == h) pos = 7u;
-  if (u64_of(kw[3].x, kw[3].y) == h) pos = 6u;
-  if (u64_of(kw[2].z, kw[2].w) == h) pos = 5u;
-  if (u64_of(kw[2].x, kw[2].y) == h) pos = 4u;
+// Position (0..3) of h among this lane's 4 bucket words, 4 if absent.  Word 0 of the even lane is the header, not a key.
+__device__ __forceinline__ uint32_t match4(const uint4 (&kw)[2], uint64_t h, bool even) {
+  uint32_t pos = 4u;
   if (u64_of(kw[1].z, kw[1].w) == h) pos = 3u;
   if (u64_of(kw[1].x, kw[1].y) == h) pos = 2u;
   if (u64_of(kw[0].z, kw[0].w) == h) pos = 1u;
@@ -548,8 +545,8 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
   if (__builtin_expect(__any(act && (h + 1ull) <= 1ull), 0)) {             // h == 0 or h == ~0 somewhere in the request (rare)
     slot = probe(ix, h, act);
   } else {
-    const uint32_t pos = match8(q.kw, h, sub == 0u);
-    uint32_t s = pos < 8u ? q.bkt * kBucket + sub * 8u + pos : kNotFound;
+    const uint32_t pos = match4(q.kw, h, sub == 0u);
+    uint32_t s = pos < 4u ? q.bkt * kBucket + sub * 4u + pos : kNotFound;
     const uint32_t so = dpp_xor1(s);
     s = so < s ? so : s;
     uint32_t ovf = sub == 0u ? (q.kw[0].x & 1u) : 0u;  // header bit 0, seen by the even lane
@@ -562,11 +559,11 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
       for (uint32_t n = 0; n < bmask && __any(pend); ++n) {
         if (pend) {
           b = (b + 1) & bmask;
-          const uint64_t* kb = ix.keys + (size_t)b * kBucket + (size_t)sub * 8u;
+          const uint64_t* kb = ix.keys + (size_t)b * kBucket + (size_t)sub * 4u;
           uint32_t s2 = kNotFound;
 #pragma unroll 1
-          for (uint32_t i = 0; i < 8u; ++i)
-            if (kb[i] == h && (sub | i) != 0u) s2 = b * kBucket + sub * 8u + i;
+          for (uint32_t i = 0; i < 4u; ++i)
+            if (kb[i] == h && (sub | i) != 0u) s2 = b * kBucket + sub * 4u + i;
           uint32_t o2 = sub == 0u ? (uint32_t)(kb[0] & 1ull) : 0u;
           const uint32_t s2o = dpp_xor1(s2);
           s2 = s2o < s2 ? s2o : s2;
@@ -913,8 +910,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
   // ---- prologue: rows of the first two requests, keys of the first
   ReqRegs qa, qb;
-  qa.kw[0] = qa.kw[1] = qa.kw[2] = qa.kw[3] = make_uint4(0, 0, 0, 0);
-  qb.kw[0] = qb.kw[1] = qb.kw[2] = qb.kw[3] = make_uint4(0, 0, 0, 0);
+  qa.kw[0] = qa.kw[1] = make_uint4(0, 0, 0, 0);
+  qb.kw[0] = qb.kw[1] = make_uint4(0, 0, 0, 0);
   qa.bkt = qb.bkt = 0;
   issue_row(gwave, gwave, qa);
   issue_row(gwave + nwaves, gwave, qb);

@@ -164,7 +164,7 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     index_pods = np.concatenate(idx_p) if idx_p else np.zeros(0, dtype=np.uint32)
     n_keys = n_groups * Bs if B > 0 else 0
     slots = 64
-    while slots < 2 * n_keys:   # load factor 0.5
+    while slots < 4 * n_keys:   # load factor <= 0.25: the sizing libeppk recommends (bucket overflows become negligible)
         slots *= 2
     index_slots = slots if B > 0 else 0
 

@@ -233,12 +233,12 @@ def _home_bucket(h: np.ndarray, n_buckets: int) -> np.ndarray:
 
 @pytest.mark.parametrize("chain", [[(KV, 1), (PF, 5)], [(PF, 5), (Q, 1), (KV, 1)]], ids=["fast", "generic"])
 def test_overflowed_buckets(pkg, orc, chain):
-    """More keys than a 15-key bucket holds hash to the same home bucket: the surplus lives in the following buckets and
-    look-ups (hits and misses) must walk there.  64 slots = 4 buckets, 30 keys, 24 of them with home bucket 1."""
+    """More keys than a 7-key bucket holds hash to the same home bucket: the surplus lives in the following buckets and
+    look-ups (hits and misses) must walk there.  64 slots = 8 buckets, 30 keys, 24 of them with home bucket 1."""
     P, B, slots = 200, 8, 64
     rng = np.random.default_rng(11)
     cand = rng.integers(1, 2**63, 200000, dtype=np.uint64)
-    hb = _home_bucket(cand, slots // 16)
+    hb = _home_bucket(cand, slots // 8)
     hot = cand[hb == 1][:24]
     cold = cand[hb == 3][:6]
     absent = cand[hb == 1][24:40]           # never inserted; their home bucket is full and overflowed

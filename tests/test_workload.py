@@ -17,7 +17,7 @@ def test_workload_is_deterministic_and_shaped(pkg):
     pc = lambda w: np.unpackbits(w.view(np.uint8).reshape(w.shape[0], -1), axis=1).sum(1)
     assert (pc(a.pods["active"]) <= a.pods["max_lora"]).all() and (pc(a.pods["waiting"]) <= 2).all()
     assert (a.n_blocks == 32).all() and a.adapter.min() >= -1 and a.adapter.max() < 128
-    assert a.index_slots == 8192 and a.index_hashes.shape[0] == 256 * 16 * 8
+    assert a.index_slots == 16384 and a.index_hashes.shape[0] == 256 * 16 * 8
     # shared prefixes: requests of the most popular group share their first 16 hashes, tails are unique
     first = a.reqs[:, 1]
     vals, counts = np.unique(first, return_counts=True)
