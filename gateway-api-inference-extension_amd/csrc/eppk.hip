@@ -34,9 +34,8 @@ struct SnapBuf {
   double*   base = nullptr;
   uint32_t* queue = nullptr;
   double*   kv = nullptr;
-  void*     act_t = nullptr;
-  void*     wait_t = nullptr;
-  void*     free_t = nullptr;
+  void*     thi_t = nullptr;   // [129][64] LW LoRA tier planes (eppk_kernels.hip.h: KSnap)
+  void*     tlo_t = nullptr;
   void*     qmin_t = nullptr;  // [64] LW pods at the global min / max queue depth
   void*     qmax_t = nullptr;
   double*   topv = nullptr;   // [129][64]
@@ -44,7 +43,7 @@ struct SnapBuf {
 };
 
 struct SnapLayout {            // byte offsets inside a snapshot blob
-  size_t base = 0, queue = 0, kv = 0, act = 0, wait = 0, freew = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
+  size_t base = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -141,7 +140,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   const SnapBuf& s = c->snap[c->cur];
   KSnap k{};
   k.base = s.base; k.queue = s.queue; k.kv = s.kv;
-  k.act_t = s.act_t; k.wait_t = s.wait_t; k.free_t = s.free_t;
+  k.thi_t = s.thi_t; k.tlo_t = s.tlo_t;
   k.topv = s.topv; k.topi = s.topi;
   k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
   k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.lead_queue = c->lead_queue ? 1u : 0u;
@@ -363,7 +362,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   }
 
   const size_t np64 = (size_t)c->jmax * 64u;
-  const size_t lora_bytes = (size_t)EPPK_MAX_ADAPTERS * 64u * (size_t)c->lw_bytes;
+  const size_t lora_bytes = ((size_t)EPPK_MAX_ADAPTERS + 1u) * 64u * (size_t)c->lw_bytes;   // + the base-model row
   {
     SnapLayout& L = c->lay;
     size_t off = 0;
@@ -371,17 +370,17 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     // per-adapter tables first, back to back: the fast kernel addresses them with the compile-time offsets SnapOff<LW>
     L.topv = off; off += 129u * 64u * 8u;
     L.topi = off; off += 129u * 64u * 4u;
-    L.act = off; off += lora_bytes;
-    L.wait = off; off += lora_bytes;
+    L.thi = off; off += lora_bytes;
+    L.tlo = off; off += lora_bytes;
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
-    L.freew = take(64u * (size_t)c->lw_bytes); L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
+    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
     L.bytes = off;
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
       CHK(hipMalloc((void**)&s.blob, L.bytes));
       s.base = (double*)(s.blob + L.base); s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
-      s.act_t = s.blob + L.act; s.wait_t = s.blob + L.wait; s.free_t = s.blob + L.freew;
+      s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
       s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax;
       s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
     }
@@ -468,16 +467,20 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
     base[p] = t;
   }
 
-  // lane-transposed LoRA sets
+  // lane-transposed LoRA tier planes per adapter row (row 128 = base model: in no set):
+  //   hi = active | free, lo = active | (~free & waiting)  ->  tier = 2*hi + lo (SEMANTICS.md §3 LORA)
   const size_t lw = (size_t)c->lw_bytes;
-  std::vector<uint8_t> act((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), wait((size_t)EPPK_MAX_ADAPTERS * 64u * lw, 0), freeb(64u * lw, 0), qminb(64u * lw, 0), qmaxb(64u * lw, 0);
+  const size_t nrows = (size_t)EPPK_MAX_ADAPTERS + 1u;
+  std::vector<uint8_t> thi(nrows * 64u * lw, 0), tlo(nrows * 64u * lw, 0), qminb(64u * lw, 0), qmaxb(64u * lw, 0);
   for (uint32_t p = 0; p < n_pods; ++p) {
     const eppk_pod_row& r = rows[p];
-    for (uint32_t a = 0; a < EPPK_MAX_ADAPTERS; ++a) {
-      if ((r.active[a >> 6] >> (a & 63u)) & 1u) set_lane_bit(act, c->lw_bytes, a, p);
-      if ((r.waiting[a >> 6] >> (a & 63u)) & 1u) set_lane_bit(wait, c->lw_bytes, a, p);
+    const bool freeslot = pop128(r.active) + pop128(r.waiting) < r.max_lora;
+    for (uint32_t a = 0; a <= EPPK_MAX_ADAPTERS; ++a) {
+      const bool act = a < EPPK_MAX_ADAPTERS && ((r.active[a >> 6] >> (a & 63u)) & 1u);
+      const bool wai = a < EPPK_MAX_ADAPTERS && ((r.waiting[a >> 6] >> (a & 63u)) & 1u);
+      if (act || freeslot) set_lane_bit(thi, c->lw_bytes, a, p);
+      if (act || (!freeslot && wai)) set_lane_bit(tlo, c->lw_bytes, a, p);
     }
-    if (pop128(r.active) + pop128(r.waiting) < r.max_lora) set_lane_bit(freeb, c->lw_bytes, 0, p);
     if (r.queue == qmin) set_lane_bit(qminb, c->lw_bytes, 0, p);
     if (r.queue == qmax) set_lane_bit(qmaxb, c->lw_bytes, 0, p);
   }
@@ -518,9 +521,8 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
     HIPCHK(c, hipMemcpyAsync(s.kv, kv.data(), np64 * 8u, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s.queue, queue.data(), np64 * 4u, hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, hipMemcpyAsync(s.act_t, act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.wait_t, wait.data(), wait.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.free_t, freeb.data(), freeb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.thi_t, thi.data(), thi.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.tlo_t, tlo.data(), tlo.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.qmin_t, qminb.data(), qminb.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.qmax_t, qmaxb.data(), qmaxb.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.topv, topv.data(), topv.size() * 8u, hipMemcpyHostToDevice, c->stream));

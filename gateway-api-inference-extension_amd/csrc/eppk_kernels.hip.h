@@ -55,9 +55,9 @@ struct KSnap {
   const double*   base;    // [J*64] fused leading pod-only terms (fast path)
   const uint32_t* queue;   // [J*64]
   const double*   kv;      // [J*64]
-  const void*     act_t;   // [A][64] LW  bit j of [a][l] : adapter a active on pod j*64+l
-  const void*     wait_t;  // [A][64] LW
-  const void*     free_t;  // [64] LW     loaded < max_lora
+  const void*     thi_t;   // [129][64] LW LoRA tier planes per adapter row (row 128 = base model), bit j of [a][l] = pod j*64+l:
+  const void*     tlo_t;   //   tier = 2*hi + lo -> {0: 0.0, 1: 0.6 waiting, 2: 0.8 free slot, 3: 1.0 active};
+                           //   hi = active | free, lo = active | (~free & waiting), precomputed at publish
   const double*   topv;    // [129][64] per adapter row (128 = base model): the 64 best pods by
   const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
   const void*     qmin_t;  // [64] LW  pods whose queue == qmin / qmax (masked fast path: are the request's
@@ -66,8 +66,8 @@ struct KSnap {
   const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
   uint32_t pterm_ld;
   const uint8_t*  blob;    // all of the above live in ONE allocation: the fast kernel reads them through a single buffer
-  uint32_t blob_bytes;     // descriptor (SGPR base + 32-bit offsets: no 64-bit per-lane pointers in VGPRs).  topv, topi, act_t
-                           // and wait_t sit at the compile-time offsets of SnapOff<LW> (immediates, not SGPRs)
+  uint32_t blob_bytes;     // descriptor (SGPR base + 32-bit offsets: no 64-bit per-lane pointers in VGPRs).  topv, topi, thi_t
+                           // and tlo_t sit at the compile-time offsets of SnapOff<LW> (immediates, not SGPRs)
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
@@ -95,9 +95,9 @@ struct KIndex {
 template <typename LW> struct SnapOff {
   static constexpr uint32_t topv = 0u;                                   // f64 [129][64]
   static constexpr uint32_t topi = 129u * 64u * 8u;                      // u32 [129][64]
-  static constexpr uint32_t act = topi + 129u * 64u * 4u;                // LW  [128][64]
-  static constexpr uint32_t wait = act + 128u * 64u * (uint32_t)sizeof(LW);
-  static constexpr uint32_t end = wait + 128u * 64u * (uint32_t)sizeof(LW);
+  static constexpr uint32_t thi = topi + 129u * 64u * 4u;                // LW  [129][64]
+  static constexpr uint32_t tlo = thi + 129u * 64u * (uint32_t)sizeof(LW);
+  static constexpr uint32_t end = tlo + 129u * 64u * (uint32_t)sizeof(LW);
 };
 
 struct KChain {            // the whole weighted chain (generic kernel)
@@ -676,7 +676,6 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
   const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
 
-  const LW freew = HAS_L ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
   const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
@@ -730,13 +729,22 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
     // ---- B. loads that depend on the request header only
     const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
-    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
-    LW a_w = 0, w_w = 0;
-    if (HAS_L && adapter >= 0) {
-      a_w = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::act + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
-      w_w = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::wait + (uint32_t)adapter * (uint32_t)(64u * sizeof(LW)));
+    // top table of the adapter row: only its first 16 entries are fetched up front (lanes 0..15; the first entry outside M
+    // is almost always among them), the other 48 on demand
+    double top_t = -__builtin_inf();
+    uint32_t top_p = kNoPod;
+    if (lane < 16) {
+      top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
+      top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
     }
+    // LoRA tier planes of the request's adapter row: only pods of M (and the rare full scan) need them
+    LW thi = 0, tlo = 0;
+    auto load_tiers = [&]() {
+      thi = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::thi + arow * (uint32_t)(64u * sizeof(LW)));
+      if (adapter >= 0) tlo = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::tlo + arow * (uint32_t)(64u * sizeof(LW)));   // base model: lo plane is all-zero
+    };
+    const bool tiers_loaded = HAS_L && (MASKED || m0 > 0u);
+    if (tiers_loaded) load_tiers();
 
     // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
     LW w[16];
@@ -810,9 +818,6 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       for (int k = 0; k < NPL; ++k) nz |= c[k];
       nz &= valid;
     }
-    // LoRA tier planes: tier = 2*hi + lo -> {0: 0.0, 1: 0.6 waiting, 2: 0.8 free slot, 3: 1.0 active}
-    LW thi = 0, tlo = 0;
-    if (HAS_L) { thi = a_w | freew; tlo = a_w | ((LW)~freew & w_w); }
     LW cand = valid;   // Filter: the request's candidate subset (request.go:104-133 as a bitmask), lane-transposed
     if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
 
@@ -860,24 +865,35 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
       // Best candidate outside M: the first entry of the adapter's top table that is in okset.  No pod outside M can beat
       // the first entry's T, so the look-up is skipped when the best pod of M already beats it.
-      const bool has = top_p != kNoPod;
       const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), 0),
                                            __builtin_amdgcn_readlane(__double2loint(top_t), 0));
       if (!(any_m && best > top0)) {
-        bool ok = has;
-        if (MASKED || (HAS_P && hits)) {
-          const uint32_t ql = has ? (top_p & 63u) : 0u, qj = has ? (top_p >> 6) : 0u;
-          LW okq;
-          if constexpr (sizeof(LW) == 8) {
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)okset, (int)ql);
-            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(okset >> 32), (int)ql);
-            okq = ((uint64_t)hi << 32) | lo;
-          } else {
-            okq = (LW)__shfl((int)(uint32_t)okset, (int)ql);
+        // lanes whose table entry is a candidate outside M
+        auto entry_ok = [&](uint32_t tp) -> unsigned long long {
+          const bool has = tp != kNoPod;
+          bool ok = has;
+          if (MASKED || (HAS_P && hits)) {
+            const uint32_t ql = has ? (tp & 63u) : 0u, qj = has ? (tp >> 6) : 0u;
+            LW okq;
+            if constexpr (sizeof(LW) == 8) {
+              const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)okset, (int)ql);
+              const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(okset >> 32), (int)ql);
+              okq = ((uint64_t)hi << 32) | lo;
+            } else {
+              okq = (LW)__shfl((int)(uint32_t)okset, (int)ql);
+            }
+            ok = has && ((okq >> qj) & 1);
           }
-          ok = has && ((okq >> qj) & 1);
+          return __ballot(ok);
+        };
+        unsigned long long okm = entry_ok(top_p);
+        if (__builtin_expect(okm == 0ull && sn.n_pods > 16u, 0)) {     // none of the first 16: fetch entries 16..63
+          if (lane >= 16) {
+            top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
+            top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
+          }
+          okm = entry_ok(top_p);
         }
-        const unsigned long long okm = __ballot(ok);
         if (okm) {
           const int f = __builtin_ctzll(okm);
           cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), f),
@@ -885,6 +901,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
         } else if (__builtin_expect(sn.n_pods > 64u && __any(okset != 0), 0)) {
           // rare: table exhausted although eligible pods remain -> T_a over every eligible pod outside M (total == T_a there)
+          if (HAS_L && !tiers_loaded) load_tiers();
           double rbest = -__builtin_inf();
           uint32_t ridx = kNoPod;
           for (uint32_t j = 0; j < sn.J; ++j) {
@@ -956,7 +973,6 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
   for (uint32_t k = 0; k < ch.n; ++k) {
     has_q |= ch.kind[k] == 1u; has_l |= ch.kind[k] == 3u; has_p |= ch.kind[k] == 4u;
   }
-  const LW freew = has_l ? ((const LW*)sn.free_t)[lane] : (LW)0;
   const LW valid = valid_word<LW>(sn.n_pods, lane);
   unsigned long long w_hits = 0, w_lookups = 0;
 
@@ -992,13 +1008,9 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
 
     LW thi = 0, tlo = 0;
     if (has_l) {
-      LW a = 0, w = 0;
-      if (adapter >= 0) {
-        a = ((const LW*)sn.act_t)[(size_t)adapter * 64u + (uint32_t)lane];
-        w = ((const LW*)sn.wait_t)[(size_t)adapter * 64u + (uint32_t)lane];
-      }
-      thi = a | freew;
-      tlo = a | ((LW)~freew & w);
+      const uint32_t arow = adapter >= 0 ? (uint32_t)adapter : 128u;
+      thi = ((const LW*)sn.thi_t)[(size_t)arow * 64u + (uint32_t)lane];
+      tlo = ((const LW*)sn.tlo_t)[(size_t)arow * 64u + (uint32_t)lane];
     }
 
     // QUEUE normalisers over the request's candidates
