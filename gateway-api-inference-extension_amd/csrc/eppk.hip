@@ -90,6 +90,7 @@ struct eppk_ctx {
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
   void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
   void* d_tmp = nullptr; size_t d_tmp_bytes = 0;  // index insert staging
+  eppk_pod_row* h_rows = nullptr; eppk_pod_row* d_rows = nullptr;  // raw pod rows of a publish (pinned staging + device copy)
 
   // measurement
   bool prof = false;
@@ -123,17 +124,6 @@ inline double h_clamp01(double s) {
   if (!(s >= 0.0)) return 0.0;
   if (s > 1.0) return 1.0;
   return s;
-}
-
-inline uint32_t pop128(const uint64_t w[2]) {
-  return (uint32_t)__builtin_popcountll(w[0]) + (uint32_t)__builtin_popcountll(w[1]);
-}
-
-// set bit j of lane word `lane` in a [rows][64] LW table
-inline void set_lane_bit(std::vector<uint8_t>& tab, int lw_bytes, size_t row, uint32_t pod) {
-  const uint32_t lane = pod & 63u, j = pod >> 6;
-  uint8_t* e = tab.data() + (row * 64u + lane) * (size_t)lw_bytes;
-  e[j >> 3] |= (uint8_t)(1u << (j & 7u));  // little-endian lane words
 }
 
 KSnap make_ksnap(const eppk_ctx* c) {
@@ -395,6 +385,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMemcpy(c->pterm, tab.data(), tab.size() * 8u, hipMemcpyHostToDevice));
     c->pterm_ld = ld;
   }
+  CHK(hipHostMalloc((void**)&c->h_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row), hipHostMallocDefault));
+  CHK(hipMalloc((void**)&c->d_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row)));
   CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
   CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
   if (cfg->index_slots) {
@@ -423,6 +415,8 @@ void eppk_destroy(eppk_ctx* c) {
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
+  if (c->h_rows) (void)hipHostFree(c->h_rows);
+  (void)hipFree(c->d_rows);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_pick) (void)hipHostFree(c->h_pick);
@@ -449,84 +443,32 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
     else { qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax; }
   }
 
-  // fused leading pod-only terms: the same binary64 operations, in chain order (SEMANTICS.md §2)
-  std::vector<double> base(np64 ? np64 : 1, 0.0), kv(np64 ? np64 : 1, 0.0);
-  std::vector<uint32_t> queue(np64 ? np64 : 1, 0u);
-  for (uint32_t p = 0; p < n_pods; ++p) {
-    kv[p] = rows[p].kv_util;
-    queue[p] = rows[p].queue;
-    double t = 0.0;
-    for (uint32_t k = 0; k < c->n_lead; ++k) {
-      double s;
-      if (c->cfg.chain[k].kind == EPPK_SCORER_QUEUE)
-        s = (qmax == qmin) ? 1.0 : (double)(qmax - rows[p].queue) / (double)(qmax - qmin);
-      else
-        s = 1.0 - rows[p].kv_util;
-      t = t + h_clamp01(s) * (double)c->cfg.chain[k].weight;
-    }
-    base[p] = t;
-  }
-
-  // lane-transposed LoRA tier planes per adapter row (row 128 = base model: in no set):
-  //   hi = active | free, lo = active | (~free & waiting)  ->  tier = 2*hi + lo (SEMANTICS.md §3 LORA)
-  const size_t lw = (size_t)c->lw_bytes;
-  const size_t nrows = (size_t)EPPK_MAX_ADAPTERS + 1u;
-  std::vector<uint8_t> thi(nrows * 64u * lw, 0), tlo(nrows * 64u * lw, 0), qminb(64u * lw, 0), qmaxb(64u * lw, 0);
-  for (uint32_t p = 0; p < n_pods; ++p) {
-    const eppk_pod_row& r = rows[p];
-    const bool freeslot = pop128(r.active) + pop128(r.waiting) < r.max_lora;
-    for (uint32_t a = 0; a <= EPPK_MAX_ADAPTERS; ++a) {
-      const bool act = a < EPPK_MAX_ADAPTERS && ((r.active[a >> 6] >> (a & 63u)) & 1u);
-      const bool wai = a < EPPK_MAX_ADAPTERS && ((r.waiting[a >> 6] >> (a & 63u)) & 1u);
-      if (act || freeslot) set_lane_bit(thi, c->lw_bytes, a, p);
-      if (act || (!freeslot && wai)) set_lane_bit(tlo, c->lw_bytes, a, p);
-    }
-    if (r.queue == qmin) set_lane_bit(qminb, c->lw_bytes, 0, p);
-    if (r.queue == qmax) set_lane_bit(qmaxb, c->lw_bytes, 0, p);
-  }
-
-  // per-adapter top-64 tables for the sparse fast path (eppk_kernels.hip.h, FAST pick kernel):
-  // T_a[p] = base[p] (+ lw[tier(a,p)]), the exact total of every pod without a prefix match.
-  std::vector<double> topv(129u * 64u, -HUGE_VAL);
-  std::vector<uint32_t> topi(129u * 64u, 0xFFFFFFFFu);
-  if (c->canonical && n_pods) {
-    std::vector<double> T(n_pods);
-    std::vector<uint32_t> order(n_pods);
-    std::vector<uint8_t> freeflag(n_pods);
-    for (uint32_t p = 0; p < n_pods; ++p) freeflag[p] = pop128(rows[p].active) + pop128(rows[p].waiting) < rows[p].max_lora;
-    const uint32_t K = n_pods < 64u ? n_pods : 64u;
-    for (uint32_t arow = 0; arow <= 128u; ++arow) {
-      if (!c->has_l && arow != 128u) continue;  // without a LoRA scorer only the base row is read
-      for (uint32_t p = 0; p < n_pods; ++p) {
-        double t = base[p];
-        if (c->has_l) {
-          const bool act = arow < 128u && ((rows[p].active[arow >> 6] >> (arow & 63u)) & 1u);
-          const bool wai = arow < 128u && ((rows[p].waiting[arow >> 6] >> (arow & 63u)) & 1u);
-          const int tier = act ? 3 : freeflag[p] ? 2 : wai ? 1 : 0;
-          t = t + c->tail.lw[tier];
-        }
-        T[p] = t;
-        order[p] = p;
-      }
-      std::partial_sort(order.begin(), order.begin() + K, order.end(),
-                        [&](uint32_t a, uint32_t b) { return T[a] > T[b] || (T[a] == T[b] && a < b); });
-      for (uint32_t k = 0; k < K; ++k) { topv[arow * 64u + k] = T[order[k]]; topi[arow * 64u + k] = order[k]; }
-    }
-  }
-
+  // Snapshot producer on the device (eppk_kernels.hip.h "snapshot producer"): one H2D copy of the raw rows, then
+  // fused terms, tier planes and the per-adapter top-64 tables are built by three launches into the idle buffer.
   const int nxt = c->cur ^ 1;
   SnapBuf& s = c->snap[nxt];
-  if (np64) {
-    HIPCHK(c, hipMemcpyAsync(s.base, base.data(), np64 * 8u, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s.kv, kv.data(), np64 * 8u, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s.queue, queue.data(), np64 * 4u, hipMemcpyHostToDevice, c->stream));
+  if (n_pods) {
+    std::memcpy(c->h_rows, rows, (size_t)n_pods * sizeof(eppk_pod_row));
+    HIPCHK(c, hipMemcpyAsync(c->d_rows, c->h_rows, (size_t)n_pods * sizeof(eppk_pod_row), hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, hipMemcpyAsync(s.thi_t, thi.data(), thi.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.tlo_t, tlo.data(), tlo.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.qmin_t, qminb.data(), qminb.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.qmax_t, qmaxb.data(), qmaxb.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.topv, topv.data(), topv.size() * 8u, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(s.topi, topi.data(), topi.size() * 4u, hipMemcpyHostToDevice, c->stream));
+  KChain lead{};
+  lead.n = c->n_lead;
+  for (uint32_t k = 0; k < c->n_lead; ++k) { lead.kind[k] = c->cfg.chain[k].kind; lead.w[k] = (double)c->cfg.chain[k].weight; }
+  const uint32_t n64 = (uint32_t)np64;
+  if (n64)
+    hipLaunchKernelGGL(snap_terms_kernel, dim3((n64 + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows, n_pods, n64,
+                       qmin, qmax, lead, s.base, s.queue, s.kv);
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((130u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
+                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t);
+    if (c->canonical)
+      hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, c->stream, (const double*)s.base, (const LW*)s.thi_t,
+                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, s.topv, s.topi);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cur = nxt;
   c->n_pods = n_pods; c->qmin = qmin; c->qmax = qmax; c->epoch = epoch;

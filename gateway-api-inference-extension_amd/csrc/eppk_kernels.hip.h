@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/eppk.h"   // eppk_pod_row (the snapshot producer reads raw rows)
+
 // Build-time knobs
 #ifndef EPPK_FAST_MAX_THREADS
 #define EPPK_FAST_MAX_THREADS 1024 // largest workgroup the fast kernel may be launched with (caps its VGPR budget at 512 * 256 / threads)
@@ -1128,6 +1130,116 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
   }
   for (uint32_t b = nblk; b < max_blocks; ++b) out[1 + b] = 0ull;
   out[0] = (uint64_t)(uint32_t)adapters[r] | ((uint64_t)nblk << 32);
+}
+
+// ---- snapshot producer: raw pod rows -> the device layout, on the device ------------------------
+// A publish is one H2D copy of the raw 64-byte rows plus three small launches; every value is computed with the same
+// binary64 operations, in the same order, as SEMANTICS.md §2 prescribes (so the fused terms stay bit-exact).
+
+// (1) thread per pod: fused leading pod-only terms base[p] (chain order), raw gauges for the generic kernel
+__global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t np64, uint32_t qmin, uint32_t qmax,
+                                  KChain lead, double* __restrict__ base, uint32_t* __restrict__ queue, double* __restrict__ kv) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np64) return;
+  double t = 0.0, k = 0.0;
+  uint32_t q = 0;
+  if (p < n_pods) {
+    q = rows[p].queue;
+    k = rows[p].kv_util;
+    for (uint32_t i = 0; i < lead.n; ++i) {
+      double s;
+      if (lead.kind[i] == 1u) s = (qmax == qmin) ? 1.0 : (double)(qmax - q) / (double)(qmax - qmin);
+      else s = 1.0 - k;
+      t = t + clamp01(s) * lead.w[i];
+    }
+  }
+  base[p] = t; queue[p] = q; kv[p] = k;
+}
+
+// (2) thread per (adapter row a, lane l): lane-transposed LoRA tier planes (row 128 = base model: in no set)
+//       hi = active | free, lo = active | (~free & waiting)  ->  tier = 2*hi + lo (SEMANTICS.md §3 LORA);
+//     row 129 of the launch builds the lane words of the pods at the minimum / maximum queue depth instead.
+template <typename LW>
+__global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t J, uint32_t qmin, uint32_t qmax,
+                                   LW* __restrict__ thi, LW* __restrict__ tlo, LW* __restrict__ qmin_t, LW* __restrict__ qmax_t) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t a = t >> 6, l = t & 63u;
+  if (a > 129u) return;
+  LW hi = 0, lo = 0;
+  for (uint32_t j = 0; j < J; ++j) {
+    const uint32_t p = j * 64u + l;
+    if (p >= n_pods) break;
+    const eppk_pod_row& r = rows[p];
+    if (a == 129u) {
+      if (r.queue == qmin) hi |= (LW)((LW)1 << j);
+      if (r.queue == qmax) lo |= (LW)((LW)1 << j);
+    } else {
+      const uint32_t loaded = (uint32_t)(__popcll(r.active[0]) + __popcll(r.active[1]) + __popcll(r.waiting[0]) + __popcll(r.waiting[1]));
+      const bool freeslot = loaded < r.max_lora;
+      const bool act = a < 128u && ((r.active[a >> 6] >> (a & 63u)) & 1ull);
+      const bool wai = a < 128u && ((r.waiting[a >> 6] >> (a & 63u)) & 1ull);
+      if (act || freeslot) hi |= (LW)((LW)1 << j);
+      if (act || (!freeslot && wai)) lo |= (LW)((LW)1 << j);
+    }
+  }
+  if (a == 129u) { qmin_t[l] = hi; qmax_t[l] = lo; }
+  else { thi[(size_t)a * 64u + l] = hi; tlo[(size_t)a * 64u + l] = lo; }
+}
+
+// (3) workgroup per adapter row: the 64 best pods by T_a[p] = base[p] (+ lw[tier(a,p)]) under (T desc, p asc) -- the exact
+//     total of every pod without a prefix match (FAST pick kernel).  64 rounds of a block-wide argmax over T staged in LDS.
+template <typename LW>
+__global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict__ base, const LW* __restrict__ thi, const LW* __restrict__ tlo,
+                                                       uint32_t n_pods, uint32_t np64, uint32_t has_l, KTail tl,
+                                                       double* __restrict__ topv, uint32_t* __restrict__ topi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* sT = (double*)smem;                         // [np64]
+  __shared__ double red_t[4];
+  __shared__ uint32_t red_p[4];
+  const uint32_t a = blockIdx.x, tid = threadIdx.x;
+  if ((!has_l && a != 128u) || n_pods == 0u) {        // without a LoRA scorer only the base row is read
+    if (tid < 64u) { topv[(size_t)a * 64u + tid] = -__builtin_inf(); topi[(size_t)a * 64u + tid] = kNoPod; }
+    return;
+  }
+  for (uint32_t p = tid; p < np64; p += blockDim.x) {
+    double t = -__builtin_inf();
+    if (p < n_pods) {
+      t = base[p];
+      if (has_l) {
+        const uint32_t l = p & 63u, j = p >> 6;
+        const uint32_t tier = (uint32_t)(((thi[(size_t)a * 64u + l] >> j) & 1) << 1) | (uint32_t)((tlo[(size_t)a * 64u + l] >> j) & 1);
+        t = t + tier_term(tl, tier);
+      }
+    }
+    sT[p] = t;
+  }
+  __syncthreads();
+  const uint32_t K = n_pods < 64u ? n_pods : 64u;
+  for (uint32_t k = 0; k < 64u; ++k) {
+    if (k >= K) {                                     // fewer than 64 pods: pad
+      if (tid == 0) { topv[(size_t)a * 64u + k] = -__builtin_inf(); topi[(size_t)a * 64u + k] = kNoPod; }
+      continue;
+    }
+    double best = -__builtin_inf();
+    uint32_t bi = kNoPod;
+    for (uint32_t p = tid; p < np64; p += blockDim.x) {   // ascending p, strict >: the lowest index among equal T
+      const double v = sT[p];
+      if (v > best) { best = v; bi = p; }
+    }
+    wave_argmax_dpp(best, bi);
+    if ((tid & 63u) == 0u) { red_t[tid >> 6] = best; red_p[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double bt = red_t[0];
+      uint32_t bp = red_p[0];
+      for (uint32_t w = 1; w < (blockDim.x >> 6); ++w)
+        if (red_t[w] > bt || (red_t[w] == bt && red_p[w] < bp)) { bt = red_t[w]; bp = red_p[w]; }
+      topv[(size_t)a * 64u + k] = bt;
+      topi[(size_t)a * 64u + k] = bp;
+      sT[bp] = -__builtin_inf();                      // taken
+    }
+    __syncthreads();
+  }
 }
 
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
