@@ -283,3 +283,13 @@ def test_long_chains_beyond_the_pipelined_gather(pkg, orc, B, R):
     synchronous chunk loop (9 counter planes when B >= 64)."""
     wl = pkg.workload.make_workload(3, R=R, P=700, B=B)
     assert_same(*run_both(pkg, orc, wl, max_pods=1024))
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 7, 4099])
+def test_tiny_and_odd_batches(pkg, orc, R):
+    """Batches smaller than the software pipeline's depth (prologue/epilogue with clamped row prefetches) and batches that
+    do not divide evenly over the persistent wavefronts."""
+    wl = pkg.workload.make_workload(5, R=R, P=4096)
+    assert_same(*run_both(pkg, orc, wl))
+    wm = pkg.workload.make_workload(3, R=R, P=1000, masked=True)
+    assert_same(*run_both(pkg, orc, wm, mask=wm.mask, max_pods=1024))
