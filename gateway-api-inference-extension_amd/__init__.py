@@ -17,4 +17,4 @@ every pick raises.
 """
 from . import _lib, distributed, picker, workload  # noqa: F401
 from ._lib import EppkError, lib_path, load_library  # noqa: F401
-from .picker import BatchedPicker, RoundRobinPicker, ScorerKind, subset_mask  # noqa: F401
+from .picker import BatchedPicker, Endpoint, PickResult, RoundRobinPicker, ScorerKind, Unavailable, subset_mask  # noqa: F401

@@ -19,7 +19,7 @@ SYMBOLS = [
     "eppk_snapshot_publish", "eppk_snapshot_info",
     "eppk_index_clear", "eppk_index_insert", "eppk_index_insert_picks_device", "eppk_index_remove_pod",
     "eppk_index_size",
-    "eppk_pick_batch", "eppk_pick_batch_device",
+    "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
     "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
@@ -76,6 +76,8 @@ def load_library() -> C.CDLL:
     lib.eppk_index_size.argtypes = [vp, C.POINTER(u32)]
     lib.eppk_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp]
     lib.eppk_pick_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    lib.eppk_pick_topk.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    lib.eppk_pick_topk_device.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp]
     lib.eppk_hash_prompt.argtypes = [vp, C.c_size_t, vp, C.c_size_t, u32, vp, u32]
     lib.eppk_hash_prompts_device.argtypes = [vp, vp, u64, vp, vp, vp, u32, u32, vp, vp]
     lib.eppk_xxh64.argtypes = [vp, C.c_size_t, u64]

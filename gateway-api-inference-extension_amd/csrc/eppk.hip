@@ -161,35 +161,37 @@ const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first) {
 }
 
 template <typename LW, int NPL>
-const void* generic_kernel_ptr(bool masked) {
-  return masked ? (const void*)pick_generic_kernel<LW, NPL, true> : (const void*)pick_generic_kernel<LW, NPL, false>;
+const void* generic_kernel_ptr(bool masked, bool topk) {
+  if (topk) return masked ? (const void*)pick_generic_kernel<LW, NPL, true, (int)EPPK_MAX_TOPK> : (const void*)pick_generic_kernel<LW, NPL, false, (int)EPPK_MAX_TOPK>;
+  return masked ? (const void*)pick_generic_kernel<LW, NPL, true, 1> : (const void*)pick_generic_kernel<LW, NPL, false, 1>;
 }
 
 template <typename LW, int NPL>
-const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
-  if (!fast) return generic_kernel_ptr<LW, NPL>(masked);
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
+  if (!fast) return generic_kernel_ptr<LW, NPL>(masked, topk);
   return masked ? fast_kernel_ptr<LW, NPL, true>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false>(c->has_l, c->has_p, c->p_first);
 }
 
 template <typename LW>
-const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
-  return c->npl == 6 ? pick_kernel_ptr<LW, 6>(c, fast, masked) : pick_kernel_ptr<LW, 9>(c, fast, masked);
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
+  return c->npl == 6 ? pick_kernel_ptr<LW, 6>(c, fast, masked, topk) : pick_kernel_ptr<LW, 9>(c, fast, masked, topk);
 }
 
-const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked) {
+const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
   switch (c->lw_bytes) {
-    case 2: return pick_kernel_ptr<uint16_t>(c, fast, masked);
-    case 4: return pick_kernel_ptr<uint32_t>(c, fast, masked);
-    default: return pick_kernel_ptr<uint64_t>(c, fast, masked);
+    case 2: return pick_kernel_ptr<uint16_t>(c, fast, masked, topk);
+    case 4: return pick_kernel_ptr<uint32_t>(c, fast, masked, topk);
+    default: return pick_kernel_ptr<uint64_t>(c, fast, masked, topk);
   }
 }
 
+// topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries), always the generic kernel
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
-                double* d_score, hipStream_t st) {
+                double* d_score, hipStream_t st, uint32_t topk = 1) {
   const bool masked = d_mask != nullptr;
   // masked batches use the fast kernel's MASKED instantiation; an index of 4 GiB and more (32-bit buffer offsets) -> generic kernel
-  const bool fast = c->canonical && (c->slots == 0 || c->index_bytes < (1ull << 32));
-  const void* fn = pick_kernel_ptr(c, fast, masked);
+  const bool fast = topk == 1 && c->canonical && (c->slots == 0 || c->index_bytes < (1ull << 32));
+  const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
   const uint32_t threads = fast ? c->fast_threads : 512u, wpb = threads / 64;
@@ -240,7 +242,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   } else {
     KChain ch = c->kchain;
-    void* args[] = {&sn, &ix, &ch, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats};
+    void* args[] = {&sn, &ix, &ch, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &topk};
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   }
   if (c->prof) {
@@ -634,6 +636,68 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
   if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
   if (cand_mask && !J) for (uint32_t r = 0; r < n_reqs; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+  return EPPK_OK;
+}
+
+// ---- ordered fallbacks ---------------------------------------------------------------------------------
+
+int eppk_pick_topk_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
+                          int32_t* d_out_pick, double* d_out_score, void* stream) {
+  if (!c || ((!d_reqs || !d_out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_topk_device: null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return fail(c, EPPK_ERR_ARG, "eppk_pick_topk_device: k out of range (1..8)");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_topk_device: no snapshot published");
+  if (n_reqs == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const uint32_t per = (uint32_t)((1ull << 31) / c->stride);
+  const size_t J = (c->n_pods + 63u) / 64u;
+  for (uint32_t r0 = 0; r0 < n_reqs; r0 += per) {
+    const uint32_t n = (n_reqs - r0 < per) ? n_reqs - r0 : per;
+    int rc = launch_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
+                         d_out_pick + (size_t)r0 * k, d_out_score ? d_out_score + (size_t)r0 * k : nullptr, st, k);
+    if (rc) return rc;
+  }
+  return EPPK_OK;
+}
+
+int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, int32_t* out_pick,
+                   double* out_score) {
+  if (!c || ((!reqs || !out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_topk: null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return fail(c, EPPK_ERR_ARG, "eppk_pick_topk: k out of range (1..8)");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_topk: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_topk: n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  for (uint32_t r = 0; r < n_reqs; ++r) {
+    eppk_req_hdr hd;
+    std::memcpy(&hd, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof hd);
+    if (hd.n_blocks > c->cfg.max_blocks || hd.adapter < -1 || hd.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
+      return fail(c, EPPK_ERR_ARG, "eppk_pick_topk: request row " + std::to_string(r) + " out of range");
+  }
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t J = (c->n_pods + 63u) / 64u;
+  if (cand_mask && !J) {
+    for (size_t i = 0; i < (size_t)n_reqs * k; ++i) { out_pick[i] = EPPK_NO_PICK; if (out_score) out_score[i] = 0.0; }
+    return EPPK_OK;
+  }
+  // plain (pageable) transfers: the fallback list is not the latency-critical entry point
+  void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_reqs); (void)hipFree(d_mask); (void)hipFree(d_pick); (void)hipFree(d_score); };
+#define TK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, EPPK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+  TK(hipMalloc(&d_reqs, (size_t)n_reqs * c->stride));
+  TK(hipMalloc((void**)&d_pick, (size_t)n_reqs * k * 4u));
+  TK(hipMalloc((void**)&d_score, (size_t)n_reqs * k * 8u));
+  TK(hipMemcpyAsync(d_reqs, reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+  if (cand_mask) {
+    TK(hipMalloc((void**)&d_mask, (size_t)n_reqs * J * 8u));
+    TK(hipMemcpyAsync(d_mask, cand_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = launch_pick(c, d_reqs, n_reqs, d_mask, d_pick, d_score, c->stream, k);
+  if (rc) { cleanup(); return rc; }
+  TK(hipMemcpyAsync(out_pick, d_pick, (size_t)n_reqs * k * 4u, hipMemcpyDeviceToHost, c->stream));
+  if (out_score) TK(hipMemcpyAsync(out_score, d_score, (size_t)n_reqs * k * 8u, hipMemcpyDeviceToHost, c->stream));
+  TK(hipStreamSynchronize(c->stream));
+#undef TK
+  cleanup();
   return EPPK_OK;
 }
 

@@ -954,12 +954,16 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 // chain order.  Slower; it is both the fallback for non-canonical chains / masked batches and an
 // independent on-device statement of SEMANTICS.md.
 // LDS: queue[J*64] u32 | kv[J*64] f64 | per wave pw[pwn] f64 (raw ratios cnt/n).
-template <typename LW, int NPL, bool MASKED>
+// TOPK > 1: ordered fallbacks (PickResult.Fallbacks, handlers/server.go:72-77; 004-…/README.md:73): the `topk` (<= TOPK) best
+// candidates per request under (total desc, index asc) go to out_pick[r*topk + i] / out_score[r*topk + i], padded with
+// EPPK_NO_PICK / 0.0 when the request has fewer candidates.  Every lane keeps a sorted list of its TOPK best pods; the wave
+// then merges the lists head by head (topk argmax rounds).
+template <typename LW, int NPL, bool MASKED, int TOPK>
 __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, KChain ch, const uint8_t* __restrict__ reqs,
                                                            uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                            const uint64_t* __restrict__ cand_mask,
                                                            int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                           unsigned long long* __restrict__ stats) {
+                                                           unsigned long long* __restrict__ stats, uint32_t topk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_kv = (double*)smem;
   uint32_t* s_q = (uint32_t*)(s_kv + (size_t)sn.J * 64u);
@@ -1036,8 +1040,10 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
     }
     const double qden = (double)(qmax - qmin);
 
-    double best = -__builtin_inf();
-    uint32_t bidx = kNoPod;
+    double bt[TOPK];       // this lane's best pods so far, (total desc, index asc)
+    uint32_t bp[TOPK];
+#pragma unroll
+    for (int i = 0; i < TOPK; ++i) { bt[i] = -__builtin_inf(); bp[i] = kNoPod; }
     for (uint32_t j = 0; j < sn.J; ++j) {
       const uint32_t p = j * 64u + (uint32_t)lane;
       const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
@@ -1056,13 +1062,43 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
         t = t + clamp01(s) * ch.w[k];
       }
       const bool ok = (cand >> j) & 1;
-      if (ok && t > best) { best = t; bidx = p; }
+      if (ok) {              // sorted insert; pods arrive in ascending index, so an equal total stays behind the earlier pod
+#pragma unroll
+        for (int i = TOPK - 1; i >= 0; --i) {
+          const bool gt = t > bt[i];
+          if (i + 1 < TOPK && gt) { bt[i + 1] = bt[i]; bp[i + 1] = bp[i]; }
+          bool place = gt;
+          if (i > 0) place = gt && !(t > bt[i - 1]);
+          if (place) { bt[i] = t; bp[i] = p; }
+        }
+      }
     }
-    wave_argmax(best, bidx);
-    if (lane == 0) {
-      const bool none = bidx == kNoPod;
-      out_pick[r] = none ? -1 : (int32_t)bidx;
-      if (out_score) out_score[r] = none ? 0.0 : best;
+    if (TOPK == 1) {
+      double best = bt[0];
+      uint32_t bidx = bp[0];
+      wave_argmax(best, bidx);
+      if (lane == 0) {
+        const bool none = bidx == kNoPod;
+        out_pick[r] = none ? -1 : (int32_t)bidx;
+        if (out_score) out_score[r] = none ? 0.0 : best;
+      }
+    } else {
+      for (uint32_t i = 0; i < topk; ++i) {
+        double best = bt[0];
+        uint32_t bidx = bp[0];
+        wave_argmax_dpp(best, bidx);
+        if (lane == 0) {
+          const bool none = bidx == kNoPod;
+          out_pick[(size_t)r * topk + i] = none ? -1 : (int32_t)bidx;
+          if (out_score) out_score[(size_t)r * topk + i] = none ? 0.0 : best;
+        }
+        if (bidx != kNoPod && (uint32_t)lane == (bidx & 63u)) {   // the owner pops its head
+#pragma unroll
+          for (int q = 0; q + 1 < TOPK; ++q) { bt[q] = bt[q + 1]; bp[q] = bp[q + 1]; }
+          bt[TOPK - 1] = -__builtin_inf();
+          bp[TOPK - 1] = kNoPod;
+        }
+      }
     }
   }
   if (stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {

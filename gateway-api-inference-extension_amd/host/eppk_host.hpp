@@ -101,6 +101,8 @@ class Backend {
   virtual ~Backend() = default;
   virtual int Publish(const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) = 0;
   virtual int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) = 0;
+  // k ordered candidates per request (pick + fallbacks), picks/scores hold n*k entries (eppk_pick_topk)
+  virtual int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) = 0;
   virtual std::string LastError() const = 0;
 };
 
@@ -116,6 +118,9 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
     return eppk_pick_batch(ctx_, reqs, n, mask, picks, scores);
   }
+  int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
+    return eppk_pick_topk(ctx_, reqs, n, mask, k, picks, scores);
+  }
   std::string LastError() const override { return eppk_last_error(ctx_); }
   eppk_ctx* ctx() { return ctx_; }
 
@@ -129,6 +134,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
 struct GpuPickerOptions {
   uint32_t max_pods = 4096, max_blocks = 32, max_batch = 4096, block_chars = 64;
   std::chrono::microseconds window{200};  // how long the dispatcher waits to fill a batch
+  uint32_t fallbacks = 0;                 // PickResult.Fallbacks entries to fill (server.go:74), 0..EPPK_MAX_TOPK-1
 };
 
 class GpuPicker : public EndpointPicker {
@@ -174,7 +180,7 @@ class GpuPicker : public EndpointPicker {
     }
     if (slot.pick < 0) return {Code::Unavailable, "no endpoints available"};
     out->endpoint = slot.endpoint;
-    out->fallbacks.clear();
+    out->fallbacks = std::move(slot.fallbacks);
     return {};
   }
 
@@ -194,6 +200,7 @@ class GpuPicker : public EndpointPicker {
     bool done = false, fail_open = false;
     int32_t pick = -1;
     std::string endpoint;
+    std::vector<std::string> fallbacks;
   };
 
   void Loop() {
@@ -245,16 +252,22 @@ class GpuPicker : public EndpointPicker {
             }
             if (found != P) any_mask = true;
           }
-          picks.resize(n);
-          scores.resize(n);
-          const int rc = be_->PickBatch(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data());
+          const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
+          picks.resize(n * k);
+          scores.resize(n * k);
+          const int rc = k == 1 ? be_->PickBatch(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data())
+                                : be_->PickTopK(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, k, picks.data(), scores.data());
           failed = rc != EPPK_OK;
           if (!failed)
             for (size_t i = 0; i < n; ++i) {
-              batch[i]->pick = picks[i];  // Slot fields other than `done` are read by the owner only after `done`
-              if (picks[i] >= 0) {
-                const Endpoint& e = snap->endpoints[(size_t)picks[i]];
-                batch[i]->endpoint = JoinHostPort(e.address, e.port);
+              batch[i]->pick = picks[i * k];  // Slot fields other than `done` are read by the owner only after `done`
+              batch[i]->fallbacks.clear();
+              for (uint32_t f = 0; f < k; ++f) {
+                const int32_t p = picks[i * k + f];
+                if (p < 0) break;
+                const Endpoint& e = snap->endpoints[(size_t)p];
+                if (f == 0) batch[i]->endpoint = JoinHostPort(e.address, e.port);
+                else batch[i]->fallbacks.push_back(JoinHostPort(e.address, e.port));
               }
             }
         }

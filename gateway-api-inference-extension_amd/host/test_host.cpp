@@ -2,6 +2,7 @@
 //   ./test_host cpu   : fake backend, no GPU — batching, concurrency, fail-open, Unavailable, masks, round robin
 //   ./test_host gpu   : real libeppk backend on device 0 — concurrent Pick() through the batcher must equal
 //                       a direct eppk_pick_batch on the same rows (oracle parity of the kernel: tests/test_gpu_parity.py)
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -31,6 +32,20 @@ class FakeBackend : public Backend {
       }
       picks[r] = best;
       scores[r] = 0.0;
+    }
+    return EPPK_OK;
+  }
+  // k candidates in ascending (queue, index) order
+  int PickTopK(const void*, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
+    calls++;
+    if (fail) return EPPK_ERR_DEVICE;
+    const uint32_t P = (uint32_t)rows_.size(), W = (P + 63u) / 64u;
+    for (uint32_t r = 0; r < n; ++r) {
+      std::vector<uint32_t> c;
+      for (uint32_t p = 0; p < P; ++p)
+        if (!mask || ((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u)) c.push_back(p);
+      std::stable_sort(c.begin(), c.end(), [&](uint32_t a, uint32_t b) { return rows_[a].queue < rows_[b].queue; });
+      for (uint32_t i = 0; i < k; ++i) { picks[(size_t)r * k + i] = i < c.size() ? (int32_t)c[i] : -1; scores[(size_t)r * k + i] = 0.0; }
     }
     return EPPK_OK;
   }
@@ -119,6 +134,25 @@ static int run_cpu() {
   CHECK(gp.Pick({}, all, &pr).ok() && pr.endpoint == "10.0.0.4:8080");
   std::printf("host cpu ok: %d backend calls for 3200 concurrent picks, largest batch %llu\n", calls,
               (unsigned long long)gp.largest_batch());
+  {  // ordered fallbacks (PickResult.Fallbacks, server.go:74) through the micro-batcher
+    auto eps = make_endpoints(5);
+    std::vector<eppk_pod_row> rows(5);
+    std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+    const uint32_t q[5] = {7, 1, 9, 3, 5};
+    for (int i = 0; i < 5; ++i) rows[(size_t)i].queue = q[i];
+    GpuPickerOptions opt;
+    opt.max_pods = 64; opt.max_blocks = 4; opt.max_batch = 8; opt.fallbacks = 2;
+    GpuPicker gp(std::unique_ptr<Backend>(new FakeBackend()), opt);
+    CHECK(gp.PublishSnapshot(eps, rows, {}, 1).ok());
+    std::vector<const Endpoint*> c{&eps[0], &eps[2], &eps[3], &eps[4]};   // pod 1 (the global best) is not a candidate
+    PickResult r;
+    PickRequest rq;
+    CHECK(gp.Pick(rq, c, &r).ok());
+    CHECK(r.endpoint == "10.0.0.4:8080");
+    CHECK(r.fallbacks.size() == 2 && r.fallbacks[0] == "10.0.0.5:8080" && r.fallbacks[1] == "10.0.0.1:8080");
+    std::vector<const Endpoint*> one{&eps[2]};                            // fewer candidates than requested fallbacks
+    CHECK(gp.Pick(rq, one, &r).ok() && r.endpoint == "10.0.0.3:8080" && r.fallbacks.empty());
+  }
   return 0;
 }
 

@@ -208,6 +208,19 @@ class BatchedPicker:
         self._check(self._lib.eppk_pick_batch(self._ctx, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data), "pick_batch")
         return picks, scores
 
+    def pick_topk(self, reqs: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """Ordered fallbacks: ([R, k] candidate indices, [R, k] totals); column 0 is the pick (include/eppk.h eppk_pick_topk)."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        picks = np.full((R, k), -1, dtype=np.int32)
+        scores = np.zeros((R, k), dtype=np.float64)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint64)
+        self._check(self._lib.eppk_pick_topk(self._ctx, reqs.ctypes.data, R, m.ctypes.data if m is not None else None, k,
+                                             picks.ctypes.data, scores.ctypes.data), "pick_topk")
+        return picks, scores
+
     def pick_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
@@ -221,17 +234,23 @@ class BatchedPicker:
         self._check(self._lib.eppk_hash_prompts_device(self._ctx, d_prompts, prompt_stride, d_prompt_len, d_seed, d_adapter, n_reqs,
                                                        block_chars, d_reqs_out, stream or None), "hash_prompts_device")
 
-    def pick_endpoints(self, endpoints: Sequence[Endpoint], reqs: np.ndarray, mask: Optional[np.ndarray] = None) -> List[PickResult]:
-        """Batched EndpointPicker.Pick: one PickResult per request; Unavailable if any request has no candidate."""
+    def pick_endpoints(self, endpoints: Sequence[Endpoint], reqs: np.ndarray, mask: Optional[np.ndarray] = None,
+                       fallbacks: int = 0) -> List[PickResult]:
+        """Batched EndpointPicker.Pick: one PickResult per request; Unavailable if any request has no candidate.
+        `fallbacks` > 0 also fills PickResult.Fallbacks (server.go:74) with the next-best endpoints, in order."""
         if len(endpoints) != self.n_pods:
             raise EppkError(-1, "endpoints must be the published snapshot's candidate slice")
-        picks, _ = self.pick(reqs, mask)
+        if fallbacks > 0:
+            picks, _ = self.pick_topk(reqs, 1 + fallbacks, mask)
+        else:
+            picks = self.pick(reqs, mask)[0].reshape(-1, 1)
         out = []
-        for p in picks:
-            if p < 0:
+        for row in picks:
+            if row[0] < 0:
                 raise Unavailable("no endpoints available")
-            e = endpoints[int(p)]
-            out.append(PickResult(endpoint=join_host_port(e.address, e.port)))
+            eps = [endpoints[int(p)] for p in row if p >= 0]
+            out.append(PickResult(endpoint=join_host_port(eps[0].address, eps[0].port),
+                                  fallbacks=[join_host_port(e.address, e.port) for e in eps[1:]]))
         return out
 
     # -- measurement ------------------------------------------------------------------------

@@ -41,6 +41,8 @@ extern "C" {
 #define EPPK_MAX_BLOCKS    256u  /* prefix blocks per request (upstream maxPrefixBlocksToMatch) */
 #define EPPK_MAX_SCORERS   8u    /* entries in a profile's weighted scorer chain             */
 
+#define EPPK_MAX_TOPK      8u    /* entries of an ordered fallback list (eppk_pick_topk)        */
+
 #define EPPK_NO_PICK       (-1)  /* out_pick value: request had zero candidates (-> 503, fail closed) */
 #define EPPK_ADAPTER_BASE  (-1)  /* req.adapter value: request targets the base model         */
 
@@ -166,6 +168,18 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
+
+/* Ordered fallbacks: the k (1..EPPK_MAX_TOPK) best candidates of every request under the picker's order (weighted total
+ * descending, candidate index ascending).  out_pick[r*k + 0] is exactly eppk_pick_batch's pick, out_pick[r*k + i] the
+ * i-th fallback; a request with fewer than k candidates is padded with EPPK_NO_PICK / 0.0.
+ * Replaces PickResult.Fallbacks (handlers/server.go:72-77); the protocol carries them as an ordered, comma-separated
+ * endpoint list (docs/proposals/004-endpoint-picker-protocol/README.md:73).
+ * out_pick / out_score (nullable) hold n_reqs * k entries. */
+int eppk_pick_topk(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k,
+                   int32_t* out_pick, double* out_score);
+/* Same with device-resident buffers, asynchronous on `stream` (see eppk_pick_batch_device). */
+int eppk_pick_topk_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
+                          int32_t* d_out_pick, double* d_out_score, void* stream);
 
 /* ---- adjacent host-side steps of the same path ---------------------------------------------- */
 

@@ -146,6 +146,23 @@ def score_row(chain, pods: np.ndarray, index: Optional[OracleIndex], req_row: np
     return out
 
 
+def pick_topk(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, k: int,
+              mask: Optional[np.ndarray] = None):
+    """Ordered fallbacks (SEMANTICS.md §2a): the k best candidates of every request under (total desc, index asc), from the
+    oracle's own per-request totals (orc_score_row); padded with -1 / 0.0."""
+    reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+    R = reqs.shape[0]
+    picks = np.full((R, k), -1, dtype=np.int32)
+    scores = np.zeros((R, k), dtype=np.float64)
+    for r in range(R):
+        tot = score_row(chain, pods, index, reqs[r], None if mask is None else mask[r])
+        cand = np.nonzero(~np.isnan(tot))[0]
+        order = cand[np.lexsort((cand, -tot[cand]))][:k]      # primary: total descending; ties: lowest index
+        picks[r, :order.size] = order
+        scores[r, :order.size] = tot[order]
+    return picks, scores
+
+
 def xxh64(data: bytes, seed: int = 0) -> int:
     return int(load().orc_xxh64(data, len(data), seed))
 

@@ -293,3 +293,41 @@ def test_tiny_and_odd_batches(pkg, orc, R):
     assert_same(*run_both(pkg, orc, wl))
     wm = pkg.workload.make_workload(3, R=R, P=1000, masked=True)
     assert_same(*run_both(pkg, orc, wm, mask=wm.mask, max_pods=1024))
+
+
+@pytest.mark.parametrize("config,R,P,k,masked", [(5, 96, 4096, 4, False), (3, 128, 1000, 8, True), (2, 256, 256, 3, False),
+                                                  (4, 128, 2048, 2, True), (1, 128, 16, 8, True)])
+def test_topk_fallbacks(pkg, orc, config, R, P, k, masked):
+    """Ordered fallback lists (PickResult.Fallbacks): column 0 is the pick, the rest the next best candidates under
+    (total desc, index asc) -- bitwise against the oracle's totals; requests with fewer than k candidates are padded."""
+    wl = pkg.workload.make_workload(config, R=R, P=P, masked=masked)
+    mask = wl.mask
+    if masked:
+        mask = mask.copy()
+        mask[0, :] = 0                                     # no candidate at all
+        mask[1, :] = 0; mask[1, 0] = np.uint64(0b101)      # two candidates (< k)
+    with pkg.BatchedPicker(wl.chain, max_pods=max(P, 1), max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        if wl.index_slots:
+            pk.index_insert(wl.index_hashes, wl.index_pods)
+        picks, scores = pk.pick_topk(wl.reqs, k, mask)
+        p1, s1 = pk.pick(wl.reqs, mask)
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    op, osc = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, k, mask)
+    assert np.array_equal(picks, op), f"fallback lists differ at rows {np.nonzero((picks != op).any(axis=1))[0][:5]}"
+    assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64))
+    assert np.array_equal(picks[:, 0], p1) and np.array_equal(scores[:, 0].view(np.uint64), s1.view(np.uint64))
+    if masked:
+        assert (picks[0] == -1).all() and (picks[1, 2:] == -1).all() and set(picks[1, :2]) == {0, 2}
+
+
+def test_pick_endpoints_fills_fallbacks(pkg):
+    wl = pkg.workload.make_workload(2, R=16, P=64)
+    eps = [pkg.Endpoint(address=f"10.0.{i // 256}.{i % 256}", port="8000") for i in range(64)]
+    with pkg.BatchedPicker(wl.chain, max_pods=64, max_blocks=wl.B, max_batch=16) as pk:
+        pk.publish(wl.pods)
+        res = pk.pick_endpoints(eps, wl.reqs, fallbacks=2)
+        plain = pk.pick_endpoints(eps, wl.reqs)
+    assert all(len(r.fallbacks) == 2 and r.endpoint not in r.fallbacks for r in res)
+    assert [r.endpoint for r in res] == [r.endpoint for r in plain]
