@@ -1281,57 +1281,75 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
 // stats[2] = occupied keys, stats[3] = dropped inserts (table at its load limit)
 
+// Set pod's bit in the row of `slot`.  Re-inserting a cached block is the common case of the post-pick update, so the word is
+// read first and the atomic issued only when the bit is still clear (bits are only cleared by remove_pod, never concurrently).
 template <typename LW>
 __device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_t pod) {
   const uint32_t lane = pod & 63u, j = pod >> 6;
   if constexpr (sizeof(LW) == 8) {
-    atomicOr((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, 1ull << j);
+    unsigned long long* w = (unsigned long long*)bitmaps + (size_t)slot * 64u + lane;
+    if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull)) atomicOr(w, 1ull << j);
   } else if constexpr (sizeof(LW) == 4) {
-    atomicOr((unsigned int*)bitmaps + (size_t)slot * 64u + lane, 1u << j);
+    unsigned int* w = (unsigned int*)bitmaps + (size_t)slot * 64u + lane;
+    if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1u)) atomicOr(w, 1u << j);
   } else {
     const size_t e = (size_t)slot * 64u + lane;           // u16 element index
-    atomicOr((unsigned int*)bitmaps + (e >> 1), (1u << j) << (16u * (uint32_t)(e & 1u)));
+    unsigned int* w = (unsigned int*)bitmaps + (e >> 1);
+    const unsigned int bit = (1u << j) << (16u * (uint32_t)(e & 1u));
+    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
   }
 }
 
+// Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the occupancy counter stats[2] is bumped
+// once per wavefront (ballot + popcount) -- a same-address atomic per new key serialises at ~12 ns each, 12 ms per million keys.
+// The load-limit test therefore sees a count that lags by the keys of in-flight wavefronts (a few thousand at most): the
+// limit is slots/2 while a table is only ever full at 7/8 slots, so the slack is harmless.
 template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift,
-                                                 uint32_t limit, unsigned long long* stats, uint64_t h, uint32_t pod) {
+                                                 uint32_t limit, unsigned long long* stats, uint64_t h, uint32_t pod, bool active) {
   uint32_t slot = kNotFound;
-  if (h == 0 || h == kTomb) {
-    slot = h == 0 ? slots : slots + 1u;
-    __hip_atomic_store((unsigned long long*)&keys[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    // first free word of the home bucket; a full bucket is flagged "overflowed" and the search moves to the next one
-    const uint32_t bmask = slots / kBucket - 1u;
-    uint32_t b = home_bucket(h, shift);
-    bool stop = false;
-    for (uint32_t n = 0; n <= bmask && !stop && slot == kNotFound; ++n) {
-      unsigned long long* kb = (unsigned long long*)keys + (size_t)b * kBucket;
-      for (uint32_t i = 1; i < kBucket; ++i) {
-        unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == 0ull) {
-          if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
-          k = atomicCAS(&kb[i], 0ull, (unsigned long long)h);
-          if (k == 0ull) { atomicAdd(&stats[2], 1ull); slot = b * kBucket + i; break; }
+  bool newkey = false;
+  if (active) {
+    if (h == 0 || h == kTomb) {
+      slot = h == 0 ? slots : slots + 1u;
+      __hip_atomic_store((unsigned long long*)&keys[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // first free word of the home bucket; a full bucket is flagged "overflowed" and the search moves to the next one
+      const uint32_t bmask = slots / kBucket - 1u;
+      uint32_t b = home_bucket(h, shift);
+      bool stop = false;
+      for (uint32_t n = 0; n <= bmask && !stop && slot == kNotFound; ++n) {
+        unsigned long long* kb = (unsigned long long*)keys + (size_t)b * kBucket;
+        for (uint32_t i = 1; i < kBucket; ++i) {
+          unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (k == 0ull) {
+            if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
+            k = atomicCAS(&kb[i], 0ull, (unsigned long long)h);
+            if (k == 0ull) { newkey = true; slot = b * kBucket + i; break; }
+          }
+          if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
         }
-        if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
-      }
-      if (slot == kNotFound && !stop) {
-        atomicOr(&kb[0], 1ull);
-        b = (b + 1) & bmask;
+        if (slot == kNotFound && !stop) {
+          atomicOr(&kb[0], 1ull);
+          b = (b + 1) & bmask;
+        }
       }
     }
   }
-  if (slot == kNotFound) { atomicAdd(&stats[3], 1ull); return; }
-  bitmap_set<LW>(bitmaps, slot, pod);
+  const unsigned long long nk = __ballot(newkey), dropped = __ballot(active && slot == kNotFound);
+  if ((threadIdx.x & 63u) == 0u) {
+    if (nk) atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(nk));
+    if (dropped) atomicAdd(&stats[3], (unsigned long long)__builtin_popcountll(dropped));
+  }
+  if (active && slot != kNotFound) bitmap_set<LW>(bitmaps, slot, pod);
 }
 
 template <typename LW>
 __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift, uint32_t limit,
                                     unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, hashes[i], pods[i]);
+  const bool active = i < n;
+  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
@@ -1341,12 +1359,17 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
-  if (r >= n_reqs) return;
-  const int32_t pick = picks[r];
-  const uint8_t* row = reqs + (size_t)r * stride;
-  const uint32_t nb = ((const uint32_t*)row)[1];
-  if (pick < 0 || i >= nb) return;
-  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, ((const uint64_t*)(row + 8))[i], (uint32_t)pick);
+  bool active = r < n_reqs;
+  int32_t pick = -1;
+  uint64_t h = 0;
+  if (active) {
+    pick = picks[r];
+    const uint8_t* row = reqs + (size_t)r * stride;
+    const uint32_t nb = ((const uint32_t*)row)[1];
+    active = pick >= 0 && i < nb;
+    if (active) h = ((const uint64_t*)(row + 8))[i];
+  }
+  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, h, (uint32_t)pick, active);
 }
 
 // Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never

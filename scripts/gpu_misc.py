@@ -39,4 +39,20 @@ for _ in range(5): pk.pick_device(d_reqs.data_ptr(), 8192, d_mask.data_ptr(), d_
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 out["masked_generic_8k_x_4096"] = {"ms": ms, "decisions_per_s": 8192 / ms * 1e3}
+# post-pick index update (SEMANTICS.md §6) at C5 size: 64k requests x 32 blocks appended after a pick
+R5 = 65536
+d_reqs5 = torch.from_numpy(wl.reqs.view(np.int64)).cuda(); d_pick5 = torch.empty(R5, dtype=torch.int32, device="cuda"); d_sc5 = torch.empty(R5, dtype=torch.float64, device="cuda")
+pk2 = pkg.BatchedPicker(wl.chain, max_pods=4096, max_blocks=32, max_batch=65536, index_slots=1 << 22)
+pk2.publish(wl.pods); pk2.index_insert(wl.index_hashes, wl.index_pods)
+pk2.pick_device(d_reqs5.data_ptr(), R5, None, d_pick5.data_ptr(), d_sc5.data_ptr(), st)
+torch.cuda.synchronize()
+ts = []
+for i in range(4):
+    e0.record(); pk2.index_insert_picks_device(d_reqs5.data_ptr(), d_pick5.data_ptr(), R5, st); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+out["insert_picks_64k_x_32"] = {"first_ms": ts[0], "repeat_ms": float(np.median(ts[1:])), "index_keys_after": pk2.index_size()}
+e0.record()
+for _ in range(5): pk2.pick_device(d_reqs5.data_ptr(), R5, None, d_pick5.data_ptr(), d_sc5.data_ptr(), st)
+e1.record(); torch.cuda.synchronize()
+out["pick_after_insert_picks_ms"] = e0.elapsed_time(e1) / 5
 print(json.dumps(out))
