@@ -84,6 +84,8 @@ struct eppk_ctx {
   void* bitmaps = nullptr;
   uint32_t slots = 0, shift = 0, limit = 0;
   size_t rows_bytes = 0, index_bytes = 0;   // rows | keys in one allocation
+  uint32_t* stamps = nullptr;               // [slots + 2] index epoch of the last insert of every key (ageing)
+  uint32_t index_epoch = 1;
   unsigned long long* stats = nullptr;  // device [4 + 2*kStatSlots]: -, -, occupied keys, dropped inserts, then per-wave {hits, lookups}
 
   // staging for the host-buffer entry point
@@ -403,6 +405,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc(&c->bitmaps, c->index_bytes));
     c->keys = (uint64_t*)((uint8_t*)c->bitmaps + c->rows_bytes);
     CHK(hipMemset(c->bitmaps, 0, c->index_bytes));
+    CHK(hipMalloc((void**)&c->stamps, ((size_t)c->slots + 2u) * 4u));
+    CHK(hipMemset(c->stamps, 0, ((size_t)c->slots + 2u) * 4u));
   }
   CHK(hipDeviceSynchronize());
 #undef CHK
@@ -415,7 +419,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows);
@@ -493,6 +497,7 @@ int eppk_index_clear(eppk_ctx* c) {
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->stamps, 0, ((size_t)c->slots + 2u) * 4u, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
@@ -516,8 +521,8 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   const uint32_t threads = 256, grid = (n + threads - 1) / threads;
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, c->shift,
-                       c->limit, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n);
+    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->stamps, c->slots, c->shift,
+                       c->limit, c->index_epoch, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -540,8 +545,8 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   if (grid64 > 0x7FFFFFFFull) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert_picks_device: batch too large");
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->slots,
-                       c->shift, c->limit, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs);
+    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->stamps, c->slots,
+                       c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -553,10 +558,12 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (pod >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_remove_pod: pod >= max_pods");
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  const uint32_t rows = c->slots + 2u, threads = 256, grid = (rows * 64u + threads - 1) / threads;
+  const uint32_t rows = c->slots + 2u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, pod);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, pod, c->stats);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -570,8 +577,39 @@ int eppk_index_size(eppk_ctx* c, uint32_t* n_entries) {
   unsigned long long st[4];
   HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *n_entries = (uint32_t)st[2];
+  *n_entries = (uint32_t)st[1];   // live keys (st[2] counts non-empty words, tombstones included)
   return EPPK_OK;
+}
+
+int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
+  if (!c) return EPPK_ERR_ARG;
+  if (c->index_epoch == 0xFFFFFFFFu) return fail(c, EPPK_ERR_LIMIT, "eppk_index_advance_epoch: epoch counter exhausted (clear the index)");
+  ++c->index_epoch;
+  if (new_epoch) *new_epoch = c->index_epoch;
+  return EPPK_OK;
+}
+
+int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted) {
+  if (!c) return EPPK_ERR_ARG;
+  if (n_evicted) *n_evicted = 0;
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long), c->stream));   // stats[0]: evicted by this launch
+  const uint32_t rows = c->slots + 2u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, (const uint32_t*)c->stamps, c->slots,
+                       min_epoch, c->stats);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  unsigned long long ev = 0;
+  HIPCHK(c, hipMemcpyAsync(&ev, c->stats, sizeof ev, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_evicted) *n_evicted = (uint32_t)ev;
+  return rc;
 }
 
 // ---- the hot path ----------------------------------------------------------------------------------

@@ -1300,62 +1300,84 @@ __device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_
   }
 }
 
-// Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the occupancy counter stats[2] is bumped
-// once per wavefront (ballot + popcount) -- a same-address atomic per new key serialises at ~12 ns each, 12 ms per million keys.
-// The load-limit test therefore sees a count that lags by the keys of in-flight wavefronts (a few thousand at most): the
-// limit is slots/2 while a table is only ever full at 7/8 slots, so the slack is harmless.
+// Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters (stats[1] = live keys,
+// stats[2] = non-empty words, stats[3] = dropped inserts) are bumped once per wavefront (ballot + popcount) -- a same-address
+// atomic per new key serialises at ~12 ns each, 12 ms per million keys.  The load-limit test therefore sees a count that lags
+// by the keys of in-flight wavefronts (a few thousand at most): the limit is slots/2 while a table is only ever full at
+// 7/8 slots, so the slack is harmless.
+//
+// A key goes into the first FREE word (empty, or a tombstone left by an eviction) of its bucket chain -- home bucket, then
+// the following buckets for as long as the overflow flags say the chain continues -- but only after the whole chain has
+// been searched for the key itself (a tombstone may sit in front of it).  Free words only disappear while an insert kernel
+// runs (evictions are separate launches), so every inserter of one key converges on the same word: no duplicates.
+// Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
 template <typename LW>
-__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift,
-                                                 uint32_t limit, unsigned long long* stats, uint64_t h, uint32_t pod, bool active) {
+__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift,
+                                                 uint32_t limit, uint32_t epoch, unsigned long long* stats, uint64_t h, uint32_t pod, bool active) {
   uint32_t slot = kNotFound;
-  bool newkey = false;
+  bool newkey = false, newword = false;
   if (active) {
     if (h == 0 || h == kTomb) {
       slot = h == 0 ? slots : slots + 1u;
-      __hip_atomic_store((unsigned long long*)&keys[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long was = atomicExch((unsigned long long*)&keys[slot], 1ull);
+      newkey = was == 0ull;
     } else {
-      // first free word of the home bucket; a full bucket is flagged "overflowed" and the search moves to the next one
       const uint32_t bmask = slots / kBucket - 1u;
-      uint32_t b = home_bucket(h, shift);
+      unsigned long long* K = (unsigned long long*)keys;
       bool stop = false;
-      for (uint32_t n = 0; n <= bmask && !stop && slot == kNotFound; ++n) {
-        unsigned long long* kb = (unsigned long long*)keys + (size_t)b * kBucket;
-        for (uint32_t i = 1; i < kBucket; ++i) {
-          unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (k == 0ull) {
-            if (__hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
-            k = atomicCAS(&kb[i], 0ull, (unsigned long long)h);
-            if (k == 0ull) { newkey = true; slot = b * kBucket + i; break; }
+      while (slot == kNotFound && !stop) {
+        uint32_t b = home_bucket(h, shift);
+        uint32_t free_slot = kNotFound;
+        unsigned long long free_val = 0ull;
+        bool chain_end = false;
+        for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
+          unsigned long long* kb = K + (size_t)b * kBucket;
+          for (uint32_t i = 1; i < kBucket; ++i) {
+            const unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
+            if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = b * kBucket + i; free_val = k; }
+            if (k == 0ull) { chain_end = true; break; }          // buckets fill front to back: nothing lives behind an empty word
           }
-          if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
-        }
-        if (slot == kNotFound && !stop) {
-          atomicOr(&kb[0], 1ull);
+          if (slot != kNotFound || chain_end) break;
+          if (__hip_atomic_load(&kb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull) { b = (b + 1) & bmask; continue; }   // chain continues
+          if (free_slot != kNotFound) break;                      // chain ends here and a tombstone is free
+          atomicOr(&kb[0], 1ull);                                 // full bucket, no free word anywhere: extend the chain
           b = (b + 1) & bmask;
         }
+        if (slot != kNotFound) break;
+        if (free_slot == kNotFound) { stop = true; break; }       // walked the whole table
+        if (free_val == 0ull && __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
+        const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
+        if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
+        else if (seen == (unsigned long long)h) slot = free_slot;
+        // else: somebody else took the word for another key -> search again
       }
     }
   }
-  const unsigned long long nk = __ballot(newkey), dropped = __ballot(active && slot == kNotFound);
+  const unsigned long long nk = __ballot(newkey), nw = __ballot(newword), dropped = __ballot(active && slot == kNotFound);
   if ((threadIdx.x & 63u) == 0u) {
-    if (nk) atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(nk));
+    if (nk) atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(nk));
+    if (nw) atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(nw));
     if (dropped) atomicAdd(&stats[3], (unsigned long long)__builtin_popcountll(dropped));
   }
-  if (active && slot != kNotFound) bitmap_set<LW>(bitmaps, slot, pod);
+  if (active && slot != kNotFound) {
+    if (__hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) atomicMax(&stamps[slot], epoch);
+    bitmap_set<LW>(bitmaps, slot, pod);
+  }
 }
 
 template <typename LW>
-__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift, uint32_t limit,
-                                    unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+                                    uint32_t epoch, unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
+  index_insert_one<LW>(keys, bitmaps, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
 template <typename LW>
-__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t shift, uint32_t limit,
-                                          unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
+__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+                                          uint32_t epoch, unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
@@ -1369,26 +1391,56 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, slots, shift, limit, stats, h, (uint32_t)pick, active);
+  index_insert_one<LW>(keys, bitmaps, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active);
 }
 
 // Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
-// meets a present key with an empty pod set.  One wavefront per row (rows = slots + 2: the reserved rows too).
+// meets a present key with an empty pod set.  A wavefront per row, looping (rows = slots + 2: the reserved rows too).
 template <typename LW>
-__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t pod) {
+__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t pod, unsigned long long* stats) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= slots + 2u) return;
-  if (row < slots && (row & (kBucket - 1u)) == 0u) return;   // bucket header words are not keys (their rows are unused)
-  LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
-  LW v = *w;
-  if (lane == (pod & 63u)) {
-    const LW nv = (LW)(v & (LW)~((LW)1 << (pod >> 6)));
-    if (nv != v) *w = nv;
-    v = nv;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t gone = 0;
+  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
+    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;   // bucket header words are not keys (their rows are unused)
+    const uint64_t k = keys[row];
+    if (k == 0ull || (row < slots && k == kTomb)) continue;
+    LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
+    LW v = *w;
+    if (lane == (pod & 63u)) {
+      const LW nv = (LW)(v & (LW)~((LW)1 << (pod >> 6)));
+      if (nv != v) *w = nv;
+      v = nv;
+    }
+    if (__ballot(v != 0) == 0ull) {
+      if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;     // reserved rows: clear presence
+      ++gone;
+    }
   }
-  const bool empty = __ballot(v != 0) == 0ull;
-  if (empty && lane == 0 && keys[row] != 0ull) keys[row] = row < slots ? kTomb : 0ull;  // reserved rows: clear presence
+  if (lane == 0 && gone) atomicAdd(&stats[1], (unsigned long long)(0ull - (unsigned long long)gone));
+}
+
+// Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
+// drop every key last stamped before min_epoch -- row zeroed, key tombstoned (reusable by later inserts).
+template <typename LW>
+__global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
+                                   unsigned long long* stats) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t gone = 0;
+  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
+    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
+    const uint64_t k = keys[row];
+    if (k == 0ull || (row < slots && k == kTomb)) continue;
+    if (stamps[row] >= min_epoch) continue;
+    ((LW*)bitmaps)[(size_t)row * 64u + lane] = 0;
+    if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;
+    ++gone;
+  }
+  if (lane == 0 && gone) {
+    atomicAdd(&stats[1], (unsigned long long)(0ull - (unsigned long long)gone));
+    atomicAdd(&stats[0], (unsigned long long)gone);   // evicted by this launch (host zeroes it first)
+  }
 }
 
 }  // namespace eppk

@@ -187,6 +187,18 @@ class BatchedPicker:
     def index_remove_pod(self, pod: int) -> None:
         self._check(self._lib.eppk_index_remove_pod(self._ctx, pod), "index_remove_pod")
 
+    def index_advance_epoch(self) -> int:
+        """Tick the index epoch that stamps every later insert (ageing, include/eppk.h)."""
+        e = C.c_uint32(0)
+        self._check(self._lib.eppk_index_advance_epoch(self._ctx, C.byref(e)), "index_advance_epoch")
+        return e.value
+
+    def index_evict_older(self, min_epoch: int) -> int:
+        """Drop every hash last inserted before `min_epoch`; returns how many were dropped."""
+        n = C.c_uint32(0)
+        self._check(self._lib.eppk_index_evict_older(self._ctx, min_epoch, C.byref(n)), "index_evict_older")
+        return n.value
+
     def index_size(self) -> int:
         n = C.c_uint32(0)
         self._check(self._lib.eppk_index_size(self._ctx, C.byref(n)), "index_size")

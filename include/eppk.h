@@ -145,8 +145,15 @@ int eppk_index_insert_picks_device(eppk_ctx* ctx, const void* d_reqs, const int3
                                    uint32_t n_reqs, void* stream);
 /* Drop pod from every entry (endpoint deleted / cache flushed). */
 int eppk_index_remove_pod(eppk_ctx* ctx, uint32_t pod);
-/* Number of occupied slots (diagnostic; synchronises). */
+/* Number of hashes with a non-empty pod set (synchronises). */
 int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
+/* Ageing -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)", 0602-…/README.md:82.
+ * Every insert (eppk_index_insert, eppk_index_insert_picks_device) stamps its hashes with the context's index epoch
+ * (starts at 1); eppk_index_advance_epoch increments it; eppk_index_evict_older drops every hash whose last stamp is
+ * < min_epoch (for all pods) and makes its table word reusable.  A shim ticks the epoch once per interval and evicts
+ * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches. */
+int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
+int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 

@@ -39,6 +39,10 @@ def load() -> C.CDLL:
     lib.orc_index_insert.restype = None
     lib.orc_index_remove_pod.argtypes = [vp, u32]
     lib.orc_index_remove_pod.restype = None
+    lib.orc_index_advance_epoch.argtypes = [vp]
+    lib.orc_index_advance_epoch.restype = u32
+    lib.orc_index_evict_older.argtypes = [vp, u32]
+    lib.orc_index_evict_older.restype = u32
     lib.orc_index_size.argtypes = [vp]
     lib.orc_index_size.restype = u64
     lib.orc_index_lookup.argtypes = [vp, u64, vp, u32]
@@ -79,6 +83,12 @@ class OracleIndex:
 
     def clear(self) -> None:
         self.lib.orc_index_clear(self.h)
+
+    def advance_epoch(self) -> int:
+        return int(self.lib.orc_index_advance_epoch(self.h))
+
+    def evict_older(self, min_epoch: int) -> int:
+        return int(self.lib.orc_index_evict_older(self.h, min_epoch))
 
     def size(self) -> int:
         return int(self.lib.orc_index_size(self.h))

@@ -112,12 +112,14 @@ typedef struct {
   uint32_t* pods;
   uint32_t  n, cap;
   int       used;
+  uint32_t  stamp; /* index epoch of the last insert of this hash (SEMANTICS.md 6a) */
 } orc_entry;
 
 struct orc_index {
   orc_entry* tab;
   uint64_t   cap;  /* power of two */
   uint64_t   used; /* entries allocated (including ones whose set became empty) */
+  uint32_t   epoch; /* current index epoch, starts at 1 */
 };
 
 static uint64_t ix_home(uint64_t h, uint64_t cap) {
@@ -131,6 +133,7 @@ orc_index* orc_index_new(void) {
   orc_index* ix = (orc_index*)calloc(1, sizeof(*ix));
   if (!ix) return NULL;
   ix->cap = 1024;
+  ix->epoch = 1;
   ix->tab = (orc_entry*)calloc(ix->cap, sizeof(orc_entry));
   if (!ix->tab) { free(ix); return NULL; }
   return ix;
@@ -178,8 +181,10 @@ void orc_index_insert(orc_index* ix, uint64_t hash, uint32_t pod) {
     e->hash = hash;
     e->pods = NULL;
     e->n = e->cap = 0;
+    e->stamp = 0;
     ix->used++;
   }
+  if (e->stamp < ix->epoch) e->stamp = ix->epoch; /* every insert stamps the hash, present pod or not */
   uint32_t lo = 0;
   while (lo < e->n && e->pods[lo] < pod) ++lo;
   if (lo < e->n && e->pods[lo] == pod) return; /* set semantics */
@@ -203,6 +208,18 @@ void orc_index_remove_pod(orc_index* ix, uint32_t pod) {
         break;
       }
   }
+}
+
+/* Ageing (SEMANTICS.md 6a; docs/proposals/0602-…/README.md:82 "mimicking a similar cache eviction strategy"). */
+uint32_t orc_index_advance_epoch(orc_index* ix) { return ++ix->epoch; }
+
+uint32_t orc_index_evict_older(orc_index* ix, uint32_t min_epoch) {
+  uint32_t gone = 0;
+  for (uint64_t i = 0; i < ix->cap; ++i) {
+    orc_entry* e = &ix->tab[i];
+    if (e->used && e->n > 0 && e->stamp < min_epoch) { e->n = 0; ++gone; }
+  }
+  return gone;
 }
 
 uint64_t orc_index_size(const orc_index* ix) {

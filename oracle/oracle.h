@@ -30,6 +30,9 @@ void       orc_index_clear(orc_index* ix);
 /* "hash(chunk i): append s" — docs/proposals/0602-…/README.md:101-108 (set semantics). */
 void       orc_index_insert(orc_index* ix, uint64_t hash, uint32_t pod);
 void       orc_index_remove_pod(orc_index* ix, uint32_t pod);
+/* ageing: ++epoch (inserts stamp their hash with it); drop every hash last stamped before min_epoch -> number dropped */
+uint32_t   orc_index_advance_epoch(orc_index* ix);
+uint32_t   orc_index_evict_older(orc_index* ix, uint32_t min_epoch);
 /* number of hashes with a non-empty pod set */
 uint64_t   orc_index_size(const orc_index* ix);
 /* copy out the pod set of one hash (sorted ascending); returns its size */

@@ -331,3 +331,54 @@ def test_pick_endpoints_fills_fallbacks(pkg):
         plain = pk.pick_endpoints(eps, wl.reqs)
     assert all(len(r.fallbacks) == 2 and r.endpoint not in r.fallbacks for r in res)
     assert [r.endpoint for r in res] == [r.endpoint for r in plain]
+
+
+def test_index_ageing_and_word_reuse(pkg, orc):
+    """SEMANTICS.md §6a: inserts stamp hashes with the index epoch, evict_older drops the stale ones, their table words are
+    reused by later inserts -- picks, scores and live-key counts stay equal to the oracle through several generations, in a
+    table small enough (512 slots, at most 256 non-empty words) that the later generations only fit because evicted words are
+    recycled (4 x 96 new hashes + re-inserted ones)."""
+    P, B, slots = 300, 8, 512
+    pods = pkg.workload.make_pods(7, P, 128)
+    rng = np.random.default_rng(21)
+    chain = [(Q, 1), (KV, 2), (L, 1), (PF, 4)]
+
+    def generation(seed, n_chains=12):
+        g = np.random.default_rng(seed)
+        chains = g.integers(1, 2**63, (n_chains, B), dtype=np.uint64)
+        ih = np.repeat(chains.ravel(), 2)
+        ip = g.integers(0, P, ih.size).astype(np.uint32)
+        return chains, ih, ip
+
+    def requests(chains_list, R=256):
+        allc = np.concatenate(chains_list)
+        pick = rng.integers(0, allc.shape[0], R)
+        cut = rng.integers(0, B + 1, R)
+        hs = allc[pick].copy()
+        for r in range(R):                        # break the chain at a random depth with an unknown hash
+            hs[r, cut[r]:] = rng.integers(1, 2**63, B - cut[r], dtype=np.uint64)
+        return pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+
+    with pkg.BatchedPicker(chain, max_pods=1024, max_blocks=B, max_batch=256, index_slots=slots) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        gens = []
+        for gen in range(4):
+            chains, ih, ip = generation(100 + gen)
+            gens.append(chains)
+            pk.index_insert(ih, ip); oix.insert(ih, ip)                       # 96 new hashes, stamped with the current epoch
+            if gen >= 1:                                                      # keep a few old hashes alive by re-inserting them
+                keep_h = gens[gen - 1][:3].ravel(); keep_p = np.full(keep_h.size, gen, dtype=np.uint32)
+                pk.index_insert(keep_h, keep_p); oix.insert(keep_h, keep_p)
+            reqs = requests(gens)
+            picks, scores = pk.pick(reqs)
+            op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert_same(picks, scores, op, osc)
+            assert pk.index_size() == oix.size()
+            e_dev, e_orc = pk.index_advance_epoch(), oix.advance_epoch()
+            assert e_dev == e_orc == gen + 2
+            n_dev, n_orc = pk.index_evict_older(e_dev - 1), oix.evict_older(e_orc - 1)   # drop everything not touched this epoch
+            assert n_dev == n_orc and pk.index_size() == oix.size()
+            picks, scores = pk.pick(reqs)
+            op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert_same(picks, scores, op, osc)
