@@ -153,13 +153,13 @@ KIndex make_kindex(const eppk_ctx* c) {
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
 
-template <typename LW, int NPL, bool MASKED>
+template <typename LW, int NPL, bool MASKED, bool BIG>
 const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first) {
-  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED>
-                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED>;
-  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED>;
-  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED>;
-  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED>;
+  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG>
+                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG>;
+  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false>;     // no prefix scorer: no index access
+  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false>;
 }
 
 template <typename LW, int NPL>
@@ -171,7 +171,9 @@ const void* generic_kernel_ptr(bool masked, bool topk) {
 template <typename LW, int NPL>
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
   if (!fast) return generic_kernel_ptr<LW, NPL>(masked, topk);
-  return masked ? fast_kernel_ptr<LW, NPL, true>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false>(c->has_l, c->has_p, c->p_first);
+  const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: structured row descriptor
+  if (big) return masked ? fast_kernel_ptr<LW, NPL, true, true>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false, true>(c->has_l, c->has_p, c->p_first);
+  return masked ? fast_kernel_ptr<LW, NPL, true, false>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false, false>(c->has_l, c->has_p, c->p_first);
 }
 
 template <typename LW>
@@ -191,8 +193,8 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st, uint32_t topk = 1) {
   const bool masked = d_mask != nullptr;
-  // masked batches use the fast kernel's MASKED instantiation; an index of 4 GiB and more (32-bit buffer offsets) -> generic kernel
-  const bool fast = topk == 1 && c->canonical && (c->slots == 0 || c->index_bytes < (1ull << 32));
+  // masked batches use the fast kernel's MASKED instantiation, indexes of 4 GiB and more its BIG one
+  const bool fast = topk == 1 && c->canonical;
   const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);

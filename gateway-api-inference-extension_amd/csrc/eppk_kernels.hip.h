@@ -587,7 +587,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
 // Row loads.  A row address is wave-uniform (slot from v_readlane) plus lane * sizeof(LW).  Tables below 4 GiB are read
 // through ONE raw buffer descriptor with the row's byte offset in the instruction's SGPR offset operand: zero VALU ops and
 // zero 64-bit address arithmetic per row (buffer_load ... v_lane_off, s[rsrc], s_row_off offen).  Hit k of the request is in
-// lane pair k of slot_eff.  (Indexes of 4 GiB and more are served by the generic kernel.)
+// lane pair k of slot_eff.
 template <typename LW>
 __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
   if constexpr (sizeof(LW) == 8) {
@@ -599,16 +599,57 @@ __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t
     return (LW)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0);
   }
 }
-template <typename LW, int N>
-__device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
-  const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
+// Structured buffer loads (index * stride + offset addressing).  This clang has no builtin for them; the LLVM intrinsics
+// are bound by name (the descriptor is passed as its four dwords).
+typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+extern "C" __device__ u32x2_t eppk_llvm_struct_buffer_load_v2i32(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
+extern "C" __device__ uint32_t eppk_llvm_struct_buffer_load_i32(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
+extern "C" __device__ uint16_t eppk_llvm_struct_buffer_load_i16(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
+template <typename LW>
+__device__ __forceinline__ LW struct_buffer_load_lw(i32x4_t rs, uint32_t vindex, uint32_t voff) {
+  if constexpr (sizeof(LW) == 8) {
+    const u32x2_t v = eppk_llvm_struct_buffer_load_v2i32(rs, (int)vindex, (int)voff, 0, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+  } else if constexpr (sizeof(LW) == 4) {
+    return (LW)eppk_llvm_struct_buffer_load_i32(rs, (int)vindex, (int)voff, 0, 0);
+  } else {
+    return (LW)eppk_llvm_struct_buffer_load_i16(rs, (int)vindex, (int)voff, 0, 0);
+  }
+}
+// Descriptor of a structured buffer: base (48 bits) | stride << 48, num_records, gfx9 word 3 (32-bit data format).
+__device__ __forceinline__ i32x4_t make_struct_rsrc(const void* base, uint32_t stride) {
+  const uint64_t b = (uint64_t)base;
+  i32x4_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)(((uint32_t)(b >> 32) & 0xFFFFu) | (stride << 16)));
+  r.z = -1;
+  r.w = 0x00020000;
+  return r;
+}
+// BIG (index of 4 GiB and more, sized for the 288 GB of HBM): the descriptor is STRUCTURED (stride = one row), the row's slot
+// is the buffer index (32 bits x stride: 2 TiB of reach) -- one extra v_mov per row (the index must sit in a VGPR).
+struct RowSrc {                  // how the fast kernel reaches the pod-set rows
+  __amdgpu_buffer_rsrc_t raw;    // small index: raw descriptor over rows + keys, rows addressed by SGPR byte offsets
+  i32x4_t strided;               // BIG: structured descriptor over the rows (slot = buffer index)
+};
+template <typename LW, int N, bool BIG>
+__device__ __forceinline__ void load_rows(const RowSrc& src, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
   const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
+  if constexpr (BIG) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
+      w[u] = struct_buffer_load_lw<LW>(src.strided, s, voff);
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rs = src.raw;
+  const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
 #ifdef EPPK_DBG_SKIP_ROWS   // timing experiment only (wrong results): no row loads, one pseudo pod per row
     w[u] = ((uint32_t)lane == ((soff >> 9) & 63u)) ? (LW)((LW)1 << (u & 7)) : (LW)0;
-    (void)voff;
 #else
     w[u] = buffer_load_lw<LW>(rs, voff, soff);
 #endif
@@ -616,17 +657,17 @@ __device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t rs, uint32_t sl
 }
 
 // rows [k0, m) of slot_eff added into non-zero counters, 16 in flight (8 for a short tail)
-template <typename LW, int NPL>
-__device__ __forceinline__ void count_more(__amdgpu_buffer_rsrc_t rs, uint32_t slot_eff, uint32_t k0, uint32_t m, int lane, LW (&c)[NPL]) {
+template <typename LW, int NPL, bool BIG>
+__device__ __forceinline__ void count_more(const RowSrc& rs, uint32_t slot_eff, uint32_t k0, uint32_t m, int lane, LW (&c)[NPL]) {
   for (; k0 + 8u < m; k0 += 16u) {
     LW w[16], b[5];
-    load_rows<LW, 16>(rs, slot_eff, k0, lane, w);
+    load_rows<LW, 16, BIG>(rs, slot_eff, k0, lane, w);
     csa16<LW>(w, b);
     planes_addn<LW, NPL, 5>(c, b);
   }
   if (k0 < m) {
     LW w[8], b[4];
-    load_rows<LW, 8>(rs, slot_eff, k0, lane, w);
+    load_rows<LW, 8, BIG>(rs, slot_eff, k0, lane, w);
     csa8<LW>(w, b);
     planes_addn<LW, NPL, 4>(c, b);
   }
@@ -647,7 +688,7 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 //   stage 2  rows + tables of r, count, evaluate, pick.
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED>
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
@@ -670,10 +711,15 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   // wave-uniform ids in SGPRs: every per-request address below is scalar arithmetic
   const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
   const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
-  // raw buffer descriptor over the pod-set rows (gfx9 word 3: 32-bit data format); num_records = table bytes
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000);
-  // (the key table lives behind the rows in the same allocation), over the snapshot tables and over the request rows: every hot-loop load is
-  // buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR row offset) -- no 64-bit per-lane pointers, no address VALU ops.
+  // Buffer descriptors (gfx9 word 3: 32-bit data format).  Small index (< 4 GiB): ONE raw descriptor over rows + keys (one
+  // allocation, rows first), rows addressed by SGPR byte offsets.  BIG: a structured descriptor over the rows (stride = one
+  // row, the slot is the buffer index) and a raw one over the keys.  Plus the snapshot tables and the request rows: every
+  // hot-loop load is buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR/VGPR row selector) -- no 64-bit per-lane pointers.
+  RowSrc rs;
+  rs.raw = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, BIG ? 0 : (int)ix.table_bytes, 0x00020000);
+  rs.strided = make_struct_rsrc(ix.bitmaps, (uint32_t)(64u * sizeof(LW)));
+  const __amdgpu_buffer_rsrc_t rk = BIG ? __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000) : rs.raw;
+  const uint32_t keys_off = BIG ? 0u : ix.keys_off;
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
   const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
@@ -687,7 +733,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   // u64 word of a request row that this lane pair reads as "its" hash (always in bounds: word 0 when the row has no hashes)
   const uint32_t ki = (uint32_t)lane >> 1;
   const uint32_t hidx8 = ((HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u) * 8u;
-  const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u && ix.small != 0u;   // tables of 4 GiB and more: generic kernel (eppk.hip)
+  const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
 
   if (gwave >= n_reqs) return;
 
@@ -706,7 +752,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
   };
   auto issue_keys = [&](ReqRegs& q) {
-    if (use_index) pair_probe_issue(rs, ix.keys_off, q, lane);
+    if (use_index) pair_probe_issue(rk, keys_off, q, lane);
   };
 
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
@@ -751,12 +797,12 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
     LW w[16];
     if (m0 > 8u) {
-      load_rows<LW, 16>(rs, slot0, 0, lane, w);
+      load_rows<LW, 16, BIG>(rs, slot0, 0, lane, w);
     } else {
       LW t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = 0;
-      if (m0 > 0u) load_rows<LW, 8>(rs, slot0, 0, lane, t);
+      if (m0 > 0u) load_rows<LW, 8, BIG>(rs, slot0, 0, lane, t);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { w[u] = t[u]; w[8 + u] = 0; }
     }
@@ -790,7 +836,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       issue_row(r + 2u * nwaves, r, cur);
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (m0 > 16u) count_more<LW, NPL>(rs, slot0, 16u, m0, lane, c);
+      if (m0 > 16u) count_more<LW, NPL, BIG>(rs, slot0, 16u, m0, lane, c);
       if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
         uint32_t mlast = m0;
         for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
@@ -800,10 +846,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           t.h = buffer_load_u64(rq, (1u + b0 + (ki < nchunk ? ki : 0u)) * 8u, r * stride);
           t.h = (ki < nchunk) ? t.h : 0ull;
           pair_probe_prepare(ix, t);
-          pair_probe_issue(rs, ix.keys_off, t, lane);
+          pair_probe_issue(rk, keys_off, t, lane);
           uint32_t slotc;
           mlast = pair_probe_finish(ix, t, nchunk, lane, slotc);
-          count_more<LW, NPL>(rs, slotc, 0u, mlast, lane, c);
+          count_more<LW, NPL, BIG>(rs, slotc, 0u, mlast, lane, c);
           hits += mlast;
         }
       }
@@ -1303,8 +1349,8 @@ __device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_
 // Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters (stats[1] = live keys,
 // stats[2] = non-empty words, stats[3] = dropped inserts) are bumped once per wavefront (ballot + popcount) -- a same-address
 // atomic per new key serialises at ~12 ns each, 12 ms per million keys.  The load-limit test therefore sees a count that lags
-// by the keys of in-flight wavefronts (a few thousand at most): the limit is slots/2 while a table is only ever full at
-// 7/8 slots, so the slack is harmless.
+// by the keys of in-flight wavefronts (a few thousand at most): the limits are slots/2 live keys and 3/4 non-empty words
+// while a table is only ever full at 7/8 slots, so the slack is harmless.
 //
 // A key goes into the first FREE word (empty, or a tombstone left by an eviction) of its bucket chain -- home bucket, then
 // the following buckets for as long as the overflow flags say the chain continues -- but only after the whole chain has
@@ -1346,7 +1392,10 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
         }
         if (slot != kNotFound) break;
         if (free_slot == kNotFound) { stop = true; break; }       // walked the whole table
-        if (free_val == 0ull && __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
+        // capacity: at most `limit` (= slots/2) live keys, and at most 3/4 of the words non-empty (recycling is per bucket
+        // chain, so tombstones of other chains keep their words until a key of that chain arrives)
+        if (__hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
+        if (free_val == 0ull && __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)(slots / 4u * 3u)) { stop = true; break; }
         const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
         if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
         else if (seen == (unsigned long long)h) slot = free_slot;

@@ -382,3 +382,14 @@ def test_index_ageing_and_word_reuse(pkg, orc):
             picks, scores = pk.pick(reqs)
             op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
             assert_same(picks, scores, op, osc)
+
+
+def test_index_of_4gib_and_more_uses_the_structured_descriptor(pkg, orc):
+    """An index whose rows + keys exceed 4 GiB (2^23 slots x 512 B at P = 4096) is served by the BIG instantiation of the fast
+    kernel (structured buffer descriptor, slot = buffer index) -- same picks, same scores."""
+    wl = pkg.workload.make_workload(5, R=512, P=4096)
+    wl.index_slots = 1 << 23
+    assert_same(*run_both(pkg, orc, wl))
+    wm = pkg.workload.make_workload(5, R=256, P=4096, masked=True)
+    wm.index_slots = 1 << 23
+    assert_same(*run_both(pkg, orc, wm, mask=wm.mask))
