@@ -393,3 +393,25 @@ def test_index_of_4gib_and_more_uses_the_structured_descriptor(pkg, orc):
     wm = pkg.workload.make_workload(5, R=256, P=4096, masked=True)
     wm.index_slots = 1 << 23
     assert_same(*run_both(pkg, orc, wm, mask=wm.mask))
+
+
+def test_full_size_headline_batch_and_batch_properties(pkg, orc):
+    """BASELINE.json's headline size (64k requests x 4096 pods, full chain + prefix index) against the oracle on all host cores,
+    plus two size-independent properties of the batched pick: determinism (same batch twice -> identical bits) and
+    equivariance under a permutation of the requests (a pick depends on its own request row only)."""
+    import os
+    wl = pkg.workload.make_workload(5)
+    assert wl.R == 65536 and wl.P == 4096
+    with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=wl.R, index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        picks, scores = pk.pick(wl.reqs)
+        picks2, scores2 = pk.pick(wl.reqs)
+        perm = np.random.default_rng(5).permutation(wl.R)
+        pp, sp = pk.pick(np.ascontiguousarray(wl.reqs[perm]))
+    assert np.array_equal(picks, picks2) and np.array_equal(scores.view(np.uint64), scores2.view(np.uint64))
+    assert np.array_equal(pp, picks[perm]) and np.array_equal(sp.view(np.uint64), scores[perm].view(np.uint64))
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, threads=os.cpu_count() or 1)
+    assert_same(picks, scores, op, osc)
