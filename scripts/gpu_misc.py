@@ -55,4 +55,14 @@ e0.record()
 for _ in range(5): pk2.pick_device(d_reqs5.data_ptr(), R5, None, d_pick5.data_ptr(), d_sc5.data_ptr(), st)
 e1.record(); torch.cuda.synchronize()
 out["pick_after_insert_picks_ms"] = e0.elapsed_time(e1) / 5
+# small-batch latency through the host-buffer entry point (what the micro-batcher of the shim sees at low QPS)
+import time as _t
+for Rs in (1, 16, 256, 4096):
+    sub = np.ascontiguousarray(wl.reqs[:Rs])
+    for _ in range(20): pk.pick(sub)
+    lat = []
+    for _ in range(300):
+        t0 = _t.perf_counter(); pk.pick(sub); lat.append(_t.perf_counter() - t0)
+    lat = np.asarray(lat) * 1e6
+    out[f"host_pick_latency_us_R{Rs}"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))}
 print(json.dumps(out))
