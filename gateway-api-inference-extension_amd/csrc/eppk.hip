@@ -92,6 +92,7 @@ struct eppk_ctx {
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
   void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
   void* d_tmp = nullptr; size_t d_tmp_bytes = 0;  // index insert staging
+  void* d_tk_reqs = nullptr; uint64_t* d_tk_mask = nullptr; int32_t* d_tk_pick = nullptr; double* d_tk_score = nullptr;  // eppk_pick_topk
   eppk_pod_row* h_rows = nullptr; eppk_pod_row* d_rows = nullptr;  // raw pod rows of a publish (pinned staging + device copy)
 
   // measurement
@@ -422,6 +423,7 @@ void eppk_destroy(eppk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows);
@@ -719,25 +721,21 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
     for (size_t i = 0; i < (size_t)n_reqs * k; ++i) { out_pick[i] = EPPK_NO_PICK; if (out_score) out_score[i] = 0.0; }
     return EPPK_OK;
   }
-  // plain (pageable) transfers: the fallback list is not the latency-critical entry point
-  void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
-  auto cleanup = [&]() { (void)hipFree(d_reqs); (void)hipFree(d_mask); (void)hipFree(d_pick); (void)hipFree(d_score); };
-#define TK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, EPPK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-  TK(hipMalloc(&d_reqs, (size_t)n_reqs * c->stride));
-  TK(hipMalloc((void**)&d_pick, (size_t)n_reqs * k * 4u));
-  TK(hipMalloc((void**)&d_score, (size_t)n_reqs * k * 8u));
-  TK(hipMemcpyAsync(d_reqs, reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
-  if (cand_mask) {
-    TK(hipMalloc((void**)&d_mask, (size_t)n_reqs * J * 8u));
-    TK(hipMemcpyAsync(d_mask, cand_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  // device buffers are kept in the context (allocated on first use); transfers are plain pageable copies
+  const size_t mb = c->cfg.max_batch;
+  if (!c->d_tk_reqs) {
+    HIPCHK(c, hipMalloc(&c->d_tk_reqs, mb * c->stride));
+    HIPCHK(c, hipMalloc((void**)&c->d_tk_pick, mb * EPPK_MAX_TOPK * 4u));
+    HIPCHK(c, hipMalloc((void**)&c->d_tk_score, mb * EPPK_MAX_TOPK * 8u));
   }
-  int rc = launch_pick(c, d_reqs, n_reqs, d_mask, d_pick, d_score, c->stream, k);
-  if (rc) { cleanup(); return rc; }
-  TK(hipMemcpyAsync(out_pick, d_pick, (size_t)n_reqs * k * 4u, hipMemcpyDeviceToHost, c->stream));
-  if (out_score) TK(hipMemcpyAsync(out_score, d_score, (size_t)n_reqs * k * 8u, hipMemcpyDeviceToHost, c->stream));
-  TK(hipStreamSynchronize(c->stream));
-#undef TK
-  cleanup();
+  if (cand_mask && !c->d_tk_mask) HIPCHK(c, hipMalloc((void**)&c->d_tk_mask, mb * c->jmax * 8u));
+  HIPCHK(c, hipMemcpyAsync(c->d_tk_reqs, reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+  if (cand_mask) HIPCHK(c, hipMemcpyAsync(c->d_tk_mask, cand_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_pick(c, c->d_tk_reqs, n_reqs, cand_mask ? c->d_tk_mask : nullptr, c->d_tk_pick, c->d_tk_score, c->stream, k);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(out_pick, c->d_tk_pick, (size_t)n_reqs * k * 4u, hipMemcpyDeviceToHost, c->stream));
+  if (out_score) HIPCHK(c, hipMemcpyAsync(out_score, c->d_tk_score, (size_t)n_reqs * k * 8u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
 }
 
