@@ -32,6 +32,7 @@ std::string g_create_err;
 struct SnapBuf {
   uint8_t*  blob = nullptr;
   double*   base = nullptr;
+  double*   post[2] = {nullptr, nullptr};   // products of the pod-only scorers behind LORA / PREFIX (GEN fast path)
   uint32_t* queue = nullptr;
   double*   kv = nullptr;
   void*     thi_t = nullptr;   // [129][64] LW LoRA tier planes (eppk_kernels.hip.h: KSnap)
@@ -43,7 +44,7 @@ struct SnapBuf {
 };
 
 struct SnapLayout {            // byte offsets inside a snapshot blob
-  size_t base = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
+  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -65,6 +66,8 @@ struct eppk_ctx {
   uint32_t n_lead = 0;
   bool lead_queue = false;  // a QUEUE scorer is fused into base[]
   bool has_l = false, has_p = false, p_first = false;
+  bool gen = false;        // pod-only scorers behind LORA / PREFIX: interpreted tail (GEN instantiation)
+  KChain postc{};          // those scorers (n <= 2)
   KTail tail{};
   KChain kchain{};
   double* pterm = nullptr;  // device [(B+1)*(B+1)] exact prefix terms (fast path, max_blocks <= 64)
@@ -132,7 +135,7 @@ inline double h_clamp01(double s) {
 KSnap make_ksnap(const eppk_ctx* c) {
   const SnapBuf& s = c->snap[c->cur];
   KSnap k{};
-  k.base = s.base; k.queue = s.queue; k.kv = s.kv;
+  k.base = s.base; k.post[0] = s.post[0]; k.post[1] = s.post[1]; k.queue = s.queue; k.kv = s.kv;
   k.thi_t = s.thi_t; k.tlo_t = s.tlo_t;
   k.topv = s.topv; k.topi = s.topi;
   k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
@@ -155,12 +158,17 @@ KIndex make_kindex(const eppk_ctx* c) {
 // ---- kernel dispatch ---------------------------------------------------------------------------
 
 template <typename LW, int NPL, bool MASKED, bool BIG>
-const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first) {
-  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG>
-                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG>;
-  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false>;     // no prefix scorer: no index access
-  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG>;
-  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false>;
+const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first, bool gen) {
+  if (gen) {   // interpreted tail (pod-only scorers behind LORA / PREFIX); the order lives in KTail
+    if (has_l && has_p) return (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, true>;
+    if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, true>;
+    return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, true>;     // gen implies LORA or PREFIX
+  }
+  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG, false>
+                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, false>;
+  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, false>;     // no prefix scorer: no index access
+  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, false>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false, false>;
 }
 
 template <typename LW, int NPL>
@@ -173,8 +181,8 @@ template <typename LW, int NPL>
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
   if (!fast) return generic_kernel_ptr<LW, NPL>(masked, topk);
   const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: structured row descriptor
-  if (big) return masked ? fast_kernel_ptr<LW, NPL, true, true>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false, true>(c->has_l, c->has_p, c->p_first);
-  return masked ? fast_kernel_ptr<LW, NPL, true, false>(c->has_l, c->has_p, c->p_first) : fast_kernel_ptr<LW, NPL, false, false>(c->has_l, c->has_p, c->p_first);
+  if (big) return masked ? fast_kernel_ptr<LW, NPL, true, true>(c->has_l, c->has_p, c->p_first, c->gen) : fast_kernel_ptr<LW, NPL, false, true>(c->has_l, c->has_p, c->p_first, c->gen);
+  return masked ? fast_kernel_ptr<LW, NPL, true, false>(c->has_l, c->has_p, c->p_first, c->gen) : fast_kernel_ptr<LW, NPL, false, false>(c->has_l, c->has_p, c->p_first, c->gen);
 }
 
 template <typename LW>
@@ -205,7 +213,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   size_t lds;
   if (fast) {
     pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
-    lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u;   // base | lw[4] | pterm
+    lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (c->gen ? (size_t)sn.J * 64u * 16u : 0u);   // base | lw[4] | pterm | post0 | post1
   } else {
     lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
   }
@@ -337,16 +345,31 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   while (lead < cfg->n_scorers && (cfg->chain[lead].kind == EPPK_SCORER_QUEUE || cfg->chain[lead].kind == EPPK_SCORER_KV)) ++lead;
   c->n_lead = lead;
   for (uint32_t k = 0; k < lead; ++k) c->lead_queue |= cfg->chain[k].kind == EPPK_SCORER_QUEUE;
+  // Fast path: at most one LORA and one PREFIX scorer, at most two pod-only scorers behind the first of them (each of those
+  // needs its own per-pod product array: they are added one by one).  Everything else -> generic kernel.
   c->canonical = true;
   int nl = 0, np = 0;
+  c->tail.n_tail = 0;
   for (uint32_t k = lead; k < cfg->n_scorers; ++k) {
-    if (cfg->chain[k].kind == EPPK_SCORER_LORA) { if (nl++ == 0 && np) c->p_first = true; }
-    else if (cfg->chain[k].kind == EPPK_SCORER_PREFIX) ++np;
-    else c->canonical = false;
+    const uint32_t kind = cfg->chain[k].kind;
+    uint32_t code;
+    if (kind == EPPK_SCORER_LORA) { if (nl++ == 0 && np) c->p_first = true; code = 0u; }
+    else if (kind == EPPK_SCORER_PREFIX) { ++np; code = 1u; }
+    else {
+      if (c->postc.n >= 2u) { c->canonical = false; break; }
+      code = 2u + c->postc.n;
+      c->postc.kind[c->postc.n] = kind;
+      c->postc.w[c->postc.n] = (double)cfg->chain[k].weight;
+      c->postc.n++;
+      c->lead_queue |= kind == EPPK_SCORER_QUEUE;   // (any fused QUEUE term embeds the snapshot-wide normalisers)
+    }
+    if (c->tail.n_tail >= 4u) { c->canonical = false; break; }
+    c->tail.kind[c->tail.n_tail++] = code;
   }
   if (nl > 1 || np > 1) c->canonical = false;
   c->has_l = nl > 0; c->has_p = np > 0;
-  if (!(c->has_l && c->has_p)) c->p_first = false;
+  c->gen = c->canonical && c->postc.n > 0;
+  if (!(c->has_l && c->has_p) || c->gen) c->p_first = false;
   if (c->canonical) {
     static const double tier_score[4] = {0.0, 0.6, 0.8, 1.0};
     double wl = 0.0, wp = 0.0;
@@ -370,13 +393,14 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.thi = off; off += lora_bytes;
     L.tlo = off; off += lora_bytes;
     off = (off + 255u) & ~(size_t)255u;
-    L.base = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
+    L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
     L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
     L.bytes = off;
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
       CHK(hipMalloc((void**)&s.blob, L.bytes));
-      s.base = (double*)(s.blob + L.base); s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
+      s.base = (double*)(s.blob + L.base); s.post[0] = (double*)(s.blob + L.post0); s.post[1] = (double*)(s.blob + L.post1);
+      s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
       s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
       s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax;
       s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
@@ -467,14 +491,14 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   const uint32_t n64 = (uint32_t)np64;
   if (n64)
     hipLaunchKernelGGL(snap_terms_kernel, dim3((n64 + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows, n_pods, n64,
-                       qmin, qmax, lead, s.base, s.queue, s.kv);
+                       qmin, qmax, lead, c->postc, s.base, s.post[0], s.post[1], s.queue, s.kv);
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((130u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
                        n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t);
     if (c->canonical)
       hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, c->stream, (const double*)s.base, (const LW*)s.thi_t,
-                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, s.topv, s.topi);
+                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1], s.topv, s.topi);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -759,6 +783,11 @@ int eppk_hash_prompts_device(eppk_ctx* c, const void* d_prompts, uint64_t prompt
 }
 
 // ---- measurement -----------------------------------------------------------------------------------
+
+int eppk_chain_is_fused(const eppk_ctx* c) {
+  if (!c) return EPPK_ERR_ARG;
+  return c->canonical ? (c->gen ? 2 : 1) : 0;
+}
 
 int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;

@@ -55,6 +55,7 @@ constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots
 
 struct KSnap {
   const double*   base;    // [J*64] fused leading pod-only terms (fast path)
+  const double*   post[2]; // [J*64] products of the pod-only scorers that FOLLOW a LORA / PREFIX scorer (GEN fast path)
   const uint32_t* queue;   // [J*64]
   const double*   kv;      // [J*64]
   const void*     thi_t;   // [129][64] LW LoRA tier planes per adapter row (row 128 = base model), bit j of [a][l] = pod j*64+l:
@@ -111,6 +112,10 @@ struct KChain {            // the whole weighted chain (generic kernel)
 struct KTail {             // the request-dependent tail after fusion (fast kernel)
   double lw[4];            // clamp01(tier score) * w_lora, tier 0..3 = {0.0, 0.6, 0.8, 1.0}
   double wp;               // (double) w_prefix
+  // GEN instantiations: the chain behind the fused leading pod-only scorers, in chain order.  kind 0 = LORA, 1 = PREFIX,
+  // 2 / 3 = a pod-only scorer whose exact per-pod product clamp01(s) * w is the array post[0] / post[1] of the snapshot.
+  uint32_t n_tail;
+  uint32_t kind[4];
 };
 
 // ---- small device helpers --------------------------------------------------------------------
@@ -688,7 +693,7 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 //   stage 2  rows + tables of r, count, evaluate, pick.
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG>
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
@@ -698,10 +703,15 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
   double* s_pterm = s_lw + 4;
+  // GEN: the per-pod products of the (at most two) pod-only scorers behind LORA / PREFIX, behind the prefix-term table
+  double* s_post0 = s_pterm + pwn;
+  double* s_post1 = s_post0 + (size_t)sn.J * 64u;
   // the exact prefix-term table exists whenever max_blocks <= 63, i.e. for every NPL == 6 instantiation (eppk.hip)
   constexpr bool pterm_tab = HAS_P && NPL == 6;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
   if (threadIdx.x < 4u) s_lw[threadIdx.x] = tl.lw[threadIdx.x];
+  if (GEN)
+    for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_post0[i] = sn.post[0][i]; s_post1[i] = sn.post[1][i]; }
   if (pterm_tab)
     for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
   __syncthreads();
@@ -905,7 +915,16 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           else pterm = clamp01((double)cnt / nbd) * tl.wp;
           double lterm = 0.0;
           if (HAS_L) lterm = s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
-          const double t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
+          double t;
+          if constexpr (GEN) {               // interpreted tail: one binary64 add per scorer, in chain order
+            t = s_base[p];
+            for (uint32_t i = 0; i < tl.n_tail; ++i) {
+              const uint32_t kd = tl.kind[i];
+              t = t + (kd == 0u ? lterm : kd == 1u ? pterm : kd == 2u ? s_post0[p] : s_post1[p]);
+            }
+          } else {
+            t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
+          }
           if (t > best) { best = t; bidx = p; }
         }
         wave_argmax_dpp(best, bidx);
@@ -955,7 +974,15 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           for (uint32_t j = 0; j < sn.J; ++j) {
             const uint32_t p = j * 64u + (uint32_t)lane;
             double t = s_base[p];
-            if (HAS_L) t = t + s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
+            if constexpr (GEN) {             // T_a[p]: the chain without its PREFIX entry (adding +-0.0 is the identity)
+              const double lterm = HAS_L ? s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)] : 0.0;
+              for (uint32_t i = 0; i < tl.n_tail; ++i) {
+                const uint32_t kd = tl.kind[i];
+                if (kd != 1u) t = t + (kd == 0u ? lterm : kd == 2u ? s_post0[p] : s_post1[p]);
+              }
+            } else {
+              if (HAS_L) t = t + s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
+            }
             const bool okp = (okset >> j) & 1;
             if (okp && t > rbest) { rbest = t; ridx = p; }
           }
@@ -1219,23 +1246,23 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
 // binary64 operations, in the same order, as SEMANTICS.md §2 prescribes (so the fused terms stay bit-exact).
 
 // (1) thread per pod: fused leading pod-only terms base[p] (chain order), raw gauges for the generic kernel
+// `lead` = the pod-only scorers in front of the first LORA / PREFIX (folded into base[p]); `postc` = the pod-only scorers
+// behind it (n <= 2): their products clamp01(s) * w go to post0[p] / post1[p], one array each (they are added one by one).
 __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t np64, uint32_t qmin, uint32_t qmax,
-                                  KChain lead, double* __restrict__ base, uint32_t* __restrict__ queue, double* __restrict__ kv) {
+                                  KChain lead, KChain postc, double* __restrict__ base, double* __restrict__ post0, double* __restrict__ post1,
+                                  uint32_t* __restrict__ queue, double* __restrict__ kv) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np64) return;
-  double t = 0.0, k = 0.0;
+  double t = 0.0, k = 0.0, pp[2] = {0.0, 0.0};
   uint32_t q = 0;
   if (p < n_pods) {
     q = rows[p].queue;
     k = rows[p].kv_util;
-    for (uint32_t i = 0; i < lead.n; ++i) {
-      double s;
-      if (lead.kind[i] == 1u) s = (qmax == qmin) ? 1.0 : (double)(qmax - q) / (double)(qmax - qmin);
-      else s = 1.0 - k;
-      t = t + clamp01(s) * lead.w[i];
-    }
+    auto score = [&](uint32_t kind) { return kind == 1u ? ((qmax == qmin) ? 1.0 : (double)(qmax - q) / (double)(qmax - qmin)) : 1.0 - k; };
+    for (uint32_t i = 0; i < lead.n; ++i) t = t + clamp01(score(lead.kind[i])) * lead.w[i];
+    for (uint32_t i = 0; i < postc.n && i < 2u; ++i) pp[i] = clamp01(score(postc.kind[i])) * postc.w[i];
   }
-  base[p] = t; queue[p] = q; kv[p] = k;
+  base[p] = t; post0[p] = pp[0]; post1[p] = pp[1]; queue[p] = q; kv[p] = k;
 }
 
 // (2) thread per (adapter row a, lane l): lane-transposed LoRA tier planes (row 128 = base model: in no set)
@@ -1273,6 +1300,7 @@ __global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32
 template <typename LW>
 __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict__ base, const LW* __restrict__ thi, const LW* __restrict__ tlo,
                                                        uint32_t n_pods, uint32_t np64, uint32_t has_l, KTail tl,
+                                                       const double* __restrict__ post0, const double* __restrict__ post1,
                                                        double* __restrict__ topv, uint32_t* __restrict__ topi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* sT = (double*)smem;                         // [np64]
@@ -1287,10 +1315,18 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
     double t = -__builtin_inf();
     if (p < n_pods) {
       t = base[p];
+      double lterm = 0.0;
       if (has_l) {
         const uint32_t l = p & 63u, j = p >> 6;
         const uint32_t tier = (uint32_t)(((thi[(size_t)a * 64u + l] >> j) & 1) << 1) | (uint32_t)((tlo[(size_t)a * 64u + l] >> j) & 1);
-        t = t + tier_term(tl, tier);
+        lterm = tier_term(tl, tier);
+      }
+      // the chain behind base[], in order, WITHOUT its PREFIX entry (a pod without a prefix match adds +-0.0 there: identity)
+      for (uint32_t i = 0; i < tl.n_tail; ++i) {
+        const uint32_t kd = tl.kind[i];
+        if (kd == 0u) t = t + lterm;
+        else if (kd == 2u) t = t + post0[p];
+        else if (kd == 3u) t = t + post1[p];
       }
     }
     sT[p] = t;

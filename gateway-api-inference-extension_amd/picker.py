@@ -265,6 +265,10 @@ class BatchedPicker:
                                   fallbacks=[join_host_port(e.address, e.port) for e in eps[1:]]))
         return out
 
+    def chain_is_fused(self) -> int:
+        """0 = generic per-pair kernel, 1 = fused sparse kernel, 2 = fused with an interpreted tail (include/eppk.h)."""
+        return int(self._lib.eppk_chain_is_fused(self._ctx))
+
     # -- measurement ------------------------------------------------------------------------
     def profile(self, on: bool) -> None:
         self._check(self._lib.eppk_profile_enable(self._ctx, 1 if on else 0), "profile_enable")

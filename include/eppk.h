@@ -225,6 +225,12 @@ int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
 
+/* Which kernel serves this context's chain: 1 = fused sparse kernel (chain = pod-only scorers, then LORA / PREFIX in either
+ * order), 2 = the same kernel with an interpreted tail (at most two pod-only scorers behind the first LORA / PREFIX, e.g. the
+ * reference example's `score: [prefix-cache: 3, kv-cache-util: 5]`, 0845-…/examples/example.yaml:21-25), 0 = generic
+ * per-pair kernel (duplicated LORA / PREFIX scorers, more than two trailing pod-only scorers). */
+int eppk_chain_is_fused(const eppk_ctx* ctx);
+
 /* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,
  * every pick launch is bracketed by HIP events recorded on the launch stream and accumulates its
  * index-probe counts on device (one atomic per wavefront). */

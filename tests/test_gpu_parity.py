@@ -56,7 +56,11 @@ def test_ragged_pod_counts(pkg, orc, P):
     [(PF, 3)],
     [(L, 2)],
     [(KV, 5)],
-    [(L, 1), (Q, 2), (PF, 3), (KV, 2)],   # non-canonical -> generic kernel
+    [(L, 1), (Q, 2), (PF, 3), (KV, 2)],   # pod-only scorers between / behind LORA and PREFIX -> interpreted tail
+    [(PF, 3), (KV, 5)],                   # the reference example's decode profile (0845-…/examples/example.yaml:21-25)
+    [(PF, 3), (Q, 1), (KV, 1)],
+    [(KV, 2), (PF, 4), (Q, -3), (L, 2)],
+    [(L, 1), (Q, 2), (KV, 2), (Q, 1), (PF, 3)],   # three trailing pod-only scorers -> generic kernel
     [(PF, 3), (Q, 1), (PF, 3)],           # duplicates
     [(Q, -2), (KV, 3), (L, -1), (PF, 4)], # negative weights
     [],                                   # no scorers: every total is +0.0, pick = first candidate
@@ -415,3 +419,26 @@ def test_full_size_headline_batch_and_batch_properties(pkg, orc):
     oix.insert(wl.index_hashes, wl.index_pods)
     op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, threads=os.cpu_count() or 1)
     assert_same(picks, scores, op, osc)
+
+
+@pytest.mark.parametrize("chain,kind", [
+    ([(Q, 2), (KV, 2), (L, 1), (PF, 3)], 1),
+    ([(PF, 3), (L, 1)], 1),
+    ([(PF, 3), (KV, 5)], 2),                         # reference example (0845-…/examples/example.yaml:21-25)
+    ([(L, 1), (Q, 2), (PF, 3), (KV, 2)], 2),
+    ([(L, 1), (Q, 2), (KV, 2), (Q, 1), (PF, 3)], 0),
+    ([(PF, 3), (Q, 1), (PF, 3)], 0),
+])
+def test_which_kernel_serves_a_chain(pkg, chain, kind):
+    with pkg.BatchedPicker(chain, max_pods=64, max_blocks=4, max_batch=8, index_slots=64) as pk:
+        assert pk.chain_is_fused() == kind
+
+
+def test_interpreted_tail_at_headline_shape(pkg, orc):
+    """The reference example's `[prefix-cache: 3, kv-cache-util: 5]` and a chain with scorers on both sides of LORA / PREFIX at
+    the headline pod count (P = 4096, u64 lane words), masked and unmasked."""
+    for chain in ([(PF, 3), (KV, 5)], [(Q, 1), (L, 2), (KV, 2), (PF, 3), (Q, 2)]):
+        wl = pkg.workload.make_workload(5, R=768, P=4096)
+        assert_same(*run_both(pkg, orc, wl, chain=chain))
+        wm = pkg.workload.make_workload(5, R=384, P=4096, masked=True)
+        assert_same(*run_both(pkg, orc, wm, chain=chain, mask=wm.mask))
