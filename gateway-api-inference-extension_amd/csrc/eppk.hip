@@ -5,7 +5,9 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off (binary64 mul/add never fused;
 // SEMANTICS.md §2) — see __graft_entry__.build().
+#define EPPK_MAIN_UNIT
 #include "eppk_kernels.hip.h"
+#include "eppk_pick_inst.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -156,55 +158,30 @@ KIndex make_kindex(const eppk_ctx* c) {
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
-
-template <typename LW, int NPL, bool MASKED, bool BIG>
-const void* fast_kernel_ptr(bool has_l, bool has_p, bool p_first, bool gen) {
-  if (gen) {   // interpreted tail (pod-only scorers behind LORA / PREFIX); the order lives in KTail
-    if (has_l && has_p) return (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, true>;
-    if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, true>;
-    return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, true>;     // gen implies LORA or PREFIX
-  }
-  if (has_l && has_p) return p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG, false>
-                                     : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, false>;
-  if (has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, false>;     // no prefix scorer: no index access
-  if (has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, false>;
-  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false, false>;
-}
-
-template <typename LW, int NPL>
-const void* generic_kernel_ptr(bool masked, bool topk) {
-  if (topk) return masked ? (const void*)pick_generic_kernel<LW, NPL, true, (int)EPPK_MAX_TOPK> : (const void*)pick_generic_kernel<LW, NPL, false, (int)EPPK_MAX_TOPK>;
-  return masked ? (const void*)pick_generic_kernel<LW, NPL, true, 1> : (const void*)pick_generic_kernel<LW, NPL, false, 1>;
-}
-
-template <typename LW, int NPL>
-const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
-  if (!fast) return generic_kernel_ptr<LW, NPL>(masked, topk);
-  const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: structured row descriptor
-  if (big) return masked ? fast_kernel_ptr<LW, NPL, true, true>(c->has_l, c->has_p, c->p_first, c->gen) : fast_kernel_ptr<LW, NPL, false, true>(c->has_l, c->has_p, c->p_first, c->gen);
-  return masked ? fast_kernel_ptr<LW, NPL, true, false>(c->has_l, c->has_p, c->p_first, c->gen) : fast_kernel_ptr<LW, NPL, false, false>(c->has_l, c->has_p, c->p_first, c->gen);
-}
-
-template <typename LW>
-const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
-  return c->npl == 6 ? pick_kernel_ptr<LW, 6>(c, fast, masked, topk) : pick_kernel_ptr<LW, 9>(c, fast, masked, topk);
-}
+// The pick kernels are instantiated in six translation units (eppk_pick_inst.hip.h: one per lane-word type and counter-plane
+// count) so that the build compiles them in parallel; each exports one look-up function.
 
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
+  eppk::PickVariant v{};
+  v.fast = fast; v.masked = masked; v.topk = topk;
+  v.big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: structured row descriptor
+  v.has_l = c->has_l; v.has_p = c->has_p; v.p_first = c->p_first; v.gen = c->gen;
+  const bool six = c->npl == 6;
   switch (c->lw_bytes) {
-    case 2: return pick_kernel_ptr<uint16_t>(c, fast, masked, topk);
-    case 4: return pick_kernel_ptr<uint32_t>(c, fast, masked, topk);
-    default: return pick_kernel_ptr<uint64_t>(c, fast, masked, topk);
+    case 2: return six ? eppk::pick_kernel_u16_6(v) : eppk::pick_kernel_u16_9(v);
+    case 4: return six ? eppk::pick_kernel_u32_6(v) : eppk::pick_kernel_u32_9(v);
+    default: return six ? eppk::pick_kernel_u64_6(v) : eppk::pick_kernel_u64_9(v);
   }
 }
 
-// topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries), always the generic kernel
+// topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries): extra selection rounds of the
+// fast kernel for fused chains, the TOPK generic kernel otherwise
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st, uint32_t topk = 1) {
   const bool masked = d_mask != nullptr;
   // masked batches use the fast kernel's MASKED instantiation, indexes of 4 GiB and more its BIG one
-  const bool fast = topk == 1 && c->canonical;
-  const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);
+  const bool fast = c->canonical;   // (ordered fallbacks: extra selection rounds of the same kernel; generic TOPK kernel otherwise)
+  const void* fn = pick_kernel_ptr(c, fast, masked, !fast && topk > 1);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
   const uint32_t threads = fast ? c->fast_threads : 512u, wpb = threads / 64;
@@ -251,7 +228,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (fast) {
     KTail tl = c->tail;
     KChain chf = c->kchain;
-    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats};
+    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk};
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   } else {
     KChain ch = c->kchain;

@@ -311,7 +311,9 @@ __device__ __forceinline__ double tier_term(const KTail& tl, uint32_t tier) {
 // request's QUEUE normalisers differ from the snapshot-wide ones (so base[] / the top tables do not apply);
 // cost is proportional to the candidates per lane — small subsets (the common reason for that case) are cheap.
 template <typename LW, int NPL>
-__device__ __forceinline__ void masked_exact(const KSnap& sn, const KChain& ch, LW cand, const LW (&c)[NPL], LW thi, LW tlo,
+// `cand` = the request's candidates (the QUEUE normalisers range over all of them); `eval` = the ones to evaluate (a fallback
+// round excludes the pods already reported).
+__device__ __forceinline__ void masked_exact(const KSnap& sn, const KChain& ch, LW cand, LW eval, const LW (&c)[NPL], LW thi, LW tlo,
                                              uint32_t nb, int lane, double& best, uint32_t& bidx) {
   bool has_q = false;
   for (uint32_t k = 0; k < ch.n; ++k) has_q |= ch.kind[k] == 1u;
@@ -337,7 +339,7 @@ __device__ __forceinline__ void masked_exact(const KSnap& sn, const KChain& ch, 
     qmin = mn; qmax = mx;
   }
   const double qden = (double)(qmax - qmin);
-  LW rem = cand;
+  LW rem = eval;
   while (__any(rem != 0)) {
     if (rem != 0) {
       const uint32_t j = (sizeof(LW) == 8) ? (uint32_t)__builtin_ctzll((unsigned long long)rem) : (uint32_t)__builtin_ctz((uint32_t)rem);
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                        unsigned long long* __restrict__ stats) {
+                                                        unsigned long long* __restrict__ stats, uint32_t topk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
@@ -884,18 +886,22 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     bool exact = false;
     if (MASKED && sn.lead_queue) exact = !(__any((cand & qminw) != 0) && __any((cand & qmaxw) != 0));
 
+    // One selection round per requested output: round 0 is the pick; rounds 1..topk-1 (ordered fallbacks, eppk_pick_topk)
+    // repeat the selection over the candidates not yet reported (`excl`, lane-transposed).  topk == 1: one trip, excl == 0.
+    auto select_round = [&](const uint32_t round, LW& excl) __attribute__((always_inline)) -> bool {
     double best = -__builtin_inf();
     uint32_t bidx = kNoPod;
     double cand_t = -__builtin_inf();
     uint32_t cand_p = kNoPod;
     if (MASKED && exact) {
-      if (__any(cand != 0)) {
-        masked_exact<LW, NPL>(sn, ch, cand, c, thi, tlo, nb, lane, best, bidx);
+      const LW cand_e = (LW)(cand & (LW)~excl);
+      if (__any(cand_e != 0)) {
+        masked_exact<LW, NPL>(sn, ch, cand, cand_e, c, thi, tlo, nb, lane, best, bidx);
         wave_argmax_dpp(best, bidx);
       }
     } else {
-      const LW mset = MASKED ? (LW)(nz & cand) : nz;         // candidates with a prefix match: evaluated in full
-      const LW okset = (LW)(cand & (LW)~nz);                 // candidates whose total is exactly T_a[p]
+      const LW mset = (LW)((MASKED ? (LW)(nz & cand) : nz) & (LW)~excl);   // candidates with a prefix match: evaluated in full
+      const LW okset = (LW)(cand & (LW)~nz & (LW)~excl);                    // candidates whose total is exactly T_a[p]
       const bool any_m = HAS_P && __any(mset != 0);
 
       if (any_m) {
@@ -934,12 +940,12 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       // the first entry's T, so the look-up is skipped when the best pod of M already beats it.
       const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), 0),
                                            __builtin_amdgcn_readlane(__double2loint(top_t), 0));
-      if (!(any_m && best > top0)) {
+      if (!(round == 0u && any_m && best > top0)) {    // (a fallback round cannot use the bound: the table's head may be taken)
         // lanes whose table entry is a candidate outside M
         auto entry_ok = [&](uint32_t tp) -> unsigned long long {
           const bool has = tp != kNoPod;
           bool ok = has;
-          if (MASKED || (HAS_P && hits)) {
+          if (MASKED || (HAS_P && hits) || round != 0u) {
             const uint32_t ql = has ? (tp & 63u) : 0u, qj = has ? (tp >> 6) : 0u;
             LW okq;
             if constexpr (sizeof(LW) == 8) {
@@ -993,10 +999,26 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       }
     }
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
+    const bool none = bidx == kNoPod;
     if (lane == 0) {
-      const bool none = bidx == kNoPod;
-      out_pick[r] = none ? -1 : (int32_t)bidx;
-      if (out_score) out_score[r] = none ? 0.0 : best;
+      out_pick[(size_t)r * topk + round] = none ? -1 : (int32_t)bidx;
+      if (out_score) out_score[(size_t)r * topk + round] = none ? 0.0 : best;
+    }
+    if (!none && (uint32_t)lane == (bidx & 63u)) excl |= (LW)((LW)1 << (bidx >> 6));
+    return none;
+    };
+    if (__builtin_expect(topk == 1u, 1)) {   // the pick: one round, nothing excluded (everything about `round` / `excl` folds away)
+      LW none_excluded = 0;
+      select_round(0u, none_excluded);
+    } else {
+      LW excl = 0;
+      for (uint32_t round = 0; round < topk; ++round) {
+        if (select_round(round, excl)) {     // candidates exhausted: pad the rest of the list
+          if (lane == 0)
+            for (uint32_t i = round + 1u; i < topk; ++i) { out_pick[(size_t)r * topk + i] = -1; if (out_score) out_score[(size_t)r * topk + i] = 0.0; }
+          break;
+        }
+      }
     }
   };
 
@@ -1222,6 +1244,7 @@ __device__ __forceinline__ uint64_t xxh64_words_plus(const uint64_t* w, uint32_t
   return h ^ (h >> 32);
 }
 
+#ifdef EPPK_MAIN_UNIT   // non-template kernels are defined once, in eppk.hip (the pick units include this header too)
 __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_t prompt_stride, const uint32_t* __restrict__ prompt_len,
                                     const uint64_t* __restrict__ seeds, const int32_t* __restrict__ adapters, uint32_t n_reqs,
                                     uint32_t block_chars, uint32_t max_blocks, uint8_t* __restrict__ rows, uint32_t stride) {
@@ -1240,6 +1263,7 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
   for (uint32_t b = nblk; b < max_blocks; ++b) out[1 + b] = 0ull;
   out[0] = (uint64_t)(uint32_t)adapters[r] | ((uint64_t)nblk << 32);
 }
+#endif
 
 // ---- snapshot producer: raw pod rows -> the device layout, on the device ------------------------
 // A publish is one H2D copy of the raw 64-byte rows plus three small launches; every value is computed with the same
@@ -1248,6 +1272,7 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
 // (1) thread per pod: fused leading pod-only terms base[p] (chain order), raw gauges for the generic kernel
 // `lead` = the pod-only scorers in front of the first LORA / PREFIX (folded into base[p]); `postc` = the pod-only scorers
 // behind it (n <= 2): their products clamp01(s) * w go to post0[p] / post1[p], one array each (they are added one by one).
+#ifdef EPPK_MAIN_UNIT
 __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t np64, uint32_t qmin, uint32_t qmax,
                                   KChain lead, KChain postc, double* __restrict__ base, double* __restrict__ post0, double* __restrict__ post1,
                                   uint32_t* __restrict__ queue, double* __restrict__ kv) {
@@ -1264,6 +1289,7 @@ __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_
   }
   base[p] = t; post0[p] = pp[0]; post1[p] = pp[1]; queue[p] = q; kv[p] = k;
 }
+#endif
 
 // (2) thread per (adapter row a, lane l): lane-transposed LoRA tier planes (row 128 = base model: in no set)
 //       hi = active | free, lo = active | (~free & waiting)  ->  tier = 2*hi + lo (SEMANTICS.md §3 LORA);

@@ -1,0 +1,49 @@
+// eppk_pick_inst.hip.h — the pick kernels are instantiated in six translation units (one per lane-word type and counter-plane
+// count), compiled in parallel by __graft_entry__.build().  A unit defines EPPK_PICK_INST_LW / _NPL / _NAME and includes this
+// header after eppk_kernels.hip.h; eppk.hip includes it for the declarations only.
+#pragma once
+
+namespace eppk {
+
+struct PickVariant {       // which instantiation a context needs (eppk.hip: pick_kernel_ptr)
+  bool fast;               // fused sparse kernel (else generic per-pair kernel)
+  bool masked, topk;       // candidate masks; generic TOPK instantiation (ordered fallbacks of non-fused chains)
+  bool big;                // index of 4 GiB and more
+  bool has_l, has_p, p_first, gen;
+};
+
+const void* pick_kernel_u16_6(const PickVariant& v);
+const void* pick_kernel_u16_9(const PickVariant& v);
+const void* pick_kernel_u32_6(const PickVariant& v);
+const void* pick_kernel_u32_9(const PickVariant& v);
+const void* pick_kernel_u64_6(const PickVariant& v);
+const void* pick_kernel_u64_9(const PickVariant& v);
+
+#ifdef EPPK_PICK_INST_NAME
+template <typename LW, int NPL, bool MASKED, bool BIG>
+static const void* fast_kernel_ptr(const PickVariant& v) {
+  if (v.gen) {   // interpreted tail (pod-only scorers behind LORA / PREFIX); the order lives in KTail
+    if (v.has_l && v.has_p) return (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, true>;
+    if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, true>;
+    return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, true>;     // gen implies LORA or PREFIX
+  }
+  if (v.has_l && v.has_p) return v.p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG, false>
+                                           : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, false>;
+  if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, false>;     // no prefix scorer: no index access
+  if (v.has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, false>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false, false>;
+}
+
+const void* EPPK_PICK_INST_NAME(const PickVariant& v) {
+  using LW = EPPK_PICK_INST_LW;
+  constexpr int NPL = EPPK_PICK_INST_NPL;
+  if (!v.fast) {
+    if (v.topk) return v.masked ? (const void*)pick_generic_kernel<LW, NPL, true, (int)EPPK_MAX_TOPK> : (const void*)pick_generic_kernel<LW, NPL, false, (int)EPPK_MAX_TOPK>;
+    return v.masked ? (const void*)pick_generic_kernel<LW, NPL, true, 1> : (const void*)pick_generic_kernel<LW, NPL, false, 1>;
+  }
+  if (v.big) return v.masked ? fast_kernel_ptr<LW, NPL, true, true>(v) : fast_kernel_ptr<LW, NPL, false, true>(v);
+  return v.masked ? fast_kernel_ptr<LW, NPL, true, false>(v) : fast_kernel_ptr<LW, NPL, false, false>(v);
+}
+#endif
+
+}  // namespace eppk

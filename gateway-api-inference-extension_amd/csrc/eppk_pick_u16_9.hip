@@ -1,0 +1,6 @@
+// Pick-kernel instantiations for uint16_t lane words, 9 counter planes (see eppk_pick_inst.hip.h).
+#include "eppk_kernels.hip.h"
+#define EPPK_PICK_INST_LW uint16_t
+#define EPPK_PICK_INST_NPL 9
+#define EPPK_PICK_INST_NAME pick_kernel_u16_9
+#include "eppk_pick_inst.hip.h"

@@ -1,0 +1,6 @@
+// Pick-kernel instantiations for uint64_t lane words, 9 counter planes (see eppk_pick_inst.hip.h).
+#include "eppk_kernels.hip.h"
+#define EPPK_PICK_INST_LW uint64_t
+#define EPPK_PICK_INST_NPL 9
+#define EPPK_PICK_INST_NAME pick_kernel_u64_9
+#include "eppk_pick_inst.hip.h"

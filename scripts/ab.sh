@@ -4,14 +4,23 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname $0)/..}"
 CS=gateway-api-inference-extension_amd/csrc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function"
 mkdir -p ab
 if [ "$1" = build ]; then
-  shift; rm -f ab/*.so
+  shift; rm -rf ab/*.so ab/obj
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function $flags -o ab/libeppk_$name.so $CS/eppk.hip $CS/eppk_host.cpp &
+    mkdir -p ab/obj/$name
+    for u in $CS/eppk.hip $CS/eppk_host.cpp $CS/eppk_pick_*.hip; do
+      /opt/rocm/bin/hipcc $FLAGS $flags -c -o ab/obj/$name/$(basename ${u%.*}).o $u &
+    done
   done
-  wait; ls -la ab/
+  wait
+  for spec in "$@"; do
+    name=${spec%%:*}
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libeppk_$name.so ab/obj/$name/*.o
+  done
+  rm -rf ab/obj; ls -la ab/
 else
   shift
   mkdir -p gpurun_out
