@@ -586,6 +586,16 @@ int eppk_index_size(eppk_ctx* c, uint32_t* n_entries) {
   return EPPK_OK;
 }
 
+int eppk_index_dropped(eppk_ctx* c, uint64_t* n_dropped) {
+  if (!c || !n_dropped) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  unsigned long long st[4];
+  HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_dropped = (uint64_t)st[3];
+  return EPPK_OK;
+}
+
 int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
   if (!c) return EPPK_ERR_ARG;
   if (c->index_epoch == 0xFFFFFFFFu) return fail(c, EPPK_ERR_LIMIT, "eppk_index_advance_epoch: epoch counter exhausted (clear the index)");

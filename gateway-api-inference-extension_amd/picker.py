@@ -187,6 +187,12 @@ class BatchedPicker:
     def index_remove_pod(self, pod: int) -> None:
         self._check(self._lib.eppk_index_remove_pod(self._ctx, pod), "index_remove_pod")
 
+    def index_dropped(self) -> int:
+        """Inserts dropped so far because the table was at capacity (include/eppk.h eppk_index_dropped)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.eppk_index_dropped(self._ctx, C.byref(n)), "index_dropped")
+        return n.value
+
     def index_advance_epoch(self) -> int:
         """Tick the index epoch that stamps every later insert (ageing, include/eppk.h)."""
         e = C.c_uint32(0)

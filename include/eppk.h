@@ -148,6 +148,10 @@ int eppk_index_insert_picks_device(eppk_ctx* ctx, const void* d_reqs, const int3
 int eppk_index_remove_pod(eppk_ctx* ctx, uint32_t pod);
 /* Number of hashes with a non-empty pod set (synchronises). */
 int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
+/* (hash, pod) inserts dropped so far because the table was at its capacity (cumulative since create / clear; synchronises).
+ * eppk_index_insert reports them as EPPK_ERR_INDEX_FULL; the asynchronous eppk_index_insert_picks_device cannot, so a shim
+ * polls this counter (and grows or ages the index). */
+int eppk_index_dropped(eppk_ctx* ctx, uint64_t* n_dropped);
 /* Ageing -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)", 0602-…/README.md:82.
  * Every insert (eppk_index_insert, eppk_index_insert_picks_device) stamps its hashes with the context's index epoch
  * (starts at 1); eppk_index_advance_epoch increments it; eppk_index_evict_older drops every hash whose last stamp is

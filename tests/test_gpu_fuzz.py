@@ -1,0 +1,140 @@
+"""Differential fuzzing of the HIP path against the oracle: random scorer chains (every kernel variant: fused, interpreted
+tail, generic), pod counts across the three lane-word widths, block counts across both counter-plane widths, random candidate
+masks (including empty / single-candidate rows), tiny index tables (bucket overflows), reserved hashes, ties by construction
+(few distinct gauge values), ordered fallbacks.  Seeds are fixed: a failure names its case."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q, KV, L, PF = 1, 2, 3, 4
+
+
+def _case(pkg, seed):
+    rng = np.random.default_rng(seed)
+    P = int(rng.choice([1, 3, 64, 65, 200, 1000, 1024, 1500, 2048, 2500, 4096]))
+    B = int(rng.choice([0, 1, 5, 8, 31, 33, 40, 70]))
+    R = int(rng.integers(1, 200))
+    n_sc = int(rng.integers(0, 7))
+    chain = [(int(rng.choice([Q, KV, L, PF])), int(rng.integers(-3, 6))) for _ in range(n_sc)]
+    pods = pkg.workload.make_pods(int(rng.integers(1, 1 << 30)), P, 128)
+    if rng.random() < 0.5:                                 # coarse gauges: many exact ties
+        pods["queue"] = rng.integers(0, 3, P)
+        pods["kv_util"] = rng.integers(0, 3, P) / 2.0
+    # index: a few chains of random hashes (sometimes the reserved values), each block cached on a few pods
+    n_chains = int(rng.integers(1, 6))
+    chains = rng.integers(1, 2**63, (n_chains, max(B, 1)), dtype=np.uint64)
+    if rng.random() < 0.3:
+        chains[0, 0] = 0
+    if rng.random() < 0.3 and B > 1:
+        chains[-1, 1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    ih, ip = [], []
+    for ci in range(n_chains):
+        depth = int(rng.integers(0, B + 1))
+        for b in range(depth):
+            for pod in rng.integers(0, P, int(rng.integers(1, 6))):
+                ih.append(chains[ci, b]); ip.append(pod)
+    ih = np.asarray(ih, dtype=np.uint64); ip = np.asarray(ip, dtype=np.uint32)
+    n_keys = max(len(set(ih.tolist())), 1)
+    slots = 64
+    while slots < (2 if rng.random() < 0.3 else 4) * n_keys:
+        slots *= 2
+    hs = chains[rng.integers(0, n_chains, R)].copy()
+    for r in range(R):                                     # break chains at random depths
+        if B and rng.random() < 0.7:
+            cut = int(rng.integers(0, B))
+            hs[r, cut:] = rng.integers(1, 2**63, B - cut, dtype=np.uint64)
+    nblk = rng.integers(0, B + 1, R) if B else np.zeros(R, dtype=np.int64)
+    reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, R), nblk, hs[:, :B] if B else None, B)
+    mask = None
+    if rng.random() < 0.5:
+        W = (P + 63) // 64
+        mask = rng.integers(0, 2**63, (R, W), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (R, W), dtype=np.uint64)
+        if rng.random() < 0.5:                             # sparse subsets
+            mask &= rng.integers(0, 2**63, (R, W), dtype=np.uint64) & rng.integers(0, 2**63, (R, W), dtype=np.uint64)
+        if P % 64:
+            mask[:, -1] &= np.uint64((1 << (P % 64)) - 1)
+        mask[0, :] = 0
+        if R > 1:
+            mask[1, :] = 0; mask[1, 0] = np.uint64(1)
+    return chain, pods, ih, ip, slots, reqs, mask, P, B, R
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_fuzz_pick(pkg, orc, seed):
+    chain, pods, ih, ip, slots, reqs, mask, P, B, R = _case(pkg, 1000 + seed)
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=slots if B else 0) as pk:
+        pk.publish(pods)
+        if B and ih.size:
+            pk.index_insert(ih, ip)
+        picks, scores = pk.pick(reqs, mask)
+        k = 1 + seed % 5
+        tp, ts = pk.pick_topk(reqs, k, mask)
+    oix = orc.OracleIndex()
+    if B and ih.size:
+        oix.insert(ih, ip)
+    op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B, mask)
+    info = f"seed {seed}: chain {chain} P {P} B {B} R {R} masked {mask is not None} slots {slots}"
+    assert np.array_equal(picks, op), info + f" rows {np.nonzero(picks != op)[0][:5]}"
+    assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), info
+    otp, ots = orc.pick_topk(chain, pods, oix, reqs, k, mask)
+    assert np.array_equal(tp, otp), info + f" topk {k}"
+    assert np.array_equal(ts.view(np.uint64), ots.view(np.uint64)), info + f" topk {k}"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_index_maintenance(pkg, orc, seed):
+    """Random sequences of index operations (bulk insert, post-pick insert on device, pod removal, epoch ticks, eviction) applied
+    to the device index and to the oracle's; after every operation the picks of a probe batch, their scores and the number of
+    live hashes must agree."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    P = int(rng.choice([40, 300, 1500, 4096]))
+    B = int(rng.choice([4, 8, 16]))
+    chain = [[(KV, 1), (PF, 5)], [(Q, 1), (KV, 2), (L, 1), (PF, 4)], [(PF, 3), (KV, 5)], [(PF, 2), (Q, 1), (PF, 1)]][seed % 4]
+    pods = pkg.workload.make_pods(int(rng.integers(1, 1 << 30)), P, 128)
+    universe = rng.integers(1, 2**63, (24, B), dtype=np.uint64)          # 24 chains of B blocks
+    R = 96
+
+    def probe_batch():
+        hs = universe[rng.integers(0, universe.shape[0], R)].copy()
+        for r in range(R):
+            if rng.random() < 0.5:
+                cut = int(rng.integers(0, B))
+                hs[r, cut:] = rng.integers(1, 2**63, B - cut, dtype=np.uint64)
+        return pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=8192) as pk:   # 4096 live hashes: never full here
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        for step in range(14):
+            op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick_evict"])
+            if op == "insert":
+                ci = rng.integers(0, universe.shape[0], 3)
+                ih = np.concatenate([universe[c, : int(rng.integers(1, B + 1))] for c in ci])
+                ip = rng.integers(0, P, ih.size).astype(np.uint32)
+                pk.index_insert(ih, ip); oix.insert(ih, ip)
+            elif op == "insert_picks":
+                reqs = probe_batch()
+                picks, _ = pk.pick(reqs)
+                d_reqs = torch.from_numpy(reqs.view(np.int64)).cuda(); d_picks = torch.from_numpy(picks).cuda()
+                pk.index_insert_picks_device(d_reqs.data_ptr(), d_picks.data_ptr(), R)
+                torch.cuda.synchronize()
+                op_picks, _, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+                assert np.array_equal(picks, op_picks)
+                oix.insert_picks(reqs, B, op_picks)
+            elif op == "remove_pod":
+                pod = int(rng.integers(0, P))
+                pk.index_remove_pod(pod); oix.remove_pod(pod)
+            else:
+                e = pk.index_advance_epoch(); eo = oix.advance_epoch()
+                assert e == eo
+                keep = int(rng.integers(1, 3))
+                assert pk.index_evict_older(max(e - keep, 0)) == oix.evict_older(max(e - keep, 0))
+            assert pk.index_dropped() == 0
+            assert pk.index_size() == oix.size(), f"seed {seed} step {step} after {op}"
+            reqs = probe_batch()
+            picks, scores = pk.pick(reqs)
+            opk, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert np.array_equal(picks, opk), f"seed {seed} step {step} after {op}"
+            assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), f"seed {seed} step {step} after {op}"
