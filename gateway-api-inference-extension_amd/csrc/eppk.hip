@@ -181,7 +181,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const bool masked = d_mask != nullptr;
   // masked batches use the fast kernel's MASKED instantiation, indexes of 4 GiB and more its BIG one
   const bool fast = c->canonical;   // (ordered fallbacks: extra selection rounds of the same kernel; generic TOPK kernel otherwise)
-  const void* fn = pick_kernel_ptr(c, fast, masked, !fast && topk > 1);
+  const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
   const uint32_t threads = fast ? c->fast_threads : 512u, wpb = threads / 64;

@@ -695,7 +695,7 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 //   stage 2  rows + tables of r, count, evaluate, pick.
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN>
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (!none && (uint32_t)lane == (bidx & 63u)) excl |= (LW)((LW)1 << (bidx >> 6));
     return none;
     };
-    if (__builtin_expect(topk == 1u, 1)) {   // the pick: one round, nothing excluded (everything about `round` / `excl` folds away)
+    if constexpr (!TOPK) {                   // the pick: one round, nothing excluded (everything about `round` / `excl` folds away)
       LW none_excluded = 0;
       select_round(0u, none_excluded);
     } else {

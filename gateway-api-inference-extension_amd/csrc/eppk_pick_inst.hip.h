@@ -7,7 +7,7 @@ namespace eppk {
 
 struct PickVariant {       // which instantiation a context needs (eppk.hip: pick_kernel_ptr)
   bool fast;               // fused sparse kernel (else generic per-pair kernel)
-  bool masked, topk;       // candidate masks; generic TOPK instantiation (ordered fallbacks of non-fused chains)
+  bool masked, topk;       // candidate masks; ordered fallbacks (TOPK instantiation of the fast / generic kernel)
   bool big;                // index of 4 GiB and more
   bool has_l, has_p, p_first, gen;
 };
@@ -20,18 +20,22 @@ const void* pick_kernel_u64_6(const PickVariant& v);
 const void* pick_kernel_u64_9(const PickVariant& v);
 
 #ifdef EPPK_PICK_INST_NAME
-template <typename LW, int NPL, bool MASKED, bool BIG>
+template <typename LW, int NPL, bool MASKED, bool BIG, bool TOPK>
 static const void* fast_kernel_ptr(const PickVariant& v) {
   if (v.gen) {   // interpreted tail (pod-only scorers behind LORA / PREFIX); the order lives in KTail
-    if (v.has_l && v.has_p) return (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, true>;
-    if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, true>;
-    return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, true>;     // gen implies LORA or PREFIX
+    if (v.has_l && v.has_p) return (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, true, TOPK>;
+    if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, true, TOPK>;
+    return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, true, TOPK>;     // gen implies LORA or PREFIX
   }
-  if (v.has_l && v.has_p) return v.p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG, false>
-                                           : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, false>;
-  if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, false>;     // no prefix scorer: no index access
-  if (v.has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, false>;
-  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false, false>;
+  if (v.has_l && v.has_p) return v.p_first ? (const void*)pick_fast_kernel<LW, NPL, true, true, true, MASKED, BIG, false, TOPK>
+                                           : (const void*)pick_fast_kernel<LW, NPL, true, true, false, MASKED, BIG, false, TOPK>;
+  if (v.has_l) return (const void*)pick_fast_kernel<LW, NPL, true, false, false, MASKED, false, false, TOPK>;     // no prefix scorer: no index access
+  if (v.has_p) return (const void*)pick_fast_kernel<LW, NPL, false, true, false, MASKED, BIG, false, TOPK>;
+  return (const void*)pick_fast_kernel<LW, NPL, false, false, false, MASKED, false, false, TOPK>;
+}
+template <typename LW, int NPL, bool MASKED, bool BIG>
+static const void* fast_kernel_ptr(const PickVariant& v) {
+  return v.topk ? fast_kernel_ptr<LW, NPL, MASKED, BIG, true>(v) : fast_kernel_ptr<LW, NPL, MASKED, BIG, false>(v);
 }
 
 const void* EPPK_PICK_INST_NAME(const PickVariant& v) {
