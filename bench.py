@@ -63,7 +63,7 @@ def main() -> None:
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold-cache index variant)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
-    ap.add_argument("--host-path", type=int, default=0, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H)")
+    ap.add_argument("--host-path", type=int, default=40, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the p99 pick latency a host caller observes; 0 = skip")
     args = ap.parse_args()
 
     import torch
