@@ -769,66 +769,64 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
   // r + 2 nwaves (into `cur`, which is free once the probe of r is finished).
-  auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
-    const int32_t adapter = (int32_t)(uint32_t)cur.hdr;            // wave-uniform (scalar load)
-    const uint32_t nb = (uint32_t)(cur.hdr >> 32);
+  // ---- the stages of one request, as building blocks of the two loop orders below ------------------------------------
+  struct ReqS {              // wave-uniform facts of a request in flight
+    uint32_t r;              // request index
+    int32_t adapter;
+    uint32_t nb, m0, hits, arow;
+  };
+  struct Tabs {              // per-adapter tables of a request: first 16 top-table entries (lanes 0..15), LoRA tier planes
+    double top_t;
+    uint32_t top_p;
+    LW thi, tlo;
+  };
 
-    // ---- A. finish the probe of r: number of leading hits and their rows.  The hash of r + 1 is consumed here too (its
-    // home bucket), so that the wait for its prefetch sits at the top of the iteration and not behind the row loads.
-    uint32_t m0 = 0, slot0 = ix.slots + 2u;
-#if EPPK_SW_PIPE
-    if (use_index && nb != 0u) m0 = pair_probe_finish(ix, cur, nb < kKeysPerProbe ? nb : kKeysPerProbe, lane, slot0);
-    prepare_keys(nxt);
-#else
-    if (use_index && nb != 0u) {
-      prepare_keys(cur);
-      issue_keys(cur);
-      m0 = pair_probe_finish(ix, cur, nb < kKeysPerProbe ? nb : kKeysPerProbe, lane, slot0);
-    }
-#endif
-
-    // ---- B. loads that depend on the request header only
-    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    // top table of the adapter row: only its first 16 entries are fetched up front (lanes 0..15; the first entry outside M
-    // is almost always among them), the other 48 on demand
-    double top_t = -__builtin_inf();
-    uint32_t top_p = kNoPod;
+  // finish the probe of the request in `q` (its keys were gathered earlier): m0 leading hits, slot map
+  auto stage_finish = [&](uint32_t r, const ReqRegs& q, ReqS& s, uint32_t& slot_eff) {
+    s.r = r;
+    s.adapter = (int32_t)(uint32_t)q.hdr;            // wave-uniform (scalar load)
+    s.nb = (uint32_t)(q.hdr >> 32);
+    s.arow = (HAS_L && s.adapter >= 0) ? (uint32_t)s.adapter : 128u;
+    s.m0 = 0;
+    slot_eff = ix.slots + 2u;
+    if (use_index && s.nb != 0u) s.m0 = pair_probe_finish(ix, q, s.nb < kKeysPerProbe ? s.nb : kKeysPerProbe, lane, slot_eff);
+    s.hits = s.m0;
+  };
+  // top table of the adapter row: only its first 16 entries are fetched up front (lanes 0..15; the first entry outside M
+  // is almost always among them), the other 48 on demand.  LoRA tier planes: only pods of M (and the rare full scan) need them.
+  auto load_tiers = [&](const ReqS& s, Tabs& t) {
+    t.thi = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::thi + s.arow * (uint32_t)(64u * sizeof(LW)));
+    if (s.adapter >= 0) t.tlo = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::tlo + s.arow * (uint32_t)(64u * sizeof(LW)));   // base model: lo plane is all-zero
+  };
+  auto stage_tables = [&](const ReqS& s, Tabs& t) {
+    t.top_t = -__builtin_inf();
+    t.top_p = kNoPod;
     if (lane < 16) {
-      top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
-      top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
+      t.top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + s.arow * 512u));
+      t.top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + s.arow * 256u), 0);
     }
-    // LoRA tier planes of the request's adapter row: only pods of M (and the rare full scan) need them
-    LW thi = 0, tlo = 0;
-    auto load_tiers = [&]() {
-      thi = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::thi + arow * (uint32_t)(64u * sizeof(LW)));
-      if (adapter >= 0) tlo = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::tlo + arow * (uint32_t)(64u * sizeof(LW)));   // base model: lo plane is all-zero
-    };
-    const bool tiers_loaded = HAS_L && (MASKED || m0 > 0u);
-    if (tiers_loaded) load_tiers();
-
-    // ---- C. rows of r, up to 16 in flight; behind them the key gather of the next request and the row prefetch of the one after
-    LW w[16];
-    if (m0 > 8u) {
-      load_rows<LW, 16, BIG>(rs, slot0, 0, lane, w);
+    t.thi = 0; t.tlo = 0;
+    if (HAS_L && (MASKED || s.m0 > 0u)) load_tiers(s, t);
+  };
+  // rows of the request, up to 16 in flight
+  auto stage_rows = [&](const ReqS& s, uint32_t slot_eff, LW (&w)[16]) {
+    if (s.m0 > 8u) {
+      load_rows<LW, 16, BIG>(rs, slot_eff, 0, lane, w);
     } else {
       LW t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = 0;
-      if (m0 > 0u) load_rows<LW, 8, BIG>(rs, slot0, 0, lane, t);
+      if (s.m0 > 0u) load_rows<LW, 8, BIG>(rs, slot_eff, 0, lane, t);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { w[u] = t[u]; w[8 + u] = 0; }
     }
-#if !EPPK_LATE_HOOK
-    if (EPPK_SW_PIPE) issue_keys(nxt);
-    issue_row(r + 2u * nwaves, r, cur);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-
-    LW c[NPL];
+  };
+  // count the loaded rows into the bit-sliced counters (+ the rare continuations)
+  auto stage_count = [&](ReqS& s, uint32_t slot_eff, const LW (&w)[16], LW (&c)[NPL]) {
 #pragma unroll
     for (int k = 0; k < NPL; ++k) c[k] = 0;
-    uint32_t hits = m0;
     if (HAS_P) {
+      const uint32_t m0 = s.m0, nb = s.nb;
       if (m0 > 8u) {
         LW b[5];
         csa16<LW>(w, b);
@@ -842,32 +840,35 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = b[k];
       }
-#if EPPK_LATE_HOOK   // later stages issued once the 16 landing registers of the rows are free again (lower VGPR peak)
-      __builtin_amdgcn_sched_barrier(0);
-      if (EPPK_SW_PIPE) issue_keys(nxt);
-      issue_row(r + 2u * nwaves, r, cur);
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if (m0 > 16u) count_more<LW, NPL, BIG>(rs, slot0, 16u, m0, lane, c);
+      if (m0 > 16u) count_more<LW, NPL, BIG>(rs, slot_eff, 16u, m0, lane, c);
       if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {                 // hashes beyond the first 32 (every earlier key hit): not pipelined
         uint32_t mlast = m0;
         for (uint32_t b0 = kKeysPerProbe; b0 < nb && mlast == kKeysPerProbe; b0 += kKeysPerProbe) {
           const uint32_t nchunk = (nb - b0) < kKeysPerProbe ? (nb - b0) : kKeysPerProbe;
           ReqRegs t;
           t.hdr = 0;
-          t.h = buffer_load_u64(rq, (1u + b0 + (ki < nchunk ? ki : 0u)) * 8u, r * stride);
+          t.h = buffer_load_u64(rq, (1u + b0 + (ki < nchunk ? ki : 0u)) * 8u, s.r * stride);
           t.h = (ki < nchunk) ? t.h : 0ull;
           pair_probe_prepare(ix, t);
           pair_probe_issue(rk, keys_off, t, lane);
           uint32_t slotc;
           mlast = pair_probe_finish(ix, t, nchunk, lane, slotc);
           count_more<LW, NPL, BIG>(rs, slotc, 0u, mlast, lane, c);
-          hits += mlast;
+          s.hits += mlast;
         }
       }
-      if (stats) { w_hits += hits; w_lookups += (hits + 1u < nb) ? hits + 1u : nb; }
+      if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < nb) ? s.hits + 1u : nb; }
     }
-
+  };
+  // evaluate, select, store
+  auto stage_eval = [&](const ReqS& s, const LW (&c)[NPL], Tabs& tb) {
+    const uint32_t r = s.r, nb = s.nb, hits = s.hits, arow = s.arow, m0 = s.m0;
+    const int32_t adapter = s.adapter;
+    double& top_t = tb.top_t;
+    uint32_t& top_p = tb.top_p;
+    LW& thi = tb.thi;
+    LW& tlo = tb.tlo;
+    (void)adapter; (void)arow; (void)m0;
 #ifdef EPPK_DBG_SKIP_EVAL     // timing experiment only (wrong results): no evaluation phase
     if (lane == 0) { out_pick[r] = (int32_t)(uint32_t)c[0] + (int32_t)hits; }
     return;
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           cand_p = (uint32_t)__builtin_amdgcn_readlane((int)top_p, f);
         } else if (__builtin_expect(sn.n_pods > 64u && __any(okset != 0), 0)) {
           // rare: table exhausted although eligible pods remain -> T_a over every eligible pod outside M (total == T_a there)
-          if (HAS_L && !tiers_loaded) load_tiers();
+          if (HAS_L && !(MASKED || m0 > 0u)) load_tiers(s, tb);   // (not loaded up front: the request had no prefix hit)
           double rbest = -__builtin_inf();
           uint32_t ridx = kNoPod;
           for (uint32_t j = 0; j < sn.J; ++j) {
@@ -1022,6 +1023,25 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
   };
 
+  // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + 1 (row in `nxt`) and stage 0 of
+  // r + 2 (into `cur`, which is free once the probe of r is finished).
+  auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
+    ReqS s;
+    uint32_t slot0;
+    stage_finish(r, cur, s, slot0);
+    prepare_keys(nxt);     // the hash of r + 1 is consumed here (its home bucket): the wait for its prefetch sits at the top
+    Tabs tb;
+    stage_tables(s, tb);
+    LW w[16];
+    stage_rows(s, slot0, w);
+    issue_keys(nxt);
+    issue_row(r + 2u * nwaves, r, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    LW c[NPL];
+    stage_count(s, slot0, w, c);
+    stage_eval(s, c, tb);
+  };
+
   // ---- prologue: rows of the first two requests, keys of the first
   ReqRegs qa, qb;
   qa.kw[0] = qa.kw[1] = make_uint4(0, 0, 0, 0);
@@ -1029,13 +1049,14 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   qa.bkt = qb.bkt = 0;
   issue_row(gwave, gwave, qa);
   issue_row(gwave + nwaves, gwave, qb);
-  if (EPPK_SW_PIPE) { prepare_keys(qa); issue_keys(qa); }
+  prepare_keys(qa); issue_keys(qa);
   // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
   for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
     process(r, qa, qb);
     if (r + nwaves >= n_reqs) break;
     process(r + nwaves, qb, qa);
   }
+
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
   if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
