@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 EPPK_MAX_SCORERS = 8
 EPPK_MAX_PODS = 4096
@@ -59,6 +60,14 @@ def load_library() -> C.CDLL:
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback for the pick.")
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7) but links it by the
+    # unversioned name: if libeppk brought in /opt/rocm's copy first, a later `import torch` would load a second runtime
+    # that finds no GPU ("No HIP GPUs are available").  With torch imported first, libeppk binds to the copy torch loaded.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     lib.eppk_abi_version.restype = u32

@@ -767,9 +767,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (use_index) pair_probe_issue(rk, keys_off, q, lane);
   };
 
-  // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + nwaves (row in `nxt`) and stage 0 of
-  // r + 2 nwaves (into `cur`, which is free once the probe of r is finished).
-  // ---- the stages of one request, as building blocks of the two loop orders below ------------------------------------
+  // ---- the stages of one request ------------------------------------------------------------------------------------
   struct ReqS {              // wave-uniform facts of a request in flight
     uint32_t r;              // request index
     int32_t adapter;

@@ -3,6 +3,7 @@
 Bar: picks identical, scores BITWISE identical (binary64), for every BASELINE.json config shape,
 with and without candidate masks, canonical and non-canonical chain orders.
 """
+import os
 import numpy as np
 import pytest
 
@@ -442,3 +443,29 @@ def test_interpreted_tail_at_headline_shape(pkg, orc):
         assert_same(*run_both(pkg, orc, wl, chain=chain))
         wm = pkg.workload.make_workload(5, R=384, P=4096, masked=True)
         assert_same(*run_both(pkg, orc, wm, chain=chain, mask=wm.mask))
+
+
+def test_library_before_torch_shares_one_hip_runtime():
+    """A process that loads libeppk first and PyTorch second must still see the GPU from both (one HIP runtime per process:
+    _lib.load_library imports torch ahead of the dlopen, see the comment there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import __graft_entry__ as g\n"
+        "pkg = g.load_package()\n"
+        "wl = pkg.workload.make_workload(3, R=64, P=100)\n"
+        "pk = pkg.BatchedPicker(wl.chain, max_pods=128, max_blocks=wl.B, max_batch=wl.R, index_slots=wl.index_slots)\n"
+        "pk.publish(wl.pods); pk.index_insert(wl.index_hashes, wl.index_pods)\n"
+        "p0, s0 = pk.pick(wl.reqs)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "d = torch.from_numpy(wl.reqs.view(np.int64)).cuda()\n"
+        "dp = torch.empty(wl.R, dtype=torch.int32, device='cuda'); ds = torch.empty(wl.R, dtype=torch.float64, device='cuda')\n"
+        "pk.pick_device(d.data_ptr(), wl.R, None, dp.data_ptr(), ds.data_ptr()); torch.cuda.synchronize()\n"
+        "assert np.array_equal(dp.cpu().numpy(), p0)\n"
+        "pk.close(); print('ok')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
