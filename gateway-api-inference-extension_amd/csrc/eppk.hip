@@ -90,6 +90,7 @@ struct eppk_ctx {
   uint32_t slots = 0, shift = 0, limit = 0;
   size_t rows_bytes = 0, index_bytes = 0;   // rows | keys in one allocation
   uint32_t* stamps = nullptr;               // [slots + 2] index epoch of the last insert of every key (ageing)
+  uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists beside the dense rows (EPPK_LISTS=0: not maintained)
   uint32_t index_epoch = 1;
   unsigned long long* stats = nullptr;  // device [4 + 2*kStatSlots]: -, -, occupied keys, dropped inserts, then per-wave {hits, lookups}
 
@@ -109,6 +110,7 @@ struct eppk_ctx {
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
+  int max_wg_per_cu = 0;         // EPPK_MAX_WG_PER_CU: cap on resident workgroups per CU (0 = what the occupancy query allows; tuning knob)
 
   std::string err;
 };
@@ -154,6 +156,7 @@ KIndex make_kindex(const eppk_ctx* c) {
   k.small = (c->slots && c->index_bytes < (1ull << 32)) ? 1u : 0u;
   k.table_bytes = k.small ? (uint32_t)c->index_bytes : 0u;
   k.keys_off = k.small ? (uint32_t)c->rows_bytes : 0u;
+  k.lists = c->lists;
   return k;
 }
 
@@ -199,6 +202,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
+    if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
     c->occ_fn = fn; c->occ_lds = lds; c->occ_per_cu = per_cu < 1 ? 1 : per_cu;
   }
   uint32_t grid = (n_reqs + wpb - 1) / wpb;
@@ -309,6 +313,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     const int v = atoi(ft);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->fast_threads = (uint32_t)v;
   }
+  if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;
@@ -411,6 +416,14 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMemset(c->bitmaps, 0, c->index_bytes));
     CHK(hipMalloc((void**)&c->stamps, ((size_t)c->slots + 2u) * 4u));
     CHK(hipMemset(c->stamps, 0, ((size_t)c->slots + 2u) * 4u));
+    const char* le = getenv("EPPK_LISTS");
+    if (!(le && atoi(le) == 0)) {
+      const size_t nd = ((size_t)c->slots + 4u) * eppk::kListDwords;
+      CHK(hipMalloc((void**)&c->lists, nd * 4u));
+      hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, nd);
+      CHK(hipGetLastError());
+      CHK(hipStreamSynchronize(c->stream));
+    }
   }
   CHK(hipDeviceSynchronize());
 #undef CHK
@@ -423,7 +436,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
@@ -503,6 +516,10 @@ int eppk_index_clear(eppk_ctx* c) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stamps, 0, ((size_t)c->slots + 2u) * 4u, c->stream));
+  if (c->lists) {
+    hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
@@ -526,7 +543,7 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   const uint32_t threads = 256, grid = (n + threads - 1) / threads;
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->stamps, c->slots, c->shift,
+    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
                        c->limit, c->index_epoch, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n);
     return EPPK_OK;
   });
@@ -550,7 +567,7 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   if (grid64 > 0x7FFFFFFFull) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert_picks_device: batch too large");
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->stamps, c->slots,
+    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs);
     return EPPK_OK;
   });
@@ -568,7 +585,7 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->slots, pod, c->stats);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->stats);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -596,6 +613,29 @@ int eppk_index_dropped(eppk_ctx* c, uint64_t* n_dropped) {
   return EPPK_OK;
 }
 
+int eppk_index_selfcheck(eppk_ctx* c, uint64_t* n_bad) {
+  if (!c || !n_bad) return EPPK_ERR_ARG;
+  *n_bad = 0;
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long), c->stream));   // stats[0]: scratch counter of maintenance launches
+  const uint32_t rows = c->slots + 3u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_selfcheck_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
+                       (const uint32_t*)c->lists, c->slots, c->stats);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  unsigned long long bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, c->stats, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_bad = (uint64_t)bad;
+  return rc;
+}
+
 int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
   if (!c) return EPPK_ERR_ARG;
   if (c->index_epoch == 0xFFFFFFFFu) return fail(c, EPPK_ERR_LIMIT, "eppk_index_advance_epoch: epoch counter exhausted (clear the index)");
@@ -615,7 +655,7 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, (const uint32_t*)c->stamps, c->slots,
+    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
                        min_epoch, c->stats);
     return EPPK_OK;
   });

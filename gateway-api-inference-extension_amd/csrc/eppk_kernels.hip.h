@@ -92,7 +92,20 @@ struct KIndex {
   uint32_t small;          // rows + keys (ONE allocation, rows first) are < 4 GiB: both are read through one buffer descriptor
   uint32_t table_bytes;    // bytes of that allocation when small
   uint32_t keys_off;       // byte offset of keys inside it
+  const uint32_t* lists;   // [slots+4][16] short pod lists (kListCap ids of 16 bits + count), nullptr = not maintained
 };
+
+// Short pod lists.  Beside its dense row (one bit per pod: 64 * sizeof(LW) bytes) every slot keeps the same pod set as a list
+// of 16-bit pod ids while it has at most kListCap members -- 64 bytes instead of 512 at P = 4096, and what a prefix block's
+// pod set looks like in practice (a block is cached on a handful of replicas).  The pick kernel reads the lists of a
+// request's hits with ONE 16-byte load per lane and falls back to the dense rows when a hit's list has overflowed.
+// Layout (u16 view, 32 entries): four 16-byte chunks; id number j lives in chunk j & 3 at position j >> 2, so that the ids
+// of a short list are spread over the four lanes that read the slot; entries 6..7 of chunk 0 (dword 3) are the 32-bit count;
+// unused entries are 0xFFFF.  count > kListCap: overflowed (ids unspecified), the dense row alone is authoritative.
+constexpr uint32_t kListCap = 24u;
+constexpr uint32_t kListDwords = 16u;
+constexpr uint32_t kListNone = 0xFFFFu;
+__host__ __device__ __forceinline__ constexpr uint32_t list_pos(uint32_t j) { return 8u * (j & 3u) + (j >> 2); }   // u16 index of id j
 
 // Byte offsets of the per-adapter tables at the head of a snapshot blob (eppk.hip lays the blob out with the same constants).
 template <typename LW> struct SnapOff {
@@ -808,6 +821,15 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   };
   // rows of the request, up to 16 in flight
   auto stage_rows = [&](const ReqS& s, uint32_t slot_eff, LW (&w)[16]) {
+#ifdef EPPK_DBG_ONE_ROW     // timing experiment only (wrong results): one row load per request, no carry-save counting
+    {
+      LW t[1];
+      load_rows<LW, 1, BIG>(rs, slot_eff, 0, lane, t);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = t[0];
+      return;
+    }
+#endif
     if (s.m0 > 8u) {
       load_rows<LW, 16, BIG>(rs, slot_eff, 0, lane, w);
     } else {
@@ -825,6 +847,11 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     for (int k = 0; k < NPL; ++k) c[k] = 0;
     if (HAS_P) {
       const uint32_t m0 = s.m0, nb = s.nb;
+#ifdef EPPK_DBG_ONE_ROW
+      c[4] = w[0];
+      if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < nb) ? s.hits + 1u : nb; }
+      return;
+#endif
       if (m0 > 8u) {
         LW b[5];
         csa16<LW>(w, b);
@@ -1408,24 +1435,75 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
 // stats[2] = occupied keys, stats[3] = dropped inserts (table at its load limit)
 
-// Set pod's bit in the row of `slot`.  Re-inserting a cached block is the common case of the post-pick update, so the word is
-// read first and the atomic issued only when the bit is still clear (bits are only cleared by remove_pod, never concurrently).
+// Set pod's bit in the row of `slot`; true iff this call set it.  Re-inserting a cached block is the common case of the
+// post-pick update, so the word is read first and the atomic issued only when the bit is still clear (bits are only
+// cleared by remove_pod / evict, never concurrently).
 template <typename LW>
-__device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_t pod) {
+__device__ __forceinline__ bool bitmap_set(void* bitmaps, uint32_t slot, uint32_t pod) {
   const uint32_t lane = pod & 63u, j = pod >> 6;
   if constexpr (sizeof(LW) == 8) {
     unsigned long long* w = (unsigned long long*)bitmaps + (size_t)slot * 64u + lane;
-    if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull)) atomicOr(w, 1ull << j);
+    if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull) return false;
+    return !((atomicOr(w, 1ull << j) >> j) & 1ull);
   } else if constexpr (sizeof(LW) == 4) {
     unsigned int* w = (unsigned int*)bitmaps + (size_t)slot * 64u + lane;
-    if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1u)) atomicOr(w, 1u << j);
+    if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1u) return false;
+    return !((atomicOr(w, 1u << j) >> j) & 1u);
   } else {
     const size_t e = (size_t)slot * 64u + lane;           // u16 element index
     unsigned int* w = (unsigned int*)bitmaps + (e >> 1);
     const unsigned int bit = (1u << j) << (16u * (uint32_t)(e & 1u));
-    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return false;
+    return !(atomicOr(w, bit) & bit);
   }
 }
+
+// Append a pod whose bit was just set to the slot's short list.  Positions are handed out by an atomic counter; once it has
+// passed kListCap the list is overflowed and stays so (the counter is not bumped any further) until the row is rebuilt
+// (remove_pod) or freed (evict / clear).
+__device__ __forceinline__ void list_append(uint32_t* lists, uint32_t slot, uint32_t pod) {
+  uint32_t* L = lists + (size_t)slot * kListDwords;
+  if (__hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kListCap) return;
+  const uint32_t j = atomicAdd(&L[3], 1u);
+  if (j < kListCap) ((uint16_t*)L)[list_pos(j)] = (uint16_t)pod;
+}
+
+// Rebuild the short list of a slot from its dense row (one wavefront; v = this lane's word of the row).
+template <typename LW>
+__device__ __forceinline__ void list_rebuild(uint32_t* lists, uint32_t slot, LW v, uint32_t lane) {
+  const uint32_t cnt = (uint32_t)__builtin_popcountll((unsigned long long)v);
+  uint32_t incl = cnt;
+  for (uint32_t d = 1; d < 64u; d <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)d);
+    if (lane >= d) incl += t;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63), excl = incl - cnt;
+  uint32_t mine = 0xFFFFFFFFu;                                  // lane q < 16 assembles dword q of the list
+  if (total <= kListCap) {
+    for (uint32_t j = 0; j < total; ++j) {
+      const int own = __builtin_ctzll(__ballot(excl <= j && j < incl));   // the lane whose word holds member j
+      uint32_t pod = 0;
+      if ((int)lane == own) {
+        LW t = v;
+        for (uint32_t n = j - excl; n; --n) t = (LW)(t & (LW)(t - 1));
+        pod = ctz_lw<LW>(t) * 64u + lane;
+      }
+      pod = (uint32_t)__shfl((int)pod, own);
+      const uint32_t u = list_pos(j);
+      if (lane == (u >> 1)) mine = (u & 1u) ? ((mine & 0x0000FFFFu) | (pod << 16)) : ((mine & 0xFFFF0000u) | pod);
+    }
+  }
+  if (lane == 3u) mine = total;                                 // the count (> kListCap: overflowed)
+  if (lane < kListDwords) lists[(size_t)slot * kListDwords + lane] = mine;
+}
+
+#ifdef EPPK_MAIN_UNIT
+// every list empty: count 0, ids 0xFFFF
+__global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x)
+    lists[i] = (i & (kListDwords - 1u)) == 3u ? 0u : 0xFFFFFFFFu;
+}
+#endif
 
 // Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters (stats[1] = live keys,
 // stats[2] = non-empty words, stats[3] = dropped inserts) are bumped once per wavefront (ballot + popcount) -- a same-address
@@ -1439,7 +1517,7 @@ __device__ __forceinline__ void bitmap_set(void* bitmaps, uint32_t slot, uint32_
 // runs (evictions are separate launches), so every inserter of one key converges on the same word: no duplicates.
 // Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
 template <typename LW>
-__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift,
+__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
                                                  uint32_t limit, uint32_t epoch, unsigned long long* stats, uint64_t h, uint32_t pod, bool active) {
   uint32_t slot = kNotFound;
   bool newkey = false, newword = false;
@@ -1492,21 +1570,21 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   }
   if (active && slot != kNotFound) {
     if (__hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) atomicMax(&stamps[slot], epoch);
-    bitmap_set<LW>(bitmaps, slot, pod);
+    if (bitmap_set<LW>(bitmaps, slot, pod) && lists) list_append(lists, slot, pod);
   }
 }
 
 template <typename LW>
-__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                     uint32_t epoch, unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
 template <typename LW>
-__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1521,13 +1599,13 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active);
 }
 
 // Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
 // meets a present key with an empty pod set.  A wavefront per row, looping (rows = slots + 2: the reserved rows too).
 template <typename LW>
-__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t slots, uint32_t pod, unsigned long long* stats) {
+__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* stats) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   uint32_t gone = 0;
@@ -1537,11 +1615,14 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t 
     if (k == 0ull || (row < slots && k == kTomb)) continue;
     LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
     LW v = *w;
+    bool changed = false;
     if (lane == (pod & 63u)) {
       const LW nv = (LW)(v & (LW)~((LW)1 << (pod >> 6)));
-      if (nv != v) *w = nv;
+      changed = nv != v;
+      if (changed) *w = nv;
       v = nv;
     }
+    if (lists && __any(changed)) list_rebuild<LW>(lists, row, v, lane);   // (also brings an overflowed list back when it fits again)
     if (__ballot(v != 0) == 0ull) {
       if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;     // reserved rows: clear presence
       ++gone;
@@ -1553,7 +1634,7 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t 
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
 // drop every key last stamped before min_epoch -- row zeroed, key tombstoned (reusable by later inserts).
 template <typename LW>
-__global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
+__global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
                                    unsigned long long* stats) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1564,6 +1645,7 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, const uint32_t
     if (k == 0ull || (row < slots && k == kTomb)) continue;
     if (stamps[row] >= min_epoch) continue;
     ((LW*)bitmaps)[(size_t)row * 64u + lane] = 0;
+    if (lists && lane < kListDwords) lists[(size_t)row * kListDwords + lane] = lane == 3u ? 0u : 0xFFFFFFFFu;
     if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;
     ++gone;
   }
@@ -1571,6 +1653,50 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, const uint32_t
     atomicAdd(&stats[1], (unsigned long long)(0ull - (unsigned long long)gone));
     atomicAdd(&stats[0], (unsigned long long)gone);   // evicted by this launch (host zeroes it first)
   }
+}
+
+// Diagnostic (eppk_index_selfcheck): counts the rows that break an invariant of the index -- a present key with an empty pod
+// set, an absent key (or a bucket header / the zero row) with a non-empty one, a short list that is not exactly the pod set
+// of its dense row (count, members, no duplicates, unused entries 0xFFFF), an overflowed list on an absent key.
+// A wavefront per row.
+template <typename LW>
+__global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, uint32_t slots, unsigned long long* bad) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nbad = 0;
+  for (uint32_t row = wave; row < slots + 3u; row += nwaves) {
+    const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
+    const uint64_t k = row < slots + 2u ? keys[row] : 0ull;
+    const bool present = !header && row < slots + 2u && k != 0ull && !(row < slots && k == kTomb);
+    const LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
+    uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)v);
+    for (uint32_t d = 32; d; d >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)d);
+    bool wrong = present ? members == 0u : members != 0u;
+    if (lists) {
+      const uint32_t* L = lists + (size_t)row * kListDwords;
+      const uint32_t count = L[3];
+      if (count <= kListCap) {
+        if (count != members) wrong = true;
+        // lane u < 32 owns u16 entry u: chunk u >> 3, position u & 7 -> id number (u & 7) * 4 + (u >> 3)
+        const uint32_t u = lane & 31u;
+        const uint32_t e = ((const uint16_t*)L)[u];
+        const bool is_count = u == 6u || u == 7u;
+        const bool used = !is_count && (u & 7u) <= 5u && (u & 7u) * 4u + (u >> 3) < count;
+        bool ok = is_count || (used ? e != kListNone : e == kListNone);
+        for (uint32_t t = 0; t < 32u; ++t) {                 // every listed id: a member of the row, listed once
+          const uint32_t et = (uint32_t)__shfl((int)e, (int)t);
+          const bool ut = __shfl((int)used, (int)t) != 0;
+          if (ut && et != kListNone) {
+            if (lane == (et & 63u) && ((et >> 6) >= 8u * sizeof(LW) || !((v >> (et >> 6)) & 1))) ok = false;
+            if (lane < 32u && lane != t && used && e == et) ok = false;
+          }
+        }
+        if (__any(!ok)) wrong = true;
+      } else if (!present) wrong = true;
+    }
+    if (wrong) ++nbad;
+  }
+  if (lane == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
 }  // namespace eppk

@@ -193,6 +193,12 @@ class BatchedPicker:
         self._check(self._lib.eppk_index_dropped(self._ctx, C.byref(n)), "index_dropped")
         return n.value
 
+    def index_selfcheck(self) -> int:
+        """Diagnostic: index rows violating an internal invariant (0 on a healthy index; include/eppk.h eppk_index_selfcheck)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.eppk_index_selfcheck(self._ctx, C.byref(n)), "index_selfcheck")
+        return n.value
+
     def index_advance_epoch(self) -> int:
         """Tick the index epoch that stamps every later insert (ageing, include/eppk.h)."""
         e = C.c_uint32(0)

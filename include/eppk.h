@@ -152,6 +152,9 @@ int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
  * eppk_index_insert reports them as EPPK_ERR_INDEX_FULL; the asynchronous eppk_index_insert_picks_device cannot, so a shim
  * polls this counter (and grows or ages the index). */
 int eppk_index_dropped(eppk_ctx* ctx, uint64_t* n_dropped);
+/* Diagnostic: number of index rows that violate an internal invariant (present hash with an empty pod set, pod set left
+ * behind a removed hash, short pod list out of step with its dense row).  0 on a healthy index; synchronous full scan. */
+int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
 /* Ageing -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)", 0602-…/README.md:82.
  * Every insert (eppk_index_insert, eppk_index_insert_picks_device) stamps its hashes with the context's index epoch
  * (starts at 1); eppk_index_advance_epoch increments it; eppk_index_evict_older drops every hash whose last stamp is

@@ -133,6 +133,7 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
                 assert pk.index_evict_older(max(e - keep, 0)) == oix.evict_older(max(e - keep, 0))
             assert pk.index_dropped() == 0
             assert pk.index_size() == oix.size(), f"seed {seed} step {step} after {op}"
+            assert pk.index_selfcheck() == 0, f"seed {seed} step {step} after {op}"
             reqs = probe_batch()
             picks, scores = pk.pick(reqs)
             opk, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)

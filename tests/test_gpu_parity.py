@@ -469,3 +469,73 @@ def test_library_before_torch_shares_one_hip_runtime():
         "pk.close(); print('ok')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("P", [700, 2000, 4096])
+def test_short_lists_follow_the_dense_rows(pkg, orc, P):
+    """Every slot keeps its pod set twice: dense row + short list of pod ids (<= 24 members, csrc/eppk_kernels.hip.h).  Grow pod
+    sets across the list capacity, shrink them again with pod removals, evict, re-insert: the self-check finds list and row
+    in step after every operation and picks stay identical to the oracle's."""
+    rng = np.random.default_rng(77 + P)
+    B = 8
+    chain = [(Q, 2), (KV, 2), (L, 1), (PF, 3)]
+    pods = pkg.workload.make_pods(4242, P, 128)
+    chains = rng.integers(1, 2**63, (12, B), dtype=np.uint64)
+    R = 128
+
+    def batch():
+        hs = chains[rng.integers(0, chains.shape[0], R)].copy()
+        for r in range(R):
+            if rng.random() < 0.4:
+                cut = int(rng.integers(0, B))
+                hs[r, cut:] = rng.integers(1, 2**63, B - cut, dtype=np.uint64)
+        return pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=4096) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+
+        def check(what):
+            assert pk.index_selfcheck() == 0, what
+            assert pk.index_size() == oix.size(), what
+            reqs = batch()
+            picks, scores = pk.pick(reqs)
+            op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert_same(picks, scores, op, osc)
+
+        members = {c: [] for c in range(chains.shape[0])}
+        # grow: chain c gets (c + 1) * 4 pods in three rounds -> sets of 4 .. 48 members, the larger ones cross the capacity
+        for rnd in range(3):
+            ih, ip = [], []
+            for c in range(chains.shape[0]):
+                want = (c + 1) * 4 * (rnd + 1) // 3
+                new = rng.choice(P, size=min(want, P), replace=False)[: max(want - len(members[c]), 0)]
+                members[c] += [int(x) for x in new]
+                for p_ in new:
+                    depth = int(rng.integers(1, B + 1))
+                    ih.append(chains[c, :depth]); ip.append(np.full(depth, p_, dtype=np.uint32))
+            ih = np.concatenate(ih); ip = np.concatenate(ip)
+            pk.index_insert(ih, ip); oix.insert(ih, ip)
+            check(f"grow round {rnd}")
+        # shrink: remove pods that many sets contain, until the big sets fit a list again
+        for step in range(30):
+            c = int(rng.integers(6, chains.shape[0]))
+            if not members[c]:
+                continue
+            pod = members[c].pop()
+            pk.index_remove_pod(pod); oix.remove_pod(pod)
+            for m in members.values():
+                if pod in m:
+                    m.remove(pod)
+            if step % 5 == 4:
+                check(f"shrink step {step}")
+        check("after shrinking")
+        # age everything out, then start over
+        e = pk.index_advance_epoch(); oix.advance_epoch()
+        assert pk.index_evict_older(e) == oix.evict_older(e)
+        check("after evicting everything")
+        ih = chains[:, :4].reshape(-1); ip = rng.integers(0, P, ih.size).astype(np.uint32)
+        pk.index_insert(ih, ip); oix.insert(ih, ip)
+        check("re-inserted")
+        pk.index_clear(); oix = orc.OracleIndex()
+        check("cleared")
