@@ -110,6 +110,7 @@ struct eppk_ctx {
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
+  size_t max_lds = 65536;        // LDS a workgroup may use (160 KB on gfx950)
   int max_wg_per_cu = 0;         // EPPK_MAX_WG_PER_CU: cap on resident workgroups per CU (0 = what the occupancy query allows; tuning knob)
 
   std::string err;
@@ -156,7 +157,8 @@ KIndex make_kindex(const eppk_ctx* c) {
   k.small = (c->slots && c->index_bytes < (1ull << 32)) ? 1u : 0u;
   k.table_bytes = k.small ? (uint32_t)c->index_bytes : 0u;
   k.keys_off = k.small ? (uint32_t)c->rows_bytes : 0u;
-  k.lists = c->lists;
+  // the pick reads the lists through one raw buffer descriptor: only while the list table is below 4 GiB (slots < 2^26)
+  k.lists = (c->lists && ((size_t)c->slots + 4u) * 64u < (1ull << 32)) ? c->lists : nullptr;
   return k;
 }
 
@@ -194,6 +196,11 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (fast) {
     pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
     lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (c->gen ? (size_t)sn.J * 64u * 16u : 0u);   // base | lw[4] | pterm | post0 | post1
+    if (c->has_p && c->npl == 6 && !masked && topk == 1 && ix.lists) {                                     // | per-wave pod histogram (SPARSE)
+      const size_t hist = (size_t)wpb * sn.J * 64u;
+      if (lds + hist <= c->max_lds) lds += hist;
+      else ix.lists = nullptr;               // (interpreted tail at P = 4096: no room in the 160 KB -> dense rows only)
+    }
   } else {
     lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
   }
@@ -307,6 +314,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, cfg->device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (prop.maxSharedMemoryPerMultiProcessor > c->max_lds) c->max_lds = prop.maxSharedMemoryPerMultiProcessor;
   CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
   if (const char* ft = getenv("EPPK_FAST_THREADS")) {

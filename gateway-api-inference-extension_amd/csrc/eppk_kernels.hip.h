@@ -723,12 +723,19 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   double* s_post1 = s_post0 + (size_t)sn.J * 64u;
   // the exact prefix-term table exists whenever max_blocks <= 63, i.e. for every NPL == 6 instantiation (eppk.hip)
   constexpr bool pterm_tab = HAS_P && NPL == 6;
+  // SPARSE: requests whose hits all have a short pod list are counted from the lists (one 16-byte load per lane instead of
+  // 64 * sizeof(LW) bytes per hit) in a per-wave byte histogram in LDS; everything else takes the dense rows as before.
+  constexpr bool SPARSE = HAS_P && NPL == 6 && !MASKED && !TOPK;
+  uint32_t* s_hist_all = (uint32_t*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);   // [waves][J * 16] dwords: one byte per pod
+  const bool use_lists = SPARSE && ix.lists != nullptr;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
   if (threadIdx.x < 4u) s_lw[threadIdx.x] = tl.lw[threadIdx.x];
   if (GEN)
     for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_post0[i] = sn.post[0][i]; s_post1[i] = sn.post[1][i]; }
   if (pterm_tab)
     for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
+  if (use_lists)
+    for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * sn.J * 16u; i += blockDim.x) s_hist_all[i] = 0u;
   __syncthreads();
 
   const int lane = (int)(threadIdx.x & 63u);
@@ -747,6 +754,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const uint32_t keys_off = BIG ? 0u : ix.keys_off;
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)ix.lists, 0, use_lists ? (int)((ix.slots + 4u) * 64u) : 0, 0x00020000);
+  uint32_t* s_hist = s_hist_all + (threadIdx.x >> 6) * sn.J * 16u;
   const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
 
   const LW valid = valid_word<LW>(sn.n_pods, lane);
@@ -885,6 +894,168 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < nb) ? s.hits + 1u : nb; }
     }
   };
+  // total of pod p with cnt matched blocks and LoRA tier `tier` (2 bits: thi, tlo), binary64 adds in chain order
+  auto pod_total = [&](uint32_t p, uint32_t cnt, uint32_t tier, const double* pt_row, double nbd) __attribute__((always_inline)) -> double {
+    // pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table (NPL == 6), else one binary64 division
+    double pterm;
+    if constexpr (pterm_tab) pterm = pt_row[cnt];
+    else pterm = clamp01((double)cnt / nbd) * tl.wp;
+    double lterm = 0.0;
+    if (HAS_L) lterm = s_lw[tier];
+    double t;
+    if constexpr (GEN) {               // interpreted tail: one binary64 add per scorer, in chain order
+      t = s_base[p];
+      for (uint32_t i = 0; i < tl.n_tail; ++i) {
+        const uint32_t kd = tl.kind[i];
+        t = t + (kd == 0u ? lterm : kd == 1u ? pterm : kd == 2u ? s_post0[p] : s_post1[p]);
+      }
+    } else {
+      t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
+    }
+    return t;
+  };
+
+  // ---- SPARSE: the request's pod sets as short lists -------------------------------------------------------------------
+  // Lane (k = lane & 15, c = lane >> 4) reads chunk c of the list of hit k (la) and of hit 16 + k (lb): 8 ids each.
+  auto issue_lists = [&](const ReqS& s, uint32_t slot_eff, u32x4_t& la, u32x4_t& lb) {
+    const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
+    const uint32_t sa = (uint32_t)__shfl((int)slot_eff, (int)(2u * k));
+    la = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sa * 64u + cch * 16u), 0, 0);
+    lb = (u32x4_t)(0xFFFFFFFFu);
+    if (s.m0 > 16u) {
+      const uint32_t sb = (uint32_t)__shfl((int)slot_eff, (int)(2u * (16u + k)));
+      lb = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sb * 64u + cch * 16u), 0, 0);
+    }
+  };
+  // true iff one of the request's hits has an overflowed list (the dense rows must be used)
+  auto lists_overflowed = [&](const ReqS& s, const u32x4_t& la, const u32x4_t& lb) -> bool {
+    const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
+    const bool o = cch == 0u && ((k < s.m0 && la.w > kListCap) || (16u + k < s.m0 && lb.w > kListCap));
+    return __any(o);
+  };
+  auto stage_sparse = [&](const ReqS& s, u32x4_t la, u32x4_t lb, Tabs& tb) {
+    const uint32_t r = s.r, nb = s.nb, m0 = s.m0, arow = s.arow;
+    const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
+    if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < nb) ? s.hits + 1u : nb; }
+    if (cch == 0u) { la.w = 0xFFFFFFFFu; lb.w = 0xFFFFFFFFu; }            // (the count)
+    if (k >= m0) la = (u32x4_t)(0xFFFFFFFFu);
+    if (16u + k >= m0) lb = (u32x4_t)(0xFFFFFFFFu);
+    const uint32_t d[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+    // pass 1: matched[p] += 1 per listed pod (byte counters: <= 32 hits); the lane that finds the byte at zero owns the pod.
+    // Ids fill every chunk front to back, so the first step without a valid id ends a half.
+    uint32_t first = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t id = (d[half * 4 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+        if (!__any(id != kListNone)) break;
+        const bool v = id < sn.n_pods;                                    // (a pod beyond the published snapshot is no candidate)
+        if (v) {
+          const uint32_t sh = (id & 3u) * 8u;
+          const uint32_t old = atomicAdd(&s_hist[id >> 2], 1u << sh);
+          if (((old >> sh) & 0xFFu) == 0u) first |= 1u << (half * 8 + i);
+        }
+      }
+    }
+    // pass 2: the owners evaluate their pods in full (every lane takes part in the tier look-up: bpermute reads active lanes only)
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
+    const double* pt_row = s_pterm + (size_t)nb * sn.pterm_ld;
+    const double nbd = (double)nb;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!__any((first >> (half * 8 + i)) != 0u)) break;              // no owner at this or any later step
+        const bool f = (first >> (half * 8 + i)) & 1u;
+        const uint32_t id = (d[half * 4 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+        const uint32_t p = f ? id : 0u;
+        const uint32_t cnt = (s_hist[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu;
+        uint32_t tier = 0;
+        if (HAS_L) {
+          const uint32_t src = p & 63u, jb = p >> 6;
+          LW th, tl_;
+          if constexpr (sizeof(LW) == 8) {
+            th = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(tb.thi >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)tb.thi, (int)src);
+            tl_ = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(tb.tlo >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)tb.tlo, (int)src);
+          } else {
+            th = (LW)__shfl((int)(uint32_t)tb.thi, (int)src);
+            tl_ = (LW)__shfl((int)(uint32_t)tb.tlo, (int)src);
+          }
+          tier = (uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1);
+        }
+        const double t = pod_total(p, f ? cnt : 0u, tier, pt_row, nbd);
+        if (f && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
+      }
+    }
+    wave_argmax_dpp(best, bidx);
+    // best pod outside M: first entry of the adapter's top table whose counter byte is zero
+    double cand_t = -__builtin_inf();
+    uint32_t cand_p = kNoPod;
+    const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), 0),
+                                         __builtin_amdgcn_readlane(__double2loint(tb.top_t), 0));
+    if (!(best > top0)) {
+      auto entry_ok = [&](uint32_t tp) -> unsigned long long {
+        const bool has = tp != kNoPod;
+        const uint32_t q = has ? tp : 0u;
+        return __ballot(has && ((s_hist[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu) == 0u);
+      };
+      unsigned long long okm = entry_ok(tb.top_p);
+      if (__builtin_expect(okm == 0ull && sn.n_pods > 16u, 0)) {         // none of the first 16: fetch entries 16..63
+        if (lane >= 16) {
+          tb.top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
+          tb.top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
+        }
+        okm = entry_ok(tb.top_p);
+      }
+      if (okm) {
+        const int f = __builtin_ctzll(okm);
+        cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), f),
+                                  __builtin_amdgcn_readlane(__double2loint(tb.top_t), f));
+        cand_p = (uint32_t)__builtin_amdgcn_readlane((int)tb.top_p, f);
+      } else if (__builtin_expect(sn.n_pods > 64u, 0)) {
+        // rare: all 64 table entries are in M -> T_a over every pod outside M (total == T_a there)
+        double rbest = -__builtin_inf();
+        uint32_t ridx = kNoPod;
+        for (uint32_t j = 0; j < sn.J; ++j) {
+          const uint32_t p = j * 64u + (uint32_t)lane;
+          double t = s_base[p];
+          if constexpr (GEN) {
+            const double lterm = HAS_L ? s_lw[(uint32_t)(((tb.thi >> j) & 1) << 1) | (uint32_t)((tb.tlo >> j) & 1)] : 0.0;
+            for (uint32_t i = 0; i < tl.n_tail; ++i) {
+              const uint32_t kd = tl.kind[i];
+              if (kd != 1u) t = t + (kd == 0u ? lterm : kd == 2u ? s_post0[p] : s_post1[p]);
+            }
+          } else {
+            if (HAS_L) t = t + s_lw[(uint32_t)(((tb.thi >> j) & 1) << 1) | (uint32_t)((tb.tlo >> j) & 1)];
+          }
+          const bool okp = p < sn.n_pods && ((s_hist[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu) == 0u;
+          if (okp && t > rbest) { rbest = t; ridx = p; }
+        }
+        wave_argmax_dpp(rbest, ridx);
+        cand_t = rbest;
+        cand_p = ridx;
+      }
+    }
+    if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
+    // pass 3: the touched counters back to zero
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t id = (d[half * 4 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+        if (!__any(id != kListNone)) break;
+        if (id < sn.n_pods) s_hist[id >> 2] = 0u;
+      }
+    }
+    const bool none = bidx == kNoPod;
+    if (lane == 0) {
+      out_pick[r] = none ? -1 : (int32_t)bidx;
+      if (out_score) out_score[r] = none ? 0.0 : best;
+    }
+  };
+
   // evaluate, select, store
   auto stage_eval = [&](const ReqS& s, const LW (&c)[NPL], Tabs& tb) {
     const uint32_t r = s.r, nb = s.nb, hits = s.hits, arow = s.arow, m0 = s.m0;
@@ -941,22 +1112,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           uint32_t cnt = 0;
 #pragma unroll
           for (int k = 0; k < NPL; ++k) cnt |= (uint32_t)((c[k] >> j) & 1) << k;
-          // pterm = clamp01(cnt / nb) * w_prefix: from the host-built exact table (NPL == 6), else one binary64 division
-          double pterm;
-          if constexpr (pterm_tab) pterm = pt_row[cnt];
-          else pterm = clamp01((double)cnt / nbd) * tl.wp;
-          double lterm = 0.0;
-          if (HAS_L) lterm = s_lw[(uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)];
-          double t;
-          if constexpr (GEN) {               // interpreted tail: one binary64 add per scorer, in chain order
-            t = s_base[p];
-            for (uint32_t i = 0; i < tl.n_tail; ++i) {
-              const uint32_t kd = tl.kind[i];
-              t = t + (kd == 0u ? lterm : kd == 1u ? pterm : kd == 2u ? s_post0[p] : s_post1[p]);
-            }
-          } else {
-            t = eval_total<HAS_L, HAS_P, P_FIRST>(s_base[p], lterm, pterm);
-          }
+          const uint32_t tier = HAS_L ? ((uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1)) : 0u;
+          const double t = pod_total(p, cnt, tier, pt_row, nbd);
           if (t > best) { best = t; bidx = p; }
         }
         wave_argmax_dpp(best, bidx);
@@ -1057,14 +1214,26 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     prepare_keys(nxt);     // the hash of r + 1 is consumed here (its home bucket): the wait for its prefetch sits at the top
     Tabs tb;
     stage_tables(s, tb);
+    // SPARSE: hits beyond the first 32 (chunks) and hits with an overflowed list take the dense rows
+    bool sp = SPARSE && use_lists && s.m0 > 0u && !(s.m0 == kKeysPerProbe && s.nb > kKeysPerProbe);
+    u32x4_t la = (u32x4_t)(0xFFFFFFFFu), lb = (u32x4_t)(0xFFFFFFFFu);
     LW w[16];
-    stage_rows(s, slot0, w);
+    if (sp) issue_lists(s, slot0, la, lb);
+    else stage_rows(s, slot0, w);
     issue_keys(nxt);
     issue_row(r + 2u * nwaves, r, cur);
     __builtin_amdgcn_sched_barrier(0);
-    LW c[NPL];
-    stage_count(s, slot0, w, c);
-    stage_eval(s, c, tb);
+    if (SPARSE && sp && __builtin_expect(lists_overflowed(s, la, lb), 0)) {
+      sp = false;
+      stage_rows(s, slot0, w);
+    }
+    if (SPARSE && sp) {
+      stage_sparse(s, la, lb, tb);
+    } else {
+      LW c[NPL];
+      stage_count(s, slot0, w, c);
+      stage_eval(s, c, tb);
+    }
   };
 
   // ---- prologue: rows of the first two requests, keys of the first
