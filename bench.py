@@ -189,10 +189,25 @@ def main() -> None:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # What the library's OWN layout moves through L2 -> L1 per launch (an estimate from the probe counts):
+        # request rows + pod rows + picks, one 64-byte key bucket per probed hash (all of a request's first 32 are gathered),
+        # one 64-byte pod list per hit (the dense 64 * sizeof(LW)-byte row when the lists are off), the adapter tables.
+        # `achieved` / `frac` above stay on SURVEY §8(d)'s byte model (u64 key + P/8-byte bitmap per index entry).
+        lw_bytes = 2 if wl.P <= 1024 else 4 if wl.P <= 2048 else 8
+        stride = 8 + 8 * wl.B
+        fixed = wl.P * 64 + R * (stride + 4)
+        lk = lookups / max(launches, 1)
+        row_model = 8 + 64 * lw_bytes
+        hits = max(per_launch_bytes - fixed - 8 * lk, 0.0) / (row_model - 8) if wl.B else 0.0
+        lists_on = os.environ.get("EPPK_LISTS", "1") != "0"
+        layout_bytes = fixed + (R * min(wl.B, 32) * 64 + hits * (64 if lists_on else 64 * lw_bytes) if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "pick_fast_kernel", "kernel_avg_ms": avg_ms,
                            "kernel_p99_ms": float(np.percentile(k, 99)) if k.size else None,
-                           "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lookups / max(launches, 1)}
+                           "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lk,
+                           "byte_model": "SURVEY 8(d): u64 key + P/8-byte bitmap per index entry (the reference-shaped index)",
+                           "layout_bytes_per_launch": layout_bytes,
+                           "layout_GBps": layout_bytes / (avg_ms * 1e-3) / 1e9 if k.size else None}
         out["config"]["p99_step_ms"] = out["roofline"]["kernel_p99_ms"]
         if args.host_path and world == 1:
             # host-observed pick latency: request rows in host memory -> pinned staging -> H2D -> kernel -> D2H (PCIe-inclusive;
@@ -211,7 +226,14 @@ def main() -> None:
             out["cpu_baseline"] = cb
             out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks)),
                              "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores.view(np.uint64)))}
-        print(json.dumps(out))
+        # RCCL writes a version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON
+        # line is the last thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   // Lane (k = lane & 15, c = lane >> 4) reads chunk c of the list of hit k (la) and of hit 16 + k (lb): 8 ids each.
   auto issue_lists = [&](const ReqS& s, uint32_t slot_eff, u32x4_t& la, u32x4_t& lb) {
     const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
-    const uint32_t sa = (uint32_t)__shfl((int)slot_eff, (int)(2u * k));
+    const uint32_t sa = (uint32_t)__shfl((int)slot_eff, (int)(2u * (k < s.m0 ? k : 0u)));   // (lanes beyond the hits re-read hit 0: stage_uniform)
     la = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sa * 64u + cch * 16u), 0, 0);
     lb = (u32x4_t)(0xFFFFFFFFu);
     if (s.m0 > 16u) {
@@ -933,10 +933,71 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     const bool o = cch == 0u && ((k < s.m0 && la.w > kListCap) || (16u + k < s.m0 && lb.w > kListCap));
     return __any(o);
   };
+  // The common shape of a request: all its hits list the SAME pods (the blocks of one shared prefix are cached together), so
+  // matched = m0 for every listed pod.  The 16 lanes of a DPP row hold the same chunk of the 16 hits: one row_shr:1 compare
+  // per dword detects it; lane (k, c) then evaluates id k of chunk c -- all pods of the list in ONE step, no histogram.
+  // Returns false (nothing stored) when the lists differ or the top table's first 16 entries are all listed.
+  auto stage_uniform = [&](const ReqS& s, const u32x4_t& la, const u32x4_t& lb, Tabs& tb) -> bool {
+    const uint32_t r = s.r, nb = s.nb, m0 = s.m0;
+    const uint32_t k = (uint32_t)lane & 15u;
+    auto shr1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); };   // lane k-1 of the row (k = 0: itself)
+    uint32_t diff = 0;
+    if (k < m0) diff = (la.x ^ shr1(la.x)) | (la.y ^ shr1(la.y)) | (la.z ^ shr1(la.z)) | (la.w ^ shr1(la.w));
+    if (16u + k < m0) diff |= (lb.x ^ la.x) | (lb.y ^ la.y) | (lb.z ^ la.z) | (lb.w ^ la.w);
+    if (__any(diff != 0u)) return false;
+    // id k of this lane's chunk (positions 6..7 of chunk 0 are the count, of the other chunks unused)
+    const uint32_t dw = (k & 4u) ? ((k & 2u) ? la.w : la.z) : ((k & 2u) ? la.y : la.x);
+    uint32_t id = (k & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
+    if (k >= 6u) id = kListNone;
+    const bool v = id < sn.n_pods;
+    const uint32_t p = v ? id : 0u;
+    uint32_t tier = 0;
+    if (HAS_L) {
+      const uint32_t src = p & 63u, jb = p >> 6;
+      LW th, tl_;
+      if constexpr (sizeof(LW) == 8) {
+        th = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(tb.thi >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)tb.thi, (int)src);
+        tl_ = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(tb.tlo >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)tb.tlo, (int)src);
+      } else {
+        th = (LW)__shfl((int)(uint32_t)tb.thi, (int)src);
+        tl_ = (LW)__shfl((int)(uint32_t)tb.tlo, (int)src);
+      }
+      tier = (uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1);
+    }
+    const double t = pod_total(p, v ? m0 : 0u, tier, s_pterm + (size_t)nb * sn.pterm_ld, (double)nb);
+    double best = v ? t : -__builtin_inf();
+    uint32_t bidx = v ? p : kNoPod;
+    wave_argmax_dpp(best, bidx);
+    // best pod outside M: the first top-table entry that is not listed
+    double cand_t = -__builtin_inf();
+    uint32_t cand_p = kNoPod;
+    const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), 0),
+                                         __builtin_amdgcn_readlane(__double2loint(tb.top_t), 0));
+    if (!(best > top0)) {
+      uint32_t e = 0;
+      for (; e < 16u; ++e) {
+        const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tb.top_p, (int)e);
+        if (tp == kNoPod) break;                                          // fewer than 16 pods: the table ends here
+        if (!__any(v && id == tp)) {
+          cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), (int)e),
+                                    __builtin_amdgcn_readlane(__double2loint(tb.top_t), (int)e));
+          cand_p = tp;
+          break;
+        }
+      }
+      if (__builtin_expect(e == 16u && sn.n_pods > 16u, 0)) return false;  // all listed: the general path fetches the rest of the table
+    }
+    if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
+    const bool none = bidx == kNoPod;
+    if (lane == 0) {
+      out_pick[r] = none ? -1 : (int32_t)bidx;
+      if (out_score) out_score[r] = none ? 0.0 : best;
+    }
+    return true;
+  };
   auto stage_sparse = [&](const ReqS& s, u32x4_t la, u32x4_t lb, Tabs& tb) {
     const uint32_t r = s.r, nb = s.nb, m0 = s.m0, arow = s.arow;
     const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
-    if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < nb) ? s.hits + 1u : nb; }
     if (cch == 0u) { la.w = 0xFFFFFFFFu; lb.w = 0xFFFFFFFFu; }            // (the count)
     if (k >= m0) la = (u32x4_t)(0xFFFFFFFFu);
     if (16u + k >= m0) lb = (u32x4_t)(0xFFFFFFFFu);
@@ -1228,7 +1289,11 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       stage_rows(s, slot0, w);
     }
     if (SPARSE && sp) {
-      stage_sparse(s, la, lb, tb);
+      if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < s.nb) ? s.hits + 1u : s.nb; }
+#ifndef EPPK_DBG_NO_UNIFORM
+      if (!stage_uniform(s, la, lb, tb))
+#endif
+        stage_sparse(s, la, lb, tb);
     } else {
       LW c[NPL];
       stage_count(s, slot0, w, c);
