@@ -98,33 +98,40 @@ def main() -> None:
 
     dev = torch.device("cuda", local_rank)
     d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
-    # double-buffered picks: the RCCL all-gather of step i (comm stream) overlaps the kernel of step i+1 (compute stream)
-    d_picks = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(2)]
+    # a ring of pick buffers: the RCCL all-gather of step i (comm stream) overlaps the kernels of the following steps (compute
+    # stream).  The compute stream waits for the collectives only once per trip around the ring (a cross-stream barrier packet
+    # in front of every kernel costs more dispatch latency than the kernel can spare at 35 us).
+    NBUF = 8
+    d_picks = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(NBUF)]
     d_score = torch.empty(R, dtype=torch.float64, device=dev)
-    d_alls = [torch.empty(R * world, dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    d_alls = [torch.empty(R * world, dtype=torch.int32, device=dev) for _ in range(NBUF)] if use_dist else None
     # Explicit streams: the kernel and its HIP-event brackets are ordered on `compute`, the collective on `comm`.
     # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
     compute = torch.cuda.Stream(device=dev)
     comm = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(compute)
+    # torch's CURRENT stream is `comm` (c10d enqueues the collective on the current stream); the pick kernel gets `compute`
+    # by handle.  No per-step stream context manager: at 35 us per kernel the host enqueue path is what limits the N > 1 rate.
+    torch.cuda.set_stream(comm if use_dist else compute)
     stream = compute.cuda_stream
     assert stream != 0
-    ev_kernel = [torch.cuda.Event() for _ in range(2)]   # kernel of buffer b finished
-    ev_gather = [torch.cuda.Event() for _ in range(2)]   # all-gather of buffer b finished (buffer reusable)
+    ev_kernel = [torch.cuda.Event() for _ in range(NBUF)]   # kernel of buffer b finished
+    ev_gather = torch.cuda.Event()                           # the all-gather of the last buffer of a trip finished (ring reusable)
     step_no = [0]
 
+    p_reqs, p_score, p_picks = d_reqs.data_ptr(), d_score.data_ptr(), [t.data_ptr() for t in d_picks]
+
     def step():
-        b = step_no[0] & 1
+        b = step_no[0] % NBUF
+        if use_dist and b == 0 and step_no[0]:
+            compute.wait_event(ev_gather)                # every all-gather of the previous trip is done: the ring is free again
         step_no[0] += 1
-        if use_dist:
-            compute.wait_event(ev_gather[b])             # the previous all-gather out of this buffer is done
-        pk.pick_device(d_reqs.data_ptr(), R, None, d_picks[b].data_ptr(), d_score.data_ptr(), stream)
+        pk.pick_device(p_reqs, R, None, p_picks[b], p_score, stream)
         if use_dist:
             ev_kernel[b].record(compute)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev_kernel[b])
-                dist.all_gather_into_tensor(d_alls[b], d_picks[b])
-                ev_gather[b].record(comm)
+            comm.wait_event(ev_kernel[b])
+            dist.all_gather_into_tensor(d_alls[b], d_picks[b])       # on `comm`, the current stream
+            if b == NBUF - 1:
+                ev_gather.record(comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -149,7 +156,7 @@ def main() -> None:
     abytes, lookups, launches = pk.profile_bytes()
     pk.profile(False)
 
-    last = (step_no[0] - 1) & 1
+    last = (step_no[0] - 1) % NBUF
     picks = d_picks[last].cpu().numpy()
     scores = d_score.cpu().numpy()
     if use_dist:
