@@ -114,7 +114,7 @@ def main() -> None:
     torch.cuda.set_stream(comm if use_dist else compute)
     stream = compute.cuda_stream
     assert stream != 0
-    ev_kernel = [torch.cuda.Event() for _ in range(NBUF)]   # kernel of buffer b finished
+    comm_handle = comm.cuda_stream
     ev_gather = torch.cuda.Event()                           # the all-gather of the last buffer of a trip finished (ring reusable)
     step_no = [0]
 
@@ -127,8 +127,7 @@ def main() -> None:
         step_no[0] += 1
         pk.pick_device(p_reqs, R, None, p_picks[b], p_score, stream)
         if use_dist:
-            ev_kernel[b].record(compute)
-            comm.wait_event(ev_kernel[b])
+            pk.stream_wait_pick(comm_handle)                       # comm waits for the kernel's own completion event
             dist.all_gather_into_tensor(d_alls[b], d_picks[b])       # on `comm`, the current stream
             if b == NBUF - 1:
                 ev_gather.record(comm)

@@ -108,6 +108,10 @@ struct eppk_ctx {
   uint64_t fixed_bytes = 0;  // per-launch request/pod/pick bytes accumulated while profiling
   uint32_t launches = 0;
 
+  hipEvent_t last_done = nullptr;     // completion event riding on the most recent pick launch (profiling), else null
+  hipStream_t last_stream = nullptr;  // the stream of that launch
+  hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
+
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
   size_t max_lds = 65536;        // LDS a workgroup may use (160 KB on gfx950)
@@ -246,6 +250,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     void* args[] = {&sn, &ix, &ch, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &topk};
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   }
+  c->last_done = e1;
+  c->last_stream = st;
   if (c->prof) {
     c->fixed_bytes += (uint64_t)c->n_pods * sizeof(eppk_pod_row) + (uint64_t)n_reqs * ((uint64_t)c->stride + 4u);
     c->launches++;
@@ -444,7 +450,8 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
+  if (c->wait_ev) (void)hipEventDestroy(c->wait_ev); (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
@@ -693,6 +700,19 @@ int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
                          d_out_pick + r0, d_out_score ? d_out_score + r0 : nullptr, st);
     if (rc) return rc;
   }
+  return EPPK_OK;
+}
+
+int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
+  if (!c || !waiting_stream) return fail(c, EPPK_ERR_ARG, "eppk_stream_wait_pick: null argument");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipEvent_t ev = c->last_done;
+  if (!ev) {                                  // the launch carried no completion event: record one behind it
+    if (!c->wait_ev) HIPCHK(c, hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
+    ev = c->wait_ev;
+    HIPCHK(c, hipEventRecord(ev, c->last_stream ? c->last_stream : c->stream));
+  }
+  HIPCHK(c, hipStreamWaitEvent((hipStream_t)waiting_stream, ev, 0));
   return EPPK_OK;
 }
 

@@ -249,6 +249,10 @@ class BatchedPicker:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
 
+    def stream_wait_pick(self, waiting_stream: int) -> None:
+        """Make `waiting_stream` (hipStream_t as int) wait for the most recent pick launch (include/eppk.h eppk_stream_wait_pick)."""
+        self._check(self._lib.eppk_stream_wait_pick(self._ctx, waiting_stream), "stream_wait_pick")
+
     def index_insert_picks_device(self, d_reqs: int, d_picks: int, n_reqs: int, stream: int = 0) -> None:
         self._check(self._lib.eppk_index_insert_picks_device(self._ctx, d_reqs, d_picks, n_reqs, stream or None), "index_insert_picks_device")
 

@@ -183,6 +183,10 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
+/* Make `waiting_stream` (a hipStream_t) wait for the most recent pick launch of this context -- a cross-stream dependency
+ * without a separate event record behind the kernel when the launch already carries a completion event (profiling on).
+ * What a caller uses to start a collective or a copy of the picks on another stream (bench.py: the RCCL all-gather). */
+int eppk_stream_wait_pick(eppk_ctx* ctx, void* waiting_stream);
 
 /* Ordered fallbacks: the k (1..EPPK_MAX_TOPK) best candidates of every request under the picker's order (weighted total
  * descending, candidate index ascending).  out_pick[r*k + 0] is exactly eppk_pick_batch's pick, out_pick[r*k + i] the

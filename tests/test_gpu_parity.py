@@ -539,3 +539,32 @@ def test_short_lists_follow_the_dense_rows(pkg, orc, P):
         check("re-inserted")
         pk.index_clear(); oix = orc.OracleIndex()
         check("cleared")
+
+
+@pytest.mark.parametrize("profiling", [False, True])
+def test_stream_wait_pick_orders_a_second_stream(pkg, orc, profiling):
+    """eppk_stream_wait_pick: work enqueued on another stream after it sees the picks of the launch it waited for
+    (with the kernel's own completion event while profiling, with an event recorded behind the launch otherwise)."""
+    import torch
+    wl = pkg.workload.make_workload(3, R=4096, P=1000)
+    with pkg.BatchedPicker(wl.chain, max_pods=1024, max_blocks=wl.B, max_batch=wl.R, index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        oix = orc.OracleIndex(); oix.insert(wl.index_hashes, wl.index_pods)
+        op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+        d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).cuda()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        pk.profile(profiling)
+        for _ in range(5):
+            d_pick = torch.full((wl.R,), -7, dtype=torch.int32, device="cuda")
+            d_copy = torch.full((wl.R,), -9, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            pk.pick_device(d_reqs.data_ptr(), wl.R, None, d_pick.data_ptr(), None, s1.cuda_stream)
+            pk.stream_wait_pick(s2.cuda_stream)
+            with torch.cuda.stream(s2):
+                d_copy.copy_(d_pick, non_blocking=True)
+            s2.synchronize()
+            assert np.array_equal(d_copy.cpu().numpy(), op)
+        if profiling:
+            pk.profile_drain()
+            pk.profile(False)
