@@ -7,6 +7,11 @@ N=1 workload: BASELINE.json configs[4] ("64k req x 4096 pods, full scorer chain 
 configuration the metric is quoted on; it fits one GPU.  N>1: weak scaling, every rank scores its own
 64k-request shard against the replicated snapshot + prefix index, picks are all-gathered.
 
+Batches are independent, so by default two of them are in flight (`--inflight 2`: consecutive launches alternate between two
+streams, which hides the dispatch gap between back-to-back kernels); every launch still processes one whole batch and
+`roofline.kernel_avg_ms` is the per-launch duration measured in the timed region -- about twice the kernel's duration
+with the GPU to itself (`--inflight 1`, or `--alone-ref` for both in one run), because two launches share the GPU.
+
 Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by torch.distributed.run
 (one rank per GPU).  Rank 0 prints ONE JSON line.
 """
@@ -63,6 +68,8 @@ def main() -> None:
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold-cache index variant)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
+    ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams; 1 = strictly back-to-back launches on one stream")
+    ap.add_argument("--alone-ref", action="store_true", help="after the timed region also time 50 launches back to back on one stream (the kernel with the GPU to itself) and report them as roofline.kernel_alone_*")
     ap.add_argument("--host-path", type=int, default=40, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the p99 pick latency a host caller observes; 0 = skip")
     args = ap.parse_args()
 
@@ -103,29 +110,34 @@ def main() -> None:
     # in front of every kernel costs more dispatch latency than the kernel can spare at 35 us).
     NBUF = 8
     d_picks = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(NBUF)]
-    d_score = torch.empty(R, dtype=torch.float64, device=dev)
+    d_scores = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(NBUF)]
     d_alls = [torch.empty(R * world, dtype=torch.int32, device=dev) for _ in range(NBUF)] if use_dist else None
     # Explicit streams: the kernel and its HIP-event brackets are ordered on `compute`, the collective on `comm`.
     # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
-    compute = torch.cuda.Stream(device=dev)
+    # Consecutive batches are independent, so their kernels alternate between TWO compute streams: the next launch is already
+    # queued when a kernel drains and its workgroups start as CUs free up (hides most of the ~5 us dispatch gap between
+    # back-to-back launches on one stream).  Every kernel still processes one whole batch; kernel time is per launch.
+    computes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+    compute = computes[0]
     comm = torch.cuda.Stream(device=dev)
     # torch's CURRENT stream is `comm` (c10d enqueues the collective on the current stream); the pick kernel gets `compute`
     # by handle.  No per-step stream context manager: at 35 us per kernel the host enqueue path is what limits the N > 1 rate.
     torch.cuda.set_stream(comm if use_dist else compute)
-    stream = compute.cuda_stream
-    assert stream != 0
+    streams = [c.cuda_stream for c in computes]
+    assert all(h != 0 for h in streams)
     comm_handle = comm.cuda_stream
     ev_gather = torch.cuda.Event()                           # the all-gather of the last buffer of a trip finished (ring reusable)
     step_no = [0]
 
-    p_reqs, p_score, p_picks = d_reqs.data_ptr(), d_score.data_ptr(), [t.data_ptr() for t in d_picks]
+    p_reqs, p_scores, p_picks = d_reqs.data_ptr(), [t.data_ptr() for t in d_scores], [t.data_ptr() for t in d_picks]
 
     def step():
         b = step_no[0] % NBUF
         if use_dist and b == 0 and step_no[0]:
-            compute.wait_event(ev_gather)                # every all-gather of the previous trip is done: the ring is free again
+            for c in computes:
+                c.wait_event(ev_gather)                  # every all-gather of the previous trip is done: the ring is free again
         step_no[0] += 1
-        pk.pick_device(p_reqs, R, None, p_picks[b], p_score, stream)
+        pk.pick_device(p_reqs, R, None, p_picks[b], p_scores[b], streams[b % len(streams)])
         if use_dist:
             pk.stream_wait_pick(comm_handle)                       # comm waits for the kernel's own completion event
             dist.all_gather_into_tensor(d_alls[b], d_picks[b])       # on `comm`, the current stream
@@ -153,11 +165,18 @@ def main() -> None:
         elapsed = float(t.item())
     kern_ms = pk.profile_drain()
     abytes, lookups, launches = pk.profile_bytes()
+    alone_ms = None
+    if args.alone_ref and world == 1:
+        # reference figure, outside the timed region: the same kernel with the GPU to itself (launches back to back on one stream)
+        for _ in range(60):
+            pk.pick_device(p_reqs, R, None, p_picks[0], p_scores[0], streams[0])
+        torch.cuda.synchronize()
+        alone_ms = np.asarray(pk.profile_drain(), dtype=np.float64)[10:]
     pk.profile(False)
 
     last = (step_no[0] - 1) % NBUF
     picks = d_picks[last].cpu().numpy()
-    scores = d_score.cpu().numpy()
+    scores = d_scores[last].cpu().numpy()
     if use_dist:
         allp = d_alls[last].cpu().numpy()
         assert np.array_equal(allp[rank * R:(rank + 1) * R], picks), "all-gather returned a different shard"
@@ -179,6 +198,7 @@ def main() -> None:
             "config": {"workload": wl.name, "requests_per_gpu": R, "pods": wl.P, "adapters": wl.A, "blocks_per_request": wl.B,
                        "chain": "queue:2,kv:2,lora:1,prefix:3" if args.config in (3, 5) else str(wl.chain),
                        "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} per rank, RCCL all-gather of picks overlapped with the next kernel" if use_dist else "single GPU",
+                       "batches_in_flight": args.inflight,
                        "p99_step_ms": None},
         }
         k = np.asarray(kern_ms, dtype=np.float64)
@@ -213,7 +233,15 @@ def main() -> None:
                            "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lk,
                            "byte_model": "SURVEY 8(d): u64 key + P/8-byte bitmap per index entry (the reference-shaped index)",
                            "layout_bytes_per_launch": layout_bytes,
-                           "layout_GBps": layout_bytes / (avg_ms * 1e-3) / 1e9 if k.size else None}
+                           "layout_GBps": layout_bytes / (avg_ms * 1e-3) / 1e9 if k.size else None,
+                           "launches_in_flight": args.inflight}
+        if alone_ms is not None and alone_ms.size:
+            # with two batches in flight the kernels share the GPU, so each launch lasts about twice as long as it does alone
+            # while two of them finish per that time; `achieved` / `frac` above use the duration measured in the timed region
+            a = float(alone_ms.mean())
+            out["roofline"]["kernel_alone_avg_ms"] = a
+            out["roofline"]["kernel_alone_p99_ms"] = float(np.percentile(alone_ms, 99))
+            out["roofline"]["frac_alone"] = per_launch_bytes / (a * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["config"]["p99_step_ms"] = out["roofline"]["kernel_p99_ms"]
         if args.host_path and world == 1:
             # host-observed pick latency: request rows in host memory -> pinned staging -> H2D -> kernel -> D2H (PCIe-inclusive;

@@ -92,7 +92,10 @@ struct eppk_ctx {
   uint32_t* stamps = nullptr;               // [slots + 2] index epoch of the last insert of every key (ageing)
   uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists beside the dense rows (EPPK_LISTS=0: not maintained)
   uint32_t index_epoch = 1;
-  unsigned long long* stats = nullptr;  // device [4 + 2*kStatSlots]: -, -, occupied keys, dropped inserts, then per-wave {hits, lookups}
+  unsigned long long* stats = nullptr;  // device [4 + kStatBanks*2*kStatSlots]: scratch, live keys, non-empty words, dropped inserts, then
+                                        // banks of per-wave {hits, lookups}: consecutive launches use different banks, so pick
+                                        // kernels overlapping on two streams never share a slot
+  uint32_t stat_bank = 0;
 
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
@@ -121,6 +124,8 @@ struct eppk_ctx {
 };
 
 namespace {
+
+constexpr uint32_t kStatBanks = 4;
 
 int fail(eppk_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -222,7 +227,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
   if (grid < 1) grid = 1;
 
-  unsigned long long* stats = c->prof ? c->stats : nullptr;
+  unsigned long long* stats = c->prof ? c->stats + (size_t)(c->stat_bank++ % kStatBanks) * 2u * kStatSlots : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->ev_used + 2 > c->ev.size()) {
@@ -414,8 +419,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   }
   CHK(hipHostMalloc((void**)&c->h_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row), hipHostMallocDefault));
   CHK(hipMalloc((void**)&c->d_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row)));
-  CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
-  CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots) * sizeof(unsigned long long)));
+  CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
+  CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
   if (cfg->index_slots) {
     c->slots = cfg->index_slots;
     uint32_t lg = 0;
@@ -848,7 +853,7 @@ int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemset(c->stats + 4, 0, 2 * (size_t)kStatSlots * sizeof(unsigned long long)));
+  HIPCHK(c, hipMemset(c->stats + 4, 0, 2 * (size_t)kStatSlots * kStatBanks * sizeof(unsigned long long)));
   c->prof = on != 0;
   c->ev_used = 0;
   c->fixed_bytes = 0;
@@ -875,7 +880,7 @@ int eppk_profile_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* lookups, uint32_t
   if (!c || !bytes) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
-  std::vector<unsigned long long> slots(2 * (size_t)kStatSlots);
+  std::vector<unsigned long long> slots(2 * (size_t)kStatSlots * kStatBanks);
   HIPCHK(c, hipMemcpy(slots.data(), c->stats + 4, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   unsigned long long st[2] = {0, 0};
   for (size_t i = 0; i < slots.size(); i += 2) { st[0] += slots[i]; st[1] += slots[i + 1]; }
