@@ -69,6 +69,7 @@ def main() -> None:
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
     ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams; 1 = strictly back-to-back launches on one stream")
+    ap.add_argument("--gather-every", type=int, default=4, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
     ap.add_argument("--alone-ref", action="store_true", help="after the timed region also time 50 launches back to back on one stream (the kernel with the GPU to itself) and report them as roofline.kernel_alone_*")
     ap.add_argument("--host-path", type=int, default=40, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the p99 pick latency a host caller observes; 0 = skip")
     args = ap.parse_args()
@@ -105,13 +106,18 @@ def main() -> None:
 
     dev = torch.device("cuda", local_rank)
     d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
-    # a ring of pick buffers: the RCCL all-gather of step i (comm stream) overlaps the kernels of the following steps (compute
-    # stream).  The compute stream waits for the collectives only once per trip around the ring (a cross-stream barrier packet
-    # in front of every kernel costs more dispatch latency than the kernel can spare at 35 us).
+    # A ring of NBUF pick buffers (one contiguous tensor).  The picks are all-gathered in BUCKETS of `--gather-every` batches
+    # (default 4): one RCCL call moves the picks of four batches -- a 256 KiB per-rank message is pure latency on xGMI, so
+    # fewer, larger collectives it is -- on the `comm` stream, overlapping the kernels of the following batches.  The
+    # compute streams wait for the collectives once per trip around the ring.
     NBUF = 8
-    d_picks = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(NBUF)]
+    G = max(1, min(args.gather_every, NBUF))
+    while NBUF % G:
+        G -= 1
+    d_picks_all = torch.empty(NBUF * R, dtype=torch.int32, device=dev)
+    d_picks = [d_picks_all[i * R:(i + 1) * R] for i in range(NBUF)]
     d_scores = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(NBUF)]
-    d_alls = [torch.empty(R * world, dtype=torch.int32, device=dev) for _ in range(NBUF)] if use_dist else None
+    d_alls = [torch.empty(world * G * R, dtype=torch.int32, device=dev) for _ in range(NBUF // G)] if use_dist else None
     # Explicit streams: the kernel and its HIP-event brackets are ordered on `compute`, the collective on `comm`.
     # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
     # Consecutive batches are independent, so their kernels alternate between TWO compute streams: the next launch is already
@@ -126,8 +132,18 @@ def main() -> None:
     streams = [c.cuda_stream for c in computes]
     assert all(h != 0 for h in streams)
     comm_handle = comm.cuda_stream
-    ev_gather = torch.cuda.Event()                           # the all-gather of the last buffer of a trip finished (ring reusable)
+    ev_gather = torch.cuda.Event()                           # the all-gather of the last bucket of a trip finished (ring reusable)
     step_no = [0]
+    pending = [0, 0]                                         # first ring slot not yet gathered, number of such slots
+    last_gather = [None]                                     # (bucket tensor view, slots in it) of the most recent all-gather
+
+    def gather_pending():
+        b0, n = pending
+        if n:
+            out = d_alls[b0 // G][: world * n * R]
+            dist.all_gather_into_tensor(out, d_picks_all[b0 * R:(b0 + n) * R])   # on `comm`, the current stream
+            last_gather[0] = (out, n)
+            pending[0], pending[1] = (b0 + n) % NBUF, 0
 
     p_reqs, p_scores, p_picks = d_reqs.data_ptr(), [t.data_ptr() for t in d_scores], [t.data_ptr() for t in d_picks]
 
@@ -140,11 +156,15 @@ def main() -> None:
         pk.pick_device(p_reqs, R, None, p_picks[b], p_scores[b], streams[b % len(streams)])
         if use_dist:
             pk.stream_wait_pick(comm_handle)                       # comm waits for the kernel's own completion event
-            dist.all_gather_into_tensor(d_alls[b], d_picks[b])       # on `comm`, the current stream
-            if b == NBUF - 1:
-                ev_gather.record(comm)
+            pending[1] += 1
+            if (b + 1) % G == 0:
+                gather_pending()
+                if b == NBUF - 1:
+                    ev_gather.record(comm)
 
     def fence():
+        if use_dist:
+            gather_pending()                             # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -178,8 +198,9 @@ def main() -> None:
     picks = d_picks[last].cpu().numpy()
     scores = d_scores[last].cpu().numpy()
     if use_dist:
-        allp = d_alls[last].cpu().numpy()
-        assert np.array_equal(allp[rank * R:(rank + 1) * R], picks), "all-gather returned a different shard"
+        out, n = last_gather[0]                          # layout [world][n][R]; the last step is the last slot of this rank's slab
+        allp = out.cpu().numpy().reshape(world, n, R)
+        assert np.array_equal(allp[rank, n - 1], picks), "all-gather returned a different shard"
 
     if rank == 0:
         out = {
@@ -197,7 +218,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": wl.name, "requests_per_gpu": R, "pods": wl.P, "adapters": wl.A, "blocks_per_request": wl.B,
                        "chain": "queue:2,kv:2,lora:1,prefix:3" if args.config in (3, 5) else str(wl.chain),
-                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} per rank, RCCL all-gather of picks overlapped with the next kernel" if use_dist else "single GPU",
+                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels" if use_dist else "single GPU",
                        "batches_in_flight": args.inflight,
                        "p99_step_ms": None},
         }
