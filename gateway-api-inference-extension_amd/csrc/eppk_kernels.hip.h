@@ -13,8 +13,14 @@
 //   * pod-only scorers that lead the chain are fused on the host into base[p] (same binary64 ops in
 //     the same order, so bit-exact) and staged once per workgroup into LDS; the pair loop is then
 //     two binary64 adds, two LDS table look-ups, and a strict-greater running argmax.
-//   * argmax across lanes: 6-step xor-shuffle on (score desc, index asc).
-//   * no MFMA: this is integer/bit/f64-add work (north_star); the bound is HBM for index rows.
+//   * beside its dense row every index slot keeps the same pod set as a SHORT LIST of 16-bit pod ids (<= 24 members, 64 B):
+//     a request whose hits all have lists is scored from the lists -- one 16-byte load per lane for 16 hits -- and when the
+//     lists are identical (the blocks of a shared prefix are cached together) without any counting at all.
+//   * argmax across lanes: DPP max reduction on the score, ties to the lowest pod index.
+//   * no MFMA: this is integer/bit/f64-add work (north_star); the bound is instruction issue once the index bytes are
+//     lists (HBM for a cold index).
+//   * "EPPK_DBG_NO_UNIFORM" (correct results, slower) sends every list request through the general histogram route: the
+//     GPU suite is run once with such a build whenever that route changes.
 //
 // Replaces (reference, all spec-only or Go): Scorer.Score + weighted sum + Picker.Pick
 //   docs/proposals/0845-scheduler-architecture-proposal/interfaces/interface.go:113-142,
