@@ -110,10 +110,8 @@ def main() -> None:
     # (default 4): one RCCL call moves the picks of four batches -- a 256 KiB per-rank message is pure latency on xGMI, so
     # fewer, larger collectives it is -- on the `comm` stream, overlapping the kernels of the following batches.  The
     # compute streams wait for the collectives once per trip around the ring.
-    NBUF = 8
-    G = max(1, min(args.gather_every, NBUF))
-    while NBUF % G:
-        G -= 1
+    ring = pkg.distributed.GatherRing(nbuf=8, gather_every=args.gather_every)   # the bookkeeping (tests/test_distributed_cpu.py)
+    NBUF, G = ring.nbuf, ring.gather_every
     d_picks_all = torch.empty(NBUF * R, dtype=torch.int32, device=dev)
     d_picks = [d_picks_all[i * R:(i + 1) * R] for i in range(NBUF)]
     d_scores = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(NBUF)]
@@ -133,38 +131,35 @@ def main() -> None:
     assert all(h != 0 for h in streams)
     comm_handle = comm.cuda_stream
     ev_gather = torch.cuda.Event()                           # the all-gather of the last bucket of a trip finished (ring reusable)
-    step_no = [0]
-    pending = [0, 0]                                         # first ring slot not yet gathered, number of such slots
     last_gather = [None]                                     # (bucket tensor view, slots in it) of the most recent all-gather
 
-    def gather_pending():
-        b0, n = pending
-        if n:
-            out = d_alls[b0 // G][: world * n * R]
-            dist.all_gather_into_tensor(out, d_picks_all[b0 * R:(b0 + n) * R])   # on `comm`, the current stream
-            last_gather[0] = (out, n)
-            pending[0], pending[1] = (b0 + n) % NBUF, 0
+    def gather(due):
+        if due is None:
+            return
+        b0, n, closes_trip = due
+        out = d_alls[ring.bucket_of(b0)][: world * n * R]
+        dist.all_gather_into_tensor(out, d_picks_all[b0 * R:(b0 + n) * R])       # on `comm`, the current stream
+        last_gather[0] = (out, n)
+        if closes_trip:
+            ev_gather.record(comm)
 
     p_reqs, p_scores, p_picks = d_reqs.data_ptr(), [t.data_ptr() for t in d_scores], [t.data_ptr() for t in d_picks]
 
     def step():
-        b = step_no[0] % NBUF
-        if use_dist and b == 0 and step_no[0]:
+        if use_dist and ring.begins_trip():
             for c in computes:
                 c.wait_event(ev_gather)                  # every all-gather of the previous trip is done: the ring is free again
-        step_no[0] += 1
+        b = ring.next_slot()
         pk.pick_device(p_reqs, R, None, p_picks[b], p_scores[b], streams[b % len(streams)])
+        due = ring.after_batch()
         if use_dist:
             pk.stream_wait_pick(comm_handle)                       # comm waits for the kernel's own completion event
-            pending[1] += 1
-            if (b + 1) % G == 0:
-                gather_pending()
-                if b == NBUF - 1:
-                    ev_gather.record(comm)
+            gather(due)
 
     def fence():
+        due = ring.flush()
         if use_dist:
-            gather_pending()                             # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
+            gather(due)                                  # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -194,7 +189,7 @@ def main() -> None:
         alone_ms = np.asarray(pk.profile_drain(), dtype=np.float64)[10:]
     pk.profile(False)
 
-    last = (step_no[0] - 1) % NBUF
+    last = (ring.steps - 1) % NBUF
     picks = d_picks[last].cpu().numpy()
     scores = d_scores[last].cpu().numpy()
     if use_dist:

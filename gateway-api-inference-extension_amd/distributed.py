@@ -61,3 +61,60 @@ def sharded_pick(reqs: np.ndarray, mask: Optional[np.ndarray], rank: int, world:
     if hi > lo:
         local[: hi - lo] = pick_fn(reqs[lo:hi], None if mask is None else mask[lo:hi])
     return all_gather_picks(torch.from_numpy(local), n, world, group).numpy()
+
+
+class GatherRing:
+    """Bookkeeping of a ring of `nbuf` per-batch pick buffers whose contents are all-gathered in buckets.
+
+    A stream of batches writes slot `step % nbuf`; after every `gather_every` batches (and whenever `flush()` is called)
+    the slots written since the last collective -- always one contiguous range of at most `gather_every` slots that
+    does not wrap -- are gathered with ONE collective ("fewer, larger collectives": a per-batch message of a few hundred
+    KiB is pure latency on xGMI).  The caller must not let a batch overwrite a slot before the collective that reads
+    it has finished: `begins_trip()` tells when a new trip around the ring starts, which is where bench.py makes
+    the compute streams wait for the last collective of the previous trip.  Pure bookkeeping: no torch in here.
+    """
+
+    def __init__(self, nbuf: int = 8, gather_every: int = 4) -> None:
+        if nbuf < 1:
+            raise ValueError("nbuf must be positive")
+        g = max(1, min(int(gather_every), nbuf))
+        while nbuf % g:          # buckets tile the ring, so a bucket never wraps
+            g -= 1
+        self.nbuf, self.gather_every = nbuf, g
+        self.steps = 0           # batches issued so far
+        self._first = 0          # first slot written but not yet gathered
+        self._count = 0          # number of such slots
+
+    @property
+    def n_buckets(self) -> int:
+        return self.nbuf // self.gather_every
+
+    def begins_trip(self) -> bool:
+        """True iff the NEXT batch starts a new trip around the ring (and it is not the very first batch)."""
+        return self.steps > 0 and self.steps % self.nbuf == 0
+
+    def next_slot(self) -> int:
+        """Slot the next batch writes; call once per batch, before `after_batch()`."""
+        return self.steps % self.nbuf
+
+    def after_batch(self) -> Optional[Tuple[int, int, bool]]:
+        """Account for one issued batch.  Returns (first_slot, n_slots, closes_trip) when a bucket is due, else None;
+        `closes_trip` marks the collective after which the whole ring may be reused."""
+        slot = self.steps % self.nbuf
+        self.steps += 1
+        self._count += 1
+        if (slot + 1) % self.gather_every == 0:
+            return self._take(slot == self.nbuf - 1)
+        return None
+
+    def flush(self) -> Optional[Tuple[int, int, bool]]:
+        """The slots of a partly filled bucket (None if nothing is pending)."""
+        return self._take(False) if self._count else None
+
+    def bucket_of(self, first_slot: int) -> int:
+        return first_slot // self.gather_every
+
+    def _take(self, closes_trip: bool) -> Tuple[int, int, bool]:
+        first, n = self._first, self._count
+        self._first, self._count = (first + n) % self.nbuf, 0
+        return first, n, closes_trip

@@ -1,0 +1,139 @@
+"""bench.py's control flow, end to end on CPU: torch.cuda, the process group and the HIP picker are replaced by stand-ins
+(streams and events that do nothing, gloo, the oracle writing picks through the same raw pointers), so that the N>1 code
+path -- ring of pick buffers, bucketed all-gather, flush before the fence, result checks, the JSON line -- runs here,
+where there is no GPU.  Nothing about speed is asserted: the numbers of such a run are meaningless by construction."""
+import ctypes
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Stream:
+    _next = 1
+
+    def __init__(self, device=None):
+        _Stream._next += 1
+        self.cuda_stream = 0x1000 + _Stream._next
+
+    def wait_event(self, ev):
+        assert ev.recorded, "waiting for an event that was never recorded"
+
+    def synchronize(self):
+        pass
+
+
+class _Event:
+    def __init__(self):
+        self.recorded = False
+
+    def record(self, stream=None):
+        self.recorded = True
+
+
+def _fake_picker_class(pkg, orc, log):
+    class FakePicker:
+        def __init__(self, chain, max_pods, max_blocks, max_batch, index_slots=0, device=0):
+            self.chain, self.B, self.oix, self.pods = chain, max_blocks, orc.OracleIndex(), None
+            self.stride = 8 + 8 * max_blocks
+            self.prof, self.launches, self.last_stream = False, 0, None
+
+        def publish(self, pods):
+            self.pods = pods
+
+        def index_insert(self, h, p):
+            self.oix.insert(h, p)
+
+        def _pick(self, reqs):
+            p, s, _ = orc.pick_batch(self.chain, self.pods, self.oix, reqs, self.B)
+            return p, s
+
+        def pick(self, reqs):
+            return self._pick(reqs)
+
+        def pick_device(self, p_reqs, n, mask, p_pick, p_score, stream=0):
+            assert mask is None and stream != 0
+            raw = (ctypes.c_uint8 * (n * self.stride)).from_address(p_reqs)
+            reqs = np.frombuffer(raw, dtype=np.uint64).reshape(n, 1 + self.B).copy()
+            picks, scores = self._pick(reqs)
+            ctypes.memmove(p_pick, picks.astype(np.int32).ctypes.data, 4 * n)
+            if p_score:
+                ctypes.memmove(p_score, scores.astype(np.float64).ctypes.data, 8 * n)
+            self.launches += self.prof
+            self.last_stream = stream
+            log.append(("pick", p_pick, stream))
+
+        def stream_wait_pick(self, waiting_stream):
+            assert self.last_stream is not None and waiting_stream != self.last_stream
+            log.append(("wait", waiting_stream))
+
+        def profile(self, on):
+            self.prof = bool(on)
+
+        def profile_drain(self):
+            n, self.launches = self.launches, 0
+            return [0.05] * n
+
+        def profile_bytes(self):
+            return 1000 * max(self.launches, 1), 17 * max(self.launches, 1), max(self.launches, 1)
+
+        def close(self):
+            pass
+
+    return FakePicker
+
+
+@pytest.mark.parametrize("argv", [["--force-dist", "--steps", "11", "--warmup", "3"],
+                                  ["--force-dist", "--steps", "8", "--warmup", "8", "--gather-every", "1", "--inflight", "1"],
+                                  ["--steps", "5", "--warmup", "2"]])
+def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+
+    log = []
+    real_device = torch.device
+    monkeypatch.setattr(torch, "device", lambda *a, **k: real_device("cpu"))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "set_stream", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
+    real_init = dist.init_process_group
+    monkeypatch.setattr(dist, "init_process_group", lambda backend=None, device_id=None, **k: real_init("gloo", rank=0, world_size=1))
+    monkeypatch.setattr(pkg, "BatchedPicker", _fake_picker_class(pkg, orc, log))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(29600 + os.getpid() % 300))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "3", "--requests", "96", "--host-path", "3"] + argv)
+    out = io.StringIO()
+    try:
+        with redirect_stdout(out):
+            bench.main()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    d = json.loads(lines[-1])                                           # the JSON line is the last thing on stdout
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["n_gpus"] == 1 and d["unit"] == "decisions/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["steps"] == int(argv[argv.index("--steps") + 1]) and d["parity"]["picks_equal_oracle"]
+    n_picks = sum(1 for e in log if e[0] == "pick")
+    assert n_picks >= d["steps"] + d["warmup"]
+    if "--force-dist" in argv:
+        assert sum(1 for e in log if e[0] == "wait") == d["steps"] + d["warmup"]      # one cross-stream dependency per batch
