@@ -11,6 +11,7 @@ from contextlib import redirect_stdout
 
 import numpy as np
 import pytest
+import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -137,3 +138,44 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     assert n_picks >= d["steps"] + d["warmup"]
     if "--force-dist" in argv:
         assert sum(1 for e in log if e[0] == "wait") == d["steps"] + d["warmup"]      # one cross-stream dependency per batch
+
+
+def _bench_worker(rank, world, port, outdir):
+    """One rank of a world-size-2 dry run: the same stand-ins, patched by hand (no pytest fixtures in a spawned process)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    import bench
+    pkg, orc = g.load_package(), g.load_oracle()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    real_device, real_init = torch.device, dist.init_process_group
+    torch.device = lambda *a, **k: real_device("cpu")
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = torch.cuda.set_stream = torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.Stream, torch.cuda.Event = _Stream, _Event
+    dist.init_process_group = lambda backend=None, device_id=None, **k: real_init("gloo", rank=rank, world_size=world)
+    log = []
+    pkg.BatchedPicker = _fake_picker_class(pkg, orc, log)
+    sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", "64", "--steps", "10", "--warmup", "3"]
+    out = io.StringIO()
+    with redirect_stdout(out):
+        bench.main()
+    with open(os.path.join(outdir, f"bench_rank{rank}.out"), "w") as f:
+        f.write(out.getvalue())
+
+
+def test_bench_two_ranks_on_cpu(tmp_path):
+    """World size 2 over gloo: both ranks run bench.py's N>1 path to the end, rank 0 alone prints the JSON line, with the
+    whole-job aggregate (requests of BOTH ranks) in it."""
+    world = 2
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bench_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
+    out1 = [ln for ln in open(tmp_path / "bench_rank1.out").read().splitlines() if ln.strip()]
+    assert not any(ln.lstrip().startswith("{") for ln in out1)
+    d = json.loads(out0[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["config"]["requests_per_gpu"] == 64
+    assert "cpu_baseline" not in d and "requests/2 per rank" in d["config"]["sharding"]
+    assert abs(d["value"] - 2 * 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
