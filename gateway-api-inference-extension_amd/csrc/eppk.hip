@@ -456,7 +456,8 @@ void eppk_destroy(eppk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
-  if (c->wait_ev) (void)hipEventDestroy(c->wait_ev); (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+  (void)hipFree(c->stats); (void)hipFree(c->pterm);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);

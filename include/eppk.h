@@ -131,7 +131,10 @@ const char* eppk_last_error(const eppk_ctx* ctx);
 
 /* Publish a frozen snapshot of n_pods rows; row i is candidate index i (the order of the
  * `endpoints` slice handed to Pick, handlers/server.go:90; the datastore's PodList order,
- * datastore.go:181-193).  Takes effect for every later pick.  epoch is caller bookkeeping. */
+ * datastore.go:181-193).  Takes effect for every later pick.  epoch is caller bookkeeping.
+ * The snapshot is double buffered: a publish builds the idle buffer, so picks already launched through the *_device entry
+ * points on the caller's own streams keep reading the rows they started with -- across ONE publish; before a second
+ * publish the caller must have synchronised those streams (the host-buffer entry points are synchronous and need nothing). */
 int eppk_snapshot_publish(eppk_ctx* ctx, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch);
 int eppk_snapshot_info(const eppk_ctx* ctx, uint32_t* n_pods, uint64_t* epoch);
 
