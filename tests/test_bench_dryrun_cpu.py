@@ -16,6 +16,15 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 class _Stream:
     _next = 1
 
@@ -112,7 +121,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     monkeypatch.setattr(dist, "init_process_group", lambda backend=None, device_id=None, **k: real_init("gloo", rank=0, world_size=1))
     monkeypatch.setattr(pkg, "BatchedPicker", _fake_picker_class(pkg, orc, log))
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", str(29600 + os.getpid() % 300))
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "3", "--requests", "96", "--host-path", "3"] + argv)
@@ -169,9 +178,7 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     """World size 2 over gloo: both ranks run bench.py's N>1 path to the end, rank 0 alone prints the JSON line, with the
     whole-job aggregate (requests of BOTH ranks) in it."""
     world = 2
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_bench_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
     out1 = [ln for ln in open(tmp_path / "bench_rank1.out").read().splitlines() if ln.strip()]
     assert not any(ln.lstrip().startswith("{") for ln in out1)
