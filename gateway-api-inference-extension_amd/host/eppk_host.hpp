@@ -103,6 +103,8 @@ class Backend {
   virtual int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) = 0;
   // k ordered candidates per request (pick + fallbacks), picks/scores hold n*k entries (eppk_pick_topk)
   virtual int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) = 0;
+  // prefix index: pods[i] has cached the block with hash hashes[i] ("hash(chunk i): append server", 0602-…/README.md:101-108)
+  virtual int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) = 0;
   virtual std::string LastError() const = 0;
 };
 
@@ -121,6 +123,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
     return eppk_pick_topk(ctx_, reqs, n, mask, k, picks, scores);
   }
+  int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) override { return eppk_index_insert(ctx_, hashes, pods, n); }
   std::string LastError() const override { return eppk_last_error(ctx_); }
   eppk_ctx* ctx() { return ctx_; }
 
@@ -135,6 +138,10 @@ struct GpuPickerOptions {
   uint32_t max_pods = 4096, max_blocks = 32, max_batch = 4096, block_chars = 64;
   std::chrono::microseconds window{200};  // how long the dispatcher waits to fill a batch
   uint32_t fallbacks = 0;                 // PickResult.Fallbacks entries to fill (server.go:74), 0..EPPK_MAX_TOPK-1
+  // After every batch record that the picked pod now holds the request's prompt blocks (SEMANTICS.md §6; "the approximate
+  // prefix cache index is updated after a request is routed", 0602-…/README.md:101-108).  Needs a context created with an
+  // index (index_slots > 0); a full table is not an error of the pick: the update is dropped and counted.
+  bool learn_prefixes = false;
 };
 
 class GpuPicker : public EndpointPicker {
@@ -187,6 +194,7 @@ class GpuPicker : public EndpointPicker {
   uint64_t batches() const { return batches_.load(); }
   uint64_t fail_opens() const { return fail_open_count_.load(); }
   uint64_t largest_batch() const { return largest_batch_.load(); }
+  uint64_t learn_drops() const { return learn_drops_.load(); }
 
  private:
   struct Snapshot {
@@ -209,6 +217,8 @@ class GpuPicker : public EndpointPicker {
     std::vector<uint64_t> mask;
     std::vector<int32_t> picks;
     std::vector<double> scores;
+    std::vector<uint64_t> learn_h;
+    std::vector<uint32_t> learn_p;
     std::unique_lock<std::mutex> g(mu_);
     for (;;) {
       cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
@@ -270,6 +280,20 @@ class GpuPicker : public EndpointPicker {
                 else batch[i]->fallbacks.push_back(JoinHostPort(e.address, e.port));
               }
             }
+          if (!failed && opt_.learn_prefixes) {  // index[hash[r][i]] gains pick[r], for every block of every routed request
+            learn_h.clear();
+            learn_p.clear();
+            for (size_t i = 0; i < n; ++i) {
+              const int32_t p = picks[i * k];
+              if (p < 0) continue;
+              eppk_req_hdr hdr;
+              std::memcpy(&hdr, rows.data() + i * stride_, sizeof hdr);
+              const uint64_t* h = (const uint64_t*)(rows.data() + i * stride_ + 8);
+              for (uint32_t b = 0; b < hdr.n_blocks; ++b) { learn_h.push_back(h[b]); learn_p.push_back((uint32_t)p); }
+            }
+            if (!learn_h.empty() && be_->IndexInsert(learn_h.data(), learn_p.data(), (uint32_t)learn_h.size()) != EPPK_OK)
+              learn_drops_.fetch_add(1, std::memory_order_relaxed);  // (e.g. EPPK_ERR_INDEX_FULL: the picks themselves stand)
+          }
         }
       }
       g.lock();
@@ -290,7 +314,7 @@ class GpuPicker : public EndpointPicker {
   std::vector<Slot*> queue_;
   std::shared_ptr<Snapshot> snap_;
   bool stop_ = false;
-  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0};
+  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0};
   std::thread th_;  // last member: started after everything above is constructed
 };
 

@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
+#include <utility>
 
 #include "eppk_host.hpp"
 
@@ -49,7 +51,16 @@ class FakeBackend : public Backend {
     }
     return EPPK_OK;
   }
+  int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) override {
+    std::lock_guard<std::mutex> g(learn_mu);
+    if (index_full) return EPPK_ERR_INDEX_FULL;
+    for (uint32_t i = 0; i < n; ++i) learned.emplace_back(hashes[i], pods[i]);
+    return EPPK_OK;
+  }
   std::string LastError() const override { return "fake failure"; }
+  std::mutex learn_mu;
+  std::vector<std::pair<uint64_t, uint32_t>> learned;
+  std::atomic<bool> index_full{false};
   std::vector<eppk_pod_row> rows_;
   std::atomic<int> calls{0};
   std::atomic<bool> fail{false};
@@ -152,6 +163,36 @@ static int run_cpu() {
     CHECK(r.fallbacks.size() == 2 && r.fallbacks[0] == "10.0.0.5:8080" && r.fallbacks[1] == "10.0.0.1:8080");
     std::vector<const Endpoint*> one{&eps[2]};                            // fewer candidates than requested fallbacks
     CHECK(gp.Pick(rq, one, &r).ok() && r.endpoint == "10.0.0.3:8080" && r.fallbacks.empty());
+  }
+  {  // learn_prefixes: after a batch the picked pod is recorded for every block hash of the request's prompt
+    auto eps = make_endpoints(3);
+    std::vector<eppk_pod_row> rows(3);
+    std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+    const uint32_t q[3] = {4, 2, 6};
+    for (int i = 0; i < 3; ++i) rows[(size_t)i].queue = q[i];
+    GpuPickerOptions opt;
+    opt.max_pods = 64; opt.max_blocks = 4; opt.max_batch = 8; opt.block_chars = 8; opt.learn_prefixes = true;
+    auto fk = new FakeBackend();
+    GpuPicker gp(std::unique_ptr<Backend>(fk), opt);
+    CHECK(gp.PublishSnapshot(eps, rows, {}, 1).ok());
+    std::vector<const Endpoint*> c{&eps[0], &eps[1], &eps[2]};
+    PickRequest rq;
+    rq.model = "base";
+    rq.body = "0123456789abcdefXYZ";          // two full 8-character blocks (+ a 3-character tail that is not a block)
+    PickResult r;
+    CHECK(gp.Pick(rq, c, &r).ok() && r.endpoint == "10.0.0.2:8080");
+    uint64_t want[4];
+    const int nb = eppk_hash_prompt((const uint8_t*)rq.model.data(), rq.model.size(), (const uint8_t*)rq.body.data(), rq.body.size(), 8, want, 4);
+    CHECK(nb == 2);
+    {
+      std::lock_guard<std::mutex> g(fk->learn_mu);
+      CHECK(fk->learned.size() == 2 && fk->learned[0] == std::make_pair(want[0], 1u) && fk->learned[1] == std::make_pair(want[1], 1u));
+    }
+    PickRequest empty;                        // no blocks: nothing to learn, no backend call needed
+    CHECK(gp.Pick(empty, c, &r).ok());
+    { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->learned.size() == 2); }
+    fk->index_full = true;                    // a full table never fails the pick; the drop is counted
+    CHECK(gp.Pick(rq, c, &r).ok() && r.endpoint == "10.0.0.2:8080" && gp.learn_drops() == 1 && gp.fail_opens() == 0);
   }
   return 0;
 }
