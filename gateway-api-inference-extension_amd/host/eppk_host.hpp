@@ -16,11 +16,13 @@
 // picker must never take the stream down).  Nothing here scores on the CPU.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -105,6 +107,8 @@ class Backend {
   virtual int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) = 0;
   // prefix index: pods[i] has cached the block with hash hashes[i] ("hash(chunk i): append server", 0602-…/README.md:101-108)
   virtual int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) = 0;
+  // prefix index: forget everything recorded for candidate index `pod` (its slot is about to be handed to another endpoint)
+  virtual int IndexRemovePod(uint32_t pod) = 0;
   virtual std::string LastError() const = 0;
 };
 
@@ -124,6 +128,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
     return eppk_pick_topk(ctx_, reqs, n, mask, k, picks, scores);
   }
   int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) override { return eppk_index_insert(ctx_, hashes, pods, n); }
+  int IndexRemovePod(uint32_t pod) override { return eppk_index_remove_pod(ctx_, pod); }
   std::string LastError() const override { return eppk_last_error(ctx_); }
   eppk_ctx* ctx() { return ctx_; }
 
@@ -142,6 +147,12 @@ struct GpuPickerOptions {
   // prefix cache index is updated after a request is routed", 0602-…/README.md:101-108).  Needs a context created with an
   // index (index_slots > 0); a full table is not an error of the pick: the update is dropped and counted.
   bool learn_prefixes = false;
+  // Stable candidate slots under churn.  The prefix index stores candidate indices, so an endpoint must
+  // keep its index from one snapshot to the next: with this option an endpoint ("ip:port") keeps the slot it was first given,
+  // a slot freed by a departed endpoint is wiped from the index (eppk_index_remove_pod) and handed to the next newcomer, and the
+  // slots that are empty in between are published as copies of an active row (the snapshot-wide QUEUE normalisers stay those
+  // of the active pods) and kept out of every request's candidate mask.  While holes exist every batch is a masked batch.
+  bool stable_slots = false;
 };
 
 class GpuPicker : public EndpointPicker {
@@ -160,14 +171,74 @@ class GpuPicker : public EndpointPicker {
                          const std::unordered_map<std::string, int32_t>& adapters, uint64_t epoch) {
     if (endpoints.size() != rows.size()) return {Code::Internal, "endpoints/rows size mismatch"};
     auto snap = std::make_shared<Snapshot>();
-    snap->endpoints = endpoints;
     snap->adapters = adapters;
-    for (size_t i = 0; i < endpoints.size(); ++i) snap->by_addr[JoinHostPort(endpoints[i].address, endpoints[i].port)] = (uint32_t)i;
     std::lock_guard<std::mutex> bg(be_mu_);  // serialised with the dispatcher's PickBatch (contexts are single-caller)
-    if (be_->Publish(rows.data(), (uint32_t)rows.size(), epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
+    if (!opt_.stable_slots) {
+      snap->endpoints = endpoints;
+      snap->n_active = (uint32_t)endpoints.size();
+      for (size_t i = 0; i < endpoints.size(); ++i) snap->by_addr[JoinHostPort(endpoints[i].address, endpoints[i].port)] = (uint32_t)i;
+      if (be_->Publish(rows.data(), (uint32_t)rows.size(), epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
+    } else {
+      // 1. endpoints that left free their slots (lowest slot first is reused first: the table stays as dense as the churn allows)
+      std::unordered_map<std::string, size_t> now;
+      for (size_t i = 0; i < endpoints.size(); ++i) now[JoinHostPort(endpoints[i].address, endpoints[i].port)] = i;
+      if (now.size() != endpoints.size()) return {Code::Internal, "duplicate endpoint address in snapshot"};
+      {  // refuse before anything is changed: newcomers must fit into freed + free + never-used slots
+        size_t staying = 0;
+        for (const auto& kv : slot_of_) staying += now.count(kv.first);
+        const size_t newcomers = endpoints.size() - staying, leavers = slot_of_.size() - staying;
+        if (newcomers > leavers + free_slots_.size() + (size_t)(opt_.max_pods - n_slots_)) return {Code::Internal, "more endpoints than max_pods"};
+      }
+      for (auto it = slot_of_.begin(); it != slot_of_.end();) {
+        if (now.count(it->first)) { ++it; continue; }
+        if (be_->IndexRemovePod(it->second) != EPPK_OK) return {Code::Internal, be_->LastError()};
+        free_slots_.push_back(it->second);
+        it = slot_of_.erase(it);
+      }
+      std::sort(free_slots_.begin(), free_slots_.end(), std::greater<uint32_t>());   // back() = lowest free slot
+      // 2. newcomers take free slots, then fresh ones
+      for (size_t i = 0; i < endpoints.size(); ++i) {
+        const std::string key = JoinHostPort(endpoints[i].address, endpoints[i].port);
+        if (slot_of_.count(key)) continue;
+        uint32_t slot;
+        if (!free_slots_.empty()) { slot = free_slots_.back(); free_slots_.pop_back(); }
+        else if (n_slots_ < opt_.max_pods) slot = n_slots_++;
+        else return {Code::Internal, "more endpoints than max_pods"};
+        slot_of_[key] = slot;
+      }
+      while (n_slots_ > 0 && std::find(free_slots_.begin(), free_slots_.end(), n_slots_ - 1) != free_slots_.end()) {   // trailing holes: shrink
+        free_slots_.erase(std::find(free_slots_.begin(), free_slots_.end(), n_slots_ - 1));
+        --n_slots_;
+      }
+      // 3. rows by slot; a hole repeats an active row so that it moves neither the minimum nor the maximum queue depth
+      std::vector<eppk_pod_row> by_slot(n_slots_);
+      std::vector<bool> active(n_slots_, false);
+      snap->endpoints.assign(n_slots_, Endpoint());
+      for (size_t i = 0; i < endpoints.size(); ++i) {
+        const std::string key = JoinHostPort(endpoints[i].address, endpoints[i].port);
+        const uint32_t slot = slot_of_[key];
+        by_slot[slot] = rows[i];
+        active[slot] = true;
+        snap->endpoints[slot] = endpoints[i];
+        snap->by_addr[key] = slot;
+      }
+      snap->n_active = (uint32_t)endpoints.size();
+      if (!endpoints.empty())
+        for (uint32_t sidx = 0; sidx < n_slots_; ++sidx)
+          if (!active[sidx]) by_slot[sidx] = rows[0];
+      if (be_->Publish(by_slot.data(), n_slots_, epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
+    }
     std::lock_guard<std::mutex> g(mu_);
     snap_ = snap;
     return {};
+  }
+
+  // candidate index of an endpoint in the current snapshot (-1: unknown) -- tests and diagnostics
+  int32_t SlotOf(const std::string& addr_port) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!snap_) return -1;
+    auto it = snap_->by_addr.find(addr_port);
+    return it == snap_->by_addr.end() ? -1 : (int32_t)it->second;
   }
 
   // server.go:79-82 — safe to call from many threads; returns when this request's batch has been picked.
@@ -198,7 +269,8 @@ class GpuPicker : public EndpointPicker {
 
  private:
   struct Snapshot {
-    std::vector<Endpoint> endpoints;
+    std::vector<Endpoint> endpoints;  // by candidate index (stable_slots: by slot, holes are default-constructed)
+    uint32_t n_active = 0;            // endpoints that are candidates (== endpoints.size() unless there are holes)
     std::unordered_map<std::string, uint32_t> by_addr;
     std::unordered_map<std::string, int32_t> adapters;
   };
@@ -260,7 +332,7 @@ class GpuPicker : public EndpointPicker {
               if (!(mask[i * W + (a->second >> 6)] & bit)) ++found;
               mask[i * W + (a->second >> 6)] |= bit;
             }
-            if (found != P) any_mask = true;
+            if (found != P) any_mask = true;   // (a snapshot with holes has n_active < P: every request is masked)
           }
           const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
           picks.resize(n * k);
@@ -313,6 +385,10 @@ class GpuPicker : public EndpointPicker {
   std::condition_variable cv_, done_cv_;
   std::vector<Slot*> queue_;
   std::shared_ptr<Snapshot> snap_;
+  // stable_slots (guarded by be_mu_): "ip:port" -> slot across snapshots, freed slots, high-water mark
+  std::unordered_map<std::string, uint32_t> slot_of_;
+  std::vector<uint32_t> free_slots_;
+  uint32_t n_slots_ = 0;
   bool stop_ = false;
   std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0};
   std::thread th_;  // last member: started after everything above is constructed

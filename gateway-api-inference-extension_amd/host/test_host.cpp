@@ -57,7 +57,13 @@ class FakeBackend : public Backend {
     for (uint32_t i = 0; i < n; ++i) learned.emplace_back(hashes[i], pods[i]);
     return EPPK_OK;
   }
+  int IndexRemovePod(uint32_t pod) override {
+    std::lock_guard<std::mutex> g(learn_mu);
+    removed.push_back(pod);
+    return EPPK_OK;
+  }
   std::string LastError() const override { return "fake failure"; }
+  std::vector<uint32_t> removed;
   std::mutex learn_mu;
   std::vector<std::pair<uint64_t, uint32_t>> learned;
   std::atomic<bool> index_full{false};
@@ -193,6 +199,47 @@ static int run_cpu() {
     { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->learned.size() == 2); }
     fk->index_full = true;                    // a full table never fails the pick; the drop is counted
     CHECK(gp.Pick(rq, c, &r).ok() && r.endpoint == "10.0.0.2:8080" && gp.learn_drops() == 1 && gp.fail_opens() == 0);
+  }
+  {  // stable_slots: an endpoint keeps its candidate index across snapshots; a freed slot is wiped from the index, is never
+     // picked while it is a hole, and goes to the next newcomer
+    GpuPickerOptions opt;
+    opt.max_pods = 8; opt.max_blocks = 4; opt.max_batch = 8; opt.stable_slots = true;
+    auto fk = new FakeBackend();
+    GpuPicker gp(std::unique_ptr<Backend>(fk), opt);
+    auto eps = make_endpoints(4);                       // A=.1 B=.2 C=.3 D=.4
+    auto row = [](uint32_t q) { eppk_pod_row r; std::memset(&r, 0, sizeof r); r.queue = q; return r; };
+    CHECK(gp.PublishSnapshot({eps[0], eps[1], eps[2]}, {row(5), row(1), row(7)}, {}, 1).ok());
+    CHECK(gp.SlotOf("10.0.0.1:8080") == 0 && gp.SlotOf("10.0.0.2:8080") == 1 && gp.SlotOf("10.0.0.3:8080") == 2);
+    std::vector<const Endpoint*> abc{&eps[0], &eps[1], &eps[2]};
+    PickResult r;
+    CHECK(gp.Pick({}, abc, &r).ok() && r.endpoint == "10.0.0.2:8080");            // B has the shortest queue
+    // B leaves: C keeps slot 2, slot 1 becomes a hole (published as a copy of A's row) and is wiped from the index
+    CHECK(gp.PublishSnapshot({eps[0], eps[2]}, {row(5), row(7)}, {}, 2).ok());
+    CHECK(gp.SlotOf("10.0.0.3:8080") == 2 && gp.SlotOf("10.0.0.2:8080") == -1);
+    { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->removed.size() == 1 && fk->removed[0] == 1u); }
+    CHECK(fk->rows_.size() == 3 && fk->rows_[1].queue == 5u);
+    std::vector<const Endpoint*> ac{&eps[0], &eps[2]};
+    CHECK(gp.Pick({}, ac, &r).ok() && r.endpoint == "10.0.0.1:8080");             // never the hole
+    CHECK(gp.Pick({}, abc, &r).ok() && r.endpoint == "10.0.0.1:8080");            // a stale candidate (B) is simply not scoreable
+    // D arrives and takes the hole; A leaves at the same time; C is still slot 2
+    CHECK(gp.PublishSnapshot({eps[2], eps[3]}, {row(7), row(3)}, {}, 3).ok());
+    CHECK(gp.SlotOf("10.0.0.3:8080") == 2 && gp.SlotOf("10.0.0.1:8080") == -1);
+    const int32_t d = gp.SlotOf("10.0.0.4:8080");
+    CHECK(d == 0 || d == 1);                                                       // one of the two freed slots (the lowest: 0)
+    CHECK(d == 0);
+    { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->removed.size() == 2 && fk->removed[1] == 0u); }
+    std::vector<const Endpoint*> cd{&eps[2], &eps[3]};
+    CHECK(gp.Pick({}, cd, &r).ok() && r.endpoint == "10.0.0.4:8080");
+    // everything leaves, then one endpoint comes back: the table shrinks to nothing and starts again at slot 0
+    CHECK(gp.PublishSnapshot({}, {}, {}, 4).ok() && fk->rows_.empty());
+    CHECK(gp.PublishSnapshot({eps[1]}, {row(2)}, {}, 5).ok() && gp.SlotOf("10.0.0.2:8080") == 0 && fk->rows_.size() == 1);
+    // trailing holes shrink the published table
+    CHECK(gp.PublishSnapshot({eps[1], eps[0], eps[2]}, {row(2), row(4), row(6)}, {}, 6).ok() && fk->rows_.size() == 3);
+    CHECK(gp.PublishSnapshot({eps[1]}, {row(2)}, {}, 7).ok() && fk->rows_.size() == 1);
+    // more endpoints than max_pods is an error, not a crash
+    auto many = make_endpoints(9);
+    std::vector<eppk_pod_row> mrows(9, row(1));
+    CHECK(!gp.PublishSnapshot(many, mrows, {}, 8).ok());
   }
   return 0;
 }
