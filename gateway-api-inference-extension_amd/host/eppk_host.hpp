@@ -109,6 +109,9 @@ class Backend {
   virtual int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) = 0;
   // prefix index: forget everything recorded for candidate index `pod` (its slot is about to be handed to another endpoint)
   virtual int IndexRemovePod(uint32_t pod) = 0;
+  // prefix index ageing: tick the epoch that stamps later inserts / drop every hash last stamped before min_epoch
+  virtual int IndexAdvanceEpoch(uint32_t* new_epoch) = 0;
+  virtual int IndexEvictOlder(uint32_t min_epoch, uint32_t* n_evicted) = 0;
   virtual std::string LastError() const = 0;
 };
 
@@ -129,6 +132,8 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   }
   int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) override { return eppk_index_insert(ctx_, hashes, pods, n); }
   int IndexRemovePod(uint32_t pod) override { return eppk_index_remove_pod(ctx_, pod); }
+  int IndexAdvanceEpoch(uint32_t* e) override { return eppk_index_advance_epoch(ctx_, e); }
+  int IndexEvictOlder(uint32_t min_epoch, uint32_t* n) override { return eppk_index_evict_older(ctx_, min_epoch, n); }
   std::string LastError() const override { return eppk_last_error(ctx_); }
   eppk_ctx* ctx() { return ctx_; }
 
@@ -153,6 +158,11 @@ struct GpuPickerOptions {
   // slots that are empty in between are published as copies of an active row (the snapshot-wide QUEUE normalisers stay those
   // of the active pods) and kept out of every request's candidate mask.  While holes exist every batch is a masked batch.
   bool stable_slots = false;
+  // Ageing of the learned prefixes -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)",
+  // 0602-…/README.md:82.  Every `index_epoch_interval` the dispatcher ticks the index epoch (between two batches) and drops the
+  // hashes that were not re-inserted during the last `index_keep_epochs` epochs.  0 = no ageing.
+  std::chrono::microseconds index_epoch_interval{0};
+  uint32_t index_keep_epochs = 8;
 };
 
 class GpuPicker : public EndpointPicker {
@@ -266,6 +276,7 @@ class GpuPicker : public EndpointPicker {
   uint64_t fail_opens() const { return fail_open_count_.load(); }
   uint64_t largest_batch() const { return largest_batch_.load(); }
   uint64_t learn_drops() const { return learn_drops_.load(); }
+  uint64_t evicted() const { return evicted_.load(); }
 
  private:
   struct Snapshot {
@@ -291,6 +302,7 @@ class GpuPicker : public EndpointPicker {
     std::vector<double> scores;
     std::vector<uint64_t> learn_h;
     std::vector<uint32_t> learn_p;
+    auto next_tick = std::chrono::steady_clock::now() + opt_.index_epoch_interval;
     std::unique_lock<std::mutex> g(mu_);
     for (;;) {
       cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
@@ -366,6 +378,13 @@ class GpuPicker : public EndpointPicker {
             if (!learn_h.empty() && be_->IndexInsert(learn_h.data(), learn_p.data(), (uint32_t)learn_h.size()) != EPPK_OK)
               learn_drops_.fetch_add(1, std::memory_order_relaxed);  // (e.g. EPPK_ERR_INDEX_FULL: the picks themselves stand)
           }
+          if (opt_.index_epoch_interval.count() > 0 && std::chrono::steady_clock::now() >= next_tick) {
+            next_tick = std::chrono::steady_clock::now() + opt_.index_epoch_interval;
+            uint32_t epoch = 0, gone = 0;
+            if (be_->IndexAdvanceEpoch(&epoch) == EPPK_OK && epoch > opt_.index_keep_epochs &&
+                be_->IndexEvictOlder(epoch - opt_.index_keep_epochs, &gone) == EPPK_OK)
+              evicted_.fetch_add(gone, std::memory_order_relaxed);
+          }
         }
       }
       g.lock();
@@ -390,7 +409,7 @@ class GpuPicker : public EndpointPicker {
   std::vector<uint32_t> free_slots_;
   uint32_t n_slots_ = 0;
   bool stop_ = false;
-  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0};
+  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0}, evicted_{0};
   std::thread th_;  // last member: started after everything above is constructed
 };
 

@@ -62,7 +62,16 @@ class FakeBackend : public Backend {
     removed.push_back(pod);
     return EPPK_OK;
   }
+  int IndexAdvanceEpoch(uint32_t* e) override { *e = ++epoch; return EPPK_OK; }
+  int IndexEvictOlder(uint32_t min_epoch, uint32_t* n) override {
+    std::lock_guard<std::mutex> g(learn_mu);
+    evict_calls.push_back(min_epoch);
+    *n = 3;
+    return EPPK_OK;
+  }
   std::string LastError() const override { return "fake failure"; }
+  std::atomic<uint32_t> epoch{1};
+  std::vector<uint32_t> evict_calls;
   std::vector<uint32_t> removed;
   std::mutex learn_mu;
   std::vector<std::pair<uint64_t, uint32_t>> learned;
@@ -240,6 +249,29 @@ static int run_cpu() {
     auto many = make_endpoints(9);
     std::vector<eppk_pod_row> mrows(9, row(1));
     CHECK(!gp.PublishSnapshot(many, mrows, {}, 8).ok());
+  }
+  {  // index ageing: the dispatcher ticks the epoch between batches and evicts what is older than `index_keep_epochs`
+    GpuPickerOptions opt;
+    opt.max_pods = 8; opt.max_blocks = 4; opt.max_batch = 4;
+    opt.index_epoch_interval = std::chrono::microseconds(1);   // every batch is later than the previous tick
+    opt.index_keep_epochs = 2;
+    auto fk = new FakeBackend();
+    GpuPicker gp(std::unique_ptr<Backend>(fk), opt);
+    auto eps = make_endpoints(2);
+    std::vector<eppk_pod_row> rows(2);
+    std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+    CHECK(gp.PublishSnapshot(eps, rows, {}, 1).ok());
+    std::vector<const Endpoint*> c{&eps[0], &eps[1]};
+    PickResult r;
+    for (int i = 0; i < 4; ++i) {
+      CHECK(gp.Pick({}, c, &r).ok());
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    std::lock_guard<std::mutex> g(fk->learn_mu);
+    // epochs 2, 3, 4, 5 after the four batches; eviction starts once the epoch exceeds keep (3 -> evict < 1, 4 -> < 2, 5 -> < 3)
+    CHECK(fk->epoch.load() == 5u);
+    CHECK(fk->evict_calls.size() == 3 && fk->evict_calls[0] == 1u && fk->evict_calls[1] == 2u && fk->evict_calls[2] == 3u);
+    CHECK(gp.evicted() == 9u);
   }
   return 0;
 }
