@@ -163,3 +163,32 @@ def test_golden_vectors_regenerate_identically(tmp_path):
     for k in a.files:
         x, y = a[k], b[k]
         assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes(), k
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
+    """Differential test of the two independent CPU restatements (oracle/oracle.c: per-request loops; tests/golden/gen_golden.py:
+    whole-matrix numpy) on fresh random cases: random chains (any order, duplicates, negative weights), masks, tie-heavy gauges,
+    removed pods, 0..12 blocks.  Picks identical, scores bitwise identical."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gg)
+    rng = np.random.Generator(np.random.PCG64(900000 + seed))
+    P = int(rng.choice([1, 2, 17, 63, 64, 65, 130, 200]))
+    B = int(rng.choice([0, 1, 3, 8, 12]))
+    kinds = [gg.Q, gg.KV, gg.L] + ([gg.PF] if B else [])
+    chain = [(int(rng.choice(kinds)), int(rng.integers(-3, 6))) for _ in range(int(rng.integers(1, 7)))]
+    removed = tuple(int(x) for x in rng.choice(P, size=int(rng.integers(0, min(P, 4))), replace=False)) if rng.random() < 0.3 else ()
+    c = gg.rand_case(rng, 32, P, B, chain, masked=bool(rng.random() < 0.5), n_groups=int(rng.integers(1, 5)),
+                     tie_heavy=bool(rng.random() < 0.4), removed=removed)
+    hashes = c["hashes"][:, :B] if B else None
+    reqs = pkg.picker.make_req_rows(c["adapter"], c["n_blocks"], hashes, B)
+    oix = orc.OracleIndex()
+    oix.insert(c["index_hashes"], c["index_pods"])
+    for p in removed:
+        oix.remove_pod(p)
+    mask = c["mask"] if c["mask"].size else None
+    picks, scores, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, mask)
+    assert np.array_equal(picks, c["pick"]), (seed, chain, P, B)
+    assert np.array_equal(scores.view(np.uint64), c["score"].view(np.uint64)), (seed, chain, P, B)
