@@ -38,6 +38,32 @@ def popcount128(words):
 
 def numpy_pick(chain, pods, index, adapter, n_blocks, hashes, mask):
     """SEMANTICS.md §2-3 in matrix form. index: dict hash -> set(pod). mask: [R, W] u64 or None."""
+    total, cand = numpy_totals(chain, pods, index, adapter, n_blocks, hashes, mask)
+    R, P = total.shape
+    masked_total = np.where(cand, total, -np.inf)
+    pick = np.argmax(masked_total, axis=1).astype(np.int32) if P else np.zeros(R, np.int32)
+    has = cand.any(axis=1) if P else np.zeros(R, bool)
+    score = np.where(has, total[np.arange(R), pick] if P else 0.0, 0.0)
+    pick = np.where(has, pick, -1).astype(np.int32)
+    return pick, score.astype(np.float64)
+
+
+def numpy_topk(chain, pods, index, adapter, n_blocks, hashes, mask, k):
+    """Ordered fallbacks (SEMANTICS.md §3a): the k best candidates under (total descending, index ascending), -1 / 0.0 padded."""
+    total, cand = numpy_totals(chain, pods, index, adapter, n_blocks, hashes, mask)
+    R, P = total.shape
+    picks = np.full((R, k), -1, dtype=np.int32)
+    scores = np.zeros((R, k), dtype=np.float64)
+    for r in range(R):
+        c = np.nonzero(cand[r])[0]
+        order = c[np.argsort(-total[r, c], kind="stable")][:k]   # stable: equal totals stay in index order
+        picks[r, :order.size] = order
+        scores[r, :order.size] = total[r, order]
+    return picks, scores
+
+
+def numpy_totals(chain, pods, index, adapter, n_blocks, hashes, mask):
+    """Weighted totals [R, P] (binary64, scorers added in chain order) and the candidate matrix [R, P]."""
     R, P = adapter.shape[0], pods.shape[0]
     if mask is None:
         cand = np.ones((R, P), dtype=bool)
@@ -83,12 +109,7 @@ def numpy_pick(chain, pods, index, adapter, n_blocks, hashes, mask):
         else:
             raise ValueError(kind)
         total = total + clamp01(s) * float(w)
-    masked_total = np.where(cand, total, -np.inf)
-    pick = np.argmax(masked_total, axis=1).astype(np.int32) if P else np.zeros(R, np.int32)
-    has = cand.any(axis=1) if P else np.zeros(R, bool)
-    score = np.where(has, total[np.arange(R), pick] if P else 0.0, 0.0)
-    pick = np.where(has, pick, -1).astype(np.int32)
-    return pick, score.astype(np.float64)
+    return total, cand
 
 
 def rand_pods(rng, P, A=128, tie_heavy=False):

@@ -192,3 +192,15 @@ def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
     picks, scores, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, mask)
     assert np.array_equal(picks, c["pick"]), (seed, chain, P, B)
     assert np.array_equal(scores.view(np.uint64), c["score"].view(np.uint64)), (seed, chain, P, B)
+    # ordered fallbacks (SEMANTICS.md §3a): the oracle's list against the matrix form's stable sort
+    index = {}
+    for h, p_ in zip(c["index_hashes"].tolist(), c["index_pods"].tolist()):
+        index.setdefault(h, set()).add(p_)
+    for p_ in removed:
+        for s_ in index.values():
+            s_.discard(p_)
+    k = int(rng.integers(1, 9))
+    want_p, want_s = gg.numpy_topk(chain, c["pods"], index, c["adapter"], c["n_blocks"], c["hashes"], mask, k)
+    got_p, got_s = orc.pick_topk(chain, c["pods"], oix, reqs, k, mask)
+    assert np.array_equal(got_p, want_p), (seed, chain, P, B, k)
+    assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64)), (seed, chain, P, B, k)
