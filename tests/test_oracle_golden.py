@@ -204,3 +204,93 @@ def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
     got_p, got_s = orc.pick_topk(chain, c["pods"], oix, reqs, k, mask)
     assert np.array_equal(got_p, want_p), (seed, chain, P, B, k)
     assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64)), (seed, chain, P, B, k)
+
+
+class _DictIndex:
+    """SEMANTICS.md §6 / §6a as a dict of sets with per-hash stamps -- a second statement of the index state rules."""
+
+    def __init__(self):
+        self.sets, self.stamp, self.epoch = {}, {}, 1
+
+    def insert(self, hashes, pods):
+        for h, p in zip(hashes, pods):
+            self.sets.setdefault(int(h), set()).add(int(p))
+            self.stamp[int(h)] = self.epoch                      # every insert stamps the hash, present pod or not
+
+    def remove_pod(self, pod):
+        for h in list(self.sets):
+            self.sets[h].discard(pod)
+            if not self.sets[h]:
+                del self.sets[h]                                 # an empty set behaves as absent
+
+    def advance_epoch(self):
+        self.epoch += 1
+        return self.epoch
+
+    def evict_older(self, e):
+        gone = [h for h in self.sets if self.stamp[h] < e]
+        for h in gone:
+            del self.sets[h]
+        return len(gone)
+
+    def size(self):
+        return len(self.sets)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_index_state_rules_against_a_dict_model(pkg, orc, seed):
+    """Random sequences of insert / insert-after-pick / remove_pod / epoch tick / evict on the oracle's index and on a dict
+    model: live hash counts, eviction counts, every pod set and the picks computed from either index (oracle loops vs the numpy
+    matrix form) agree after every operation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gg)
+    rng = np.random.Generator(np.random.PCG64(31000 + seed))
+    P, B, R = int(rng.choice([5, 40, 130])), int(rng.choice([2, 6])), 24
+    chain = [[(gg.PF, 3), (gg.KV, 1)], [(gg.Q, 2), (gg.KV, 2), (gg.L, 1), (gg.PF, 3)], [(gg.PF, 2), (gg.Q, 1)]][seed % 3]
+    pods = gg.rand_pods(rng, P)
+    universe = rng.integers(1, 2**63, (6, B), dtype=np.uint64)
+    oix, dix = orc.OracleIndex(), _DictIndex()
+
+    def batch():
+        hs = universe[rng.integers(0, universe.shape[0], R)].copy()
+        for r in range(R):
+            if rng.random() < 0.5:
+                cut = int(rng.integers(0, B))
+                hs[r, cut:] = rng.integers(1, 2**63, B - cut, dtype=np.uint64)
+        adapter = rng.integers(-1, 128, R).astype(np.int32)
+        nb = rng.integers(0, B + 1, R).astype(np.uint32)
+        return adapter, nb, hs
+
+    for step in range(25):
+        op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick", "evict"])
+        if op == "insert":
+            c = universe[int(rng.integers(0, universe.shape[0]))][: int(rng.integers(1, B + 1))]
+            ps = rng.integers(0, P, c.size).astype(np.uint32)
+            oix.insert(c, ps); dix.insert(c.tolist(), ps.tolist())
+        elif op == "insert_picks":
+            adapter, nb, hs = batch()
+            reqs = pkg.picker.make_req_rows(adapter, nb, hs, B)
+            picks, _, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            oix.insert_picks(reqs, B, picks)
+            for r in range(R):
+                if picks[r] >= 0:
+                    dix.insert(hs[r, : int(nb[r])].tolist(), [int(picks[r])] * int(nb[r]))
+        elif op == "remove_pod":
+            p = int(rng.integers(0, P))
+            oix.remove_pod(p); dix.remove_pod(p)
+        elif op == "tick":
+            assert oix.advance_epoch() == dix.advance_epoch()
+        else:
+            e = max(dix.epoch - int(rng.integers(0, 3)), 0)
+            assert oix.evict_older(e) == dix.evict_older(e), (seed, step)
+        assert oix.size() == dix.size(), (seed, step, op)
+        for h in universe.ravel().tolist():
+            assert set(oix.lookup(h).tolist()) == dix.sets.get(h, set()), (seed, step, op)
+        adapter, nb, hs = batch()
+        reqs = pkg.picker.make_req_rows(adapter, nb, hs, B)
+        picks, scores, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+        want_p, want_s = gg.numpy_pick(chain, pods, dix.sets, adapter, nb, hs, None)
+        assert np.array_equal(picks, want_p), (seed, step, op)
+        assert np.array_equal(scores.view(np.uint64), want_s.view(np.uint64)), (seed, step, op)
