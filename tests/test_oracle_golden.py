@@ -294,3 +294,24 @@ def test_index_state_rules_against_a_dict_model(pkg, orc, seed):
         want_p, want_s = gg.numpy_pick(chain, pods, dix.sets, adapter, nb, hs, None)
         assert np.array_equal(picks, want_p), (seed, step, op)
         assert np.array_equal(scores.view(np.uint64), want_s.view(np.uint64)), (seed, step, op)
+
+
+def test_chain_hash_against_python_xxhash_random(pkg, orc):
+    """SEMANTICS.md §4 restated with python-xxhash: h[-1] = XXH64(model), h[i] = XXH64(block_i || LE64(h[i-1])), only full blocks,
+    at most max_blocks -- against the oracle's and the library's host chain on random prompts, block sizes and limits."""
+    xxhash = pytest.importorskip("xxhash")
+    import struct
+    rng = np.random.default_rng(44)
+    for _ in range(60):
+        bc = int(rng.choice([1, 7, 8, 16, 64, 100]))
+        mb = int(rng.integers(0, 9))
+        model = rng.integers(0, 256, int(rng.integers(0, 20)), dtype=np.uint8).tobytes()
+        prompt = rng.integers(0, 256, int(rng.integers(0, 5 * bc + 3)), dtype=np.uint8).tobytes()
+        h = xxhash.xxh64(model, seed=0).intdigest()
+        want = []
+        for i in range(min(len(prompt) // bc, mb)):
+            h = xxhash.xxh64(prompt[i * bc:(i + 1) * bc] + struct.pack("<Q", h), seed=0).intdigest()
+            want.append(h)
+        want = np.array(want, dtype=np.uint64)
+        assert np.array_equal(orc.hash_prompt(model, prompt, bc, mb), want), (bc, mb, len(prompt))
+        assert np.array_equal(pkg.picker.hash_prompt(model, prompt, bc, mb), want), (bc, mb, len(prompt))
