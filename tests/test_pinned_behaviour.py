@@ -105,3 +105,65 @@ def test_many_pods_mask_words(pkg, orc):
     e = [pkg.picker.Endpoint(f"10.0.{i // 256}.{i % 256}", "8000") for i in range(200)]
     sel = cands(pkg, orc, e, "10.0.0.5,10.0.0.130:8000, 10.0.0.199:9")
     assert [x.address for x in sel] == ["10.0.0.5", "10.0.0.130"]
+
+
+def _go_split_host_port(hp):
+    """net.SplitHostPort (Go standard library), restated: (host, port) or None on any of its errors."""
+    i = hp.rfind(":")
+    if i < 0:
+        return None                                   # missing port in address
+    j = k = 0
+    if hp.startswith("["):
+        end = hp.find("]")
+        if end < 0:
+            return None                               # missing ']' in address
+        if end + 1 == len(hp):
+            return None                               # missing port
+        if end + 1 != i:
+            return None                               # either "too many colons" or "missing port"
+        host = hp[1:end]
+        j, k = 1, end + 1
+    else:
+        host = hp[:i]
+        if ":" in host:
+            return None                               # too many colons in address
+    if "[" in hp[j:] or "]" in hp[k:]:
+        return None                                   # unexpected '[' / ']'
+    return host, hp[i + 1:]
+
+
+def _filter_restated(endpoints, value):
+    """request.go:104-133 in Python: entries split on ',', trimmed; host:port entries allow that port, anything else is an
+    address whose every port is allowed; returns candidate indices."""
+    if value is None:
+        return list(range(len(endpoints)))
+    allowed, allow_all = {}, set()
+    for ep in value.split(","):
+        ep = ep.strip(" \t\r\n")
+        hp = _go_split_host_port(ep)
+        if hp is not None:
+            allowed.setdefault(hp[0], set()).add(hp[1])
+        else:
+            allow_all.add(ep)
+    return [i for i, e in enumerate(endpoints) if e.address in allow_all or e.port in allowed.get(e.address, ())]
+
+
+def test_subset_filter_against_a_restatement_of_the_go_code(pkg, orc):
+    """Random subset strings (addresses, ports, brackets, stray colons, blanks, empty entries) through the library, the oracle and a
+    Python restatement of request.go:104-133 + net.SplitHostPort: identical candidate sets."""
+    rng = np.random.default_rng(2024)
+    addrs = ["10.0.0.1", "10.0.0.2", "::1", "fe80::2", "host-a", "[::1]"]
+    ports = ["80", "81", "8080", ""]
+    pieces = addrs + ports + [":", "::", "[", "]", " ", "\t", "x", "[::1]", "[fe80::2]", "10.0.0.1:80", "[::1]:81", "host-a:8080"]
+    for _ in range(400):
+        n = int(rng.integers(1, 9))
+        endpoints = [pkg.picker.Endpoint(str(rng.choice(addrs)), str(rng.choice(ports))) for _ in range(n)]
+        entries = []
+        for _ in range(int(rng.integers(0, 5))):
+            entries.append("".join(str(rng.choice(pieces)) for _ in range(int(rng.integers(0, 4)))))
+        value = ",".join(entries) if rng.random() > 0.05 else None
+        want = _filter_restated(endpoints, value)
+        cands(pkg, orc, endpoints, value)                      # (asserts library == oracle)
+        mask, cnt = pkg.picker.subset_mask(endpoints, value)
+        got = [i for i in range(n) if (int(mask[i >> 6]) >> (i & 63)) & 1]
+        assert got == want and cnt == len(want), (value, [(e.address, e.port) for e in endpoints])
