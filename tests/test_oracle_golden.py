@@ -315,3 +315,45 @@ def test_chain_hash_against_python_xxhash_random(pkg, orc):
         want = np.array(want, dtype=np.uint64)
         assert np.array_equal(orc.hash_prompt(model, prompt, bc, mb), want), (bc, mb, len(prompt))
         assert np.array_equal(pkg.picker.hash_prompt(model, prompt, bc, mb), want), (bc, mb, len(prompt))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_properties(pkg, orc, seed):
+    """Properties any implementation of SEMANTICS.md must have, checked on the oracle (the GPU suite checks the same ones on the
+    kernel at full size): request order does not matter; the ordered fallback list is prefix-closed and its head is the pick;
+    masking the pick out promotes the first fallback; the post-pick index update is idempotent."""
+    rng = np.random.default_rng(5150 + seed)
+    wl = pkg.workload.make_workload(3, R=96, P=int(rng.choice([50, 200, 700])))
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    picks, scores, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+    # (1) a batch is a set of independent requests
+    perm = rng.permutation(wl.R)
+    p2, s2, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[perm], wl.B)
+    assert np.array_equal(p2, picks[perm]) and np.array_equal(s2.view(np.uint64), scores[perm].view(np.uint64))
+    # (2) fallback lists: head == pick, lists of different k agree on their common prefix, totals never increase
+    t4p, t4s = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, 4)
+    t2p, t2s = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, 2)
+    assert np.array_equal(t4p[:, 0], picks) and np.array_equal(t4p[:, :2], t2p) and np.array_equal(t4s[:, :2].view(np.uint64), t2s.view(np.uint64))
+    assert np.all(t4s[:, :-1] >= t4s[:, 1:])
+    ties = t4s[:, :-1] == t4s[:, 1:]
+    assert np.all(t4p[:, :-1][ties] < t4p[:, 1:][ties])                       # equal totals: lowest index first
+    # (3) without the picked pod the first fallback is picked -- when removing it leaves the QUEUE normalisers alone
+    W = (wl.P + 63) // 64
+    mask = np.full((wl.R, W), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    if wl.P % 64:
+        mask[:, -1] = np.uint64((1 << (wl.P % 64)) - 1)
+    q = wl.pods["queue"]
+    unique_extreme = {int(np.argmin(q)) if (q == q.min()).sum() == 1 else -1, int(np.argmax(q)) if (q == q.max()).sum() == 1 else -1}
+    for r in range(wl.R):
+        mask[r, picks[r] >> 6] &= ~(np.uint64(1) << np.uint64(picks[r] & 63))
+    p3, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, mask)
+    keep = np.array([int(p) not in unique_extreme for p in picks])
+    assert np.array_equal(p3[keep], t4p[keep, 1])
+    # (4) index[hash] |= {pick} twice is the same as once
+    oix.insert_picks(wl.reqs, wl.B, picks)
+    n1 = oix.size()
+    a = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+    oix.insert_picks(wl.reqs, wl.B, picks)
+    b = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+    assert oix.size() == n1 and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
