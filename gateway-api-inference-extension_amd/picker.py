@@ -88,6 +88,53 @@ def subset_mask(endpoints: Sequence[Endpoint], filter_value: Optional[str]) -> T
     return mask[: (n + 63) // 64], rc
 
 
+TEST_ENDPOINT_SELECTION_HEADER = "test-epp-endpoint-selection"          # request.go:84-97
+SUBSET_FILTER_NAMESPACE = "envoy.lb.subset_hint"                        # pkg/lwepp/metadata/consts.go:21
+SUBSET_FILTER_KEY = "x-gateway-destination-endpoint-subset"             # pkg/lwepp/metadata/consts.go:24
+_GO_SPACE = " \t\n\v\f\r\x85\xa0"                                        # strings.TrimSpace on Latin-1 (the ASCII set is what libeppk trims)
+
+
+def resolve_subset_filter(headers: Sequence[Tuple[str, str]], request_metadata: Optional[dict]) -> Optional[str]:
+    """Which subset filter governs a request -- handleRequestHeaders, request.go:44-97, up to the PodList call.
+
+    `headers`: (key, value) pairs in wire order; `request_metadata`: the extracted filter metadata
+    ({namespace: {key: str | list}}).  Returns None when no filter applies (every pod is a candidate, request.go:136-137)
+    or the comma-joined entries for `subset_mask` ("" = a subset filter that is present but empty: zero candidates,
+    fail closed, request.go:128-131).  The test header wins over metadata (request.go:84-97)."""
+    metadata_endpoints: List[str] = []
+    has_subset = False
+    ns = (request_metadata or {}).get(SUBSET_FILTER_NAMESPACE)
+    if isinstance(ns, dict) and SUBSET_FILTER_KEY in ns:
+        has_subset = True
+        val = ns[SUBSET_FILTER_KEY]
+        parts = [val] if isinstance(val, str) else [v for v in val if isinstance(v, str)] if isinstance(val, (list, tuple)) else []
+        for part in parts:
+            for ep in part.split(","):
+                t = ep.strip(_GO_SPACE)
+                if t:
+                    metadata_endpoints.append(t)
+    filter_endpoints: List[str] = []
+    for key, value in headers:
+        if key == TEST_ENDPOINT_SELECTION_HEADER:
+            if value != "":
+                filter_endpoints = value.split(",")
+            break
+    if not filter_endpoints and metadata_endpoints:
+        filter_endpoints = metadata_endpoints
+    if has_subset or filter_endpoints:
+        return ",".join(filter_endpoints)
+    return None
+
+
+def handle_request_headers(endpoints: Sequence[Endpoint], headers: Sequence[Tuple[str, str]],
+                           request_metadata: Optional[dict]) -> List[Endpoint]:
+    """reqCtx.Candidates of handleRequestHeaders (request.go:34-139) for one request; Unavailable when the datastore is empty."""
+    if len(endpoints) == 0:
+        raise Unavailable("no pods available")                          # request.go:100-102
+    mask, _ = subset_mask(endpoints, resolve_subset_filter(headers, request_metadata))
+    return [e for i, e in enumerate(endpoints) if (int(mask[i >> 6]) >> (i & 63)) & 1]
+
+
 def hash_prompt(model: bytes, prompt: bytes, block_chars: int, max_blocks: int) -> np.ndarray:
     """Chained XXH64 block hashes of one prompt (SEMANTICS.md §4)."""
     lib = _lib.load_library()
