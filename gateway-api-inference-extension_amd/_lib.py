@@ -22,6 +22,7 @@ SYMBOLS = [
     "eppk_index_size", "eppk_index_dropped", "eppk_index_selfcheck", "eppk_stream_wait_pick", "eppk_index_advance_epoch", "eppk_index_evict_older",
     "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
+    "eppk_launch_status",
     "eppk_chain_is_fused", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
@@ -99,6 +100,7 @@ def load_library() -> C.CDLL:
     lib.eppk_subset_mask.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.c_char_p, vp]
     lib.eppk_round_robin.argtypes = [C.POINTER(u64), u32]
     lib.eppk_round_robin.restype = i32
+    lib.eppk_launch_status.argtypes = [vp, C.POINTER(u32)]
     lib.eppk_chain_is_fused.argtypes = [vp]
     lib.eppk_profile_enable.argtypes = [vp, C.c_int]
     lib.eppk_profile_drain.argtypes = [vp, vp, u32, C.POINTER(u32)]

@@ -96,6 +96,7 @@ struct eppk_ctx {
                                         // banks of per-wave {hits, lookups}: consecutive launches use different banks, so pick
                                         // kernels overlapping on two streams never share a slot
   uint32_t stat_bank = 0;
+  uint32_t* d_status = nullptr;         // sticky launch-status flags (eppk_launch_status)
 
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
@@ -157,6 +158,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
+  k.status = c->d_status;
   return k;
 }
 
@@ -396,10 +398,11 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
     L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
-    L.bytes = off;
+    L.bytes = off + 256u;                      // the LAST dword is the fast kernel's launch-status word (kBlobStatusTail)
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
       CHK(hipMalloc((void**)&s.blob, L.bytes));
+      CHK(hipMemset(s.blob + L.bytes - 256u, 0, 256u));
       s.base = (double*)(s.blob + L.base); s.post[0] = (double*)(s.blob + L.post0); s.post[1] = (double*)(s.blob + L.post1);
       s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
       s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
@@ -421,6 +424,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   CHK(hipMalloc((void**)&c->d_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row)));
   CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
   CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
+  CHK(hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t)));
+  CHK(hipMemset(c->d_status, 0, 2 * sizeof(uint32_t)));
   if (cfg->index_slots) {
     c->slots = cfg->index_slots;
     uint32_t lg = 0;
@@ -457,7 +462,7 @@ void eppk_destroy(eppk_ctx* c) {
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
-  (void)hipFree(c->stats); (void)hipFree(c->pterm);
+  (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
@@ -589,7 +594,8 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
-                       c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs);
+                       c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
+                       c->cfg.max_pods, c->d_status);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -840,6 +846,22 @@ int eppk_hash_prompts_device(eppk_ctx* c, const void* d_prompts, uint64_t prompt
   hipLaunchKernelGGL(hash_prompts_kernel, dim3(grid), dim3(threads), 0, st, (const uint8_t*)d_prompts, prompt_stride, d_prompt_len, d_seed,
                      d_adapter, n_reqs, block_chars, c->cfg.max_blocks, (uint8_t*)d_reqs_out, c->stride);
   HIPCHK(c, hipGetLastError());
+  return EPPK_OK;
+}
+
+int eppk_launch_status(eppk_ctx* c, uint32_t* flags) {
+  if (!c || !flags) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipDeviceSynchronize());     // every launch of this context, on whatever stream the caller used
+  uint32_t f = 0;
+  uint32_t* words[3] = {c->d_status, (uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail), (uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail)};
+  for (uint32_t* w : words) {
+    uint32_t v = 0;
+    HIPCHK(c, hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost));
+    if (v) HIPCHK(c, hipMemset(w, 0, sizeof v));
+    f |= v;
+  }
+  *flags = f;
   return EPPK_OK;
 }
 

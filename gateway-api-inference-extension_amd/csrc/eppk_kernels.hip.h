@@ -80,7 +80,15 @@ struct KSnap {
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
   uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
+  uint32_t* status;        // sticky launch-status flags of the context (eppk_launch_status): bit 0 = a request row handed to a
+                           // *_device entry point was out of range (n_blocks > max_blocks or adapter outside [-1, 128)); such a
+                           // request is NOT scored: its pick is EPPK_NO_PICK (SEMANTICS.md §7: never silently truncated).
+                           // The fast kernel does not keep this pointer in SGPRs: it stores the flag into the LAST dword of the
+                           // snapshot blob (kBlobStatusTail bytes from its end), reachable through the blob's descriptor.
 };
+constexpr uint32_t kBlobStatusTail = 4u;
+constexpr uint32_t kStatusBadRow = 1u;      // eppk.h: EPPK_LAUNCH_BAD_REQUEST_ROW
+constexpr uint32_t kStatusBadPick = 2u;     // eppk.h: EPPK_LAUNCH_BAD_PICK
 
 // Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (8 u64 words =
 // 64 bytes: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..7 = keys, filled front
@@ -800,6 +808,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     uint32_t r;              // request index
     int32_t adapter;
     uint32_t nb, m0, hits, arow;
+    uint32_t badm;           // ~0 when the header is out of range (device entry points do not pre-validate rows), else 0: the row
+                             // is then scored as an empty base-model request (nothing is indexed out of bounds) and the stores
+                             // OR this mask into the pick (-> EPPK_NO_PICK) and clear the score with it
   };
   struct Tabs {              // per-adapter tables of a request: first 16 top-table entries (lanes 0..15), LoRA tier planes
     double top_t;
@@ -812,6 +823,12 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     s.r = r;
     s.adapter = (int32_t)(uint32_t)q.hdr;            // wave-uniform (scalar load)
     s.nb = (uint32_t)(q.hdr >> 32);
+    s.badm = 0u;
+    if (__builtin_expect(s.nb > hwords || s.adapter < -1 || s.adapter >= (int32_t)EPPK_MAX_ADAPTERS, 0)) {   // not scored + sticky flag
+      s.badm = 0xFFFFFFFFu;
+      s.adapter = -1; s.nb = 0u;
+      if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(kStatusBadRow, rsn, (int)(sn.blob_bytes - kBlobStatusTail), 0, 0);
+    }
     s.arow = (HAS_L && s.adapter >= 0) ? (uint32_t)s.adapter : 128u;
     s.m0 = 0;
     slot_eff = ix.slots + 2u;
@@ -996,8 +1013,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
     const bool none = bidx == kNoPod;
     if (lane == 0) {
-      out_pick[r] = none ? -1 : (int32_t)bidx;
-      if (out_score) out_score[r] = none ? 0.0 : best;
+      out_pick[r] = (none ? -1 : (int32_t)bidx) | (int32_t)s.badm;
+      if (out_score) out_score[r] = __longlong_as_double(__double_as_longlong(none ? 0.0 : best) & ~(long long)(int32_t)s.badm);
     }
     return true;
   };
@@ -1118,14 +1135,15 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
     const bool none = bidx == kNoPod;
     if (lane == 0) {
-      out_pick[r] = none ? -1 : (int32_t)bidx;
-      if (out_score) out_score[r] = none ? 0.0 : best;
+      out_pick[r] = (none ? -1 : (int32_t)bidx) | (int32_t)s.badm;
+      if (out_score) out_score[r] = __longlong_as_double(__double_as_longlong(none ? 0.0 : best) & ~(long long)(int32_t)s.badm);
     }
   };
 
   // evaluate, select, store
   auto stage_eval = [&](const ReqS& s, const LW (&c)[NPL], Tabs& tb) {
     const uint32_t r = s.r, nb = s.nb, hits = s.hits, arow = s.arow, m0 = s.m0;
+    const uint32_t tk = TOPK ? topk : 1u;      // entries per request in out_pick / out_score
     const int32_t adapter = s.adapter;
     double& top_t = tb.top_t;
     uint32_t& top_p = tb.top_p;
@@ -1249,10 +1267,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       }
     }
     if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
-    const bool none = bidx == kNoPod;
+    const bool none = bidx == kNoPod || (TOPK && s.badm != 0u);       // (fallback lists of an out-of-range row: all EPPK_NO_PICK)
     if (lane == 0) {
-      out_pick[(size_t)r * topk + round] = none ? -1 : (int32_t)bidx;
-      if (out_score) out_score[(size_t)r * topk + round] = none ? 0.0 : best;
+      out_pick[(size_t)r * tk + round] = (none ? -1 : (int32_t)bidx) | (int32_t)s.badm;
+      if (out_score) out_score[(size_t)r * tk + round] = __longlong_as_double(__double_as_longlong(none ? 0.0 : best) & ~(long long)(int32_t)s.badm);
     }
     if (!none && (uint32_t)lane == (bidx & 63u)) excl |= (LW)((LW)1 << (bidx >> 6));
     return none;
@@ -1262,10 +1280,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       select_round(0u, none_excluded);
     } else {
       LW excl = 0;
-      for (uint32_t round = 0; round < topk; ++round) {
+      for (uint32_t round = 0; round < tk; ++round) {
         if (select_round(round, excl)) {     // candidates exhausted: pad the rest of the list
           if (lane == 0)
-            for (uint32_t i = round + 1u; i < topk; ++i) { out_pick[(size_t)r * topk + i] = -1; if (out_score) out_score[(size_t)r * topk + i] = 0.0; }
+            for (uint32_t i = round + 1u; i < tk; ++i) { out_pick[(size_t)r * tk + i] = -1; if (out_score) out_score[(size_t)r * tk + i] = 0.0; }
           break;
         }
       }
@@ -1367,8 +1385,16 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
   const uint32_t nwaves = gridDim.x * wpb;
   for (uint32_t r = gwave; r < n_reqs; r += nwaves) {
     const uint8_t* row = reqs + (size_t)r * stride;
-    const int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
-    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
+    int32_t adapter = __builtin_amdgcn_readfirstlane(((const int32_t*)row)[0]);
+    uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane(((const int32_t*)row)[1]);
+    if (__builtin_expect(nb > (stride - 8u) / 8u || adapter < -1 || adapter >= (int32_t)EPPK_MAX_ADAPTERS, 0)) {
+      // out-of-range row on a *_device entry point: not scored (EPPK_NO_PICK), flagged (eppk_launch_status)
+      if (lane == 0) {
+        for (uint32_t i = 0; i < topk; ++i) { out_pick[(size_t)r * topk + i] = -1; if (out_score) out_score[(size_t)r * topk + i] = 0.0; }
+        atomicOr(sn.status, kStatusBadRow);
+      }
+      continue;
+    }
 
     LW cand = valid;
     if (MASKED) cand &= transpose_mask<LW>(cand_mask + (size_t)r * sn.J, sn.J, lane);
@@ -1826,7 +1852,7 @@ __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lis
 template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
-                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs) {
+                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
   bool active = r < n_reqs;
@@ -1836,7 +1862,11 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     pick = picks[r];
     const uint8_t* row = reqs + (size_t)r * stride;
     const uint32_t nb = ((const uint32_t*)row)[1];
-    active = pick >= 0 && i < nb;
+    // a pick beyond the lane words (>= max_pods) would shift into other pods' bits: ignored and flagged, like a row whose block
+    // count exceeds the row (eppk_launch_status)
+    const bool bad = (pick >= 0 && (uint32_t)pick >= max_pods) || nb > max_blocks;
+    if (bad && i == 0u) atomicOr(status, (uint32_t)pick >= max_pods && pick >= 0 ? kStatusBadPick : kStatusBadRow);
+    active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
   index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active);

@@ -281,13 +281,19 @@ class BatchedPicker:
 
     def pick_topk(self, reqs: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Ordered fallbacks: ([R, k] candidate indices, [R, k] totals); column 0 is the pick (include/eppk.h eppk_pick_topk)."""
+        if not 1 <= int(k) <= 8:
+            raise EppkError(-1, "pick_topk: k out of range (1..8)")
         reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words, "request row stride mismatch"
         R = reqs.shape[0]
+        if R > self.max_batch:
+            raise EppkError(-2, "pick_topk: more requests than max_batch")
         picks = np.full((R, k), -1, dtype=np.int32)
         scores = np.zeros((R, k), dtype=np.float64)
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert m.shape == (R, (self.n_pods + 63) // 64), "mask shape mismatch"
         self._check(self._lib.eppk_pick_topk(self._ctx, reqs.ctypes.data, R, m.ctypes.data if m is not None else None, k,
                                              picks.ctypes.data, scores.ctypes.data), "pick_topk")
         return picks, scores
@@ -295,6 +301,13 @@ class BatchedPicker:
     def pick_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
+
+    def launch_status(self) -> int:
+        """Sticky flags of the *_device launches since the last call (include/eppk.h: EPPK_LAUNCH_BAD_REQUEST_ROW = 1,
+        EPPK_LAUNCH_BAD_PICK = 2); synchronises the device."""
+        f = C.c_uint32(0)
+        self._check(self._lib.eppk_launch_status(self._ctx, C.byref(f)), "launch_status")
+        return f.value
 
     def stream_wait_pick(self, waiting_stream: int) -> None:
         """Make `waiting_stream` (hipStream_t as int) wait for the most recent pick launch (include/eppk.h eppk_stream_wait_pick)."""

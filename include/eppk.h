@@ -186,6 +186,21 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
+/* Trust contract of the *_device entry points.  The host-buffer entry points validate every request row before anything is
+ * launched (EPPK_ERR_ARG names the row).  The *_device entry points cannot read the rows, so the KERNELS check them: a row whose
+ * n_blocks exceeds max_blocks or whose adapter lies outside [-1, EPPK_MAX_ADAPTERS) is not scored -- its pick (every entry of its
+ * fallback list) is EPPK_NO_PICK, its score 0.0 -- and eppk_index_insert_picks_device ignores a pick >= max_pods (and the picks of
+ * such rows); either event sets a sticky flag that eppk_launch_status reports.  Nothing is read or written out of bounds and no
+ * input is silently truncated (SEMANTICS.md §7).
+ * Index maintenance (eppk_index_insert / _remove_pod / _evict_older / _clear, and a second eppk_snapshot_publish) synchronises the
+ * context's own stream only: it must not run while picks launched through a *_device entry point on a CALLER's stream are still
+ * in flight -- synchronise those streams first (eppk_index_insert_picks_device is ordered by the stream it is given). */
+#define EPPK_LAUNCH_BAD_REQUEST_ROW 1u   /* a request row on a *_device entry point was out of range: it got EPPK_NO_PICK */
+#define EPPK_LAUNCH_BAD_PICK        2u   /* eppk_index_insert_picks_device met a pick >= max_pods: ignored */
+/* Synchronise the device and return (and clear) the sticky launch-status flags accumulated by every *_device launch of this
+ * context since the last call.  0 = every row was in range. */
+int eppk_launch_status(eppk_ctx* ctx, uint32_t* flags);
+
 /* Make `waiting_stream` (a hipStream_t) wait for the most recent pick launch of this context -- a cross-stream dependency
  * without a separate event record behind the kernel when the launch already carries a completion event (profiling on).
  * What a caller uses to start a collective or a copy of the picks on another stream (bench.py: the RCCL all-gather). */
