@@ -1,19 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — routing decisions/s of the batched endpoint pick on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: request rows already resident in HBM ->
-fused pick kernel -> picks in HBM (+ for N>1 an RCCL all-gather of the per-rank picks).
-N=1 workload: BASELINE.json configs[4] ("64k req x 4096 pods, full scorer chain + prefix-cache"), the
-configuration the metric is quoted on; it fits one GPU.  N>1: weak scaling, every rank scores its own
-64k-request shard against the replicated snapshot + prefix index, picks are all-gathered.
+A "step" = one pass of the hot path over one batch of 64k requests: request rows already resident in HBM -> fused pick
+kernel -> picks in HBM (+ for N>1 an RCCL all-gather of the per-rank picks).  Workload: BASELINE.json configs[4]
+("64k req x 4096 pods, full scorer chain + prefix-cache"), the configuration the metric is quoted on; it fits one GPU.
 
-Batches are independent, so by default two of them are in flight (`--inflight 2`: consecutive launches alternate between two
-streams, which hides the dispatch gap between back-to-back kernels); every launch still processes one whole batch and
-`roofline.kernel_avg_ms` is the per-launch duration measured in the timed region -- about twice the kernel's duration
-with the GPU to itself (`--inflight 1`, or `--alone-ref` for both in one run), because two launches share the GPU.
+What is timed (and what is not):
+  * the timed region ROTATES through `--batches` (default 16) DISTINCT request batches -- 16 x 17.3 MB = 277 MB, more than the
+    256 MB Infinity Cache -- so request rows stream from HBM every step (a single resident batch would be served by the cache);
+  * N=1: the whole batch on one GPU.  N>1, `--scaling strong` (default; BASELINE.json configs[4] "request-sharded 8xMI355X with
+    RCCL all-gather of picks"): every step's 64k-request batch is split R/N per rank, the picks are all-gathered so that every
+    rank holds all of them; the same invocation then also times `weak` scaling (every rank scores a whole 64k batch of its own,
+    picks all-gathered) and prints it beside (`"weak": {...}`).  `--scaling weak` makes that the headline instead;
+  * `--closed-loop`: pick -> eppk_index_insert_picks_device (the post-route index update, SEMANTICS.md §6) -> next, DIFFERENT
+    batch, with ageing every `--age-every` steps; its first generations are checked against the oracle at full size.
+  * batches are independent, so two of them are in flight (`--inflight 2`: consecutive launches alternate between two streams);
+    the closed loop is strictly ordered (one stream).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by torch.distributed.run
-(one rank per GPU).  Rank 0 prints ONE JSON line.
+Roofline objects of the JSON line:
+  roofline        the headline workload.  bound "hbm": achieved = COMPULSORY HBM bytes of a launch under the library's own layout
+                  (request rows + outputs + every distinct index line / table the launch touches, once) / kernel duration.  The
+                  headline is NOT HBM-bound (`limiter`: VALU issue; `issue` = instruction counts from the stamped PMC summary);
+                  `model_frac` keeps SURVEY §8(d)'s byte model (u64 key + P/8-byte bitmap per index entry) for reference only --
+                  the kernel does not move those bytes.
+  roofline_cold   the same kernel on a COLD index (65 536 prefix groups, uniform: 1 M distinct hashes), where HBM is the bound:
+                  bytes = what the layout reads per launch (rows, one 64-byte bucket per probed hash, one 64-byte list per hit).
+  `traffic` comes from profiles/pmc_traffic.json ONLY when that file is stamped with the hash of the kernel sources this
+  library was built from (scripts/gpu_round.sh regenerates it); otherwise null.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by torch.distributed.run (one rank per GPU).
+Rank 0 prints ONE JSON line (the last line on stdout).
 """
 from __future__ import annotations
 
@@ -29,11 +45,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMD16; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 
-def cpu_baseline(pkg, wl, orc, passes: int = 2):
-    """The C restatement (oracle/) timed on this box's host cores, on the SAME workload.
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_hash() -> str:
+    csrc = os.path.join(graft.PKG_DIR, "csrc")
+    files = [os.path.join(csrc, f) for f in ("eppk_kernels.hip.h", "eppk_pick_inst.hip.h", "eppk.hip")] + [os.path.join(ROOT, "include", "eppk.h")]
+    return graft._digest(files, " ".join(graft.COMPILE_FLAGS))[:16]
+
+
+def stamped_json(name: str, khash: str):
+    """profiles/<name> if it carries this build's kernel-source hash, else None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        return j if j.get("kernel_src_sha16") == khash else None
+    except Exception:
+        return None
+
+
+def cpu_baseline(wl, orc, reqs, passes: int = 2):
+    """The C restatement (oracle/) timed on this box's host cores, on one batch of the SAME workload.
 
     Single thread on a 4096-request sample (the shape of the reference's per-request loop) and all
     cores on the whole batch.  Bounded: ~7 core-seconds per full pass at 64k x 4096."""
@@ -42,19 +80,200 @@ def cpu_baseline(pkg, wl, orc, passes: int = 2):
     cores = os.cpu_count() or 1
     n1 = min(wl.R, 4096)
     t0 = time.perf_counter()
-    p1, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:n1], wl.B)
+    p1, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs[:n1], wl.B)
     t1 = time.perf_counter() - t0
     best = None
     for _ in range(passes):
         t0 = time.perf_counter()
-        pm, sm, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, threads=cores)
+        pm, sm, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B, threads=cores)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert np.array_equal(p1, pm[:n1])
     return dict(value=wl.R / best, unit="decisions/s", cores=cores, kind="port",
-                sample=f"{passes} passes of the full {wl.R} x {wl.P} batch on {cores} threads (C restatement, not Go); "
-                       f"single thread on the first {n1} requests",
+                sample=f"{passes} passes of one full {wl.R} x {wl.P} batch on {cores} threads (C restatement, not Go); "
+                       f"single thread on its first {n1} requests",
                 single_thread_value=n1 / t1), pm, sm
+
+
+def make_batches(pkg, wl, args, n: int):
+    """`n` distinct request batches against ONE snapshot + index (batch 0 = the workload's own requests)."""
+    out = [wl.reqs]
+    base = (0x5EED0000 + args.config)
+    for b in range(1, n):
+        out.append(pkg.workload.make_requests(wl, base ^ (0x9E3779B1 * b & 0x7FFFFFFF)))
+    return out
+
+
+class Runner:
+    """One context + NB resident request batches + the stream / ring plumbing of a timed region."""
+
+    def __init__(self, pkg, torch, dist, wl, batches, args, rank, world, local_rank, index_slots=None, closed_loop=False):
+        self.pkg, self.torch, self.dist, self.wl, self.args = pkg, torch, dist, wl, args
+        self.rank, self.world = rank, world
+        self.use_dist = dist is not None
+        self.R, self.NB = wl.R, len(batches)
+        self.h_batches = batches
+        slots = wl.index_slots if index_slots is None else index_slots
+        self.pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=wl.R, index_slots=slots, device=local_rank)
+        self.pk.publish(wl.pods)
+        if slots:
+            self.pk.index_insert(wl.index_hashes, wl.index_pods)
+        self.dev = dev = torch.device("cuda", local_rank)
+        self.stride = 8 + 8 * wl.B
+        self.d_batches = [torch.from_numpy(b.view(np.int64)).to(dev) for b in batches]
+        self.p_batches = [t.data_ptr() for t in self.d_batches]
+        inflight = 1 if closed_loop else args.inflight
+        self.computes = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
+        self.comm = torch.cuda.Stream(device=dev)
+        # torch's CURRENT stream is `comm` (c10d enqueues the collective on the current stream); the pick kernel gets a compute
+        # stream by handle.  No per-step stream context manager: the host enqueue path is what limits the N > 1 rate.
+        torch.cuda.set_stream(self.comm if self.use_dist else self.computes[0])
+        self.streams = [c.cuda_stream for c in self.computes]
+        assert all(h != 0 for h in self.streams)
+        self.comm_handle = self.comm.cuda_stream
+        self.closed_loop = closed_loop
+
+    # -- a timed region ---------------------------------------------------------------------------------------------------
+    def setup(self, mode: str, gather_every: int):
+        """mode: 'single' (N=1), 'strong' (the step's batch split R/N per rank), 'weak' (a whole batch per rank)."""
+        torch, R, W = self.torch, self.R, self.world
+        self.mode = mode
+        self.per = (R + W - 1) // W if mode == "strong" else R          # requests this rank scores per step
+        self.lo = min(self.rank * self.per, R) if mode == "strong" else 0
+        self.n_mine = max(0, min(self.lo + self.per, R) - self.lo) if mode == "strong" else R
+        self.ring = self.pkg.distributed.GatherRing(nbuf=16 if mode == "strong" else 8, gather_every=gather_every)
+        NBUF, G = self.ring.nbuf, self.ring.gather_every
+        self.d_picks_all = torch.full((NBUF * self.per,), -1, dtype=torch.int32, device=self.dev)
+        self.d_picks = [self.d_picks_all[i * self.per:(i + 1) * self.per] for i in range(NBUF)]
+        self.d_scores = [torch.empty(self.per, dtype=torch.float64, device=self.dev) for _ in range(NBUF)]
+        self.p_picks = [t.data_ptr() for t in self.d_picks]
+        self.p_scores = [t.data_ptr() for t in self.d_scores]
+        self.d_alls = [torch.empty(W * G * self.per, dtype=torch.int32, device=self.dev) for _ in range(NBUF // G)] if self.use_dist else None
+        self.ev_gather = torch.cuda.Event()
+        self.last_gather = None
+        self.step_no = 0
+        self.last_batch = 0
+
+    def _gather(self, due):
+        if due is None:
+            return
+        b0, n, closes_trip = due
+        out = self.d_alls[self.ring.bucket_of(b0)][: self.world * n * self.per]
+        self.dist.all_gather_into_tensor(out, self.d_picks_all[b0 * self.per:(b0 + n) * self.per])     # on `comm`, the current stream
+        self.last_gather = (out, n)
+        if closes_trip:
+            self.ev_gather.record(self.comm)
+
+    def batch_of(self, step: int) -> int:
+        # weak scaling: ranks walk the same ring of batches at different offsets, so that no two ranks score the same batch at
+        # the same step (every rank holds all NB batches)
+        return (step + (self.rank if self.mode == "weak" else 0)) % self.NB
+
+    def step(self):
+        ring = self.ring
+        if self.use_dist and ring.begins_trip():
+            for c in self.computes:
+                c.wait_event(self.ev_gather)                 # every all-gather of the previous trip is done: the ring is free again
+        slot = ring.next_slot()
+        b = self.batch_of(self.step_no)
+        st = self.streams[slot % len(self.streams)]
+        if self.n_mine:
+            self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
+            if self.closed_loop:                              # post-route index update on the same stream: the next pick sees it
+                self.pk.index_insert_picks_device(self.p_batches[b] + self.lo * self.stride, self.p_picks[slot], self.n_mine, st)
+        due = ring.after_batch()
+        if self.use_dist:
+            if self.n_mine:
+                self.pk.stream_wait_pick(self.comm_handle)   # comm waits for the kernel's own completion event
+            self._gather(due)
+        self.last_batch, self.last_slot = b, slot
+        self.step_no += 1
+
+    def fence(self):
+        due = self.ring.flush()
+        if self.use_dist:
+            self._gather(due)                                # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed(self, steps: int, warmup: int, age=None):
+        """`warmup` untimed steps, then exactly `steps` timed ones between fences; returns (elapsed max over ranks, kernel ms list,
+        (bytes, lookups, launches))."""
+        for i in range(warmup):
+            self.step()
+            if age:
+                age(i)
+        self.pk.profile(True)          # HIP events around every pick launch on the launch stream + probe counts
+        self.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step()
+            if age:
+                age(warmup + i)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.use_dist:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kern_ms = np.asarray(self.pk.profile_drain(), dtype=np.float64)
+        stats = self.pk.profile_bytes()
+        return elapsed, kern_ms, stats
+
+    def more_kernel_samples(self, have: int, want: int):
+        """Launch durations beyond the timed region (same launch pattern, profiling still on) until `want` samples exist."""
+        out = []
+        while have + sum(len(x) for x in out) < want:
+            n = min(256, want - have - sum(len(x) for x in out))
+            for _ in range(n):
+                self.step()
+            self.fence()
+            out.append(np.asarray(self.pk.profile_drain(), dtype=np.float64))
+        return np.concatenate(out) if out else np.zeros(0)
+
+    def last_outputs(self):
+        picks = self.d_picks[self.last_slot].cpu().numpy()[: self.n_mine]
+        scores = self.d_scores[self.last_slot].cpu().numpy()[: self.n_mine]
+        return picks, scores
+
+    def check_gather(self):
+        """The most recent all-gather handed this rank its own shard back, and (strong) a full batch."""
+        if not self.use_dist or self.last_gather is None:
+            return None
+        out, n = self.last_gather
+        allp = out.cpu().numpy().reshape(self.world, n, self.per)
+        mine = self.d_picks[self.last_slot].cpu().numpy()
+        assert np.array_equal(allp[self.rank, n - 1], mine), "all-gather returned a different shard"
+        return allp[:, n - 1, :].reshape(-1)[: self.R] if self.mode == "strong" else allp[self.rank, n - 1]
+
+    def close(self):
+        self.pk.close()
+
+
+def byte_models(wl, R, kern_stats, khash, lists_on=True):
+    """Per-launch byte counts from the device-counted probe statistics: (SURVEY model, layout L2-side bytes, compulsory HBM bytes)."""
+    abytes, lookups, launches = kern_stats
+    launches = max(launches, 1)
+    model = abytes / launches
+    lk = lookups / launches
+    lw_bytes = 2 if wl.P <= 1024 else 4 if wl.P <= 2048 else 8
+    stride = 8 + 8 * wl.B
+    fixed = wl.P * 64 + R * (stride + 4)
+    row_model = 8 + 64 * lw_bytes
+    hits = max(model - fixed - 8 * lk, 0.0) / (row_model - 8) if wl.B else 0.0
+    out_bytes = R * 12                                                         # i32 pick + f64 score
+    tables = 129 * 64 * (12 + 2 * lw_bytes) + wl.P * 8 + (wl.B + 1) ** 2 * 8   # per-adapter tables + base[] + pterm (read through L2 by every workgroup)
+    # L2-side: what the layout requests per launch (all of a request's first 32 key buckets are gathered, one list or row per hit)
+    per_hit = 64 if lists_on else 64 * lw_bytes
+    l2_side = R * stride + out_bytes + (R * min(wl.B, 32) * 64 + hits * per_hit if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
+    # compulsory HBM: streams (rows in, picks/scores out) + every DISTINCT index line once + the tables once
+    n_keys = int(np.unique(wl.index_hashes).size) if wl.B else 0
+    distinct_buckets = min(R * min(wl.B, 32), wl.index_slots // 8) if wl.B else 0
+    distinct_lists = min(hits, n_keys)
+    compulsory = R * stride + out_bytes + distinct_buckets * 64 + distinct_lists * per_hit + tables
+    return dict(model=model, lookups=lk, hits=hits, l2_side=l2_side, compulsory=compulsory)
 
 
 def main() -> None:
@@ -63,15 +282,23 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json config number (1-based); 5 = headline")
-    ap.add_argument("--requests", type=int, default=None, help="override requests per rank")
+    ap.add_argument("--requests", type=int, default=None, help="override requests per batch")
+    ap.add_argument("--batches", type=int, default=16, help="distinct request batches the timed region rotates through (16 x 17.3 MB > the 256 MB Infinity Cache)")
+    ap.add_argument("--scaling", choices=("strong", "weak", "both"), default="both", help="N>1: 'both' = strong scaling is the headline `value`, weak scaling is timed too and printed beside it")
+    ap.add_argument("--closed-loop", action="store_true", help="pick -> insert_picks -> next different batch, ageing every --age-every steps (N=1; one stream)")
+    ap.add_argument("--age-every", type=int, default=2, help="closed loop: tick the index epoch and evict every this many steps")
+    ap.add_argument("--keep-epochs", type=int, default=2, help="closed loop: hashes not re-inserted during this many epochs are evicted")
+    ap.add_argument("--cl-slots", type=int, default=1 << 24, help="closed loop: index slots (live keys ~ age_every * keep_epochs * R * B/2)")
+    ap.add_argument("--cl-verify", type=int, default=3, help="closed loop: generations checked against the oracle at full size before timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold-cache index variant)")
+    ap.add_argument("--no-cold-ref", action="store_true", help="skip the cold-index sub-run (roofline_cold)")
+    ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold index)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
-    ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams; 1 = strictly back-to-back launches on one stream")
-    ap.add_argument("--gather-every", type=int, default=4, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
-    ap.add_argument("--alone-ref", action="store_true", help="after the timed region also time 50 launches back to back on one stream (the kernel with the GPU to itself) and report them as roofline.kernel_alone_*")
-    ap.add_argument("--host-path", type=int, default=40, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the p99 pick latency a host caller observes; 0 = skip")
+    ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
+    ap.add_argument("--gather-every", type=int, default=8, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
+    ap.add_argument("--p99-samples", type=int, default=1000, help="kernel durations collected for the p99 (beyond the timed region if it has fewer launches)")
+    ap.add_argument("--host-path", type=int, default=1000, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the pick latency a host caller observes; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -93,189 +320,151 @@ def main() -> None:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.closed_loop and use_dist:
+        raise SystemExit("--closed-loop is a one-GPU mode (the group API applies the gathered update on every device: tests/test_gpu_group.py)")
 
     pkg = graft.load_package()
-    # replicated snapshot + index (seed of the config), this rank's own request shard (weak scaling)
-    wl = pkg.workload.make_workload(args.config, R=args.requests, req_seed=(0x5EED0000 + args.config) ^ (0xA5A5 * rank) if rank else None,
-                                    n_groups=args.groups, zipf_s=args.zipf)
+    khash = kernel_source_hash()
+    t_gen = time.perf_counter()
+    # replicated snapshot + index; the SAME batches on every rank (strong: a rank scores its slice of each; weak: ranks walk the
+    # ring of batches at different offsets)
+    wl = pkg.workload.make_workload(args.config, R=args.requests, n_groups=args.groups, zipf_s=args.zipf)
     R = wl.R
-    pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots, device=local_rank)
-    pk.publish(wl.pods)
-    if wl.index_slots:
-        pk.index_insert(wl.index_hashes, wl.index_pods)
+    batches = make_batches(pkg, wl, args, max(1, args.batches))
+    log(f"[bench] rank {rank}: {len(batches)} batches of {R} requests generated in {time.perf_counter() - t_gen:.1f} s")
+    headline = args.config == 5 and args.requests is None and args.groups == 256 and args.zipf == 1.0 and not args.closed_loop
 
-    dev = torch.device("cuda", local_rank)
-    d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
-    # A ring of NBUF pick buffers (one contiguous tensor).  The picks are all-gathered in BUCKETS of `--gather-every` batches
-    # (default 4): one RCCL call moves the picks of four batches -- a 256 KiB per-rank message is pure latency on xGMI, so
-    # fewer, larger collectives it is -- on the `comm` stream, overlapping the kernels of the following batches.  The
-    # compute streams wait for the collectives once per trip around the ring.
-    ring = pkg.distributed.GatherRing(nbuf=8, gather_every=args.gather_every)   # the bookkeeping (tests/test_distributed_cpu.py)
-    NBUF, G = ring.nbuf, ring.gather_every
-    d_picks_all = torch.empty(NBUF * R, dtype=torch.int32, device=dev)
-    d_picks = [d_picks_all[i * R:(i + 1) * R] for i in range(NBUF)]
-    d_scores = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(NBUF)]
-    d_alls = [torch.empty(world * G * R, dtype=torch.int32, device=dev) for _ in range(NBUF // G)] if use_dist else None
-    # Explicit streams: the kernel and its HIP-event brackets are ordered on `compute`, the collective on `comm`.
-    # (torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream".)
-    # Consecutive batches are independent, so their kernels alternate between TWO compute streams: the next launch is already
-    # queued when a kernel drains and its workgroups start as CUs free up (hides most of the ~5 us dispatch gap between
-    # back-to-back launches on one stream).  Every kernel still processes one whole batch; kernel time is per launch.
-    computes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
-    compute = computes[0]
-    comm = torch.cuda.Stream(device=dev)
-    # torch's CURRENT stream is `comm` (c10d enqueues the collective on the current stream); the pick kernel gets `compute`
-    # by handle.  No per-step stream context manager: at 35 us per kernel the host enqueue path is what limits the N > 1 rate.
-    torch.cuda.set_stream(comm if use_dist else compute)
-    streams = [c.cuda_stream for c in computes]
-    assert all(h != 0 for h in streams)
-    comm_handle = comm.cuda_stream
-    ev_gather = torch.cuda.Event()                           # the all-gather of the last bucket of a trip finished (ring reusable)
-    last_gather = [None]                                     # (bucket tensor view, slots in it) of the most recent all-gather
+    run = Runner(pkg, torch, dist, wl, batches, args, rank, world, local_rank,
+                 index_slots=(args.cl_slots if args.closed_loop else None), closed_loop=args.closed_loop)
+    modes = ["single"] if not use_dist else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
+    results = {}
+    cl_info = None
+    for mode in modes:
+        run.setup(mode, args.gather_every)
+        age = None
+        if args.closed_loop:
+            cl_info = closed_loop_verify(run, wl, args)
+            state = {"epoch": cl_info["epoch"]}
 
-    def gather(due):
-        if due is None:
-            return
-        b0, n, closes_trip = due
-        out = d_alls[ring.bucket_of(b0)][: world * n * R]
-        dist.all_gather_into_tensor(out, d_picks_all[b0 * R:(b0 + n) * R])       # on `comm`, the current stream
-        last_gather[0] = (out, n)
-        if closes_trip:
-            ev_gather.record(comm)
-
-    p_reqs, p_scores, p_picks = d_reqs.data_ptr(), [t.data_ptr() for t in d_scores], [t.data_ptr() for t in d_picks]
-
-    def step():
-        if use_dist and ring.begins_trip():
-            for c in computes:
-                c.wait_event(ev_gather)                  # every all-gather of the previous trip is done: the ring is free again
-        b = ring.next_slot()
-        pk.pick_device(p_reqs, R, None, p_picks[b], p_scores[b], streams[b % len(streams)])
-        due = ring.after_batch()
-        if use_dist:
-            pk.stream_wait_pick(comm_handle)                       # comm waits for the kernel's own completion event
-            gather(due)
-
-    def fence():
-        due = ring.flush()
-        if use_dist:
-            gather(due)                                  # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    pk.profile(True)           # HIP events around every pick launch on the launch stream + probe counts
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = pk.profile_drain()
-    abytes, lookups, launches = pk.profile_bytes()
-    alone_ms = None
-    if args.alone_ref and world == 1:
-        # reference figure, outside the timed region: the same kernel with the GPU to itself (launches back to back on one stream)
-        for _ in range(60):
-            pk.pick_device(p_reqs, R, None, p_picks[0], p_scores[0], streams[0])
-        torch.cuda.synchronize()
-        alone_ms = np.asarray(pk.profile_drain(), dtype=np.float64)[10:]
-    pk.profile(False)
-
-    last = (ring.steps - 1) % NBUF
-    picks = d_picks[last].cpu().numpy()
-    scores = d_scores[last].cpu().numpy()
-    if use_dist:
-        out, n = last_gather[0]                          # layout [world][n][R]; the last step is the last slot of this rank's slab
-        allp = out.cpu().numpy().reshape(world, n, R)
-        assert np.array_equal(allp[rank, n - 1], picks), "all-gather returned a different shard"
+            def age(i, state=state):      # stream-ordered: behind the inserts of this step, ahead of the next pick
+                if (i + 1) % args.age_every == 0:
+                    state["epoch"] = run.pk.index_advance_epoch()
+                    if state["epoch"] > args.keep_epochs:
+                        run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, run.streams[0])
+        elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
+        results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per,
+                             value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
+        if mode == modes[0]:
+            extra_ms = run.more_kernel_samples(len(kern_ms), args.p99_samples) if not args.closed_loop else np.zeros(0)
+            picks, scores = run.last_outputs()
+            last_batch, lo, n_mine = run.last_batch, run.lo, run.n_mine
+            gathered = run.check_gather()
+        else:
+            run.check_gather()
+    run.pk.profile(False)
+    status = run.pk.launch_status()
+    assert status == 0, f"launch status {status}"
 
     if rank == 0:
+        main_mode = modes[0]
+        res = results[main_mode]
+        G = run.ring.gather_every
+        sharding = {"single": "single GPU",
+                    "strong": f"each 64k batch split R/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels",
+                    "weak": f"one whole batch per rank per step, RCCL all-gather of picks (buckets of {G} batches)"}[main_mode]
         out = {
-            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if args.config == 5 and args.requests is None and args.groups == 256 else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf})",
-            "value": world * R * args.steps / elapsed,
+            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if headline else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf}{', closed loop' if args.closed_loop else ''})",
+            "value": res["value"],
             "unit": "decisions/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if main_mode in ("single", "weak") else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl.name, "requests_per_gpu": R, "pods": wl.P, "adapters": wl.A, "blocks_per_request": wl.B,
+            "config": {"workload": wl.name, "requests_per_step": R if main_mode != "weak" else R * world, "requests_per_gpu": res["per"], "pods": wl.P,
+                       "adapters": wl.A, "blocks_per_request": wl.B,
                        "chain": "queue:2,kv:2,lora:1,prefix:3" if args.config in (3, 5) else str(wl.chain),
-                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": f"requests/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels" if use_dist else "single GPU",
-                       "batches_in_flight": args.inflight,
-                       "p99_step_ms": None},
+                       "index_entries": int(wl.index_hashes.shape[0]), "sharding": sharding,
+                       "distinct_batches": len(batches), "batch_bytes_resident": int(len(batches) * R * run.stride),
+                       "batches_in_flight": len(run.streams), "closed_loop": bool(args.closed_loop), "p99_step_ms": None},
         }
-        k = np.asarray(kern_ms, dtype=np.float64)
-        per_launch_bytes = abytes / max(launches, 1)
-        avg_ms = float(k.mean()) if k.size else float("nan")
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if k.size else float("nan")
-        traffic = None
-        kname = "pick_fast_kernel" if (wl.mask is None) else "pick_generic_kernel"
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured separately with rocprofv3 --pmc
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == wl.name and args.groups == 256 and args.zipf == 1.0:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # What the library's OWN layout moves through L2 -> L1 per launch (an estimate from the probe counts):
-        # request rows + pod rows + picks, one 64-byte key bucket per probed hash (all of a request's first 32 are gathered),
-        # one 64-byte pod list per hit (the dense 64 * sizeof(LW)-byte row when the lists are off), the adapter tables.
-        # `achieved` / `frac` above stay on SURVEY §8(d)'s byte model (u64 key + P/8-byte bitmap per index entry).
-        lw_bytes = 2 if wl.P <= 1024 else 4 if wl.P <= 2048 else 8
-        stride = 8 + 8 * wl.B
-        fixed = wl.P * 64 + R * (stride + 4)
-        lk = lookups / max(launches, 1)
-        row_model = 8 + 64 * lw_bytes
-        hits = max(per_launch_bytes - fixed - 8 * lk, 0.0) / (row_model - 8) if wl.B else 0.0
-        lists_on = os.environ.get("EPPK_LISTS", "1") != "0"
-        layout_bytes = fixed + (R * min(wl.B, 32) * 64 + hits * (64 if lists_on else 64 * lw_bytes) if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "pick_fast_kernel", "kernel_avg_ms": avg_ms,
-                           "kernel_p99_ms": float(np.percentile(k, 99)) if k.size else None,
-                           "algorithmic_bytes_per_launch": per_launch_bytes, "index_lookups_per_launch": lk,
-                           "byte_model": "SURVEY 8(d): u64 key + P/8-byte bitmap per index entry (the reference-shaped index)",
-                           "layout_bytes_per_launch": layout_bytes,
-                           "layout_GBps": layout_bytes / (avg_ms * 1e-3) / 1e9 if k.size else None,
-                           "launches_in_flight": args.inflight}
-        if alone_ms is not None and alone_ms.size:
-            # with two batches in flight the kernels share the GPU, so each launch lasts about twice as long as it does alone
-            # while two of them finish per that time; `achieved` / `frac` above use the duration measured in the timed region
-            a = float(alone_ms.mean())
-            out["roofline"]["kernel_alone_avg_ms"] = a
-            out["roofline"]["kernel_alone_p99_ms"] = float(np.percentile(alone_ms, 99))
-            out["roofline"]["frac_alone"] = per_launch_bytes / (a * 1e-3) / 1e9 / HBM_PEAK_GBS
-        out["config"]["p99_step_ms"] = out["roofline"]["kernel_p99_ms"]
-        if args.host_path and world == 1:
+        if "weak" in results and main_mode != "weak":
+            w = results["weak"]
+            out["weak"] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "requests_per_gpu": R,
+                           "note": "weak scaling timed in the same invocation: every rank scores one whole batch per step, picks all-gathered"}
+        if use_dist:
+            out["config"]["ranks_seen"] = int(dist.get_world_size())
+        k_timed = res["kern_ms"]
+        k_all = np.concatenate([k_timed, extra_ms]) if extra_ms.size else k_timed
+        avg_ms = float(k_timed.mean()) if k_timed.size else float("nan")
+        bm = byte_models(wl, res["per"], res["stats"], khash, lists_on=os.environ.get("EPPK_LISTS", "1") != "0")
+        kname = ("pick_fast_kernel" if run.pk.chain_is_fused() else "pick_generic_kernel")
+        achieved = bm["compulsory"] / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": kname, "kernel_avg_ms": avg_ms,
+                "kernel_p50_ms": float(np.percentile(k_all, 50)) if k_all.size else None,
+                "kernel_p99_ms": float(np.percentile(k_all, 99)) if k_all.size else None,
+                "kernel_samples": int(k_all.size), "launches_in_flight": len(run.streams),
+                "bytes_per_launch": bm["compulsory"],
+                "bytes_definition": "compulsory HBM bytes of one launch under libeppk's layout: request rows in + picks/scores out + each distinct key bucket / pod list / table touched, once",
+                "l2_side_bytes_per_launch": bm["l2_side"], "l2_side_GBps": bm["l2_side"] / (avg_ms * 1e-3) / 1e9,
+                "index_lookups_per_launch": bm["lookups"],
+                "limiter": "valu-issue (not HBM): see `issue`; the HBM-bound case is `roofline_cold`",
+                "model_bytes_per_launch": bm["model"], "model_frac": bm["model"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "model_note": "SURVEY 8(d) byte model (u64 key + P/8-byte bitmap per index entry, the reference-shaped index): NOT what this kernel moves; reference figure only, may exceed 1",
+                "kernel_src_sha16": khash}
+        tj = stamped_json("pmc_traffic.json", khash)
+        if tj and tj.get("workload") == wl.name and headline:
+            roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel build, calibrated: profiles/r02_fetchcal.txt)"
+        ij = stamped_json("pmc_issue.json", khash)
+        if ij and headline:
+            roof["issue"] = {k: ij[k] for k in ij if k not in ("kernel_src_sha16",)}
+            if "valu_per_decision" in ij:      # wave-instructions issued per second / (SIMDs x clock / 4)
+                clk = ij.get("sclk_hz", 2.4e9)
+                roof["issue"]["valu_issue_frac_live"] = ij["valu_per_decision"] * res["per"] / (avg_ms * 1e-3) / (N_SIMD * clk / 4.0)
+        out["roofline"] = roof
+        out["config"]["p99_step_ms"] = roof["kernel_p99_ms"]
+        if cl_info:
+            out["closed_loop"] = cl_info
+        if args.host_path and world == 1 and not args.closed_loop:
             # host-observed pick latency: request rows in host memory -> pinned staging -> H2D -> kernel -> D2H (PCIe-inclusive;
             # never `value`)
             lat = []
-            for _ in range(args.host_path):
+            for i in range(args.host_path + 2):
                 t0 = time.perf_counter()
-                pk.pick(wl.reqs)
+                run.pk.pick(batches[i % len(batches)])
                 lat.append(time.perf_counter() - t0)
             lat = np.asarray(lat[2:] or lat) * 1e3
             out["host_path"] = {"batches": int(lat.size), "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                                 "decisions_per_s_p50": R / (float(np.percentile(lat, 50)) * 1e-3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.closed_loop:
             orc = graft.load_oracle()
-            cb, opicks, oscores = cpu_baseline(pkg, wl, orc)
+            cb, opicks, oscores = cpu_baseline(wl, orc, batches[last_batch])
             out["cpu_baseline"] = cb
-            out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks)),
-                             "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores.view(np.uint64)))}
+            out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks[lo:lo + n_mine])),
+                             "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores[lo:lo + n_mine].view(np.uint64))),
+                             "batch": int(last_batch)}
+        elif use_dist and gathered is not None and main_mode == "strong" and not args.no_cpu_baseline and R <= 4096:
+            orc = graft.load_oracle()
+            oix = orc.OracleIndex()
+            oix.insert(wl.index_hashes, wl.index_pods)
+            op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[last_batch], wl.B)
+            out["parity"] = {"gathered_picks_equal_oracle": bool(np.array_equal(gathered, op))}
+    run.close()
+
+    # roofline_cold: the same kernel on an index that does not fit the caches (rank 0, N=1, headline runs only)
+    if rank == 0 and world == 1 and headline and not args.no_cold_ref and not use_dist:
+        try:
+            out["roofline_cold"] = cold_reference(pkg, torch, args, khash)
+        except Exception as e:  # never lose the headline line to the reference sub-run
+            out["roofline_cold"] = {"error": repr(e)}
+
+    if rank == 0:
         # RCCL writes a version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON
         # line is the last thing on stdout
         import ctypes
@@ -287,7 +476,72 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    pk.close()
+
+
+def closed_loop_verify(run, wl, args):
+    """The first generations of the closed loop, at full size, against the oracle: pick -> index[hash] U= {pick} -> next batch
+    (-> ageing), picks AND scores bit-exact on the EVOLVED index each generation.  Returns a summary for the JSON line."""
+    orc = graft.load_oracle()
+    cores = os.cpu_count() or 1
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    ok_p = ok_s = True
+    epoch = 1
+    t0 = time.perf_counter()
+    for g in range(args.cl_verify):
+        b = run.batch_of(run.step_no)
+        run.step()
+        run.torch.cuda.synchronize()
+        picks, scores = run.last_outputs()
+        op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, run.h_batches[b], wl.B, threads=cores)
+        ok_p &= bool(np.array_equal(picks, op))
+        ok_s &= bool(np.array_equal(scores.view(np.uint64), osc.view(np.uint64)))
+        oix.insert_picks(run.h_batches[b], wl.B, op)
+        if (g + 1) % args.age_every == 0:
+            epoch = run.pk.index_advance_epoch()
+            oe = oix.advance_epoch()
+            assert oe == epoch
+            if epoch > args.keep_epochs:
+                run.torch.cuda.synchronize()       # (the synchronous form runs on the context's own stream)
+                n_gpu = run.pk.index_evict_older(epoch - args.keep_epochs + 1)
+                n_orc = oix.evict_older(epoch - args.keep_epochs + 1)
+                ok_p &= n_gpu == n_orc
+    size_gpu, size_orc = run.pk.index_size(), oix.size()
+    return {"generations_verified": args.cl_verify, "picks_equal_oracle": ok_p, "scores_bitwise_equal_oracle": ok_s,
+            "index_size": size_gpu, "index_size_oracle": size_orc, "index_dropped": run.pk.index_dropped(),
+            "age_every": args.age_every, "keep_epochs": args.keep_epochs, "index_slots": args.cl_slots, "epoch": epoch,
+            "verify_seconds": time.perf_counter() - t0}
+
+
+def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
+    """The pick kernel where HBM IS the bound: 65 536 prefix groups, uniform -> 1 M distinct hashes (64 MiB of occupied lists,
+    32 MiB of key buckets, 2 GiB of dense rows: beyond L2 + Infinity Cache together with the rotating request batches)."""
+    import copy
+    a = copy.copy(args)
+    a.groups, a.zipf = 65536, 0.0
+    t0 = time.perf_counter()
+    wl = pkg.workload.make_workload(a.config, n_groups=a.groups, zipf_s=a.zipf)
+    batches = make_batches(pkg, wl, a, 4)        # (each batch draws 64k of the 65 536 groups at random: every batch touches different lists)
+    gen_s = time.perf_counter() - t0
+    run = Runner(pkg, torch, None, wl, batches, a, 0, 1, int(os.environ.get("LOCAL_RANK", "0")))
+    run.setup("single", 1)
+    elapsed, kern_ms, stats = run.timed(steps, warmup)
+    run.pk.profile(False)
+    bm = byte_models(wl, wl.R, stats, khash)
+    run.close()
+    avg_ms = float(kern_ms.mean())
+    ach = bm["l2_side"] / (avg_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "workload": f"{wl.name}, cold index: {a.groups} prefix groups, uniform ({int(np.unique(wl.index_hashes).size)} distinct hashes, {wl.index_slots} slots)",
+            "value": wl.R * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_avg_ms": avg_ms, "kernel_p99_ms": float(np.percentile(kern_ms, 99)),
+            "bytes_per_launch": bm["l2_side"],
+            "bytes_definition": "what the layout reads per launch: request rows + outputs + one 64-byte key bucket per gathered hash (32 per request) + one 64-byte pod list per hit + adapter tables",
+            "launches_in_flight": len(run.streams), "steps": steps, "generate_seconds": gen_s, "kernel_src_sha16": khash}
+    tj = stamped_json("pmc_traffic_cold.json", khash)
+    if tj:
+        roof["traffic"] = tj.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = "profiles/pmc_traffic_cold.json"
+    return roof
 
 
 if __name__ == "__main__":

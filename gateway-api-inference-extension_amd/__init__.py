@@ -7,6 +7,7 @@ Only the hot path lives here: ``csrc/`` holds the HIP kernels an
 (``include/eppk.h``); the Python files mirror the reference interface above that ABI:
 
 * ``picker.BatchedPicker``  — batched ``EndpointPicker.Pick`` (pkg/lwepp/handlers/server.go:79-82)
+* ``picker.DeviceGroup``    — the same picker over several GPUs behind the C ABI (eppk_group_*)
 * ``picker.RoundRobinPicker`` — the reference's only picker (server.go:84-101), the fail-open fallback
 * ``picker.subset_mask``    — candidate filter of handleRequestHeaders (request.go:104-133)
 * ``distributed``           — request sharding + the all-gather of picks
@@ -17,4 +18,4 @@ every pick raises.
 """
 from . import _lib, distributed, picker, workload  # noqa: F401
 from ._lib import EppkError, lib_path, load_library  # noqa: F401
-from .picker import BatchedPicker, Endpoint, PickResult, RoundRobinPicker, ScorerKind, Unavailable, subset_mask  # noqa: F401
+from .picker import BatchedPicker, DeviceGroup, Endpoint, PickResult, RoundRobinPicker, ScorerKind, Unavailable, subset_mask  # noqa: F401

@@ -20,9 +20,14 @@ SYMBOLS = [
     "eppk_snapshot_publish", "eppk_snapshot_info",
     "eppk_index_clear", "eppk_index_insert", "eppk_index_insert_picks_device", "eppk_index_remove_pod",
     "eppk_index_size", "eppk_index_dropped", "eppk_index_selfcheck", "eppk_stream_wait_pick", "eppk_index_advance_epoch", "eppk_index_evict_older",
+    "eppk_index_evict_older_device",
     "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
     "eppk_launch_status",
+    "eppk_group_create", "eppk_group_destroy", "eppk_group_last_error", "eppk_group_size", "eppk_group_ctx", "eppk_group_ranks_seen",
+    "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
+    "eppk_group_index_remove_pod", "eppk_group_index_advance_epoch", "eppk_group_index_evict_older", "eppk_group_pick_batch",
+    "eppk_group_device_picks",
     "eppk_chain_is_fused", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
@@ -89,6 +94,7 @@ def load_library() -> C.CDLL:
     lib.eppk_stream_wait_pick.argtypes = [vp, vp]
     lib.eppk_index_advance_epoch.argtypes = [vp, C.POINTER(u32)]
     lib.eppk_index_evict_older.argtypes = [vp, u32, C.POINTER(u32)]
+    lib.eppk_index_evict_older_device.argtypes = [vp, u32, vp]
     lib.eppk_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp]
     lib.eppk_pick_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     lib.eppk_pick_topk.argtypes = [vp, vp, u32, vp, u32, vp, vp]
@@ -101,6 +107,26 @@ def load_library() -> C.CDLL:
     lib.eppk_round_robin.argtypes = [C.POINTER(u64), u32]
     lib.eppk_round_robin.restype = i32
     lib.eppk_launch_status.argtypes = [vp, C.POINTER(u32)]
+    lib.eppk_group_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), u32, u32, C.POINTER(vp)]
+    lib.eppk_group_destroy.argtypes = [vp]
+    lib.eppk_group_destroy.restype = None
+    lib.eppk_group_last_error.argtypes = [vp]
+    lib.eppk_group_last_error.restype = C.c_char_p
+    lib.eppk_group_size.argtypes = [vp]
+    lib.eppk_group_size.restype = u32
+    lib.eppk_group_ctx.argtypes = [vp, u32]
+    lib.eppk_group_ctx.restype = vp
+    lib.eppk_group_ranks_seen.argtypes = [vp]
+    lib.eppk_group_set_min_shard.argtypes = [vp, u32]
+    lib.eppk_group_snapshot_publish.argtypes = [vp, vp, u32, u64]
+    lib.eppk_group_index_clear.argtypes = [vp]
+    lib.eppk_group_index_insert.argtypes = [vp, vp, vp, u32]
+    lib.eppk_group_index_remove_pod.argtypes = [vp, u32]
+    lib.eppk_group_index_advance_epoch.argtypes = [vp, C.POINTER(u32)]
+    lib.eppk_group_index_evict_older.argtypes = [vp, u32, C.POINTER(u32)]
+    lib.eppk_group_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp, u32]
+    lib.eppk_group_device_picks.argtypes = [vp, u32]
+    lib.eppk_group_device_picks.restype = vp
     lib.eppk_chain_is_fused.argtypes = [vp]
     lib.eppk_profile_enable.argtypes = [vp, C.c_int]
     lib.eppk_profile_drain.argtypes = [vp, vp, u32, C.POINTER(u32)]

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -694,6 +695,24 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   return rc;
 }
 
+int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream) {
+  if (!c) return EPPK_ERR_ARG;
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const uint32_t rows = c->slots + 2u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
+                       min_epoch, c->stats);     // (stats[0], the per-launch count of the synchronous form, just accumulates here)
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  return rc;
+}
+
 // ---- the hot path ----------------------------------------------------------------------------------
 
 int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, int32_t* d_out_pick,
@@ -728,48 +747,92 @@ int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
   return EPPK_OK;
 }
 
+// Host-buffer pick in two halves, so that a group (eppk_group_pick_batch) can overlap the devices: `begin` validates, stages and
+// enqueues H2D + kernel + D2H on the context's stream; `end` waits and copies out.  `h_src` (optional) = a pinned, portable copy of
+// the rows that the H2D may read directly (the group stages a batch ONCE for all devices); `full_n` > n_reqs uploads rows
+// [0, full_n) of `h_src` / reqs_base instead of only this context's shard (a group that learns prefixes needs the whole batch on
+// every device) and the shard starts at row `lo` of them.
+namespace {
+
+int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs) {
+  for (uint32_t r = 0; r < n_reqs; ++r) {
+    eppk_req_hdr h;
+    std::memcpy(&h, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof h);
+    if (h.n_blocks > c->cfg.max_blocks || h.adapter < -1 || h.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
+      return fail(c, EPPK_ERR_ARG, std::string(who) + ": request row " + std::to_string(r) + " out of range");
+  }
+  return EPPK_OK;
+}
+
+int ensure_host_staging(eppk_ctx* c, bool need_mask) {
+  const size_t mb = c->cfg.max_batch;
+  if (!c->d_reqs) {
+    HIPCHK(c, hipMalloc(&c->d_reqs, mb * c->stride));
+    HIPCHK(c, hipMalloc((void**)&c->d_pick, (mb + EPPK_GROUP_MAX_DEVICES) * 4u));   // (+ the padding of a group's in-place all-gather)
+    HIPCHK(c, hipMalloc((void**)&c->d_score, mb * 8u));
+    HIPCHK(c, hipHostMalloc(&c->h_reqs, mb * c->stride, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_pick, mb * 4u, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_score, mb * 8u, hipHostMallocDefault));
+  }
+  if (need_mask && !c->d_mask) {
+    HIPCHK(c, hipMalloc((void**)&c->d_mask, mb * c->jmax * 8u));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
+  }
+  return EPPK_OK;
+}
+
+// rows [lo, lo + n) of a batch of `full_n` rows starting at `base` (host memory; `pinned` = the device may DMA from it directly).
+// upload_all: rows [0, full_n) go to d_reqs (the shard is then d_reqs + lo * stride), else only the shard (at d_reqs).
+int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full_n, uint32_t lo, uint32_t n, bool upload_all,
+                    const uint64_t* cand_mask_shard) {
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t J = (c->n_pods + 63u) / 64u;
+  int rc = ensure_host_staging(c, cand_mask_shard != nullptr);
+  if (rc) return rc;
+  const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;
+  const uint8_t* src = base + (size_t)up_lo * c->stride;
+  if (up_n) {
+    if (!pinned) { std::memcpy(c->h_reqs, src, (size_t)up_n * c->stride); src = (const uint8_t*)c->h_reqs; }
+    HIPCHK(c, hipMemcpyAsync(c->d_reqs, src, (size_t)up_n * c->stride, hipMemcpyHostToDevice, c->stream));
+  }
+  if (n == 0) return EPPK_OK;
+  if (cand_mask_shard && J) {
+    std::memcpy(c->h_mask, cand_mask_shard, (size_t)n * J * 8u);
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n * J * 8u, hipMemcpyHostToDevice, c->stream));
+  }
+  const uint8_t* d_shard = (const uint8_t*)c->d_reqs + (upload_all ? (size_t)lo * c->stride : 0u);
+  rc = launch_pick(c, d_shard, n, (cand_mask_shard && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
+                   c->d_score + (upload_all ? lo : 0u), c->stream);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick + (upload_all ? lo : 0u), (size_t)n * 4u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score + (upload_all ? lo : 0u), (size_t)n * 8u, hipMemcpyDeviceToHost, c->stream));
+  return EPPK_OK;
+}
+
+int pick_host_end(eppk_ctx* c, uint32_t n, bool had_mask, int32_t* out_pick, double* out_score) {
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n == 0) return EPPK_OK;
+  const size_t J = (c->n_pods + 63u) / 64u;
+  std::memcpy(out_pick, c->h_pick, (size_t)n * 4u);
+  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n * 8u);
+  if (had_mask && !J) for (uint32_t r = 0; r < n; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+  return EPPK_OK;
+}
+
+}  // namespace
+
 int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick, double* out_score) {
   if (!c || ((!reqs || !out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch: null argument");
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
   // validate rows on the host: never hand the kernel an out-of-range adapter / block count
-  for (uint32_t r = 0; r < n_reqs; ++r) {
-    eppk_req_hdr h;
-    std::memcpy(&h, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof h);
-    if (h.n_blocks > c->cfg.max_blocks || h.adapter < -1 || h.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
-      return fail(c, EPPK_ERR_ARG, "eppk_pick_batch: request row " + std::to_string(r) + " out of range");
-  }
-  HIPCHK(c, hipSetDevice(c->cfg.device));
-  const size_t mb = c->cfg.max_batch;
-  const size_t J = (c->n_pods + 63u) / 64u;
-  if (!c->d_reqs) {
-    HIPCHK(c, hipMalloc(&c->d_reqs, mb * c->stride));
-    HIPCHK(c, hipMalloc((void**)&c->d_pick, mb * 4u));
-    HIPCHK(c, hipMalloc((void**)&c->d_score, mb * 8u));
-    HIPCHK(c, hipHostMalloc(&c->h_reqs, mb * c->stride, hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_pick, mb * 4u, hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_score, mb * 8u, hipHostMallocDefault));
-  }
-  if (cand_mask && !c->d_mask) {
-    HIPCHK(c, hipMalloc((void**)&c->d_mask, mb * c->jmax * 8u));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
-  }
-  std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
-  HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
-  if (cand_mask && J) {
-    std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
-    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
-  }
-  int rc = launch_pick(c, c->d_reqs, n_reqs, (cand_mask && J) ? c->d_mask : nullptr, c->d_pick, c->d_score, c->stream);
+  int rc = validate_rows(c, "eppk_pick_batch", reqs, n_reqs);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
-  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
-  if (cand_mask && !J) for (uint32_t r = 0; r < n_reqs; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
-  return EPPK_OK;
+  rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask);
+  if (rc) return rc;
+  return pick_host_end(c, n_reqs, cand_mask != nullptr, out_pick, out_score);
 }
 
 // ---- ordered fallbacks ---------------------------------------------------------------------------------
@@ -913,6 +976,290 @@ int eppk_profile_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* lookups, uint32_t
   if (lookups) *lookups = st[1];
   if (launches) *launches = c->launches;
   return EPPK_OK;
+}
+
+
+// ================================================================================================
+// Device groups: ONE picker over several GPUs, behind the C ABI (SURVEY.md §8(b) "device list", §8(e)).
+//
+// Snapshot and prefix index are replicated on every member device; a batch shards by request -- device g scores rows
+// [g*per, (g+1)*per), per = ceil(n / devices used) -- with NO data-path collective: a pick depends only on its own request row
+// and the replicated read-only state.  Every device returns its shard of picks to the host over its own PCIe link.  The one
+// exchange, an all-gather of the int32 picks so that EVERY device holds all of them, happens only when something on the devices
+// needs them: the post-route index update that each device applies to its own replica (EPPK_GROUP_LEARN), or a caller that asks
+// for it (EPPK_GROUP_GATHER).  Three ways to do it (eppk_group_create `gather_mode`):
+//   PEER  every device pushes its shard into each peer's pick array with hipMemcpyPeerAsync on its own stream (xGMI is
+//         point-to-point and fully connected: G-1 one-hop copies of n/G * 4 bytes each, no ring), peers wait on its event;
+//   RCCL  ncclAllGather, in place, one communicator per device in ONE process (ncclCommInitAll; librccl is dlopen'ed so that
+//         libeppk does not link it): the collective north_star names;
+//   HOST  the picks every device already returns to the host are uploaded back to all of them (no device-to-device traffic).
+struct eppk_group {
+  std::vector<eppk_ctx*> ctx;
+  std::vector<int> dev;
+  uint32_t mode = 0;
+  uint32_t min_shard = 2048;
+  uint32_t max_batch = 0;
+  void* h_stage = nullptr; size_t h_stage_bytes = 0;   // ONE pinned, portable copy of a batch: every device DMAs from it
+  std::vector<hipEvent_t> ev;                           // ev[g]: device g's shard of picks is in every peer's array (PEER)
+  // RCCL (dlopen)
+  void* rccl = nullptr;
+  std::vector<void*> comms;
+  int ranks_seen = 0;
+  int (*nccl_comm_init_all)(void**, int, const int*) = nullptr;
+  int (*nccl_comm_destroy)(void*) = nullptr;
+  int (*nccl_comm_count)(void*, int*) = nullptr;
+  int (*nccl_group_start)() = nullptr;
+  int (*nccl_group_end)() = nullptr;
+  int (*nccl_all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*nccl_err)(int) = nullptr;
+  std::string err;
+};
+
+namespace {
+
+std::string g_group_err;
+
+int gfail(eppk_group* g, int code, const std::string& msg) {
+  if (g) g->err = msg;
+  else { std::lock_guard<std::mutex> l(g_err_mu); g_group_err = msg; }
+  return code;
+}
+
+int group_load_rccl(eppk_group* g) {
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) { g->rccl = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g->rccl) break; }
+  if (!g->rccl) return gfail(g, EPPK_ERR_DEVICE, std::string("eppk_group_create: cannot load librccl: ") + dlerror());
+  auto sym = [&](const char* n) { return dlsym(g->rccl, n); };
+  g->nccl_comm_init_all = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+  g->nccl_comm_destroy = (int (*)(void*))sym("ncclCommDestroy");
+  g->nccl_comm_count = (int (*)(void*, int*))sym("ncclCommCount");
+  g->nccl_group_start = (int (*)())sym("ncclGroupStart");
+  g->nccl_group_end = (int (*)())sym("ncclGroupEnd");
+  g->nccl_all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
+  g->nccl_err = (const char* (*)(int))sym("ncclGetErrorString");
+  if (!g->nccl_comm_init_all || !g->nccl_comm_destroy || !g->nccl_group_start || !g->nccl_group_end || !g->nccl_all_gather)
+    return gfail(g, EPPK_ERR_DEVICE, "eppk_group_create: librccl lacks an expected symbol");
+  return EPPK_OK;
+}
+
+#define GFOR(g, i) for (uint32_t i = 0; i < (uint32_t)(g)->ctx.size(); ++i)
+// run `expr` (an int-returning call on member i) on every member; first failure wins
+#define GALL(g, expr)                                                                            \
+  do {                                                                                           \
+    GFOR(g, i) {                                                                                 \
+      eppk_ctx* m = (g)->ctx[i]; (void)m;                                                        \
+      const int rc_ = (expr);                                                                    \
+      if (rc_ != EPPK_OK) return gfail((g), rc_, "device " + std::to_string((g)->dev[i]) + ": " + eppk_last_error(m)); \
+    }                                                                                            \
+  } while (0)
+
+}  // namespace
+
+const char* eppk_group_last_error(const eppk_group* g) {
+  if (g) return g->err.c_str();
+  std::lock_guard<std::mutex> l(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_group_err;
+  return copy.c_str();
+}
+
+int eppk_group_create(const eppk_cfg* cfg, const int32_t* devices, uint32_t n_devices, uint32_t gather_mode, eppk_group** out) {
+  if (!cfg || !devices || !out || n_devices == 0) return gfail(nullptr, EPPK_ERR_ARG, "eppk_group_create: null argument / no devices");
+  *out = nullptr;
+  if (n_devices > EPPK_GROUP_MAX_DEVICES) return gfail(nullptr, EPPK_ERR_LIMIT, "eppk_group_create: more than EPPK_GROUP_MAX_DEVICES devices");
+  if (gather_mode > EPPK_GATHER_HOST) return gfail(nullptr, EPPK_ERR_ARG, "eppk_group_create: unknown gather mode");
+  eppk_group* g = new (std::nothrow) eppk_group();
+  if (!g) return gfail(nullptr, EPPK_ERR_NOMEM, "eppk_group_create: out of memory");
+  g->mode = gather_mode;
+  g->max_batch = cfg->max_batch;
+  auto bail = [&](int code, const std::string& m) { eppk_group_destroy(g); return gfail(nullptr, code, m); };
+  for (uint32_t i = 0; i < n_devices; ++i) {
+    eppk_cfg c = *cfg;
+    c.device = devices[i];
+    eppk_ctx* m = nullptr;
+    const int rc = eppk_create(&c, &m);
+    if (rc != EPPK_OK) return bail(rc, std::string("eppk_group_create: device ") + std::to_string(devices[i]) + ": " + eppk_last_error(nullptr));
+    g->ctx.push_back(m);
+    g->dev.push_back(devices[i]);
+  }
+  // peer access between distinct devices (hipMemcpyPeerAsync works without it, through host memory; with it the copy is one xGMI hop)
+  for (uint32_t i = 0; i < n_devices; ++i)
+    for (uint32_t j = 0; j < n_devices; ++j) {
+      if (devices[i] == devices[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[i]);
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+    }
+  for (uint32_t i = 0; i < n_devices; ++i) {
+    hipEvent_t e;
+    (void)hipSetDevice(devices[i]);
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(EPPK_ERR_DEVICE, "eppk_group_create: hipEventCreate failed");
+    g->ev.push_back(e);
+  }
+  g->ranks_seen = (int)n_devices;
+  if (gather_mode == EPPK_GATHER_RCCL) {
+    for (uint32_t i = 0; i < n_devices; ++i)
+      for (uint32_t j = i + 1; j < n_devices; ++j)
+        if (devices[i] == devices[j]) return bail(EPPK_ERR_ARG, "eppk_group_create: EPPK_GATHER_RCCL needs distinct devices (one communicator rank per GPU)");
+    const int rc = group_load_rccl(g);
+    if (rc) { const std::string m = g->err; return bail(rc, m); }
+    g->comms.assign(n_devices, nullptr);
+    std::vector<int> devs(devices, devices + n_devices);
+    const int nrc = g->nccl_comm_init_all(g->comms.data(), (int)n_devices, devs.data());
+    if (nrc != 0) { g->comms.clear(); return bail(EPPK_ERR_DEVICE, std::string("ncclCommInitAll: ") + (g->nccl_err ? g->nccl_err(nrc) : "error")); }
+    int cnt = 0;
+    if (g->nccl_comm_count && g->nccl_comm_count(g->comms[0], &cnt) == 0) g->ranks_seen = cnt;
+  }
+  *out = g;
+  return EPPK_OK;
+}
+
+void eppk_group_destroy(eppk_group* g) {
+  if (!g) return;
+  for (void* c : g->comms) if (c && g->nccl_comm_destroy) (void)g->nccl_comm_destroy(c);
+  for (size_t i = 0; i < g->ev.size(); ++i) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(g->ev[i]); }
+  for (eppk_ctx* m : g->ctx) eppk_destroy(m);
+  if (g->h_stage) (void)hipHostFree(g->h_stage);
+  delete g;     // (librccl stays loaded: unloading a library that owns device state is not worth the risk)
+}
+
+uint32_t eppk_group_size(const eppk_group* g) { return g ? (uint32_t)g->ctx.size() : 0u; }
+eppk_ctx* eppk_group_ctx(eppk_group* g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+int eppk_group_ranks_seen(const eppk_group* g) { return g ? g->ranks_seen : EPPK_ERR_ARG; }
+int eppk_group_set_min_shard(eppk_group* g, uint32_t n) { if (!g || n == 0) return EPPK_ERR_ARG; g->min_shard = n; return EPPK_OK; }
+
+int eppk_group_snapshot_publish(eppk_group* g, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) {
+  if (!g) return EPPK_ERR_ARG;
+  GALL(g, eppk_snapshot_publish(m, rows, n_pods, epoch));
+  return EPPK_OK;
+}
+int eppk_group_index_clear(eppk_group* g) { if (!g) return EPPK_ERR_ARG; GALL(g, eppk_index_clear(m)); return EPPK_OK; }
+int eppk_group_index_insert(eppk_group* g, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+  if (!g) return EPPK_ERR_ARG;
+  GALL(g, eppk_index_insert(m, hashes, pods, n));
+  return EPPK_OK;
+}
+int eppk_group_index_remove_pod(eppk_group* g, uint32_t pod) { if (!g) return EPPK_ERR_ARG; GALL(g, eppk_index_remove_pod(m, pod)); return EPPK_OK; }
+int eppk_group_index_advance_epoch(eppk_group* g, uint32_t* new_epoch) {
+  if (!g) return EPPK_ERR_ARG;
+  GALL(g, eppk_index_advance_epoch(m, new_epoch));
+  return EPPK_OK;
+}
+int eppk_group_index_evict_older(eppk_group* g, uint32_t min_epoch, uint32_t* n_evicted) {
+  if (!g) return EPPK_ERR_ARG;
+  GALL(g, eppk_index_evict_older(m, min_epoch, n_evicted));     // (replicas are identical: every member evicts the same hashes)
+  return EPPK_OK;
+}
+
+int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick,
+                          double* out_score, uint32_t flags) {
+  if (!g || ((!reqs || !out_pick) && n_reqs)) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_batch: null argument");
+  if (n_reqs > g->max_batch) return gfail(g, EPPK_ERR_LIMIT, "eppk_group_pick_batch: n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  const uint32_t G = (uint32_t)g->ctx.size();
+  eppk_ctx* c0 = g->ctx[0];
+  for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, "eppk_group_pick_batch: no snapshot published");
+  const bool learn = (flags & EPPK_GROUP_LEARN) != 0 && c0->slots != 0 && c0->cfg.max_blocks != 0;
+  const bool gather = learn || (flags & EPPK_GROUP_GATHER) != 0;
+  int rc = validate_rows(c0, "eppk_group_pick_batch", reqs, n_reqs);
+  if (rc) return gfail(g, rc, eppk_last_error(c0));
+  // devices used: a small batch stays on one GPU (north_star: shard only when requests x pods outgrow one device)
+  uint32_t used = (n_reqs + g->min_shard - 1) / g->min_shard;
+  used = used < 1 ? 1 : used > G ? G : used;
+  const uint32_t per = (n_reqs + used - 1) / used;
+  const size_t J = (c0->n_pods + 63u) / 64u;
+  // ONE pinned + portable staging copy of the batch; every device's DMA engine reads it over its own PCIe link
+  const size_t need = (size_t)g->max_batch * c0->stride;
+  if (g->h_stage_bytes < need) {
+    if (g->h_stage) (void)hipHostFree(g->h_stage);
+    g->h_stage = nullptr; g->h_stage_bytes = 0;
+    if (hipHostMalloc(&g->h_stage, need, hipHostMallocPortable) != hipSuccess) return gfail(g, EPPK_ERR_NOMEM, "eppk_group_pick_batch: pinned staging");
+    g->h_stage_bytes = need;
+  }
+  std::memcpy(g->h_stage, reqs, (size_t)n_reqs * c0->stride);
+  auto lo_of = [&](uint32_t i) { const uint64_t l = (uint64_t)i * per; return (uint32_t)(l < n_reqs ? l : n_reqs); };
+  auto cnt_of = [&](uint32_t i) { if (i >= used) return 0u; const uint32_t l = lo_of(i), h = lo_of(i + 1); return h - l; };
+  // A: every device: H2D (its shard, or the whole batch when the device-side picks will be gathered) -> kernel -> D2H of its picks
+  GFOR(g, i) {
+    const uint32_t lo = lo_of(i), cnt = cnt_of(i);
+    if (cnt == 0 && !gather) continue;
+    rc = pick_host_begin(g->ctx[i], (const uint8_t*)g->h_stage, true, n_reqs, lo, cnt, gather,
+                         (cand_mask && cnt) ? cand_mask + (size_t)lo * J : nullptr);
+    if (rc) return gfail(g, rc, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(g->ctx[i]));
+  }
+  // B: all-gather of the picks on the devices
+  if (gather && g->mode == EPPK_GATHER_PEER) {
+    GFOR(g, i) {
+      const uint32_t lo = lo_of(i), cnt = cnt_of(i);
+      eppk_ctx* m = g->ctx[i];
+      if (cnt) {
+        (void)hipSetDevice(g->dev[i]);
+        GFOR(g, p) {
+          if (p == i) continue;
+          const hipError_t e = g->dev[p] == g->dev[i]
+              ? hipMemcpyAsync(g->ctx[p]->d_pick + lo, m->d_pick + lo, (size_t)cnt * 4u, hipMemcpyDeviceToDevice, m->stream)   // (two members on one GPU: tests)
+              : hipMemcpyPeerAsync(g->ctx[p]->d_pick + lo, g->dev[p], m->d_pick + lo, g->dev[i], (size_t)cnt * 4u, m->stream);
+          if (e != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, std::string("eppk_group_pick_batch: peer copy failed: ") + hipGetErrorString(e));
+        }
+        if (hipEventRecord(g->ev[i], m->stream) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_batch: hipEventRecord failed");
+      }
+    }
+    GFOR(g, p) {
+      (void)hipSetDevice(g->dev[p]);
+      GFOR(g, i) if (i != p && cnt_of(i)) (void)hipStreamWaitEvent(g->ctx[p]->stream, g->ev[i], 0);
+    }
+  } else if (gather && g->mode == EPPK_GATHER_RCCL) {
+    // in place: rank i's send buffer is its own slice of the receive buffer (per entries per rank; d_pick has room for per * G).
+    // With fewer devices used than members the unused ranks contribute padding behind the batch.
+    const uint32_t perc = (n_reqs + G - 1) / G;
+    if (used != G) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_batch: EPPK_GATHER_RCCL shards over all members (set min_shard <= n_reqs / devices)");
+    (void)perc;
+    int nrc = g->nccl_group_start();
+    GFOR(g, i) {
+      eppk_ctx* m = g->ctx[i];
+      (void)hipSetDevice(g->dev[i]);
+      if (nrc == 0) nrc = g->nccl_all_gather(m->d_pick + (size_t)i * per, m->d_pick, per, /*ncclInt32*/ 2, g->comms[i], m->stream);
+    }
+    const int erc = g->nccl_group_end();
+    if (nrc != 0 || erc != 0) return gfail(g, EPPK_ERR_DEVICE, std::string("ncclAllGather: ") + (g->nccl_err ? g->nccl_err(nrc ? nrc : erc) : "error"));
+  }
+  // C (PEER / RCCL): every device applies the SAME post-route index update to its replica, from the gathered picks
+  if (learn && g->mode != EPPK_GATHER_HOST) {
+    GFOR(g, p) {
+      eppk_ctx* m = g->ctx[p];
+      rc = eppk_index_insert_picks_device(m, m->d_reqs, m->d_pick, n_reqs, m->stream);
+      if (rc) return gfail(g, rc, "device " + std::to_string(g->dev[p]) + ": " + eppk_last_error(m));
+    }
+  }
+  // D: wait, hand the shards to the caller
+  GFOR(g, i) {
+    const uint32_t lo = lo_of(i), cnt = cnt_of(i);
+    if (cnt == 0 && !gather) continue;
+    rc = pick_host_end(g->ctx[i], cnt, cand_mask != nullptr, out_pick + lo, out_score ? out_score + lo : nullptr);
+    if (rc) return gfail(g, rc, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(g->ctx[i]));
+  }
+  // HOST gather: the picks are on the host now; upload all of them to every device (and learn from them)
+  if (gather && g->mode == EPPK_GATHER_HOST) {
+    GFOR(g, p) {
+      eppk_ctx* m = g->ctx[p];
+      (void)hipSetDevice(g->dev[p]);
+      if (hipMemcpyAsync(m->d_pick, out_pick, (size_t)n_reqs * 4u, hipMemcpyHostToDevice, m->stream) != hipSuccess)
+        return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_batch: upload of the gathered picks failed");
+      if (learn) {
+        rc = eppk_index_insert_picks_device(m, m->d_reqs, m->d_pick, n_reqs, m->stream);
+        if (rc) return gfail(g, rc, "device " + std::to_string(g->dev[p]) + ": " + eppk_last_error(m));
+      }
+    }
+    GFOR(g, p) { (void)hipSetDevice(g->dev[p]); if (hipStreamSynchronize(g->ctx[p]->stream) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_batch: sync failed"); }
+  }
+  return EPPK_OK;
+}
+
+const int32_t* eppk_group_device_picks(eppk_group* g, uint32_t i) {
+  return (g && i < g->ctx.size()) ? g->ctx[i]->d_pick : nullptr;
 }
 
 }  // extern "C"

@@ -258,6 +258,10 @@ class BatchedPicker:
         self._check(self._lib.eppk_index_evict_older(self._ctx, min_epoch, C.byref(n)), "index_evict_older")
         return n.value
 
+    def index_evict_older_device(self, min_epoch: int, stream: int = 0) -> None:
+        """The same eviction, asynchronous on `stream` (hipStream_t as int), no count (include/eppk.h)."""
+        self._check(self._lib.eppk_index_evict_older_device(self._ctx, min_epoch, stream or None), "index_evict_older_device")
+
     def index_size(self) -> int:
         n = C.c_uint32(0)
         self._check(self._lib.eppk_index_size(self._ctx, C.byref(n)), "index_size")
@@ -360,3 +364,130 @@ class BatchedPicker:
         b, p, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
         self._check(self._lib.eppk_profile_bytes(self._ctx, C.byref(b), C.byref(p), C.byref(n)), "profile_bytes")
         return b.value, p.value, n.value
+
+
+GATHER_PEER, GATHER_RCCL, GATHER_HOST = 0, 1, 2
+GROUP_LEARN, GROUP_GATHER = 1, 2
+
+
+class DeviceGroup:
+    """One picker over several GPUs behind the C ABI (include/eppk.h "device groups"): replicated snapshot + prefix index,
+    batches sharded by request, picks all-gathered on the devices only for the post-route index update (`learn`)."""
+
+    def __init__(self, chain: Sequence[Tuple[int, int]], devices: Sequence[int], max_pods: int, max_blocks: int = 0, max_batch: int = 65536,
+                 index_slots: int = 0, gather: int = GATHER_PEER, min_shard: Optional[int] = None) -> None:
+        self._lib = _lib.load_library()
+        cfg = _lib.Cfg()
+        cfg.struct_size = C.sizeof(_lib.Cfg)
+        cfg.device = 0
+        cfg.max_pods, cfg.max_blocks, cfg.max_batch, cfg.index_slots = max_pods, max_blocks, max_batch, index_slots
+        cfg.n_scorers = len(chain)
+        for i, (kind, weight) in enumerate(chain):
+            cfg.chain[i].kind = int(kind)
+            cfg.chain[i].weight = int(weight)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        self._g = C.c_void_p()
+        rc = self._lib.eppk_group_create(C.byref(cfg), devs, len(devices), gather, C.byref(self._g))
+        if rc != 0:
+            raise EppkError(rc, (self._lib.eppk_group_last_error(None) or b"").decode())
+        self.n_pods, self.row_words, self.max_batch = 0, 1 + max_blocks, max_batch
+        if min_shard is not None:
+            self._check(self._lib.eppk_group_set_min_shard(self._g, int(min_shard)), "set_min_shard")
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise EppkError(rc, f"{what}: {(self._lib.eppk_group_last_error(self._g) or b'').decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_g", None) is not None and self._g:
+            self._lib.eppk_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.eppk_group_size(self._g))
+
+    @property
+    def ranks_seen(self) -> int:
+        return int(self._lib.eppk_group_ranks_seen(self._g))
+
+    def publish(self, pods: np.ndarray, epoch: int = 0) -> None:
+        pods = np.ascontiguousarray(pods, dtype=POD_DTYPE)
+        self._check(self._lib.eppk_group_snapshot_publish(self._g, pods.ctypes.data, pods.shape[0], epoch), "group_snapshot_publish")
+        self.n_pods = int(pods.shape[0])
+
+    def index_insert(self, hashes: np.ndarray, pods: np.ndarray) -> None:
+        h = np.ascontiguousarray(hashes, dtype=np.uint64).ravel()
+        p = np.ascontiguousarray(pods, dtype=np.uint32).ravel()
+        self._check(self._lib.eppk_group_index_insert(self._g, h.ctypes.data, p.ctypes.data, h.shape[0]), "group_index_insert")
+
+    def index_clear(self) -> None:
+        self._check(self._lib.eppk_group_index_clear(self._g), "group_index_clear")
+
+    def index_remove_pod(self, pod: int) -> None:
+        self._check(self._lib.eppk_group_index_remove_pod(self._g, pod), "group_index_remove_pod")
+
+    def index_advance_epoch(self) -> int:
+        e = C.c_uint32(0)
+        self._check(self._lib.eppk_group_index_advance_epoch(self._g, C.byref(e)), "group_index_advance_epoch")
+        return e.value
+
+    def index_evict_older(self, min_epoch: int) -> int:
+        n = C.c_uint32(0)
+        self._check(self._lib.eppk_group_index_evict_older(self._g, min_epoch, C.byref(n)), "group_index_evict_older")
+        return n.value
+
+    def pick(self, reqs: np.ndarray, mask: Optional[np.ndarray] = None, learn: bool = False, gather: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words, "request row stride mismatch"
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        mptr = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert mask.shape == (R, (self.n_pods + 63) // 64), "mask shape mismatch"
+            mptr = mask.ctypes.data
+        flags = (GROUP_LEARN if learn else 0) | (GROUP_GATHER if gather else 0)
+        self._check(self._lib.eppk_group_pick_batch(self._g, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data, flags), "group_pick_batch")
+        return picks, scores
+
+    def member_index_size(self, i: int) -> int:
+        n = C.c_uint32(0)
+        rc = self._lib.eppk_index_size(self._lib.eppk_group_ctx(self._g, i), C.byref(n))
+        if rc != 0:
+            raise EppkError(rc, "index_size")
+        return n.value
+
+    def member_selfcheck(self, i: int) -> int:
+        n = C.c_uint64(0)
+        rc = self._lib.eppk_index_selfcheck(self._lib.eppk_group_ctx(self._g, i), C.byref(n))
+        if rc != 0:
+            raise EppkError(rc, "index_selfcheck")
+        return n.value
+
+    def member_pick(self, i: int, reqs: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """eppk_pick_batch on member i alone (its replica of snapshot + index): diagnostics / tests."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        rc = self._lib.eppk_pick_batch(self._lib.eppk_group_ctx(self._g, i), reqs.ctypes.data, R, None, picks.ctypes.data, scores.ctypes.data)
+        if rc != 0:
+            raise EppkError(rc, "member pick_batch")
+        return picks, scores
+
+    def device_picks_ptr(self, i: int) -> int:
+        return int(self._lib.eppk_group_device_picks(self._g, i) or 0)

@@ -181,4 +181,31 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
     return Workload(name=c["name"], R=R, P=P, A=A, B=B, chain=[(int(k), int(w)) for k, w in c["chain"]], pods=pods,
                     reqs=reqs, index_hashes=index_hashes, index_pods=index_pods.astype(np.uint32), index_slots=index_slots,
                     mask=mask, meta=dict(config=config, seed=seed, n_groups=n_groups, pods_per_group=pods_per_group, zipf_s=zipf_s,
-                                         shared_blocks=Bs, unique_blocks=Bu))
+                                         shared_blocks=Bs, unique_blocks=Bu, group_adapter=group_adapter,
+                                         group_bytes=gbytes if B > 0 else None))
+
+
+def make_requests(wl: Workload, req_seed: int) -> np.ndarray:
+    """Another batch of request rows against the SAME snapshot, prefix groups and index as `wl` (bench.py rotates through several
+    distinct batches): exactly the rows make_workload(..., req_seed=req_seed) would produce, without rebuilding pods and index."""
+    m = wl.meta
+    R, B, n_groups = wl.R, wl.B, m["n_groups"]
+    lib = _lib.load_library()
+    gw = 1.0 / np.arange(1, n_groups + 1, dtype=np.float64) ** m["zipf_s"]
+    cdf = np.cumsum(gw) / gw.sum()
+    u = (splitmix64(_sub(req_seed, 10), R) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    group = np.minimum(np.searchsorted(cdf, u, side="right"), n_groups - 1).astype(np.int64)
+    adapter = m["group_adapter"][group]
+    hashes = np.zeros((R, max(B, 1)), dtype=np.uint64)
+    if B > 0:
+        Bu = m["unique_blocks"]
+        gbytes = m["group_bytes"]
+        tbytes = splitmix64(_sub(req_seed, 13), R * Bu * (BLOCK_CHARS // 8)).reshape(R, -1)
+        out = np.zeros(B, dtype=np.uint64)
+        for r in range(R):
+            prompt = gbytes[int(group[r])].tobytes() + tbytes[r].tobytes()
+            model = _model_name(int(adapter[r]))
+            n = lib.eppk_hash_prompt(model, len(model), prompt, len(prompt), BLOCK_CHARS, out.ctypes.data, B)
+            assert n == B
+            hashes[r, :B] = out
+    return make_req_rows(adapter, np.full(R, B, dtype=np.uint32), hashes[:, :B] if B else None, B)

@@ -165,6 +165,10 @@ int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
  * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches. */
 int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
 int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);
+/* The same eviction, asynchronous on `stream` (a hipStream_t as void*; NULL = the context's stream) and without the count: what
+ * a closed loop (pick -> eppk_index_insert_picks_device -> pick ...) issues on its own stream between two batches, ordered
+ * behind the inserts and ahead of the next pick, without draining the pipeline.  eppk_index_size reports the effect. */
+int eppk_index_evict_older_device(eppk_ctx* ctx, uint32_t min_epoch, void* stream);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 
@@ -217,6 +221,50 @@ int eppk_pick_topk(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint6
 /* Same with device-resident buffers, asynchronous on `stream` (see eppk_pick_batch_device). */
 int eppk_pick_topk_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
                           int32_t* d_out_pick, double* d_out_score, void* stream);
+
+/* ---- device groups: one picker over several GPUs (SURVEY.md §8(b) "device list", §8(e)) ------------------------------ */
+
+/* A group replicates the snapshot and the prefix index on every member device and shards each batch BY REQUEST: member g scores
+ * rows [g*per, (g+1)*per), per = ceil(n_reqs / devices used).  There is no data-path collective -- a pick depends only on its own
+ * request row and the replicated read-only state -- and every device returns its shard of picks to the host over its own PCIe
+ * link.  The one exchange of the path, an all-gather of the int32 picks so that every DEVICE holds all of them, runs only when
+ * something on the devices needs them: EPPK_GROUP_LEARN (each device applies the same post-route index update to its replica,
+ * SEMANTICS.md §6) or EPPK_GROUP_GATHER.  The same calling rules as a context: one caller at a time.
+ * What a Go host links instead of torch.distributed: INTEGRATION.md §5. */
+typedef struct eppk_group eppk_group;
+#define EPPK_GROUP_MAX_DEVICES 16u
+/* how the picks are all-gathered on the devices */
+#define EPPK_GATHER_PEER 0u   /* every device pushes its shard into each peer's array (hipMemcpyPeerAsync: one xGMI hop per peer) */
+#define EPPK_GATHER_RCCL 1u   /* ncclAllGather, in place, one communicator rank per device in this process (librccl is dlopen'ed);
+                               * needs distinct devices and shards every batch over ALL members */
+#define EPPK_GATHER_HOST 2u   /* the picks the devices return to the host are uploaded back to every device (no peer traffic) */
+/* eppk_group_pick_batch flags */
+#define EPPK_GROUP_LEARN  1u  /* after the picks: index[hash[r][i]] U= {pick[r]} on EVERY member, from the gathered picks */
+#define EPPK_GROUP_GATHER 2u  /* all-gather the picks on the devices even without LEARN (eppk_group_device_picks) */
+
+/* One member context per entry of `devices` (HIP ordinals; cfg->device is ignored; an ordinal may repeat -- two members on one GPU
+ * is how a one-GPU box tests the sharding).  cfg->max_batch bounds the WHOLE batch. */
+int         eppk_group_create(const eppk_cfg* cfg, const int32_t* devices, uint32_t n_devices, uint32_t gather_mode, eppk_group** out);
+void        eppk_group_destroy(eppk_group* g);
+const char* eppk_group_last_error(const eppk_group* g);       /* g == NULL: the last failed eppk_group_create */
+uint32_t    eppk_group_size(const eppk_group* g);
+eppk_ctx*   eppk_group_ctx(eppk_group* g, uint32_t i);        /* member i (diagnostics; per-device calls such as eppk_index_size) */
+/* Ranks the collective layer sees: the communicator's size under EPPK_GATHER_RCCL (ncclCommCount), else the member count. */
+int         eppk_group_ranks_seen(const eppk_group* g);
+/* A batch is spread over ceil(n_reqs / min_shard) members at most (default 2048): a small batch stays on one GPU. */
+int         eppk_group_set_min_shard(eppk_group* g, uint32_t min_shard);
+/* Replicated state: the same call on every member (eppk_snapshot_publish, eppk_index_*). */
+int eppk_group_snapshot_publish(eppk_group* g, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch);
+int eppk_group_index_clear(eppk_group* g);
+int eppk_group_index_insert(eppk_group* g, const uint64_t* hashes, const uint32_t* pods, uint32_t n);
+int eppk_group_index_remove_pod(eppk_group* g, uint32_t pod);
+int eppk_group_index_advance_epoch(eppk_group* g, uint32_t* new_epoch);
+int eppk_group_index_evict_older(eppk_group* g, uint32_t min_epoch, uint32_t* n_evicted);
+/* eppk_pick_batch over the group: same arguments and results (out_pick / out_score hold all n_reqs entries, in request order). */
+int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick,
+                          double* out_score, uint32_t flags);
+/* Device pointer to member i's copy of the gathered picks of the last LEARN / GATHER batch (n_reqs entries, request order). */
+const int32_t* eppk_group_device_picks(eppk_group* g, uint32_t i);
 
 /* ---- adjacent host-side steps of the same path ---------------------------------------------- */
 

@@ -79,6 +79,34 @@ def _fake_picker_class(pkg, orc, log):
             self.last_stream = stream
             log.append(("pick", p_pick, stream))
 
+        def index_insert_picks_device(self, p_reqs, p_picks, n, stream=0):
+            raw = (ctypes.c_uint8 * (n * self.stride)).from_address(p_reqs)
+            reqs = np.frombuffer(raw, dtype=np.uint64).reshape(n, 1 + self.B).copy()
+            picks = np.frombuffer((ctypes.c_int32 * n).from_address(p_picks), dtype=np.int32).copy()
+            self.oix.insert_picks(reqs, self.B, picks)
+            log.append(("learn", n))
+
+        def index_advance_epoch(self):
+            return self.oix.advance_epoch()
+
+        def index_evict_older(self, min_epoch):
+            return self.oix.evict_older(min_epoch)
+
+        def index_evict_older_device(self, min_epoch, stream=0):
+            self.oix.evict_older(min_epoch)
+
+        def index_size(self):
+            return self.oix.size()
+
+        def index_dropped(self):
+            return 0
+
+        def launch_status(self):
+            return 0
+
+        def chain_is_fused(self):
+            return 1
+
         def stream_wait_pick(self, waiting_stream):
             assert self.last_stream is not None and waiting_stream != self.last_stream
             log.append(("wait", waiting_stream))
@@ -99,9 +127,10 @@ def _fake_picker_class(pkg, orc, log):
     return FakePicker
 
 
-@pytest.mark.parametrize("argv", [["--force-dist", "--steps", "11", "--warmup", "3"],
-                                  ["--force-dist", "--steps", "8", "--warmup", "8", "--gather-every", "1", "--inflight", "1"],
-                                  ["--steps", "5", "--warmup", "2"]])
+@pytest.mark.parametrize("argv", [["--force-dist", "--steps", "11", "--warmup", "3", "--p99-samples", "40"],
+                                  ["--force-dist", "--steps", "8", "--warmup", "8", "--gather-every", "1", "--inflight", "1", "--scaling", "weak"],
+                                  ["--steps", "5", "--warmup", "2", "--batches", "3"],
+                                  ["--steps", "6", "--warmup", "2", "--batches", "4", "--closed-loop", "--cl-slots", "4096", "--cl-verify", "3"]])
 def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     import torch
     import torch.distributed as dist
@@ -124,7 +153,10 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "3", "--requests", "96", "--host-path", "3"] + argv)
+    base = ["bench.py", "--config", "3", "--requests", "96", "--host-path", "3"]
+    if "--p99-samples" not in argv:
+        base += ["--p99-samples", "0"]
+    monkeypatch.setattr(sys, "argv", base + argv)
     out = io.StringIO()
     try:
         with redirect_stdout(out):
@@ -134,19 +166,38 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
             dist.destroy_process_group()
     lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
     d = json.loads(lines[-1])                                           # the JSON line is the last thing on stdout
+    closed = "--closed-loop" in argv
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "dtype", "data", "config", "roofline") + (() if closed else ("cpu_baseline",)):
         assert key in d, key
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "model_frac", "kernel_p99_ms", "kernel_samples"):
         assert key in d["roofline"], key
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None      # no stamped PMC file for this fake build
+    assert d["n_gpus"] == 1 and d["unit"] == "decisions/s" and d["vs_baseline"] is None
+    assert d["steps"] == int(argv[argv.index("--steps") + 1])
+    n_picks = sum(1 for e in log if e[0] == "pick")
+    if closed:
+        assert d["closed_loop"]["picks_equal_oracle"] and d["closed_loop"]["scores_bitwise_equal_oracle"]
+        assert d["closed_loop"]["generations_verified"] == 3 and d["config"]["closed_loop"] is True
+        assert sum(1 for e in log if e[0] == "learn") == n_picks == 3 + d["steps"] + d["warmup"]    # every pick is followed by its index update
+        return
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
-    assert d["n_gpus"] == 1 and d["unit"] == "decisions/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["steps"] == int(argv[argv.index("--steps") + 1]) and d["parity"]["picks_equal_oracle"]
-    n_picks = sum(1 for e in log if e[0] == "pick")
-    assert n_picks >= d["steps"] + d["warmup"]
+    assert d["parity"]["picks_equal_oracle"] and d["parity"]["scores_bitwise_equal_oracle"]
     if "--force-dist" in argv:
-        assert sum(1 for e in log if e[0] == "wait") == d["steps"] + d["warmup"]      # one cross-stream dependency per batch
+        both = "--scaling" not in argv
+        assert d["scaling"] == ("strong" if both else "weak") and d["config"]["ranks_seen"] == 1
+        assert ("weak" in d) == both
+        regions = 2 if both else 1
+        extra = max(0, 40 - d["steps"]) if "--p99-samples" in argv else 0
+        assert n_picks >= regions * (d["steps"] + d["warmup"]) + extra
+        assert sum(1 for e in log if e[0] == "wait") == n_picks                          # one cross-stream dependency per batch
+        if extra:
+            assert d["roofline"]["kernel_samples"] >= 40
+    else:
+        assert d["scaling"] == "weak" and n_picks >= d["steps"] + d["warmup"]
+        if "--batches" in argv:
+            assert d["config"]["distinct_batches"] == 3
 
 
 def _bench_worker(rank, world, port, outdir):
@@ -166,7 +217,8 @@ def _bench_worker(rank, world, port, outdir):
     dist.init_process_group = lambda backend=None, device_id=None, **k: real_init("gloo", rank=rank, world_size=world)
     log = []
     pkg.BatchedPicker = _fake_picker_class(pkg, orc, log)
-    sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", "64", "--steps", "10", "--warmup", "3"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", "64", "--steps", "10", "--warmup", "3", "--p99-samples", "0",
+                "--batches", "5"]
     out = io.StringIO()
     with redirect_stdout(out):
         bench.main()
@@ -183,6 +235,12 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     out1 = [ln for ln in open(tmp_path / "bench_rank1.out").read().splitlines() if ln.strip()]
     assert not any(ln.lstrip().startswith("{") for ln in out1)
     d = json.loads(out0[-1])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["config"]["requests_per_gpu"] == 64
-    assert "cpu_baseline" not in d and "requests/2 per rank" in d["config"]["sharding"]
-    assert abs(d["value"] - 2 * 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3
+    # headline = strong scaling: each 64-request batch is split 32 + 32, every rank ends up with all 64 picks (checked against the oracle)
+    assert d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 32 and d["config"]["requests_per_step"] == 64
+    assert "cpu_baseline" not in d and "split R/2 per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
+    assert d["parity"]["gathered_picks_equal_oracle"] is True
+    assert abs(d["value"] - 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
+    # weak scaling timed beside it: a whole batch per rank and step, the aggregate counts BOTH ranks
+    w = d["weak"]
+    assert w["requests_per_gpu"] == 64 and abs(w["value"] - 2 * 64 * 10 / (w["ms_per_step"] * 1e-3 * 10)) < 1e-6 * w["value"]
