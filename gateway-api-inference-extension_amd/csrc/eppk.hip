@@ -42,12 +42,13 @@ struct SnapBuf {
   void*     tlo_t = nullptr;
   void*     qmin_t = nullptr;  // [64] LW pods at the global min / max queue depth
   void*     qmax_t = nullptr;
+  void*     act_t = nullptr;   // [64] LW active slots (holes clear)
   double*   topv = nullptr;   // [129][64]
   uint32_t* topi = nullptr;   // [129][64]
 };
 
 struct SnapLayout {            // byte offsets inside a snapshot blob
-  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, topv = 0, topi = 0, bytes = 0;
+  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, act = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -113,6 +114,9 @@ struct eppk_ctx {
   uint64_t fixed_bytes = 0;  // per-launch request/pod/pick bytes accumulated while profiling
   uint32_t launches = 0;
 
+  uint64_t h_holes[64] = {0};         // holes of the last published snapshot, lane-transposed (bit j of word l = pod j*64+l)
+  void* d_rm = nullptr;               // [64] LW device copy of a scrub mask
+
   hipEvent_t last_done = nullptr;     // completion event riding on the most recent pick launch (profiling), else null
   hipStream_t last_stream = nullptr;  // the stream of that launch
   hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
@@ -155,7 +159,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.thi_t = s.thi_t; k.tlo_t = s.tlo_t;
   k.topv = s.topv; k.topi = s.topi;
   k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
-  k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.lead_queue = c->lead_queue ? 1u : 0u;
+  k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.act_t = s.act_t; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
@@ -274,6 +278,30 @@ int by_lane_word(const eppk_ctx* c, F&& f) {
     case 4: return f((uint32_t)0);
     default: return f((uint64_t)0);
   }
+}
+
+// Remove every pod of the lane-transposed set `holes` from every index row (one pass; rows that become empty are tombstoned).
+int index_scrub(eppk_ctx* c, const uint64_t* holes) {
+  if (!c->d_rm) HIPCHK(c, hipMalloc(&c->d_rm, 64u * 8u));
+  uint8_t packed[64 * 8];
+  for (uint32_t l = 0; l < 64u; ++l) {           // narrow the u64 lane words to the context's lane-word type
+    if (c->lw_bytes == 8) std::memcpy(packed + l * 8u, &holes[l], 8u);
+    else if (c->lw_bytes == 4) { const uint32_t v = (uint32_t)holes[l]; std::memcpy(packed + l * 4u, &v, 4u); }
+    else { const uint16_t v = (uint16_t)holes[l]; std::memcpy(packed + l * 2u, &v, 2u); }
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_rm, packed, 64u * (size_t)c->lw_bytes, hipMemcpyHostToDevice, c->stream));
+  const uint32_t rows = c->slots + 2u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, 0u, c->stats,
+                       (const LW*)c->d_rm);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));    // (`packed` is a stack buffer)
+  return rc;
 }
 
 int ensure_tmp(eppk_ctx* c, size_t bytes) {
@@ -398,7 +426,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.tlo = off; off += lora_bytes;
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
-    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes);
+    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes);
     L.bytes = off + 256u;                      // the LAST dword is the fast kernel's launch-status word (kBlobStatusTail)
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
@@ -407,7 +435,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
       s.base = (double*)(s.blob + L.base); s.post[0] = (double*)(s.blob + L.post0); s.post[1] = (double*)(s.blob + L.post1);
       s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
       s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
-      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax;
+      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax; s.act_t = s.blob + L.act;
       s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
     }
   }
@@ -467,7 +495,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
-  (void)hipFree(c->d_rows);
+  (void)hipFree(c->d_rows); (void)hipFree(c->d_rm);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_pick) (void)hipHostFree(c->h_pick);
@@ -486,12 +514,29 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   const uint32_t J = (n_pods + 63u) / 64u;
   const size_t np64 = (size_t)J * 64u;
 
-  // QUEUE normalisers over all pods (the unmasked candidate set)
+  // QUEUE normalisers over all ACTIVE pods (the unmasked candidate set); holes (flags & EPPK_POD_INACTIVE) are never candidates
   uint32_t qmin = 0, qmax = 0;
+  bool any = false;
+  uint64_t act[64] = {0};                      // lane-transposed active set (u64 words serve every lane-word width)
   for (uint32_t p = 0; p < n_pods; ++p) {
+    if (rows[p].flags & EPPK_POD_INACTIVE) continue;
+    act[p & 63u] |= 1ull << (p >> 6);
     const uint32_t q = rows[p].queue;
-    if (p == 0) { qmin = qmax = q; }
+    if (!any) { qmin = qmax = q; any = true; }
     else { qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax; }
+  }
+  // A slot that turned into a hole takes its cache knowledge with it: the index forgets it (SEMANTICS.md §6b), in ONE pass over
+  // the table for all holes of this snapshot -- only when some slot became a hole since the last publish.
+  bool new_hole = false;
+  for (uint32_t l = 0; l < 64u; ++l) {
+    const uint64_t exist = ((l < n_pods) ? (n_pods - l + 63u) / 64u : 0u) >= 64u ? ~0ull : ((1ull << ((l < n_pods) ? (n_pods - l + 63u) / 64u : 0u)) - 1ull);
+    const uint64_t holes = exist & ~act[l];
+    if (holes & ~c->h_holes[l]) new_hole = true;
+    c->h_holes[l] = holes;
+  }
+  if (new_hole && c->slots) {
+    int rcs = index_scrub(c, c->h_holes);
+    if (rcs) return rcs;
   }
 
   // Snapshot producer on the device (eppk_kernels.hip.h "snapshot producer"): one H2D copy of the raw rows, then
@@ -512,10 +557,11 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((130u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
-                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t);
+                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t, (LW*)s.act_t);
     if (c->canonical)
       hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, c->stream, (const double*)s.base, (const LW*)s.thi_t,
-                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1], s.topv, s.topi);
+                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1],
+                         (const LW*)s.act_t, s.topv, s.topi);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -571,7 +617,8 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
-                       c->limit, c->index_epoch, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n);
+                       c->limit, c->index_epoch, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
+                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -596,7 +643,7 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
-                       c->cfg.max_pods, c->d_status);
+                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -613,7 +660,8 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->stats);
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->stats,
+                       (const LW*)nullptr);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());

@@ -71,6 +71,9 @@ struct KSnap {
   const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
   const void*     qmin_t;  // [64] LW  pods whose queue == qmin / qmax (masked fast path: are the request's
   const void*     qmax_t;  //          QUEUE normalisers the global ones?)
+  const void*     act_t;   // [64] LW  ACTIVE slots: bit j of lane word l clear = pod j*64+l is a hole of the snapshot
+                           //          (eppk_pod_row.flags & EPPK_POD_INACTIVE): never a candidate, outside the QUEUE normalisers
+                           //          and the top tables; the index never lists it (scrubbed at publish, inserts dropped)
   uint32_t        lead_queue;  // the fused leading run contains a QUEUE scorer
   const double*   pterm;   // [(B+1)][pterm_ld] exact clamp01(c/n) * w_prefix for 1 <= n <= B, c <= n (null when B > 64)
   uint32_t pterm_ld;
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   uint32_t* s_hist = s_hist_all + (threadIdx.x >> 6) * sn.J * 16u;
   const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
 
-  const LW valid = valid_word<LW>(sn.n_pods, lane);
+  const LW valid = (LW)(valid_word<LW>(sn.n_pods, lane) & ((const LW*)sn.act_t)[lane]);   // existing AND active pods of this lane
   const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
   const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
   uint32_t w_hits = 0, w_lookups = 0;                                               // per wavefront and launch: < 2^32
@@ -1378,7 +1381,7 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
   for (uint32_t k = 0; k < ch.n; ++k) {
     has_q |= ch.kind[k] == 1u; has_l |= ch.kind[k] == 3u; has_p |= ch.kind[k] == 4u;
   }
-  const LW valid = valid_word<LW>(sn.n_pods, lane);
+  const LW valid = (LW)(valid_word<LW>(sn.n_pods, lane) & ((const LW*)sn.act_t)[lane]);
   unsigned long long w_hits = 0, w_lookups = 0;
 
   const uint32_t gwave = blockIdx.x * wpb + wib;
@@ -1608,15 +1611,18 @@ __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_
 //     row 129 of the launch builds the lane words of the pods at the minimum / maximum queue depth instead.
 template <typename LW>
 __global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t J, uint32_t qmin, uint32_t qmax,
-                                   LW* __restrict__ thi, LW* __restrict__ tlo, LW* __restrict__ qmin_t, LW* __restrict__ qmax_t) {
+                                   LW* __restrict__ thi, LW* __restrict__ tlo, LW* __restrict__ qmin_t, LW* __restrict__ qmax_t,
+                                   LW* __restrict__ act_t) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t a = t >> 6, l = t & 63u;
   if (a > 129u) return;
-  LW hi = 0, lo = 0;
+  LW hi = 0, lo = 0, ac = 0;
   for (uint32_t j = 0; j < J; ++j) {
     const uint32_t p = j * 64u + l;
     if (p >= n_pods) break;
     const eppk_pod_row& r = rows[p];
+    if (r.flags & EPPK_POD_INACTIVE) continue;        // a hole: in no set (qmin / qmax range over the active pods only)
+    ac |= (LW)((LW)1 << j);
     if (a == 129u) {
       if (r.queue == qmin) hi |= (LW)((LW)1 << j);
       if (r.queue == qmax) lo |= (LW)((LW)1 << j);
@@ -1629,7 +1635,7 @@ __global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32
       if (act || (!freeslot && wai)) lo |= (LW)((LW)1 << j);
     }
   }
-  if (a == 129u) { qmin_t[l] = hi; qmax_t[l] = lo; }
+  if (a == 129u) { qmin_t[l] = hi; qmax_t[l] = lo; act_t[l] = ac; }
   else { thi[(size_t)a * 64u + l] = hi; tlo[(size_t)a * 64u + l] = lo; }
 }
 
@@ -1639,7 +1645,7 @@ template <typename LW>
 __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict__ base, const LW* __restrict__ thi, const LW* __restrict__ tlo,
                                                        uint32_t n_pods, uint32_t np64, uint32_t has_l, KTail tl,
                                                        const double* __restrict__ post0, const double* __restrict__ post1,
-                                                       double* __restrict__ topv, uint32_t* __restrict__ topi) {
+                                                       const LW* __restrict__ act, double* __restrict__ topv, uint32_t* __restrict__ topi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* sT = (double*)smem;                         // [np64]
   __shared__ double red_t[4];
@@ -1651,7 +1657,7 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
   }
   for (uint32_t p = tid; p < np64; p += blockDim.x) {
     double t = -__builtin_inf();
-    if (p < n_pods) {
+    if (p < n_pods && ((act[p & 63u] >> (p >> 6)) & 1)) {     // (holes never enter a table: T = -inf)
       t = base[p];
       double lterm = 0.0;
       if (has_l) {
@@ -1670,9 +1676,11 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
     sT[p] = t;
   }
   __syncthreads();
-  const uint32_t K = n_pods < 64u ? n_pods : 64u;
+  uint32_t n_act = 0;                                 // active pods (every thread counts: 64 lane words)
+  for (uint32_t l = 0; l < 64u; ++l) n_act += (uint32_t)__builtin_popcountll((unsigned long long)(LW)(act[l] & valid_word<LW>(n_pods, (int)l)));
+  const uint32_t K = n_act < 64u ? n_act : 64u;
   for (uint32_t k = 0; k < 64u; ++k) {
-    if (k >= K) {                                     // fewer than 64 pods: pad
+    if (k >= K) {                                     // fewer than 64 active pods: pad
       if (tid == 0) { topv[(size_t)a * 64u + k] = -__builtin_inf(); topi[(size_t)a * 64u + k] = kNoPod; }
       continue;
     }
@@ -1784,7 +1792,10 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 // Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
 template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
-                                                 uint32_t limit, uint32_t epoch, unsigned long long* stats, uint64_t h, uint32_t pod, bool active) {
+                                                 uint32_t limit, uint32_t epoch, unsigned long long* stats, uint64_t h, uint32_t pod, bool active,
+                                                 const LW* act) {
+  // a hole of the current snapshot has no cache to record: the pair is ignored (SEMANTICS.md §6b; act == null: no snapshot yet)
+  if (active && act && !((act[pod & 63u] >> (pod >> 6)) & 1)) active = false;
   uint32_t slot = kNotFound;
   bool newkey = false, newword = false;
   if (active) {
@@ -1842,17 +1853,18 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
 
 template <typename LW>
 __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
-                                    uint32_t epoch, unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+                                    uint32_t epoch, unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
+                                    const LW* act) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
 template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
-                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status) {
+                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
   bool active = r < n_reqs;
@@ -1869,13 +1881,16 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active, act);
 }
 
 // Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
 // meets a present key with an empty pod set.  A wavefront per row, looping (rows = slots + 2: the reserved rows too).
+// `rm` (nullable): instead of the single `pod`, clear every pod whose bit is set in the lane-transposed row rm[64] (the holes of a
+// snapshot: eppk_snapshot_publish scrubs them out of the index in one pass).
 template <typename LW>
-__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* stats) {
+__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* stats,
+                                        const LW* rm) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   uint32_t gone = 0;
@@ -1886,8 +1901,8 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
     LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
     LW v = *w;
     bool changed = false;
-    if (lane == (pod & 63u)) {
-      const LW nv = (LW)(v & (LW)~((LW)1 << (pod >> 6)));
+    if (rm || lane == (pod & 63u)) {
+      const LW nv = (LW)(v & (LW)~(rm ? rm[lane] : (LW)((LW)1 << (pod >> 6))));
       changed = nv != v;
       if (changed) *w = nv;
       v = nv;

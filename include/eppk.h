@@ -96,11 +96,17 @@ typedef struct eppk_pod_row {
   uint32_t running;     /* TotalRunningRequests (carried, not scored) */
   double   kv_util;     /* KVCacheUtilization in [0,1] */
   uint32_t max_lora;    /* max_lora label */
-  uint32_t flags;       /* reserved, 0 */
+  uint32_t flags;       /* EPPK_POD_* bits; every other bit reserved, 0 */
   uint64_t active[2];   /* running_lora_adapters as a bitset over adapter ids 0..127 */
   uint64_t waiting[2];  /* waiting_lora_adapters bitset */
   uint64_t reserved;
 } eppk_pod_row;
+
+/* flags bit 0: the slot is a HOLE of this snapshot -- a candidate index that currently names no endpoint (an endpoint left and the
+ * host keeps every other endpoint's index stable: datastore churn, pkg/lwepp/datastore/datastore.go:195-255).  A hole is never a
+ * candidate, lies outside the QUEUE normalisers, and the prefix index forgets it: publishing a snapshot in which a slot became a
+ * hole removes that slot from every pod set, and index inserts that name a hole are ignored (SEMANTICS.md §6b). */
+#define EPPK_POD_INACTIVE 1u
 
 #ifdef __cplusplus
 static_assert(sizeof(eppk_pod_row) == 64, "eppk_pod_row must be 64 bytes");
