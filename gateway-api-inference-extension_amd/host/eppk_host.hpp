@@ -154,9 +154,10 @@ struct GpuPickerOptions {
   bool learn_prefixes = false;
   // Stable candidate slots under churn.  The prefix index stores candidate indices, so an endpoint must
   // keep its index from one snapshot to the next: with this option an endpoint ("ip:port") keeps the slot it was first given,
-  // a slot freed by a departed endpoint is wiped from the index (eppk_index_remove_pod) and handed to the next newcomer, and the
-  // slots that are empty in between are published as copies of an active row (the snapshot-wide QUEUE normalisers stay those
-  // of the active pods) and kept out of every request's candidate mask.  While holes exist every batch is a masked batch.
+  // a slot freed by a departed endpoint is handed to the next newcomer, and the slots that are empty in between are published as
+  // HOLES (eppk_pod_row.flags = EPPK_POD_INACTIVE): the library keeps a hole out of every candidate set, out of the QUEUE
+  // normalisers and the top tables, and forgets it in the prefix index at publish (SEMANTICS.md §6b) -- no candidate masks, so a
+  // batch with holes stays on the unmasked fast route.
   bool stable_slots = false;
   // Ageing of the learned prefixes -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)",
   // 0602-…/README.md:82.  Every `index_epoch_interval` the dispatcher ticks the index epoch (between two batches) and drops the
@@ -201,8 +202,7 @@ class GpuPicker : public EndpointPicker {
       }
       for (auto it = slot_of_.begin(); it != slot_of_.end();) {
         if (now.count(it->first)) { ++it; continue; }
-        if (be_->IndexRemovePod(it->second) != EPPK_OK) return {Code::Internal, be_->LastError()};
-        free_slots_.push_back(it->second);
+        free_slots_.push_back(it->second);   // (the index forgets the slot when the snapshot with the hole is published)
         it = slot_of_.erase(it);
       }
       std::sort(free_slots_.begin(), free_slots_.end(), std::greater<uint32_t>());   // back() = lowest free slot
@@ -220,7 +220,7 @@ class GpuPicker : public EndpointPicker {
         free_slots_.erase(std::find(free_slots_.begin(), free_slots_.end(), n_slots_ - 1));
         --n_slots_;
       }
-      // 3. rows by slot; a hole repeats an active row so that it moves neither the minimum nor the maximum queue depth
+      // 3. rows by slot; a hole is an all-zero row flagged EPPK_POD_INACTIVE
       std::vector<eppk_pod_row> by_slot(n_slots_);
       std::vector<bool> active(n_slots_, false);
       snap->endpoints.assign(n_slots_, Endpoint());
@@ -233,9 +233,8 @@ class GpuPicker : public EndpointPicker {
         snap->by_addr[key] = slot;
       }
       snap->n_active = (uint32_t)endpoints.size();
-      if (!endpoints.empty())
-        for (uint32_t sidx = 0; sidx < n_slots_; ++sidx)
-          if (!active[sidx]) by_slot[sidx] = rows[0];
+      for (uint32_t sidx = 0; sidx < n_slots_; ++sidx)
+        if (!active[sidx]) { std::memset(&by_slot[sidx], 0, sizeof(eppk_pod_row)); by_slot[sidx].flags = EPPK_POD_INACTIVE; }
       if (be_->Publish(by_slot.data(), n_slots_, epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
     }
     std::lock_guard<std::mutex> g(mu_);
@@ -344,7 +343,7 @@ class GpuPicker : public EndpointPicker {
               if (!(mask[i * W + (a->second >> 6)] & bit)) ++found;
               mask[i * W + (a->second >> 6)] |= bit;
             }
-            if (found != P) any_mask = true;   // (a snapshot with holes has n_active < P: every request is masked)
+            if (found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
           }
           const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
           picks.resize(n * k);

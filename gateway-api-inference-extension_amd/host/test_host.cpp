@@ -29,6 +29,7 @@ class FakeBackend : public Backend {
     for (uint32_t r = 0; r < n; ++r) {
       int32_t best = -1;
       for (uint32_t p = 0; p < P; ++p) {
+        if (rows_[p].flags & EPPK_POD_INACTIVE) continue;
         if (mask && !((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u)) continue;
         if (best < 0 || rows_[p].queue < rows_[(size_t)best].queue) best = (int32_t)p;
       }
@@ -45,7 +46,7 @@ class FakeBackend : public Backend {
     for (uint32_t r = 0; r < n; ++r) {
       std::vector<uint32_t> c;
       for (uint32_t p = 0; p < P; ++p)
-        if (!mask || ((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u)) c.push_back(p);
+        if (!(rows_[p].flags & EPPK_POD_INACTIVE) && (!mask || ((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u))) c.push_back(p);
       std::stable_sort(c.begin(), c.end(), [&](uint32_t a, uint32_t b) { return rows_[a].queue < rows_[b].queue; });
       for (uint32_t i = 0; i < k; ++i) { picks[(size_t)r * k + i] = i < c.size() ? (int32_t)c[i] : -1; scores[(size_t)r * k + i] = 0.0; }
     }
@@ -222,11 +223,10 @@ static int run_cpu() {
     std::vector<const Endpoint*> abc{&eps[0], &eps[1], &eps[2]};
     PickResult r;
     CHECK(gp.Pick({}, abc, &r).ok() && r.endpoint == "10.0.0.2:8080");            // B has the shortest queue
-    // B leaves: C keeps slot 2, slot 1 becomes a hole (published as a copy of A's row) and is wiped from the index
+    // B leaves: C keeps slot 2, slot 1 becomes a hole (published with EPPK_POD_INACTIVE: the library forgets it in the index)
     CHECK(gp.PublishSnapshot({eps[0], eps[2]}, {row(5), row(7)}, {}, 2).ok());
     CHECK(gp.SlotOf("10.0.0.3:8080") == 2 && gp.SlotOf("10.0.0.2:8080") == -1);
-    { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->removed.size() == 1 && fk->removed[0] == 1u); }
-    CHECK(fk->rows_.size() == 3 && fk->rows_[1].queue == 5u);
+    CHECK(fk->rows_.size() == 3 && (fk->rows_[1].flags & EPPK_POD_INACTIVE) && !(fk->rows_[0].flags & EPPK_POD_INACTIVE) && !(fk->rows_[2].flags & EPPK_POD_INACTIVE));
     std::vector<const Endpoint*> ac{&eps[0], &eps[2]};
     CHECK(gp.Pick({}, ac, &r).ok() && r.endpoint == "10.0.0.1:8080");             // never the hole
     CHECK(gp.Pick({}, abc, &r).ok() && r.endpoint == "10.0.0.1:8080");            // a stale candidate (B) is simply not scoreable
@@ -236,7 +236,7 @@ static int run_cpu() {
     const int32_t d = gp.SlotOf("10.0.0.4:8080");
     CHECK(d == 0 || d == 1);                                                       // one of the two freed slots (the lowest: 0)
     CHECK(d == 0);
-    { std::lock_guard<std::mutex> g(fk->learn_mu); CHECK(fk->removed.size() == 2 && fk->removed[1] == 0u); }
+    CHECK(fk->rows_.size() == 3 && (fk->rows_[1].flags & EPPK_POD_INACTIVE) && !(fk->rows_[0].flags & EPPK_POD_INACTIVE));   // A's slot went to D, B's is still a hole
     std::vector<const Endpoint*> cd{&eps[2], &eps[3]};
     CHECK(gp.Pick({}, cd, &r).ok() && r.endpoint == "10.0.0.4:8080");
     // everything leaves, then one endpoint comes back: the table shrinks to nothing and starts again at slot 0

@@ -39,6 +39,8 @@ def load() -> C.CDLL:
     lib.orc_index_insert.restype = None
     lib.orc_index_remove_pod.argtypes = [vp, u32]
     lib.orc_index_remove_pod.restype = None
+    lib.orc_index_scrub_inactive.argtypes = [vp, vp, u32]
+    lib.orc_index_scrub_inactive.restype = None
     lib.orc_index_advance_epoch.argtypes = [vp]
     lib.orc_index_advance_epoch.restype = u32
     lib.orc_index_evict_older.argtypes = [vp, u32]
@@ -74,9 +76,20 @@ class OracleIndex:
         self.lib = load()
         self.h = C.c_void_p(self.lib.orc_index_new())
 
-    def insert(self, hashes, pods) -> None:
+    def insert(self, hashes, pods, snapshot=None) -> None:
+        """`snapshot` (pod rows): the published snapshot -- pairs that name one of its holes are ignored (SEMANTICS.md 6b)."""
+        hole = None
+        if snapshot is not None:
+            hole = (np.ascontiguousarray(snapshot)["flags"] & 1).astype(bool)
         for h, p in zip(np.asarray(hashes, dtype=np.uint64).ravel().tolist(), np.asarray(pods, dtype=np.uint32).ravel().tolist()):
+            if hole is not None and p < hole.shape[0] and hole[p]:
+                continue
             self.lib.orc_index_insert(self.h, h, p)
+
+    def scrub_inactive(self, snapshot) -> None:
+        """The index side of publishing `snapshot`: every slot that is a hole in it is forgotten (SEMANTICS.md 6b)."""
+        s = np.ascontiguousarray(snapshot)
+        self.lib.orc_index_scrub_inactive(self.h, s.ctypes.data, s.shape[0])
 
     def remove_pod(self, pod: int) -> None:
         self.lib.orc_index_remove_pod(self.h, pod)

@@ -210,6 +210,12 @@ void orc_index_remove_pod(orc_index* ix, uint32_t pod) {
   }
 }
 
+/* SEMANTICS.md 6b: publishing a snapshot forgets every slot that is a hole in it; an insert that names a hole is ignored. */
+void orc_index_scrub_inactive(orc_index* ix, const eppk_pod_row* pods, uint32_t n_pods) {
+  for (uint32_t p = 0; p < n_pods; ++p)
+    if (pods[p].flags & EPPK_POD_INACTIVE) orc_index_remove_pod(ix, p);
+}
+
 /* Ageing (SEMANTICS.md 6a; docs/proposals/0602-…/README.md:82 "mimicking a similar cache eviction strategy"). */
 uint32_t orc_index_advance_epoch(orc_index* ix) { return ++ix->epoch; }
 
@@ -329,8 +335,10 @@ static int schedule_one(const eppk_weighted_scorer* chain, uint32_t n_scorers, c
 
   /* Filter: the candidate subset (request.go:104-133 expressed as a bitmask) */
   uint32_t nc = 0;
-  for (uint32_t p = 0; p < n_pods; ++p)
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    if (pods[p].flags & EPPK_POD_INACTIVE) continue; /* a hole of the snapshot names no endpoint: never a candidate (SEMANTICS.md 6b) */
     if (!mask_row || ((mask_row[p >> 6] >> (p & 63)) & 1u)) s->cand[nc++] = p;
+  }
   if (nc_out) *nc_out = nc;
   if (probes_out) *probes_out = 0;
   if (nc == 0) { /* fail closed */

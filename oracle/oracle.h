@@ -30,6 +30,8 @@ void       orc_index_clear(orc_index* ix);
 /* "hash(chunk i): append s" — docs/proposals/0602-…/README.md:101-108 (set semantics). */
 void       orc_index_insert(orc_index* ix, uint64_t hash, uint32_t pod);
 void       orc_index_remove_pod(orc_index* ix, uint32_t pod);
+/* the index side of publishing `pods` (SEMANTICS.md 6b): every slot that is a hole (flags & EPPK_POD_INACTIVE) is forgotten */
+void       orc_index_scrub_inactive(orc_index* ix, const eppk_pod_row* pods, uint32_t n_pods);
 /* ageing: ++epoch (inserts stamp their hash with it); drop every hash last stamped before min_epoch -> number dropped */
 uint32_t   orc_index_advance_epoch(orc_index* ix);
 uint32_t   orc_index_evict_older(orc_index* ix, uint32_t min_epoch);

@@ -70,6 +70,7 @@ def numpy_totals(chain, pods, index, adapter, n_blocks, hashes, mask):
     else:
         bits = np.unpackbits(mask.view(np.uint8).reshape(R, -1), axis=1, bitorder="little")
         cand = bits[:, :P].astype(bool)
+    cand = cand & ((pods["flags"] & 1) == 0)[None, :]          # SEMANTICS.md §6b: a hole of the snapshot is never a candidate
     total = np.zeros((R, P), dtype=np.float64)
     q = pods["queue"].astype(np.int64)
     for kind, w in chain:
@@ -126,8 +127,11 @@ def rand_pods(rng, P, A=128, tie_heavy=False):
     return pods
 
 
-def rand_case(rng, R, P, B, chain, masked, n_groups=6, tie_heavy=False, removed=()):
+def rand_case(rng, R, P, B, chain, masked, n_groups=6, tie_heavy=False, removed=(), holes=()):
     pods = rand_pods(rng, P, tie_heavy=tie_heavy)
+    for p in holes:                              # SEMANTICS.md §6b: holes are out of every candidate set AND out of the index
+        pods["flags"][p] |= 1
+    removed = tuple(removed) + tuple(holes)
     group_hash = rng.integers(1, 2**63, (n_groups, max(B, 1)), dtype=np.uint64)
     adapter = rng.integers(-1, 128, R).astype(np.int32)
     n_blocks = rng.integers(0, B + 1, R).astype(np.uint32) if B else np.zeros(R, np.uint32)

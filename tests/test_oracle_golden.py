@@ -180,14 +180,16 @@ def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
     kinds = [gg.Q, gg.KV, gg.L] + ([gg.PF] if B else [])
     chain = [(int(rng.choice(kinds)), int(rng.integers(-3, 6))) for _ in range(int(rng.integers(1, 7)))]
     removed = tuple(int(x) for x in rng.choice(P, size=int(rng.integers(0, min(P, 4))), replace=False)) if rng.random() < 0.3 else ()
+    holes = tuple(int(x) for x in rng.choice(P, size=int(rng.integers(1, P + 1)), replace=False)) if seed % 3 == 2 else ()   # (sometimes ALL pods)
     c = gg.rand_case(rng, 32, P, B, chain, masked=bool(rng.random() < 0.5), n_groups=int(rng.integers(1, 5)),
-                     tie_heavy=bool(rng.random() < 0.4), removed=removed)
+                     tie_heavy=bool(rng.random() < 0.4), removed=removed, holes=holes)
     hashes = c["hashes"][:, :B] if B else None
     reqs = pkg.picker.make_req_rows(c["adapter"], c["n_blocks"], hashes, B)
     oix = orc.OracleIndex()
     oix.insert(c["index_hashes"], c["index_pods"])
     for p in removed:
         oix.remove_pod(p)
+    oix.scrub_inactive(c["pods"])                      # the index side of publishing a snapshot with holes (SEMANTICS.md §6b)
     mask = c["mask"] if c["mask"].size else None
     picks, scores, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, mask)
     assert np.array_equal(picks, c["pick"]), (seed, chain, P, B)
@@ -196,7 +198,7 @@ def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
     index = {}
     for h, p_ in zip(c["index_hashes"].tolist(), c["index_pods"].tolist()):
         index.setdefault(h, set()).add(p_)
-    for p_ in removed:
+    for p_ in removed + holes:
         for s_ in index.values():
             s_.discard(p_)
     k = int(rng.integers(1, 9))
