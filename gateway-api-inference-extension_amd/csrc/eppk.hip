@@ -99,6 +99,7 @@ struct eppk_ctx {
                                         // kernels overlapping on two streams never share a slot
   uint32_t stat_bank = 0;
   uint32_t* d_status = nullptr;         // sticky launch-status flags (eppk_launch_status)
+  unsigned long long* ixc = nullptr;    // [kIxShards][8] sharded index counters: live keys, non-empty words, dropped inserts, evicted
 
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
@@ -295,13 +296,24 @@ int index_scrub(eppk_ctx* c, const uint64_t* holes) {
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, 0u, c->stats,
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, 0u, c->ixc,
                        (const LW*)c->d_rm);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));    // (`packed` is a stack buffer)
   return rc;
+}
+
+// Sum one field of the sharded index counters (synchronises the context's stream).
+int ixc_sum(eppk_ctx* c, uint32_t field, unsigned long long* out) {
+  unsigned long long h[eppk::kIxShards * 8u];
+  HIPCHK(c, hipMemcpyAsync(h, c->ixc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long t = 0;
+  for (uint32_t sh = 0; sh < eppk::kIxShards; ++sh) t += h[sh * 8u + field];
+  *out = t;
+  return EPPK_OK;
 }
 
 int ensure_tmp(eppk_ctx* c, size_t bytes) {
@@ -453,6 +465,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   CHK(hipMalloc((void**)&c->d_rows, (size_t)cfg->max_pods * sizeof(eppk_pod_row)));
   CHK(hipMalloc((void**)&c->stats, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
   CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
+  CHK(hipMalloc((void**)&c->ixc, eppk::kIxShards * 8u * sizeof(unsigned long long)));
+  CHK(hipMemset(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long)));
   CHK(hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t)));
   CHK(hipMemset(c->d_status, 0, 2 * sizeof(uint32_t)));
   if (cfg->index_slots) {
@@ -491,7 +505,7 @@ void eppk_destroy(eppk_ctx* c) {
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
-  (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status);
+  (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
@@ -593,7 +607,7 @@ int eppk_index_clear(eppk_ctx* c) {
     hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemsetAsync(c->stats, 0, 4 * sizeof(unsigned long long), c->stream));  // key / drop counters
+  HIPCHK(c, hipMemsetAsync(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
 }
@@ -609,23 +623,23 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   if (rc) return rc;
   uint64_t* d_h = (uint64_t*)c->d_tmp;
   uint32_t* d_p = (uint32_t*)((uint8_t*)c->d_tmp + (size_t)n * 8u);
-  unsigned long long before[4];
-  HIPCHK(c, hipMemcpyAsync(before, c->stats, sizeof before, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long before = 0, after = 0;
+  int rcs = ixc_sum(c, eppk::kIxDropped, &before);     // (synchronises the stream: earlier asynchronous inserts are counted)
+  if (rcs) return rcs;
   HIPCHK(c, hipMemcpyAsync(d_h, hashes, (size_t)n * 8u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_p, pods, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream));
   const uint32_t threads = 256, grid = (n + threads - 1) / threads;
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
-                       c->limit, c->index_epoch, c->stats, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
+                       c->limit, c->index_epoch, c->ixc, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
                        c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
-  unsigned long long after[4];
-  HIPCHK(c, hipMemcpyAsync(after, c->stats, sizeof after, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (after[3] != before[3]) return fail(c, EPPK_ERR_INDEX_FULL, "eppk_index_insert: table at load limit, inserts dropped");
+  rcs = ixc_sum(c, eppk::kIxDropped, &after);
+  if (rcs) return rcs;
+  if (after != before) return fail(c, EPPK_ERR_INDEX_FULL, "eppk_index_insert: table at load limit, inserts dropped");
   return rc;
 }
 
@@ -642,7 +656,7 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
-                       c->shift, c->limit, c->index_epoch, c->stats, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
+                       c->shift, c->limit, c->index_epoch, c->ixc, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
                        c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
     return EPPK_OK;
   });
@@ -660,7 +674,7 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->stats,
+    hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->ixc,
                        (const LW*)nullptr);
     return EPPK_OK;
   });
@@ -672,20 +686,22 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
 int eppk_index_size(eppk_ctx* c, uint32_t* n_entries) {
   if (!c || !n_entries) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  unsigned long long st[4];
-  HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *n_entries = (uint32_t)st[1];   // live keys (st[2] counts non-empty words, tombstones included)
+  unsigned long long live = 0;
+  HIPCHK(c, hipDeviceSynchronize());      // (asynchronous updates on the caller's streams included)
+  int rc = ixc_sum(c, eppk::kIxLive, &live);   // live keys (kIxWords counts non-empty words, tombstones included)
+  if (rc) return rc;
+  *n_entries = (uint32_t)live;
   return EPPK_OK;
 }
 
 int eppk_index_dropped(eppk_ctx* c, uint64_t* n_dropped) {
   if (!c || !n_dropped) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  unsigned long long st[4];
-  HIPCHK(c, hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *n_dropped = (uint64_t)st[3];
+  unsigned long long d = 0;
+  HIPCHK(c, hipDeviceSynchronize());
+  int rc = ixc_sum(c, eppk::kIxDropped, &d);
+  if (rc) return rc;
+  *n_dropped = (uint64_t)d;
   return EPPK_OK;
 }
 
@@ -725,20 +741,21 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   if (n_evicted) *n_evicted = 0;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long), c->stream));   // stats[0]: evicted by this launch
+  for (uint32_t sh = 0; sh < eppk::kIxShards; ++sh)     // "evicted by this launch" (sharded like the other index counters)
+    HIPCHK(c, hipMemsetAsync(c->ixc + sh * 8u + eppk::kIxEvicted, 0, sizeof(unsigned long long), c->stream));
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
-                       min_epoch, c->stats);
+                       min_epoch, c->ixc);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
   unsigned long long ev = 0;
-  HIPCHK(c, hipMemcpyAsync(&ev, c->stats, sizeof ev, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rcs = ixc_sum(c, eppk::kIxEvicted, &ev);
+  if (rcs) return rcs;
   if (n_evicted) *n_evicted = (uint32_t)ev;
   return rc;
 }
@@ -754,7 +771,7 @@ int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream)
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
-                       min_epoch, c->stats);     // (stats[0], the per-launch count of the synchronous form, just accumulates here)
+                       min_epoch, c->ixc);     // (stats[0], the per-launch count of the synchronous form, just accumulates here)
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());

@@ -1707,7 +1707,6 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 }
 
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
-// stats[2] = occupied keys, stats[3] = dropped inserts (table at its load limit)
 
 // Set pod's bit in the row of `slot`; true iff this call set it.  Re-inserting a cached block is the common case of the
 // post-pick update, so the word is read first and the atomic issued only when the bit is still clear (bits are only
@@ -1779,21 +1778,56 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 }
 #endif
 
-// Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters (stats[1] = live keys,
-// stats[2] = non-empty words, stats[3] = dropped inserts) are bumped once per wavefront (ballot + popcount) -- a same-address
-// atomic per new key serialises at ~12 ns each, 12 ms per million keys.  The load-limit test therefore sees a count that lags
-// by the keys of in-flight wavefronts (a few thousand at most): the limits are slots/2 live keys and 3/4 non-empty words
-// while a table is only ever full at 7/8 slots, so the slack is harmless.
+// ---- index counters ------------------------------------------------------------------------------------------------
+// Live keys, non-empty words, dropped inserts and "evicted by this launch" are SHARDED over kIxShards cache lines
+// (ixc[shard * 8 + field]): a same-address atomic serialises at ~12 ns, and a post-pick update of a 64k x 32-block batch bumps
+// the counters from 32 768 wavefronts -- on one address that alone took 1.2 ms of the 3 ms the kernel needed (round 2 profile);
+// spread over 32 lines it is ~1 us.  Readers (host, capacity test) sum the shards.
+constexpr uint32_t kIxShards = 32u;
+constexpr uint32_t kIxLive = 0u, kIxWords = 1u, kIxDropped = 2u, kIxEvicted = 3u;
+
+struct IxBudget {            // what a workgroup learned about the table's capacity when it started (ix_budget)
+  bool safe;                 // every pair of this launch fits below both limits even if each brings a new key: no per-key checks
+  unsigned long long others_live, others_words;   // exact mode: sum of the shards other than shard 0 (exact-mode adds go to shard 0)
+};
+
+// One wavefront of the workgroup sums the shards; `n_items` = pairs of this launch (an upper bound on its new keys).
+__device__ __forceinline__ IxBudget ix_budget(const unsigned long long* ixc, uint32_t limit, uint32_t slots, unsigned long long n_items,
+                                              unsigned long long* s_tmp /* __shared__ [3] */) {
+  if (threadIdx.x < 64u) {
+    const uint32_t l = threadIdx.x;
+    unsigned long long lv = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    unsigned long long wd = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long lv0 = __shfl((long long)lv, 0), wd0 = __shfl((long long)wd, 0);
+    for (int off = 32; off >= 1; off >>= 1) { lv += __shfl_xor((long long)lv, off); wd += __shfl_xor((long long)wd, off); }
+    if (l == 0u) { s_tmp[0] = lv; s_tmp[1] = wd; s_tmp[2] = lv0; s_tmp[3] = wd0; }
+  }
+  __syncthreads();
+  IxBudget b;
+  const unsigned long long live = s_tmp[0], words = s_tmp[1];   // (live may transiently read "negative": removals land in other shards)
+  b.safe = (long long)live >= 0 && live + n_items < (unsigned long long)limit && words + n_items < (unsigned long long)(slots / 4u * 3u);
+  b.others_live = live - s_tmp[2];
+  b.others_words = words - s_tmp[3];
+  return b;
+}
+
+// Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters are bumped once per wavefront
+// (ballot + popcount).  Capacity: at most `limit` (= slots/2) live keys and 3/4 of the words non-empty.  A launch whose pairs all
+// fit (IxBudget::safe, the common case) inserts without looking at the counters; otherwise every new key is checked against an
+// exact count (shard 0 + the other shards as they were when the workgroup started) that lags by the keys of in-flight wavefronts
+// only: a table is only ever full at 7/8 slots, so the slack is harmless.
 //
 // A key goes into the first FREE word (empty, or a tombstone left by an eviction) of its bucket chain -- home bucket, then
 // the following buckets for as long as the overflow flags say the chain continues -- but only after the whole chain has
 // been searched for the key itself (a tombstone may sit in front of it).  Free words only disappear while an insert kernel
 // runs (evictions are separate launches), so every inserter of one key converges on the same word: no duplicates.
 // Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
+// Memory round trips per pair: one for the whole home bucket (its 8 words are loaded together), one CAS when the key is new,
+// one for {stamp, pod-set word, list count} together, one for the updates.
 template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
-                                                 uint32_t limit, uint32_t epoch, unsigned long long* stats, uint64_t h, uint32_t pod, bool active,
-                                                 const LW* act) {
+                                                 uint32_t limit, uint32_t epoch, unsigned long long* ixc, const IxBudget& bud, uint64_t h, uint32_t pod,
+                                                 bool active, const LW* act) {
   // a hole of the current snapshot has no cache to record: the pair is ignored (SEMANTICS.md §6b; act == null: no snapshot yet)
   if (active && act && !((act[pod & 63u] >> (pod >> 6)) & 1)) active = false;
   uint32_t slot = kNotFound;
@@ -1814,24 +1848,35 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
         bool chain_end = false;
         for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
           unsigned long long* kb = K + (size_t)b * kBucket;
+          unsigned long long w[kBucket];
+#pragma unroll
+          for (uint32_t i = 0; i < kBucket; ++i) w[i] = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8 loads in flight
+#pragma unroll
           for (uint32_t i = 1; i < kBucket; ++i) {
-            const unsigned long long k = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == (unsigned long long)h) { slot = b * kBucket + i; break; }
+            if (slot != kNotFound || chain_end) continue;
+            const unsigned long long k = w[i];
+            if (k == (unsigned long long)h) { slot = b * kBucket + i; continue; }
             if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = b * kBucket + i; free_val = k; }
-            if (k == 0ull) { chain_end = true; break; }          // buckets fill front to back: nothing lives behind an empty word
+            if (k == 0ull) chain_end = true;                      // buckets fill front to back: nothing lives behind an empty word
           }
           if (slot != kNotFound || chain_end) break;
-          if (__hip_atomic_load(&kb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull) { b = (b + 1) & bmask; continue; }   // chain continues
+          if (w[0] & 1ull) { b = (b + 1) & bmask; continue; }     // chain continues
           if (free_slot != kNotFound) break;                      // chain ends here and a tombstone is free
           atomicOr(&kb[0], 1ull);                                 // full bucket, no free word anywhere: extend the chain
           b = (b + 1) & bmask;
         }
         if (slot != kNotFound) break;
         if (free_slot == kNotFound) { stop = true; break; }       // walked the whole table
-        // capacity: at most `limit` (= slots/2) live keys, and at most 3/4 of the words non-empty (recycling is per bucket
-        // chain, so tombstones of other chains keep their words until a key of that chain arrives)
-        if (__hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)limit) { stop = true; break; }
-        if (free_val == 0ull && __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)(slots / 4u * 3u)) { stop = true; break; }
+        if (!bud.safe) {
+          // exact mode (table near a limit): recycling is per bucket chain, so tombstones of other chains keep their words until a
+          // key of that chain arrives -- hence the separate limit on non-empty words
+          const unsigned long long live = bud.others_live + __hip_atomic_load(&ixc[kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((long long)live >= (long long)limit) { stop = true; break; }
+          if (free_val == 0ull) {
+            const unsigned long long words = bud.others_words + __hip_atomic_load(&ixc[kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (words >= (unsigned long long)(slots / 4u * 3u)) { stop = true; break; }
+          }
+        }
         const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
         if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
         else if (seen == (unsigned long long)h) slot = free_slot;
@@ -1840,31 +1885,47 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     }
   }
   const unsigned long long nk = __ballot(newkey), nw = __ballot(newword), dropped = __ballot(active && slot == kNotFound);
-  if ((threadIdx.x & 63u) == 0u) {
-    if (nk) atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(nk));
-    if (nw) atomicAdd(&stats[2], (unsigned long long)__builtin_popcountll(nw));
-    if (dropped) atomicAdd(&stats[3], (unsigned long long)__builtin_popcountll(dropped));
+  if ((threadIdx.x & 63u) == 0u && (nk | nw | dropped)) {
+    // exact mode counts in shard 0 (what its capacity test reads); otherwise the wavefront's own shard
+    const uint32_t shard = bud.safe ? ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kIxShards - 1u)) : 0u;
+    if (nk) atomicAdd(&ixc[shard * 8u + kIxLive], (unsigned long long)__builtin_popcountll(nk));
+    if (nw) atomicAdd(&ixc[shard * 8u + kIxWords], (unsigned long long)__builtin_popcountll(nw));
+    if (dropped) atomicAdd(&ixc[shard * 8u + kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
   }
   if (active && slot != kNotFound) {
-    if (__hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) atomicMax(&stamps[slot], epoch);
-    if (bitmap_set<LW>(bitmaps, slot, pod) && lists) list_append(lists, slot, pod);
+    // the three things an insert may have to update, read together (one round trip): the key's stamp, the pod's bit, the list count
+    const uint32_t lane = pod & 63u, j = pod >> 6;
+    const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool have;
+    if constexpr (sizeof(LW) == 8) have = (__hip_atomic_load((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull;
+    else if constexpr (sizeof(LW) == 4) have = (__hip_atomic_load((unsigned int*)bitmaps + (size_t)slot * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1u;
+    else {
+      const size_t e = (size_t)slot * 64u + lane;
+      have = (__hip_atomic_load((unsigned int*)bitmaps + (e >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j + 16u * (uint32_t)(e & 1u))) & 1u;
+    }
+    if (st < epoch) atomicMax(&stamps[slot], epoch);
+    if (!have && bitmap_set<LW>(bitmaps, slot, pod) && lists) list_append(lists, slot, pod);
   }
 }
 
 template <typename LW>
 __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
-                                    uint32_t epoch, unsigned long long* stats, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
+                                    uint32_t epoch, unsigned long long* ixc, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
                                     const LW* act) {
+  __shared__ unsigned long long s_tmp[4];
+  const IxBudget bud = ix_budget(ixc, limit, slots, n, s_tmp);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
 template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
-                                          uint32_t epoch, unsigned long long* stats, const uint8_t* reqs, uint32_t stride,
+                                          uint32_t epoch, unsigned long long* ixc, const uint8_t* reqs, uint32_t stride,
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act) {
+  __shared__ unsigned long long s_tmp[4];
+  const IxBudget bud = ix_budget(ixc, limit, slots, (unsigned long long)n_reqs * max_blocks, s_tmp);
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
   bool active = r < n_reqs;
@@ -1881,7 +1942,7 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, stats, h, (uint32_t)pick, active, act);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, h, (uint32_t)pick, active, act);
 }
 
 // Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
@@ -1889,7 +1950,7 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
 // `rm` (nullable): instead of the single `pod`, clear every pod whose bit is set in the lane-transposed row rm[64] (the holes of a
 // snapshot: eppk_snapshot_publish scrubs them out of the index in one pass).
 template <typename LW>
-__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* stats,
+__global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* ixc,
                                         const LW* rm) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1913,30 +1974,56 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
       ++gone;
     }
   }
-  if (lane == 0 && gone) atomicAdd(&stats[1], (unsigned long long)(0ull - (unsigned long long)gone));
+  if (lane == 0 && gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
 }
 
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
-// drop every key last stamped before min_epoch -- row zeroed, key tombstoned (reusable by later inserts).
+// drop every key last stamped before min_epoch -- pod set emptied, key tombstoned (reusable by later inserts).
+// A wavefront scans 64 slots per step (lane = slot: keys and stamps stream in coalesced), then empties its victims one by one.
+// A victim whose set still fits its short list is emptied through the list: only the row words of the listed pods are cleared
+// (one 64-byte line per pod instead of the whole 64 * sizeof(LW)-byte row -- what a post-route update leaves behind is mostly
+// single-pod sets); an overflowed victim gets its whole row zeroed.
 template <typename LW>
 __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
-                                   unsigned long long* stats) {
+                                   unsigned long long* ixc) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t total = slots + 2u;
   uint32_t gone = 0;
-  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
-    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
-    const uint64_t k = keys[row];
-    if (k == 0ull || (row < slots && k == kTomb)) continue;
-    if (stamps[row] >= min_epoch) continue;
-    ((LW*)bitmaps)[(size_t)row * 64u + lane] = 0;
-    if (lists && lane < kListDwords) lists[(size_t)row * kListDwords + lane] = lane == 3u ? 0u : 0xFFFFFFFFu;
-    if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;
-    ++gone;
+  for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
+    const uint32_t row = base + lane;
+    bool victim = false;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {     // (bucket header words are not keys)
+      const uint64_t k = keys[row];
+      victim = k != 0ull && !(row < slots && k == kTomb) && stamps[row] < min_epoch;
+    }
+    unsigned long long vm = __ballot(victim);
+    gone += (uint32_t)__builtin_popcountll(vm);
+    while (vm) {
+      const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
+      vm &= vm - 1ull;
+      bool whole = true;
+      if (lists) {
+        const uint32_t d = lane < kListDwords ? lists[(size_t)v * kListDwords + lane] : 0xFFFFFFFFu;
+        const uint32_t count = (uint32_t)__shfl((int)d, 3);
+        if (count <= kListCap) {
+          whole = false;
+          // lane u < 32 holds u16 entry u of the list: chunk u >> 3, position u & 7 (positions 6, 7 of every chunk are not ids)
+          const uint32_t dw = (uint32_t)__shfl((int)d, (int)((lane & 31u) >> 1));
+          const uint32_t id = (lane & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
+          if (lane < 32u && (lane & 7u) <= 5u && id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW))
+            ((LW*)bitmaps)[(size_t)v * 64u + (id & 63u)] = 0;                  // every pod of the set is listed: its word goes to zero
+        }
+        if (lane < kListDwords) lists[(size_t)v * kListDwords + lane] = lane == 3u ? 0u : 0xFFFFFFFFu;
+      }
+      if (whole) ((LW*)bitmaps)[(size_t)v * 64u + lane] = 0;
+    }
+    if (victim) keys[row] = row < slots ? kTomb : 0ull;
   }
   if (lane == 0 && gone) {
-    atomicAdd(&stats[1], (unsigned long long)(0ull - (unsigned long long)gone));
-    atomicAdd(&stats[0], (unsigned long long)gone);   // evicted by this launch (host zeroes it first)
+    const uint32_t shard = (wave & (kIxShards - 1u)) * 8u;
+    atomicAdd(&ixc[shard + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
+    atomicAdd(&ixc[shard + kIxEvicted], (unsigned long long)gone);   // evicted by this launch (the synchronous entry point zeroes it first)
   }
 }
 
