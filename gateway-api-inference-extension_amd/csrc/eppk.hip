@@ -43,12 +43,13 @@ struct SnapBuf {
   void*     qmin_t = nullptr;  // [64] LW pods at the global min / max queue depth
   void*     qmax_t = nullptr;
   void*     act_t = nullptr;   // [64] LW active slots (holes clear)
+  uint64_t* nat = nullptr;     // [3][64] u64 natural-layout active / qmin / qmax sets (masked list routes)
   double*   topv = nullptr;   // [129][64]
   uint32_t* topi = nullptr;   // [129][64]
 };
 
 struct SnapLayout {            // byte offsets inside a snapshot blob
-  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, act = 0, topv = 0, topi = 0, bytes = 0;
+  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, act = 0, nat = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -160,7 +161,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.thi_t = s.thi_t; k.tlo_t = s.tlo_t;
   k.topv = s.topv; k.topi = s.topi;
   k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
-  k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.act_t = s.act_t; k.lead_queue = c->lead_queue ? 1u : 0u;
+  k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.act_t = s.act_t; k.nat = s.nat; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qmin = c->qmin; k.qmax = c->qmax;
@@ -213,7 +214,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (fast) {
     pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
     lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (c->gen ? (size_t)sn.J * 64u * 16u : 0u);   // base | lw[4] | pterm | post0 | post1
-    if (c->has_p && c->npl == 6 && !masked && topk == 1 && ix.lists) {                                     // | per-wave pod histogram (SPARSE)
+    if (c->has_p && c->npl == 6 && topk == 1 && ix.lists) {                                                // | per-wave pod histogram (SPARSE)
       const size_t hist = (size_t)wpb * sn.J * 64u;
       if (lds + hist <= c->max_lds) lds += hist;
       else ix.lists = nullptr;               // (interpreted tail at P = 4096: no room in the 160 KB -> dense rows only)
@@ -438,7 +439,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.tlo = off; off += lora_bytes;
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
-    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes);
+    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes); L.nat = take(3u * 64u * 8u);
     L.bytes = off + 256u;                      // the LAST dword is the fast kernel's launch-status word (kBlobStatusTail)
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
@@ -447,7 +448,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
       s.base = (double*)(s.blob + L.base); s.post[0] = (double*)(s.blob + L.post0); s.post[1] = (double*)(s.blob + L.post1);
       s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
       s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
-      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax; s.act_t = s.blob + L.act;
+      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax; s.act_t = s.blob + L.act; s.nat = (uint64_t*)(s.blob + L.nat);
       s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
     }
   }
@@ -570,8 +571,8 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
                        qmin, qmax, lead, c->postc, s.base, s.post[0], s.post[1], s.queue, s.kv);
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((130u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
-                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t, (LW*)s.act_t);
+    hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((131u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
+                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t, (LW*)s.act_t, s.nat);
     if (c->canonical)
       hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, c->stream, (const double*)s.base, (const LW*)s.thi_t,
                          (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1],

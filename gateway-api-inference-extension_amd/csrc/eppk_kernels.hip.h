@@ -71,6 +71,8 @@ struct KSnap {
   const uint32_t* topi;    //           T_a[p] = base[p] (+ lw[tier(a,p)]), sorted (T desc, p asc); kNoPod-padded
   const void*     qmin_t;  // [64] LW  pods whose queue == qmin / qmax (masked fast path: are the request's
   const void*     qmax_t;  //          QUEUE normalisers the global ones?)
+  const uint64_t* nat;     // [3][64] u64 NATURAL layout (word w = pods 64w .. 64w+63): active-and-existing pods, pods at the minimum
+                           //          queue depth, pods at the maximum -- what the masked list routes AND with a request's mask row
   const void*     act_t;   // [64] LW  ACTIVE slots: bit j of lane word l clear = pod j*64+l is a hole of the snapshot
                            //          (eppk_pod_row.flags & EPPK_POD_INACTIVE): never a candidate, outside the QUEUE normalisers
                            //          and the top tables; the index never lists it (scrubbed at publish, inserts dropped)
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   constexpr bool pterm_tab = HAS_P && NPL == 6;
   // SPARSE: requests whose hits all have a short pod list are counted from the lists (one 16-byte load per lane instead of
   // 64 * sizeof(LW) bytes per hit) in a per-wave byte histogram in LDS; everything else takes the dense rows as before.
-  constexpr bool SPARSE = HAS_P && NPL == 6 && !MASKED && !TOPK;
+  constexpr bool SPARSE = HAS_P && NPL == 6 && !TOPK;
   uint32_t* s_hist_all = (uint32_t*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);   // [waves][J * 16] dwords: one byte per pod
   const bool use_lists = SPARSE && ix.lists != nullptr;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
@@ -778,6 +780,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const LW valid = (LW)(valid_word<LW>(sn.n_pods, lane) & ((const LW*)sn.act_t)[lane]);   // existing AND active pods of this lane
   const LW qminw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmin_t)[lane] : (LW)0;
   const LW qmaxw = (MASKED && sn.lead_queue) ? ((const LW*)sn.qmax_t)[lane] : (LW)0;
+  // MASKED list routes work on the request's mask row as it is (natural layout, lane w = word w): no transposition
+  const uint64_t nat_act = (MASKED && SPARSE) ? sn.nat[lane] : 0ull;     // (the qmin / qmax words are re-read per request: 1 KiB, L1-resident)
   uint32_t w_hits = 0, w_lookups = 0;                                               // per wavefront and launch: < 2^32
   const uint32_t hwords = (stride - 8u) / 8u;                                       // hash words per request row
   const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;             // ... probed by the pipelined first gather
@@ -819,6 +823,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     double top_t;
     uint32_t top_p;
     LW thi, tlo;
+    uint64_t cn;             // MASKED list routes: the request's candidates, natural layout (lane w = pods 64w .. 64w+63)
   };
 
   // finish the probe of the request in `q` (its keys were gathered earlier): m0 leading hits, slot map
@@ -853,6 +858,17 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
     t.thi = 0; t.tlo = 0;
     if (HAS_L && (MASKED || s.m0 > 0u)) load_tiers(s, t);
+    t.cn = 0ull;
+    if (MASKED && SPARSE && use_lists) {
+      const uint64_t mw = ((uint32_t)lane < sn.J) ? cand_mask[(size_t)s.r * sn.J + (uint32_t)lane] : 0ull;   // one coalesced row load
+      t.cn = mw & nat_act;
+    }
+  };
+  // bit of pod `p` in a natural-layout set held one word per lane
+  auto nat_bit = [&](uint64_t words, uint32_t p) -> bool {
+    const uint32_t w = p >> 6;
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)words, (int)w), hi = (uint32_t)__shfl((int)(uint32_t)(words >> 32), (int)w);
+    return ((((uint64_t)hi << 32) | lo) >> (p & 63u)) & 1ull;
   };
   // rows of the request, up to 16 in flight
   auto stage_rows = [&](const ReqS& s, uint32_t slot_eff, LW (&w)[16]) {
@@ -975,8 +991,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     const uint32_t dw = (k & 4u) ? ((k & 2u) ? la.w : la.z) : ((k & 2u) ? la.y : la.x);
     uint32_t id = (k & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
     if (k >= 6u) id = kListNone;
-    const bool v = id < sn.n_pods;
-    const uint32_t p = v ? id : 0u;
+    const bool listed = id < sn.n_pods;
+    const uint32_t p = listed ? id : 0u;
+    bool v = listed;
+    if (MASKED) v = nat_bit(tb.cn, p) && listed;       // a listed pod outside the request's candidates is not evaluated
     uint32_t tier = 0;
     if (HAS_L) {
       const uint32_t src = p & 63u, jb = p >> 6;
@@ -1000,11 +1018,14 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), 0),
                                          __builtin_amdgcn_readlane(__double2loint(tb.top_t), 0));
     if (!(best > top0)) {
+      unsigned long long tcm = ~0ull;                                     // MASKED: table entries (lanes 0..15) that are candidates
+      if (MASKED) tcm = __ballot(nat_bit(tb.cn, tb.top_p != kNoPod ? tb.top_p : 0u) && tb.top_p != kNoPod);
       uint32_t e = 0;
       for (; e < 16u; ++e) {
         const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tb.top_p, (int)e);
         if (tp == kNoPod) break;                                          // fewer than 16 pods: the table ends here
-        if (!__any(v && id == tp)) {
+        if (MASKED && !((tcm >> e) & 1ull)) continue;                     // not a candidate of this request
+        if (!__any(listed && id == tp)) {
           cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), (int)e),
                                     __builtin_amdgcn_readlane(__double2loint(tb.top_t), (int)e));
           cand_p = tp;
@@ -1073,7 +1094,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           tier = (uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1);
         }
         const double t = pod_total(p, f ? cnt : 0u, tier, pt_row, nbd);
-        if (f && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
+        bool fc = f;
+        if (MASKED) fc = nat_bit(tb.cn, p) && f;                          // (every lane takes part in the shuffle)
+        if (fc && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
       }
     }
     wave_argmax_dpp(best, bidx);
@@ -1086,7 +1109,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       auto entry_ok = [&](uint32_t tp) -> unsigned long long {
         const bool has = tp != kNoPod;
         const uint32_t q = has ? tp : 0u;
-        return __ballot(has && ((s_hist[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu) == 0u);
+        bool ok = has && ((s_hist[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu) == 0u;
+        if (MASKED) ok = nat_bit(tb.cn, q) && ok;
+        return __ballot(ok);
       };
       unsigned long long okm = entry_ok(tb.top_p);
       if (__builtin_expect(okm == 0ull && sn.n_pods > 16u, 0)) {         // none of the first 16: fetch entries 16..63
@@ -1117,7 +1142,14 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
           } else {
             if (HAS_L) t = t + s_lw[(uint32_t)(((tb.thi >> j) & 1) << 1) | (uint32_t)((tb.tlo >> j) & 1)];
           }
-          const bool okp = p < sn.n_pods && ((s_hist[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu) == 0u;
+          bool okp = p < sn.n_pods && ((s_hist[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu) == 0u;
+          if (MASKED) {                      // pod j*64 + lane is bit `lane` of natural word j
+            const uint64_t cw = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb.cn >> 32), (int)j) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb.cn, (int)j);
+            okp = okp && ((cw >> lane) & 1ull);
+          } else {
+            okp = okp && ((valid >> j) & 1);   // (holes of the snapshot)
+          }
           if (okp && t > rbest) { rbest = t; ridx = p; }
         }
         wave_argmax_dpp(rbest, ridx);
@@ -1303,7 +1335,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     Tabs tb;
     stage_tables(s, tb);
     // SPARSE: hits beyond the first 32 (chunks) and hits with an overflowed list take the dense rows
-    bool sp = SPARSE && use_lists && s.m0 > 0u && !(s.m0 == kKeysPerProbe && s.nb > kKeysPerProbe);
+    // MASKED: requests without a hit go through the lists too (an empty list): the dense route would transpose the mask row
+    bool sp = SPARSE && use_lists && (MASKED || s.m0 > 0u) && !(s.m0 == kKeysPerProbe && s.nb > kKeysPerProbe);
     u32x4_t la = (u32x4_t)(0xFFFFFFFFu), lb = (u32x4_t)(0xFFFFFFFFu);
     LW w[16];
     if (sp) issue_lists(s, slot0, la, lb);
@@ -1311,6 +1344,18 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     issue_keys(nxt);
     issue_row(r + 2u * nwaves, r, cur);
     __builtin_amdgcn_sched_barrier(0);
+    if (MASKED && SPARSE && sp) {
+      // no candidate at all: fail closed right here; candidates that miss the snapshot-wide QUEUE extremes need the request's own
+      // normalisers: the exact evaluation of the dense route
+      if (!__any(tb.cn != 0ull)) {
+        if (lane == 0) { out_pick[r] = -1; if (out_score) out_score[r] = 0.0; }
+        return;
+      }
+      if (sn.lead_queue && !(__any((tb.cn & sn.nat[64 + lane]) != 0ull) && __any((tb.cn & sn.nat[128 + lane]) != 0ull))) {
+        sp = false;
+        stage_rows(s, slot0, w);
+      }
+    }
     if (SPARSE && sp && __builtin_expect(lists_overflowed(s, la, lb), 0)) {
       sp = false;
       stage_rows(s, slot0, w);
@@ -1612,9 +1657,23 @@ __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_
 template <typename LW>
 __global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t J, uint32_t qmin, uint32_t qmax,
                                    LW* __restrict__ thi, LW* __restrict__ tlo, LW* __restrict__ qmin_t, LW* __restrict__ qmax_t,
-                                   LW* __restrict__ act_t) {
+                                   LW* __restrict__ act_t, uint64_t* __restrict__ nat) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t a = t >> 6, l = t & 63u;
+  if (a == 130u) {           // natural-layout words: nat[0][l] active pods 64l .. 64l+63, nat[1][l] those at qmin, nat[2][l] at qmax
+    uint64_t ac = 0, mn = 0, mx = 0;
+    for (uint32_t b = 0; b < 64u; ++b) {
+      const uint32_t p = l * 64u + b;
+      if (p >= n_pods) break;
+      const eppk_pod_row& r = rows[p];
+      if (r.flags & EPPK_POD_INACTIVE) continue;
+      ac |= 1ull << b;
+      if (r.queue == qmin) mn |= 1ull << b;
+      if (r.queue == qmax) mx |= 1ull << b;
+    }
+    nat[l] = ac; nat[64u + l] = mn; nat[128u + l] = mx;
+    return;
+  }
   if (a > 129u) return;
   LW hi = 0, lo = 0, ac = 0;
   for (uint32_t j = 0; j < J; ++j) {

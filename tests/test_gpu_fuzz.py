@@ -57,6 +57,9 @@ def _case(pkg, seed):
         mask[0, :] = 0
         if R > 1:
             mask[1, :] = 0; mask[1, 0] = np.uint64(1)
+    if seed % 4 == 3:                                      # holes of the snapshot (SEMANTICS.md §6b); a separate stream keeps the other cases as they were
+        hr = np.random.default_rng(seed ^ 0xA11CE)
+        pods["flags"] = (hr.random(P) < hr.choice([0.05, 0.5, 0.95])).astype(np.uint32)
     return chain, pods, ih, ip, slots, reqs, mask, P, B, R
 
 
@@ -72,9 +75,9 @@ def test_fuzz_pick(pkg, orc, seed):
         tp, ts = pk.pick_topk(reqs, k, mask)
     oix = orc.OracleIndex()
     if B and ih.size:
-        oix.insert(ih, ip)
+        oix.insert(ih, ip, snapshot=pods)                  # (pairs that name a hole are ignored, like on the device)
     op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B, mask)
-    info = f"seed {seed}: chain {chain} P {P} B {B} R {R} masked {mask is not None} slots {slots}"
+    info = f"seed {seed}: chain {chain} P {P} B {B} R {R} masked {mask is not None} slots {slots} holes {int((pods['flags'] & 1).sum())}"
     assert np.array_equal(picks, op), info + f" rows {np.nonzero(picks != op)[0][:5]}"
     assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), info
     otp, ots = orc.pick_topk(chain, pods, oix, reqs, k, mask)
@@ -108,12 +111,18 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
         pk.publish(pods)
         oix = orc.OracleIndex()
         for step in range(14):
-            op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick_evict"])
+            op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick_evict", "republish"])
             if op == "insert":
                 ci = rng.integers(0, universe.shape[0], 3)
                 ih = np.concatenate([universe[c, : int(rng.integers(1, B + 1))] for c in ci])
                 ip = rng.integers(0, P, ih.size).astype(np.uint32)
-                pk.index_insert(ih, ip); oix.insert(ih, ip)
+                pk.index_insert(ih, ip); oix.insert(ih, ip, snapshot=pods)
+            elif op == "republish":                         # endpoint churn: some slots become holes, some holes are handed out again
+                pods = pods.copy()
+                flip = rng.random(P) < 0.15
+                pods["flags"] = np.where(flip, pods["flags"] ^ 1, pods["flags"]).astype(np.uint32)
+                pods["queue"] = rng.integers(0, 64, P)
+                pk.publish(pods); oix.scrub_inactive(pods)
             elif op == "insert_picks":
                 reqs = probe_batch()
                 picks, _ = pk.pick(reqs)
