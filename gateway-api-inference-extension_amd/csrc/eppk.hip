@@ -124,14 +124,6 @@ struct eppk_ctx {
   hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
-  // lean list-route kernel + work list (eppk_kernels.hip.h: pick_lean_kernel): kDeferBanks buffer sets, one per launch in flight
-  bool lean_on = true;            // EPPK_LEAN=0 switches it off (every request through pick_fast_kernel)
-  uint32_t* d_defer[4] = {nullptr, nullptr, nullptr, nullptr};   // per bank: total | cnt[segs] | list[n + segs]
-  size_t defer_words = 0;         // capacity of one bank, in u32
-  uint32_t* h_defer_total = nullptr;   // pinned [kDeferBanks]: deferred count of the launch that last used the bank (read back asynchronously)
-  uint32_t defer_bank = 0, lean_backoff = 0, defer_uses[4] = {0, 0, 0, 0};
-  uint64_t lean_launches = 0, lean_deferred_seen = 0;
-  const void* lean_occ_fn = nullptr; size_t lean_occ_lds = 0; int lean_per_cu = 1;
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
   size_t max_lds = 65536;        // LDS a workgroup may use (160 KB on gfx950)
   int max_wg_per_cu = 0;         // EPPK_MAX_WG_PER_CU: cap on resident workgroups per CU (0 = what the occupancy query allows; tuning knob)
@@ -142,8 +134,6 @@ struct eppk_ctx {
 namespace {
 
 constexpr uint32_t kStatBanks = 4;
-constexpr uint32_t kDeferBanks = 4;     // work-list buffer sets: at most this many pick launches of one context in flight
-constexpr uint32_t kLeanThreads = EPPK_LEAN_THREADS;
 
 int fail(eppk_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -247,53 +237,6 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (grid < 1) grid = 1;
 
   unsigned long long* stats = c->prof ? c->stats + (size_t)(c->stat_bank++ % kStatBanks) * 2u * kStatSlots : nullptr;
-  // The lean kernel first (the common shape of a request at 8 wavefronts per SIMD), then this kernel over what it deferred.
-  // Skipped for a while when a recent launch deferred most of its batch (a workload of differing lists: the lean pass is wasted).
-  bool lean = fast && c->lean_on && !masked && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && c->cfg.max_blocks >= 1;
-  if (lean && c->lean_backoff) { --c->lean_backoff; lean = false; }
-  const void* lean_fn = nullptr;
-  uint32_t lean_grid = 0, defer_cap = 0, lean_segs = 0;
-  size_t lean_lds = 0;
-  uint32_t* dbank = nullptr;
-  const uint32_t bank = c->defer_bank % kDeferBanks;
-  if (lean) {
-    lean_fn = c->lw_bytes == 2 ? eppk::pick_lean_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_lean_u32(c->has_l, c->p_first) : eppk::pick_lean_u64(c->has_l, c->p_first);
-    lean_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)((c->cfg.max_blocks + 1u) * c->pterm_ld) * 8u;
-    if (lean_fn != c->lean_occ_fn || lean_lds != c->lean_occ_lds) {
-      HIPCHK(c, hipFuncSetAttribute(lean_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lean_lds));
-      int per_cu = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lean_fn, (int)kLeanThreads, lean_lds));
-      c->lean_occ_fn = lean_fn; c->lean_occ_lds = lean_lds; c->lean_per_cu = per_cu < 1 ? 1 : per_cu;
-    }
-    const uint32_t lwpb = kLeanThreads / 64u;
-    lean_grid = (n_reqs + lwpb - 1) / lwpb;
-    const uint32_t lcap = (uint32_t)c->num_cu * (uint32_t)c->lean_per_cu;
-    if (lean_grid > lcap) lean_grid = lcap;
-    if (lean_grid > kStatSlots / lwpb) lean_grid = kStatSlots / lwpb;
-    if (lean_grid < 1) lean_grid = 1;
-    lean_segs = lean_grid * lwpb;
-    defer_cap = (n_reqs + lean_segs - 1) / lean_segs;
-    const size_t words = 16u + (size_t)lean_segs + (size_t)lean_segs * defer_cap;
-    if (words > c->defer_words) {          // grow every bank (rare: the first launch, or a larger batch than ever before)
-      HIPCHK(c, hipDeviceSynchronize());
-      for (uint32_t b = 0; b < kDeferBanks; ++b) {
-        if (c->d_defer[b]) HIPCHK(c, hipFree(c->d_defer[b]));
-        c->d_defer[b] = nullptr;
-        HIPCHK(c, hipMalloc((void**)&c->d_defer[b], words * 4u));
-        HIPCHK(c, hipMemset(c->d_defer[b], 0, 64));     // the two total counters
-        c->defer_uses[b] = 0;
-      }
-      c->defer_words = words;
-    }
-    dbank = c->d_defer[bank];
-    // what the launch that used this bank last deferred (its read-back has long completed; a stale value only delays the decision)
-    const uint32_t seen = c->h_defer_total[bank];
-    if (c->lean_launches >= kDeferBanks && seen > n_reqs / 2u) c->lean_backoff = 64;
-    c->lean_deferred_seen += seen;
-    c->h_defer_total[bank] = 0;
-    ++c->defer_bank;
-    ++c->lean_launches;
-  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->ev_used + 2 > c->ev.size()) {
@@ -314,21 +257,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (fast) {
     KTail tl = c->tail;
     KChain chf = c->kchain;
-    KWork wk{};
-    if (lean) {
-      // two alternating total counters per bank: a launch adds to one and zeroes the other for the bank's next launch
-      uint32_t* d_total = dbank + (c->defer_uses[bank] & 1u);
-      uint32_t* d_total_next = dbank + ((c->defer_uses[bank] + 1u) & 1u);
-      ++c->defer_uses[bank];
-      uint32_t* d_cnt = dbank + 16;
-      uint32_t* d_list = dbank + 16 + lean_segs;
-      uint32_t lpwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
-      void* largs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &lpwn, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
-      HIPCHK(c, hipExtLaunchKernel(lean_fn, dim3(lean_grid), dim3(kLeanThreads), largs, lean_lds, st, e0, nullptr, 0));
-      e0 = nullptr;                         // (the pair is timed from the lean kernel's start to this kernel's end)
-      wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = &c->h_defer_total[bank]; wk.cap = defer_cap; wk.n_segs = lean_segs;
-    }
-    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk, &wk};
+    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk};
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   } else {
     KChain ch = c->kchain;
@@ -448,9 +377,6 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->fast_threads = (uint32_t)v;
   }
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
-  if (const char* ln = getenv("EPPK_LEAN")) c->lean_on = atoi(ln) != 0;
-  CHK(hipHostMalloc((void**)&c->h_defer_total, 4 * sizeof(uint32_t), hipHostMallocDefault));
-  std::memset(c->h_defer_total, 0, 4 * sizeof(uint32_t));
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;
@@ -583,8 +509,6 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
-  for (int b = 0; b < 4; ++b) (void)hipFree(c->d_defer[b]);
-  if (c->h_defer_total) (void)hipHostFree(c->h_defer_total);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows); (void)hipFree(c->d_rm);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);

@@ -528,19 +528,7 @@ __device__ __forceinline__ void wave_argmax_dpp(double& best, uint32_t& bidx) {
 // no probe chain.
 constexpr uint32_t kKeysPerProbe = 32u;
 
-// Work list of the fast kernel (null list = every request of the batch).  The lean list-route kernel (pick_lean_kernel) scores
-// what it can and DEFERS the rest -- one private segment per wavefront: list[seg * cap + j], j < cnt[seg] -- and the fast kernel
-// then runs over exactly those requests.
-struct KWork {
-  const uint32_t* cnt;      // [n_segs] requests in each segment
-  const uint32_t* list;     // [n_segs][cap] request indices
-  const uint32_t* total;    // sum of cnt[] (the lean kernel adds to it only from wavefronts that deferred something)
-  uint32_t* report;         // pinned HOST word: the fast kernel stores *total there (the library's "is the lean pass paying off" feedback)
-  uint32_t cap, n_segs;
-};
-
 struct ReqRegs {            // pipeline registers of one request
-  uint32_t ridx;            // request index (wave-uniform)
   uint64_t hdr, h;          // row header; the hash this lane pair probes (landing registers of the row prefetch)
   uint4 kw[2];              // this lane's half of the home bucket (landing registers of the key gather)
   uint32_t bkt;             // home bucket
@@ -744,12 +732,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                        unsigned long long* __restrict__ stats, uint32_t topk, KWork wk) {
-  if (wk.list != nullptr) {                                // work-list mode
-    const uint32_t total = *wk.total;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *wk.report = total;
-    if (total == 0u) return;                               // the lean kernel deferred nothing: done before any staging
-  }
+                                                        unsigned long long* __restrict__ stats, uint32_t topk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
@@ -765,7 +748,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   uint32_t* s_hist_all = (uint32_t*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);   // [waves][J * 16] dwords: one byte per pod
   const bool use_lists = SPARSE && ix.lists != nullptr;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
-  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
+  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct: that costs scratch)
   if (GEN)
     for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_post0[i] = sn.post[0][i]; s_post1[i] = sn.post[1][i]; }
   if (pterm_tab)
@@ -807,14 +790,12 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const uint32_t hidx8 = ((HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u) * 8u;
   const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
 
-  const bool WL = wk.list != nullptr;               // work-list mode: only the requests the lean kernel deferred
-  if (!WL && gwave >= n_reqs) return;
+  if (gwave >= n_reqs) return;
 
   // Stage 0: request row.  The header is wave-uniform: a scalar load straight into SGPRs (constant address space); the
   // lane pair's hash is one buffer load.
-  auto issue_row = [&](uint32_t rr, ReqRegs& q) {
-    q.ridx = rr;
-    const uint32_t soff = rr * stride;
+  auto issue_row = [&](uint32_t rr, uint32_t r_fallback, ReqRegs& q) {
+    const uint32_t soff = (rr < n_reqs ? rr : r_fallback) * stride;
     q.hdr = *(const uint64_t __attribute__((address_space(4)))*)(reqs + soff);
     q.h = buffer_load_u64(rq, hidx8, soff);
   };
@@ -1346,10 +1327,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + 1 (row in `nxt`) and stage 0 of
   // r + 2 (into `cur`, which is free once the probe of r is finished).
-  auto process = [&](uint32_t r_next2, ReqRegs& cur, ReqRegs& nxt) {
+  auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
     ReqS s;
     uint32_t slot0;
-    const uint32_t r = cur.ridx;
     stage_finish(r, cur, s, slot0);
     prepare_keys(nxt);     // the hash of r + 1 is consumed here (its home bucket): the wait for its prefetch sits at the top
     Tabs tb;
@@ -1362,7 +1342,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (sp) issue_lists(s, slot0, la, lb);
     else stage_rows(s, slot0, w);
     issue_keys(nxt);
-    issue_row(r_next2, cur);
+    issue_row(r + 2u * nwaves, r, cur);
     __builtin_amdgcn_sched_barrier(0);
     if (MASKED && SPARSE && sp) {
       // no candidate at all: fail closed right here; candidates that miss the snapshot-wide QUEUE extremes need the request's own
@@ -1398,245 +1378,19 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   qa.kw[0] = qa.kw[1] = make_uint4(0, 0, 0, 0);
   qb.kw[0] = qb.kw[1] = make_uint4(0, 0, 0, 0);
   qa.bkt = qb.bkt = 0;
-  // A wavefront walks SEGMENTS of requests: normally one, {gwave + j * nwaves}; in work-list mode the segments the lean
-  // kernel's wavefronts left behind (segment seg = list[seg * cap .. + cnt[seg])), seg = gwave, gwave + nwaves, ...
-  const uint32_t n_segs = WL ? wk.n_segs : nwaves;
-  for (uint32_t seg = gwave; seg < n_segs; seg += nwaves) {
-    const uint32_t len = WL ? wk.cnt[seg] : (seg < n_reqs ? (n_reqs - seg - 1u) / nwaves + 1u : 0u);
-    if (len == 0u) continue;
-    // request j of the segment; a prefetch past its end re-reads the last row (never used)
-    auto req_at = [&](uint32_t j) -> uint32_t {
-      j = j < len ? j : len - 1u;
-      return WL ? wk.list[(size_t)seg * wk.cap + j] : seg + j * nwaves;
-    };
-    issue_row(req_at(0u), qa);
-    issue_row(req_at(1u), qb);
-    prepare_keys(qa); issue_keys(qa);
-    // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
-    for (uint32_t j = 0; j < len; j += 2u) {
-      process(req_at(j + 2u), qa, qb);
-      if (j + 1u >= len) break;
-      process(req_at(j + 3u), qb, qa);
-    }
+  issue_row(gwave, gwave, qa);
+  issue_row(gwave + nwaves, gwave, qb);
+  prepare_keys(qa); issue_keys(qa);
+  // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
+  for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
+    process(r, qa, qb);
+    if (r + nwaves >= n_reqs) break;
+    process(r + nwaves, qb, qa);
   }
 
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
   if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
-    stats[4 + 2 * gwave] += w_hits;
-    stats[5 + 2 * gwave] += w_lookups;
-  }
-}
-
-// ---- LEAN pick kernel --------------------------------------------------------------------------------------------------
-// The common shape of a request and nothing else: no candidate mask, one fallback-free pick, at most 32 blocks probed, every
-// hit's pod set still in its short list, all those lists IDENTICAL (the blocks of a shared prefix are cached together), the best
-// pod without a prefix match among the first 16 entries of the adapter's top table.  Such a request is scored exactly as the
-// fast kernel's uniform-lists route scores it (same arithmetic, same order); anything else -- reserved hashes, a probe that
-// would have to walk an overflowed bucket, an overflowed or differing list, a chain that continues past 32 hits, an exhausted
-// table, an out-of-range row -- is DEFERRED: the wavefront appends the request index to its private segment of the work list
-// and pick_fast_kernel (work-list mode) scores it afterwards.  What that buys: without the dense-row / histogram / fallback
-// code the kernel needs well under half the VGPRs of pick_fast_kernel and no per-wave LDS histogram, so 8 wavefronts per SIMD
-// are resident instead of 4 -- the loop is bound by the latency of dependent loads (row -> key buckets -> lists), not by issue.
-// Same 3-stage software pipeline as pick_fast_kernel (row of r+2, key gather of r+1, evaluation of r).
-#ifndef EPPK_LEAN_THREADS
-#define EPPK_LEAN_THREADS 1024  // 16 wavefronts per workgroup, two workgroups per CU (LDS: base[] + pterm per workgroup, 41 KB at P = 4096)
-#endif
-#ifndef EPPK_LEAN_WAVES
-#define EPPK_LEAN_WAVES 8       // wavefronts per SIMD the register allocation aims at (<= 64 VGPRs; it needs about 50)
-#endif
-template <typename LW, bool HAS_L, bool P_FIRST>
-__global__ __launch_bounds__(EPPK_LEAN_THREADS, EPPK_LEAN_WAVES) void pick_lean_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
-                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn,
-                                                                 int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                                 unsigned long long* __restrict__ stats,
-                                                                 uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* s_base = (double*)smem;
-  double* s_lw = s_base + (size_t)sn.J * 64u;
-  double* s_pterm = s_lw + 4;
-  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
-  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
-  for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
-  __syncthreads();
-
-  const int lane = (int)(threadIdx.x & 63u);
-  const uint32_t wpb = blockDim.x >> 6;
-  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
-  if (gwave >= n_reqs) {
-    if (lane == 0) defer_cnt[gwave] = 0u;
-    return;
-  }
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)ix.lists, 0, (int)((ix.slots + 4u) * 64u), 0x00020000);
-  const uint32_t lane8 = (uint32_t)lane * 8u, lane4 = (uint32_t)lane * 4u, laneLW = (uint32_t)lane * (uint32_t)sizeof(LW);
-  const uint32_t hwords = (stride - 8u) / 8u;
-  const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;
-  const uint32_t ki = (uint32_t)lane >> 1, sub = (uint32_t)lane & 1u;
-  const uint32_t hidx8 = (1u + (ki < hw0 ? ki : hw0 - 1u)) * 8u;     // (hw0 >= 1: the host launches this kernel only with max_blocks >= 1)
-  const uint32_t k16 = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
-  uint32_t w_hits = 0, w_lookups = 0, n_def = 0;
-  uint32_t* my_list = defer_list + (size_t)gwave * defer_cap;
-
-  auto issue_row = [&](uint32_t rr, ReqRegs& q) {
-    q.ridx = rr;
-    const uint32_t soff = rr * stride;
-    q.hdr = *(const uint64_t __attribute__((address_space(4)))*)(reqs + soff);
-    q.h = buffer_load_u64(rq, hidx8, soff);
-  };
-  auto prepare_keys = [&](ReqRegs& q) {
-    q.h = (ki < hw0) ? q.h : 0ull;
-    pair_probe_prepare(ix, q);
-  };
-  auto issue_keys = [&](ReqRegs& q) { pair_probe_issue(rk, 0u, q, lane); };
-
-  auto process = [&](uint32_t r_next2, ReqRegs& cur, ReqRegs& nxt) {
-    const uint32_t r = cur.ridx;
-    int32_t adapter = (int32_t)(uint32_t)cur.hdr;
-    uint32_t nb = (uint32_t)(cur.hdr >> 32);
-    bool defer = nb > hwords || adapter < -1 || adapter >= (int32_t)EPPK_MAX_ADAPTERS;      // the fast kernel reports the row
-    if (defer) { adapter = -1; nb = 0u; }
-    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-    // ---- finish the probe: leading hits m0, their slots (lane pair k)
-    uint32_t m0 = 0u, slot_eff = ix.slots + 2u;
-    if (nb != 0u) {
-      const uint32_t nchunk = nb < kKeysPerProbe ? nb : kKeysPerProbe;
-      const bool act = ki < nchunk;
-      const uint64_t h = cur.h;
-      const uint32_t pos = match4(cur.kw, h, sub == 0u);
-      uint32_t sl = pos < 4u ? cur.bkt * kBucket + sub * 4u + pos : kNotFound;
-      const uint32_t so = dpp_xor1(sl);
-      sl = so < sl ? so : sl;
-      uint32_t ovf = sub == 0u ? (cur.kw[0].x & 1u) : 0u;
-      ovf |= dpp_xor1(ovf);
-      const uint32_t slot = act ? sl : kNotFound;
-      const unsigned long long fm = __ballot(slot != kNotFound);
-      m0 = (~fm == 0ull) ? kKeysPerProbe : (uint32_t)__builtin_ctzll(~fm) >> 1;
-      // rare: a reserved hash among the probed keys, or the first miss sits in an overflowed bucket (the key may live further on)
-      defer |= __any(act && (h + 1ull) <= 1ull) || __any(act && ki == m0 && ovf != 0u);
-      defer |= m0 == kKeysPerProbe && nb > kKeysPerProbe;                                   // the chain continues past the gather
-      slot_eff = (ki < m0) ? slot : ix.slots + 2u;
-    }
-    prepare_keys(nxt);
-    // ---- tables + lists of this request
-    double top_t = -__builtin_inf();
-    uint32_t top_p = kNoPod;
-    if (lane < 16) {
-      top_t = __longlong_as_double((long long)buffer_load_u64(rsn, lane8, SnapOff<LW>::topv + arow * 512u));
-      top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)lane4, (int)(SnapOff<LW>::topi + arow * 256u), 0);
-    }
-    LW thi = 0, tlo = 0;
-    if (HAS_L && m0 > 0u) {
-      thi = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::thi + arow * (uint32_t)(64u * sizeof(LW)));
-      if (adapter >= 0) tlo = buffer_load_lw<LW>(rsn, laneLW, SnapOff<LW>::tlo + arow * (uint32_t)(64u * sizeof(LW)));
-    }
-    u32x4_t la = (u32x4_t)(0xFFFFFFFFu), lb = (u32x4_t)(0xFFFFFFFFu);
-    if (m0 > 0u) {
-      const uint32_t sa = (uint32_t)__shfl((int)slot_eff, (int)(2u * (k16 < m0 ? k16 : 0u)));
-      la = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sa * 64u + cch * 16u), 0, 0);
-      if (m0 > 16u) {
-        const uint32_t sb = (uint32_t)__shfl((int)slot_eff, (int)(2u * (16u + k16)));
-        lb = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sb * 64u + cch * 16u), 0, 0);
-      }
-    }
-    issue_keys(nxt);
-    issue_row(r_next2, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- evaluate
-    double best = -__builtin_inf();
-    uint32_t bidx = kNoPod;
-    uint32_t id = kListNone;
-    bool listed = false;
-    if (m0 > 0u) {
-      const bool ovfl = cch == 0u && ((k16 < m0 && la.w > kListCap) || (16u + k16 < m0 && lb.w > kListCap));
-      auto shr1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); };
-      uint32_t diff = 0;
-      if (k16 < m0) diff = (la.x ^ shr1(la.x)) | (la.y ^ shr1(la.y)) | (la.z ^ shr1(la.z)) | (la.w ^ shr1(la.w));
-      if (16u + k16 < m0) diff |= (lb.x ^ la.x) | (lb.y ^ la.y) | (lb.z ^ la.z) | (lb.w ^ la.w);
-      defer |= __any(ovfl || diff != 0u);
-      const uint32_t dw = (k16 & 4u) ? ((k16 & 2u) ? la.w : la.z) : ((k16 & 2u) ? la.y : la.x);
-      id = (k16 & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
-      if (k16 >= 6u) id = kListNone;
-      listed = id < sn.n_pods;
-      const uint32_t p = listed ? id : 0u;
-      uint32_t tier = 0;
-      if (HAS_L) {
-        const uint32_t src = p & 63u, jb = p >> 6;
-        LW th, tl_;
-        if constexpr (sizeof(LW) == 8) {
-          th = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(thi >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)thi, (int)src);
-          tl_ = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(tlo >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)tlo, (int)src);
-        } else {
-          th = (LW)__shfl((int)(uint32_t)thi, (int)src);
-          tl_ = (LW)__shfl((int)(uint32_t)tlo, (int)src);
-        }
-        tier = (uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1);
-      }
-      // total of a listed pod: matched = m0 blocks out of nb; binary64 adds in chain order (pick_fast_kernel: pod_total)
-      const double pterm = s_pterm[(size_t)nb * sn.pterm_ld + (listed ? m0 : 0u)];
-      const double lterm = HAS_L ? s_lw[tier] : 0.0;
-      const double t = eval_total<HAS_L, true, P_FIRST>(s_base[p], lterm, pterm);
-      best = listed ? t : -__builtin_inf();
-      bidx = listed ? p : kNoPod;
-      wave_argmax_dpp(best, bidx);
-    }
-    // best pod outside M: the first top-table entry that is not listed
-    double cand_t = -__builtin_inf();
-    uint32_t cand_p = kNoPod;
-    const double top0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), 0), __builtin_amdgcn_readlane(__double2loint(top_t), 0));
-    if (!(best > top0)) {
-      uint32_t e = 0;
-      for (; e < 16u; ++e) {
-        const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)top_p, (int)e);
-        if (tp == kNoPod) break;
-        if (!__any(listed && id == tp)) {
-          cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(top_t), (int)e), __builtin_amdgcn_readlane(__double2loint(top_t), (int)e));
-          cand_p = tp;
-          break;
-        }
-      }
-      defer |= e == 16u && sn.n_pods > 16u;               // all of the first 16 are listed: the fast kernel fetches the rest
-    }
-    if (cand_t > best || (cand_t == best && cand_p < bidx)) { best = cand_t; bidx = cand_p; }
-    if (__builtin_expect(defer, 0)) {
-      if (lane == 0) my_list[n_def] = r;
-    } else {
-      const bool none = bidx == kNoPod;
-      if (lane == 0) {
-        out_pick[r] = none ? -1 : (int32_t)bidx;
-        if (out_score) out_score[r] = none ? 0.0 : best;
-      }
-    }
-    // (scalar selects, not branches: the three counters stay in SGPRs)
-    n_def += defer ? 1u : 0u;
-    w_hits += defer ? 0u : m0;
-    w_lookups += defer ? 0u : ((m0 + 1u < nb) ? m0 + 1u : nb);
-  };
-
-  ReqRegs qa, qb;
-  qa.kw[0] = qa.kw[1] = make_uint4(0, 0, 0, 0);
-  qb.kw[0] = qb.kw[1] = make_uint4(0, 0, 0, 0);
-  qa.bkt = qb.bkt = 0;
-  const uint32_t len = (n_reqs - gwave - 1u) / nwaves + 1u;
-  auto req_at = [&](uint32_t j) -> uint32_t { j = j < len ? j : len - 1u; return gwave + j * nwaves; };
-  issue_row(req_at(0u), qa);
-  issue_row(req_at(1u), qb);
-  prepare_keys(qa); issue_keys(qa);
-  for (uint32_t j = 0; j < len; j += 2u) {
-    process(req_at(j + 2u), qa, qb);
-    if (j + 1u >= len) break;
-    process(req_at(j + 3u), qb, qa);
-  }
-  if (lane == 0) {
-    defer_cnt[gwave] = n_def;
-    if (n_def) atomicAdd(defer_total, n_def);
-  }
-  if (stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
     stats[4 + 2 * gwave] += w_hits;
     stats[5 + 2 * gwave] += w_lookups;
   }

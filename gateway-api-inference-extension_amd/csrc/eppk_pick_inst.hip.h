@@ -18,10 +18,6 @@ const void* pick_kernel_u32_6(const PickVariant& v);
 const void* pick_kernel_u32_9(const PickVariant& v);
 const void* pick_kernel_u64_6(const PickVariant& v);
 const void* pick_kernel_u64_9(const PickVariant& v);
-// the lean list-route kernel (pick_lean_kernel; prefix scorer present, <= 63 blocks); defined in the *_6 units
-const void* pick_lean_u16(bool has_l, bool p_first);
-const void* pick_lean_u32(bool has_l, bool p_first);
-const void* pick_lean_u64(bool has_l, bool p_first);
 
 #ifdef EPPK_PICK_INST_NAME
 template <typename LW, int NPL, bool MASKED, bool BIG, bool TOPK>
@@ -41,14 +37,6 @@ template <typename LW, int NPL, bool MASKED, bool BIG>
 static const void* fast_kernel_ptr(const PickVariant& v) {
   return v.topk ? fast_kernel_ptr<LW, NPL, MASKED, BIG, true>(v) : fast_kernel_ptr<LW, NPL, MASKED, BIG, false>(v);
 }
-
-#if EPPK_PICK_INST_NPL == 6
-const void* EPPK_PICK_LEAN_NAME(bool has_l, bool p_first) {
-  using LW = EPPK_PICK_INST_LW;
-  if (has_l) return p_first ? (const void*)pick_lean_kernel<LW, true, true> : (const void*)pick_lean_kernel<LW, true, false>;
-  return (const void*)pick_lean_kernel<LW, false, false>;
-}
-#endif
 
 const void* EPPK_PICK_INST_NAME(const PickVariant& v) {
   using LW = EPPK_PICK_INST_LW;

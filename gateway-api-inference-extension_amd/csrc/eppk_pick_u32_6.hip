@@ -3,5 +3,4 @@
 #define EPPK_PICK_INST_LW uint32_t
 #define EPPK_PICK_INST_NPL 6
 #define EPPK_PICK_INST_NAME pick_kernel_u32_6
-#define EPPK_PICK_LEAN_NAME pick_lean_u32
 #include "eppk_pick_inst.hip.h"
