@@ -23,7 +23,7 @@ SYMBOLS = [
     "eppk_index_evict_older_device",
     "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
-    "eppk_launch_status",
+    "eppk_launch_status", "eppk_pick_random_topk", "eppk_pick_random_topk_device", "eppk_set_assumed_load",
     "eppk_group_create", "eppk_group_destroy", "eppk_group_last_error", "eppk_group_size", "eppk_group_ctx", "eppk_group_ranks_seen",
     "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
     "eppk_group_index_remove_pod", "eppk_group_index_advance_epoch", "eppk_group_index_evict_older", "eppk_group_pick_batch",
@@ -107,6 +107,9 @@ def load_library() -> C.CDLL:
     lib.eppk_round_robin.argtypes = [C.POINTER(u64), u32]
     lib.eppk_round_robin.restype = i32
     lib.eppk_launch_status.argtypes = [vp, C.POINTER(u32)]
+    lib.eppk_pick_random_topk.argtypes = [vp, vp, u32, vp, u32, u64, vp, vp]
+    lib.eppk_pick_random_topk_device.argtypes = [vp, vp, u32, vp, u32, u64, vp, vp, vp]
+    lib.eppk_set_assumed_load.argtypes = [vp, u32]
     lib.eppk_group_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), u32, u32, C.POINTER(vp)]
     lib.eppk_group_destroy.argtypes = [vp]
     lib.eppk_group_destroy.restype = None

@@ -44,12 +44,13 @@ struct SnapBuf {
   void*     qmax_t = nullptr;
   void*     act_t = nullptr;   // [64] LW active slots (holes clear)
   uint64_t* nat = nullptr;     // [3][64] u64 natural-layout active / qmin / qmax sets (masked list routes)
+  uint32_t* qrange = nullptr;  // [2] min / max queue depth over the active pods
   double*   topv = nullptr;   // [129][64]
   uint32_t* topi = nullptr;   // [129][64]
 };
 
 struct SnapLayout {            // byte offsets inside a snapshot blob
-  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, act = 0, nat = 0, topv = 0, topi = 0, bytes = 0;
+  size_t base = 0, post0 = 0, post1 = 0, queue = 0, kv = 0, thi = 0, tlo = 0, qmin = 0, qmax = 0, act = 0, nat = 0, qrange = 0, topv = 0, topi = 0, bytes = 0;
 };
 
 }  // namespace
@@ -84,8 +85,9 @@ struct eppk_ctx {
   int cur = 0;
   bool have_snapshot = false;
   uint32_t n_pods = 0;
-  uint32_t qmin = 0, qmax = 0;
   uint64_t epoch = 0;
+  uint32_t assumed_epochs = 0;     // SEMANTICS.md §2b (eppk_set_assumed_load); 0 = off
+  int32_t* d_rs_pick = nullptr; double* d_rs_score = nullptr; size_t rs_cap = 0;   // fallback lists of eppk_pick_random_topk
 
   // prefix index
   uint64_t* keys = nullptr;
@@ -164,7 +166,7 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.act_t = s.act_t; k.nat = s.nat; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
-  k.qmin = c->qmin; k.qmax = c->qmax;
+  k.qrange = s.qrange;
   k.status = c->d_status;
   return k;
 }
@@ -273,6 +275,53 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   return EPPK_OK;
 }
 
+int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st);
+
+// One batch through the picker the caller asked for, in assumed-load epochs when those are on (SEMANTICS.md §2b):
+//   k == 1, !random   the pick                         (d_pick / d_score: n entries)
+//   k  > 1, !random   ordered fallbacks                (n * k entries; the request's pick is entry 0 of its list)
+//   random            picker "random-top-k" (§3b)      (n entries), r0 = batch index of the first request (the rule hashes it)
+int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick, double* d_score, hipStream_t st,
+             uint32_t k, bool random, uint64_t seed, uint32_t r0) {
+  const uint32_t E = c->assumed_epochs;
+  const uint32_t per = E ? (n_reqs + E - 1u) / E : n_reqs;
+  const size_t J = (c->n_pods + 63u) / 64u;
+  const uint32_t ok = random ? 1u : k;                        // entries per request in the caller's arrays
+  if (random && (size_t)per * k > c->rs_cap) {                // fallback lists of one epoch
+    HIPCHK(c, hipStreamSynchronize(st));
+    (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
+    c->d_rs_pick = nullptr; c->d_rs_score = nullptr; c->rs_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_rs_pick, (size_t)per * k * 4u));
+    HIPCHK(c, hipMalloc((void**)&c->d_rs_score, (size_t)per * k * 8u));
+    c->rs_cap = (size_t)per * k;
+  }
+  for (uint32_t lo = 0; lo < n_reqs; lo += per) {
+    const uint32_t cnt = n_reqs - lo < per ? n_reqs - lo : per;
+    const uint8_t* reqs = d_reqs + (size_t)lo * c->stride;
+    const uint64_t* mask = d_mask ? d_mask + (size_t)lo * J : nullptr;
+    int32_t* pick = d_pick + (size_t)lo * ok;
+    double* score = d_score ? d_score + (size_t)lo * ok : nullptr;
+    int rc;
+    if (random) {
+      rc = launch_pick(c, reqs, cnt, mask, c->d_rs_pick, c->d_rs_score, st, k);
+      if (rc) return rc;
+      hipLaunchKernelGGL(random_select_kernel, dim3((cnt + 255u) / 256u), dim3(256), 0, st, (const int32_t*)c->d_rs_pick, (const double*)c->d_rs_score,
+                         cnt, k, seed, r0 + lo, pick, score);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      rc = launch_pick(c, reqs, cnt, mask, pick, score, st, k);
+      if (rc) return rc;
+    }
+    if (E) {    // the assumed load of what this epoch routed, then everything derived from the queue gauge again
+      hipLaunchKernelGGL(assumed_bump_kernel, dim3((cnt + 255u) / 256u), dim3(256), 0, st, c->d_rows, (const int32_t*)pick, cnt, ok, c->n_pods);
+      HIPCHK(c, hipGetLastError());
+      rc = rebuild_snapshot(c, c->n_pods, st);
+      if (rc) return rc;
+    }
+  }
+  return EPPK_OK;
+}
+
 template <typename F>
 int by_lane_word(const eppk_ctx* c, F&& f) {
   switch (c->lw_bytes) {
@@ -304,6 +353,39 @@ int index_scrub(eppk_ctx* c, const uint64_t* holes) {
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));    // (`packed` is a stack buffer)
   return rc;
+}
+
+// (declared ahead of run_pick)
+// Build the idle snapshot buffer from the raw rows in c->d_rows (asynchronous on `st`) and make it the current one: the
+// publish path, and the rebuild after every assumed-load epoch (SEMANTICS.md §2b) -- same kernels, same binary64 operations.
+int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st) {
+  const uint32_t J = (n_pods + 63u) / 64u;
+  const size_t np64 = (size_t)J * 64u;
+  const int nxt = c->cur ^ 1;
+  SnapBuf& s = c->snap[nxt];
+  KChain lead{};
+  lead.n = c->n_lead;
+  for (uint32_t k = 0; k < c->n_lead; ++k) { lead.kind[k] = c->cfg.chain[k].kind; lead.w[k] = (double)c->cfg.chain[k].weight; }
+  const uint32_t n64 = (uint32_t)np64;
+  hipLaunchKernelGGL(snap_qrange_kernel, dim3(1), dim3(1024), 0, st, (const eppk_pod_row*)c->d_rows, n_pods, s.qrange);
+  if (n64)
+    hipLaunchKernelGGL(snap_terms_kernel, dim3((n64 + 255u) / 256u), dim3(256), 0, st, (const eppk_pod_row*)c->d_rows, n_pods, n64,
+                       (const uint32_t*)s.qrange, lead, c->postc, s.base, s.post[0], s.post[1], s.queue, s.kv);
+  int rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((131u * 64u + 255u) / 256u), dim3(256), 0, st, (const eppk_pod_row*)c->d_rows,
+                       n_pods, J, (const uint32_t*)s.qrange, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t, (LW*)s.act_t, s.nat);
+    if (c->canonical)
+      hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, st, (const double*)s.base, (const LW*)s.thi_t,
+                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1],
+                         (const LW*)s.act_t, s.topv, s.topi);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  if (rc) return rc;
+  c->cur = nxt;
+  c->n_pods = n_pods;
+  return EPPK_OK;
 }
 
 // Sum one field of the sharded index counters (synchronises the context's stream).
@@ -439,7 +521,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.tlo = off; off += lora_bytes;
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
-    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes); L.nat = take(3u * 64u * 8u);
+    L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes); L.nat = take(3u * 64u * 8u); L.qrange = take(8u);
     L.bytes = off + 256u;                      // the LAST dword is the fast kernel's launch-status word (kBlobStatusTail)
     for (int b = 0; b < 2; ++b) {
       SnapBuf& s = c->snap[b];
@@ -448,7 +530,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
       s.base = (double*)(s.blob + L.base); s.post[0] = (double*)(s.blob + L.post0); s.post[1] = (double*)(s.blob + L.post1);
       s.queue = (uint32_t*)(s.blob + L.queue); s.kv = (double*)(s.blob + L.kv);
       s.thi_t = s.blob + L.thi; s.tlo_t = s.blob + L.tlo;
-      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax; s.act_t = s.blob + L.act; s.nat = (uint64_t*)(s.blob + L.nat);
+      s.qmin_t = s.blob + L.qmin; s.qmax_t = s.blob + L.qmax; s.act_t = s.blob + L.act; s.nat = (uint64_t*)(s.blob + L.nat); s.qrange = (uint32_t*)(s.blob + L.qrange);
       s.topv = (double*)(s.blob + L.topv); s.topi = (uint32_t*)(s.blob + L.topi);
     }
   }
@@ -510,7 +592,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
-  (void)hipFree(c->d_rows); (void)hipFree(c->d_rm);
+  (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_pick) (void)hipHostFree(c->h_pick);
@@ -526,20 +608,11 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   if (!c || (!rows && n_pods)) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_publish: null argument");
   if (n_pods > c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_snapshot_publish: n_pods > max_pods");
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  const uint32_t J = (n_pods + 63u) / 64u;
-  const size_t np64 = (size_t)J * 64u;
 
-  // QUEUE normalisers over all ACTIVE pods (the unmasked candidate set); holes (flags & EPPK_POD_INACTIVE) are never candidates
-  uint32_t qmin = 0, qmax = 0;
-  bool any = false;
+  // holes (flags & EPPK_POD_INACTIVE) are never candidates; the QUEUE normalisers range over the ACTIVE pods (snap_qrange_kernel)
   uint64_t act[64] = {0};                      // lane-transposed active set (u64 words serve every lane-word width)
-  for (uint32_t p = 0; p < n_pods; ++p) {
-    if (rows[p].flags & EPPK_POD_INACTIVE) continue;
-    act[p & 63u] |= 1ull << (p >> 6);
-    const uint32_t q = rows[p].queue;
-    if (!any) { qmin = qmax = q; any = true; }
-    else { qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax; }
-  }
+  for (uint32_t p = 0; p < n_pods; ++p)
+    if (!(rows[p].flags & EPPK_POD_INACTIVE)) act[p & 63u] |= 1ull << (p >> 6);
   // A slot that turned into a hole takes its cache knowledge with it: the index forgets it (SEMANTICS.md §6b), in ONE pass over
   // the table for all holes of this snapshot -- only when some slot became a hole since the last publish.
   bool new_hole = false;
@@ -554,36 +627,16 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
     if (rcs) return rcs;
   }
 
-  // Snapshot producer on the device (eppk_kernels.hip.h "snapshot producer"): one H2D copy of the raw rows, then
-  // fused terms, tier planes and the per-adapter top-64 tables are built by three launches into the idle buffer.
-  const int nxt = c->cur ^ 1;
-  SnapBuf& s = c->snap[nxt];
+  // Snapshot producer on the device (eppk_kernels.hip.h "snapshot producer"): one H2D copy of the raw rows, then the queue
+  // range, fused terms, tier planes and the per-adapter top-64 tables are built by four launches into the idle buffer.
   if (n_pods) {
     std::memcpy(c->h_rows, rows, (size_t)n_pods * sizeof(eppk_pod_row));
     HIPCHK(c, hipMemcpyAsync(c->d_rows, c->h_rows, (size_t)n_pods * sizeof(eppk_pod_row), hipMemcpyHostToDevice, c->stream));
   }
-  KChain lead{};
-  lead.n = c->n_lead;
-  for (uint32_t k = 0; k < c->n_lead; ++k) { lead.kind[k] = c->cfg.chain[k].kind; lead.w[k] = (double)c->cfg.chain[k].weight; }
-  const uint32_t n64 = (uint32_t)np64;
-  if (n64)
-    hipLaunchKernelGGL(snap_terms_kernel, dim3((n64 + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows, n_pods, n64,
-                       qmin, qmax, lead, c->postc, s.base, s.post[0], s.post[1], s.queue, s.kv);
-  int rc = by_lane_word(c, [&](auto tag) {
-    using LW = decltype(tag);
-    hipLaunchKernelGGL((snap_planes_kernel<LW>), dim3((131u * 64u + 255u) / 256u), dim3(256), 0, c->stream, (const eppk_pod_row*)c->d_rows,
-                       n_pods, J, qmin, qmax, (LW*)s.thi_t, (LW*)s.tlo_t, (LW*)s.qmin_t, (LW*)s.qmax_t, (LW*)s.act_t, s.nat);
-    if (c->canonical)
-      hipLaunchKernelGGL((snap_top_kernel<LW>), dim3(129), dim3(256), np64 * 8u, c->stream, (const double*)s.base, (const LW*)s.thi_t,
-                         (const LW*)s.tlo_t, n_pods, n64, c->has_l ? 1u : 0u, c->tail, (const double*)s.post[0], (const double*)s.post[1],
-                         (const LW*)s.act_t, s.topv, s.topi);
-    return EPPK_OK;
-  });
-  HIPCHK(c, hipGetLastError());
+  int rc = rebuild_snapshot(c, n_pods, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->cur = nxt;
-  c->n_pods = n_pods; c->qmin = qmin; c->qmax = qmax; c->epoch = epoch;
+  c->epoch = epoch;
   c->have_snapshot = true;
   return EPPK_OK;
 }
@@ -793,8 +846,8 @@ int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
   const size_t J = (c->n_pods + 63u) / 64u;
   for (uint32_t r0 = 0; r0 < n_reqs; r0 += per) {
     const uint32_t n = (n_reqs - r0 < per) ? n_reqs - r0 : per;
-    int rc = launch_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
-                         d_out_pick + r0, d_out_score ? d_out_score + r0 : nullptr, st);
+    int rc = run_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
+                      d_out_pick + r0, d_out_score ? d_out_score + r0 : nullptr, st, 1u, false, 0ull, 0u);
     if (rc) return rc;
   }
   return EPPK_OK;
@@ -867,8 +920,8 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
     HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n * J * 8u, hipMemcpyHostToDevice, c->stream));
   }
   const uint8_t* d_shard = (const uint8_t*)c->d_reqs + (upload_all ? (size_t)lo * c->stride : 0u);
-  rc = launch_pick(c, d_shard, n, (cand_mask_shard && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
-                   c->d_score + (upload_all ? lo : 0u), c->stream);
+  rc = run_pick(c, d_shard, n, (cand_mask_shard && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
+                c->d_score + (upload_all ? lo : 0u), c->stream, 1u, false, 0ull, 0u);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick + (upload_all ? lo : 0u), (size_t)n * 4u, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score + (upload_all ? lo : 0u), (size_t)n * 8u, hipMemcpyDeviceToHost, c->stream));
@@ -915,8 +968,8 @@ int eppk_pick_topk_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, cons
   const size_t J = (c->n_pods + 63u) / 64u;
   for (uint32_t r0 = 0; r0 < n_reqs; r0 += per) {
     const uint32_t n = (n_reqs - r0 < per) ? n_reqs - r0 : per;
-    int rc = launch_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
-                         d_out_pick + (size_t)r0 * k, d_out_score ? d_out_score + (size_t)r0 * k : nullptr, st, k);
+    int rc = run_pick(c, (const uint8_t*)d_reqs + (size_t)r0 * c->stride, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr,
+                      d_out_pick + (size_t)r0 * k, d_out_score ? d_out_score + (size_t)r0 * k : nullptr, st, k, false, 0ull, 0u);
     if (rc) return rc;
   }
   return EPPK_OK;
@@ -951,11 +1004,65 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
   if (cand_mask && !c->d_tk_mask) HIPCHK(c, hipMalloc((void**)&c->d_tk_mask, mb * c->jmax * 8u));
   HIPCHK(c, hipMemcpyAsync(c->d_tk_reqs, reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
   if (cand_mask) HIPCHK(c, hipMemcpyAsync(c->d_tk_mask, cand_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
-  int rc = launch_pick(c, c->d_tk_reqs, n_reqs, cand_mask ? c->d_tk_mask : nullptr, c->d_tk_pick, c->d_tk_score, c->stream, k);
+  int rc = run_pick(c, (const uint8_t*)c->d_tk_reqs, n_reqs, cand_mask ? c->d_tk_mask : nullptr, c->d_tk_pick, c->d_tk_score, c->stream, k, false, 0ull, 0u);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(out_pick, c->d_tk_pick, (size_t)n_reqs * k * 4u, hipMemcpyDeviceToHost, c->stream));
   if (out_score) HIPCHK(c, hipMemcpyAsync(out_score, c->d_tk_score, (size_t)n_reqs * k * 8u, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return EPPK_OK;
+}
+
+// ---- picker "random-top-k" (SEMANTICS.md §3b) and assumed load (§2b) --------------------------------------------------
+
+int eppk_pick_random_topk_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k, uint64_t seed,
+                                 int32_t* d_out_pick, double* d_out_score, void* stream) {
+  if (!c || ((!d_reqs || !d_out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_random_topk_device: null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return fail(c, EPPK_ERR_ARG, "eppk_pick_random_topk_device: k out of range (1..8)");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_random_topk_device: no snapshot published");
+  if (n_reqs == 0) return EPPK_OK;
+  if ((uint64_t)n_reqs * c->stride >= (1ull << 31)) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_random_topk_device: batch of 2 GiB and more (split it)");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  return run_pick(c, (const uint8_t*)d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, st, k, true, seed, 0u);
+}
+
+int eppk_pick_random_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, uint64_t seed, int32_t* out_pick,
+                          double* out_score) {
+  if (!c || ((!reqs || !out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_random_topk: null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return fail(c, EPPK_ERR_ARG, "eppk_pick_random_topk: k out of range (1..8)");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_random_topk: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_random_topk: n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  int rc = validate_rows(c, "eppk_pick_random_topk", reqs, n_reqs);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t J = (c->n_pods + 63u) / 64u;
+  if (cand_mask && !J) {
+    for (uint32_t r = 0; r < n_reqs; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+    return EPPK_OK;
+  }
+  rc = ensure_host_staging(c, cand_mask != nullptr);
+  if (rc) return rc;
+  std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+  HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+  if (cand_mask) {
+    std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  }
+  rc = run_pick(c, (const uint8_t*)c->d_reqs, n_reqs, cand_mask ? c->d_mask : nullptr, c->d_pick, c->d_score, c->stream, k, true, seed, 0u);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
+  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
+  return EPPK_OK;
+}
+
+int eppk_set_assumed_load(eppk_ctx* c, uint32_t epochs) {
+  if (!c) return EPPK_ERR_ARG;
+  if (epochs > 65536u) return fail(c, EPPK_ERR_LIMIT, "eppk_set_assumed_load: more than 65536 epochs per batch");
+  c->assumed_epochs = epochs;
   return EPPK_OK;
 }
 

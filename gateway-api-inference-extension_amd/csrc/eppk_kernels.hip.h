@@ -84,7 +84,8 @@ struct KSnap {
                            // and tlo_t sit at the compile-time offsets of SnapOff<LW> (immediates, not SGPRs)
   uint32_t n_pods;
   uint32_t J;              // ceil(n_pods/64)
-  uint32_t qmin, qmax;     // over all pods (unmasked QUEUE scorer)
+  const uint32_t* qrange;  // [2] minimum / maximum queue depth over the ACTIVE pods (unmasked QUEUE scorer); device memory: the
+                           // snapshot producer computes it (snap_qrange_kernel), also when assumed load moved the gauges
   uint32_t* status;        // sticky launch-status flags of the context (eppk_launch_status): bit 0 = a request row handed to a
                            // *_device entry point was out of range (n_blocks > max_blocks or adapter outside [-1, 128)); such a
                            // request is NOT scored: its pick is EPPK_NO_PICK (SEMANTICS.md §7: never silently truncated).
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
     }
 
     // QUEUE normalisers over the request's candidates
-    uint32_t qmin = sn.qmin, qmax = sn.qmax;
+    uint32_t qmin = sn.qrange[0], qmax = sn.qrange[1];
     if (MASKED && has_q) {
       uint32_t mn = 0xFFFFFFFFu, mx = 0u;
       for (uint32_t j = 0; j < sn.J; ++j) {
@@ -1629,15 +1630,68 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
 // A publish is one H2D copy of the raw 64-byte rows plus three small launches; every value is computed with the same
 // binary64 operations, in the same order, as SEMANTICS.md §2 prescribes (so the fused terms stay bit-exact).
 
+// (0) one workgroup: minimum / maximum queue depth over the active pods (holes excluded) -> qr[0], qr[1]  (0, 0 when none)
+#ifdef EPPK_MAIN_UNIT
+__global__ __launch_bounds__(1024) void snap_qrange_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t* __restrict__ qr) {
+  __shared__ uint32_t s_mn[16], s_mx[16];
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  bool any = false;
+  for (uint32_t p = threadIdx.x; p < n_pods; p += blockDim.x)
+    if (!(rows[p].flags & EPPK_POD_INACTIVE)) {
+      const uint32_t q = rows[p].queue;
+      mn = q < mn ? q : mn; mx = q > mx ? q : mx; any = true;
+    }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t omn = (uint32_t)__shfl_xor((int)mn, off), omx = (uint32_t)__shfl_xor((int)mx, off);
+    mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+  }
+  (void)any;
+  if ((threadIdx.x & 63u) == 0u) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { mn = s_mn[w] < mn ? s_mn[w] : mn; mx = s_mx[w] > mx ? s_mx[w] : mx; }
+    if (mn > mx) { mn = 0u; mx = 0u; }         // no active pod
+    qr[0] = mn; qr[1] = mx;
+  }
+}
+
+// Assumed load (SEMANTICS.md §2b): queue[pick] += 1 for every routed request of an epoch; picks[r * k] is request r's pick.
+__global__ void assumed_bump_kernel(eppk_pod_row* __restrict__ rows, const int32_t* __restrict__ picks, uint32_t n, uint32_t k, uint32_t n_pods) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int32_t p = picks[(size_t)r * k];
+  if (p >= 0 && (uint32_t)p < n_pods) atomicAdd(&rows[p].queue, 1u);
+}
+
+// Picker "random-top-k" (SEMANTICS.md §3b): entry (splitmix64(seed + (r+1)*golden) mod n) of request r's ordered fallback list.
+// r0 = index of the first request of this launch within its batch.
+__global__ void random_select_kernel(const int32_t* __restrict__ tp, const double* __restrict__ ts, uint32_t n, uint32_t k, uint64_t seed, uint32_t r0,
+                                     int32_t* __restrict__ out_pick, double* __restrict__ out_score) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint32_t cnt = 0;
+  while (cnt < k && tp[(size_t)r * k + cnt] >= 0) ++cnt;
+  if (cnt == 0u) { out_pick[r] = -1; if (out_score) out_score[r] = 0.0; return; }
+  uint64_t z = seed + ((uint64_t)(r0 + r) + 1ull) * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const uint32_t j = (uint32_t)(z % (uint64_t)cnt);
+  out_pick[r] = tp[(size_t)r * k + j];
+  if (out_score) out_score[r] = ts[(size_t)r * k + j];
+}
+#endif
+
 // (1) thread per pod: fused leading pod-only terms base[p] (chain order), raw gauges for the generic kernel
 // `lead` = the pod-only scorers in front of the first LORA / PREFIX (folded into base[p]); `postc` = the pod-only scorers
 // behind it (n <= 2): their products clamp01(s) * w go to post0[p] / post1[p], one array each (they are added one by one).
 #ifdef EPPK_MAIN_UNIT
-__global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t np64, uint32_t qmin, uint32_t qmax,
+__global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t np64, const uint32_t* __restrict__ qr,
                                   KChain lead, KChain postc, double* __restrict__ base, double* __restrict__ post0, double* __restrict__ post1,
                                   uint32_t* __restrict__ queue, double* __restrict__ kv) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np64) return;
+  const uint32_t qmin = qr[0], qmax = qr[1];
   double t = 0.0, k = 0.0, pp[2] = {0.0, 0.0};
   uint32_t q = 0;
   if (p < n_pods) {
@@ -1655,11 +1709,12 @@ __global__ void snap_terms_kernel(const eppk_pod_row* __restrict__ rows, uint32_
 //       hi = active | free, lo = active | (~free & waiting)  ->  tier = 2*hi + lo (SEMANTICS.md §3 LORA);
 //     row 129 of the launch builds the lane words of the pods at the minimum / maximum queue depth instead.
 template <typename LW>
-__global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t J, uint32_t qmin, uint32_t qmax,
+__global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32_t n_pods, uint32_t J, const uint32_t* __restrict__ qr,
                                    LW* __restrict__ thi, LW* __restrict__ tlo, LW* __restrict__ qmin_t, LW* __restrict__ qmax_t,
                                    LW* __restrict__ act_t, uint64_t* __restrict__ nat) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t a = t >> 6, l = t & 63u;
+  const uint32_t qmin = qr[0], qmax = qr[1];
   if (a == 130u) {           // natural-layout words: nat[0][l] active pods 64l .. 64l+63, nat[1][l] those at qmin, nat[2][l] at qmax
     uint64_t ac = 0, mn = 0, mx = 0;
     for (uint32_t b = 0; b < 64u; ++b) {

@@ -302,6 +302,26 @@ class BatchedPicker:
                                              picks.ctypes.data, scores.ctypes.data), "pick_topk")
         return picks, scores
 
+    def pick_random_topk(self, reqs: np.ndarray, k: int, seed: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """Picker "random-top-k" (examples/example.yaml:25; SEMANTICS.md §3b): seeded choice among each request's k best candidates."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words, "request row stride mismatch"
+        R = reqs.shape[0]
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        mptr = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert mask.shape == (R, (self.n_pods + 63) // 64), "mask shape mismatch"
+            mptr = mask.ctypes.data
+        self._check(self._lib.eppk_pick_random_topk(self._ctx, reqs.ctypes.data, R, mptr, k, seed & 0xFFFFFFFFFFFFFFFF, picks.ctypes.data,
+                                                    scores.ctypes.data), "pick_random_topk")
+        return picks, scores
+
+    def set_assumed_load(self, epochs: int) -> None:
+        """Assumed load in `epochs` sub-batches per batch (SEMANTICS.md §2b); 0 = off."""
+        self._check(self._lib.eppk_set_assumed_load(self._ctx, int(epochs)), "set_assumed_load")
+
     def pick_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")

@@ -228,6 +228,23 @@ int eppk_pick_topk(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint6
 int eppk_pick_topk_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
                           int32_t* d_out_pick, double* d_out_score, void* stream);
 
+/* Picker "random-top-k" (0845-…/examples/example.yaml:25 `selection: random-top-3`; SEMANTICS.md §3b): the pick of request r is
+ * entry (splitmix64(seed + (r+1) * 0x9E3779B97F4A7C15) mod n) of its ordered fallback list of n <= k candidates -- a seeded,
+ * reproducible stand-in for "random" (north_star: deterministic picks).  out_pick / out_score hold n_reqs entries. */
+int eppk_pick_random_topk(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, uint64_t seed,
+                          int32_t* out_pick, double* out_score);
+int eppk_pick_random_topk_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k, uint64_t seed,
+                                 int32_t* d_out_pick, double* d_out_score, void* stream);
+
+/* Assumed load (docs/proposals/006-scheduler/README.md:154-156; SEMANTICS.md §2b).  epochs = E >= 1: every batch handed to a pick
+ * entry point of this context is scored in E epochs of ceil(n_reqs / E) consecutive requests; after each epoch the queue gauge of
+ * every picked endpoint grows by one per request routed to it and everything derived from the gauge is rebuilt on the device
+ * (four small launches, ~0.2 ms at 4096 pods) before the next epoch.  The bumped gauges persist until the next
+ * eppk_snapshot_publish.  epochs = 0 (default): off -- every batch sees the published gauges.
+ * While it is on, the context's picks must be issued on ONE stream at a time (each epoch flips the double-buffered snapshot);
+ * device groups do not support it (every member would bump only its own shard). */
+int eppk_set_assumed_load(eppk_ctx* ctx, uint32_t epochs);
+
 /* ---- device groups: one picker over several GPUs (SURVEY.md §8(b) "device list", §8(e)) ------------------------------ */
 
 /* A group replicates the snapshot and the prefix index on every member device and shards each batch BY REQUEST: member g scores

@@ -52,6 +52,8 @@ def load() -> C.CDLL:
     lib.orc_pick_batch.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, vp, vp, vp]
     lib.orc_pick_batch_mt.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, vp, vp, C.c_int]
     lib.orc_score_row.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp]
+    lib.orc_pick_batch_assumed.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, vp, vp]
+    lib.orc_pick_random_topk.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, u64, vp, vp]
     lib.orc_index_insert_picks.argtypes = [vp, vp, u32, u32, vp]
     lib.orc_index_insert_picks.restype = None
     lib.orc_xxh64.argtypes = [vp, C.c_size_t, u64]
@@ -167,6 +169,48 @@ def score_row(chain, pods: np.ndarray, index: Optional[OracleIndex], req_row: np
     if rc != 0:
         raise RuntimeError(f"oracle rc={rc}")
     return out
+
+
+def pick_batch_assumed(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, max_blocks: int, epochs: int,
+                       mask: Optional[np.ndarray] = None):
+    """SEMANTICS.md 2b: `pods` is MUTATED (queue += assumed load) -- pass the same array to the next batch of the snapshot."""
+    lib = load()
+    ch = _chain_array(chain)
+    assert pods.flags["C_CONTIGUOUS"] and pods.dtype.itemsize == 64
+    reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+    R = reqs.shape[0]
+    picks = np.empty(R, dtype=np.int32)
+    scores = np.empty(R, dtype=np.float64)
+    mptr = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        mptr = mask.ctypes.data
+    rc = lib.orc_pick_batch_assumed(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], index.h if index is not None else None,
+                                    reqs.ctypes.data, max_blocks, R, mptr, epochs, picks.ctypes.data, scores.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle rc={rc}")
+    return picks, scores
+
+
+def pick_random_topk(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, max_blocks: int, k: int, seed: int,
+                     mask: Optional[np.ndarray] = None):
+    """SEMANTICS.md 3b (picker random-top-k)."""
+    lib = load()
+    ch = _chain_array(chain)
+    pods = np.ascontiguousarray(pods)
+    reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+    R = reqs.shape[0]
+    picks = np.empty(R, dtype=np.int32)
+    scores = np.empty(R, dtype=np.float64)
+    mptr = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        mptr = mask.ctypes.data
+    rc = lib.orc_pick_random_topk(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], index.h if index is not None else None,
+                                  reqs.ctypes.data, max_blocks, R, mptr, k, seed & 0xFFFFFFFFFFFFFFFF, picks.ctypes.data, scores.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle rc={rc}")
+    return picks, scores
 
 
 def pick_topk(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, k: int,

@@ -448,6 +448,69 @@ int orc_pick_batch_mt(const eppk_weighted_scorer* chain, uint32_t n_scorers, con
   return rc;
 }
 
+int orc_pick_batch_assumed(const eppk_weighted_scorer* chain, uint32_t n_scorers, eppk_pod_row* pods, uint32_t n_pods,
+                           const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
+                           const uint64_t* cand_mask, uint32_t epochs, int32_t* out_pick, double* out_score) {
+  if (epochs == 0)
+    return orc_pick_batch(chain, n_scorers, pods, n_pods, ix, reqs, max_blocks, n_reqs, cand_mask, out_pick, out_score, NULL);
+  if ((!chain && n_scorers) || (!pods && n_pods) || (!reqs && n_reqs) || (!out_pick && n_reqs)) return -1;
+  const uint32_t per = (n_reqs + epochs - 1u) / epochs;
+  for (uint32_t lo = 0; lo < n_reqs; lo += per) {
+    const uint32_t hi = lo + per < n_reqs ? lo + per : n_reqs;
+    /* every request of the epoch against the same gauges ... */
+    int rc = pick_range(chain, n_scorers, pods, n_pods, ix, (const uint8_t*)reqs, max_blocks, lo, hi, cand_mask, out_pick,
+                        out_score, NULL);
+    if (rc) return rc;
+    /* ... then the assumed load of what was just routed (006-scheduler/README.md:154-156) */
+    for (uint32_t r = lo; r < hi; ++r)
+      if (out_pick[r] >= 0) pods[out_pick[r]].queue += 1u;
+  }
+  return 0;
+}
+
+static uint64_t splitmix64_fin(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+  z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return z;
+}
+
+int orc_pick_random_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods, uint32_t n_pods,
+                         const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
+                         const uint64_t* cand_mask, uint32_t k, uint64_t seed, int32_t* out_pick, double* out_score) {
+  if (k < 1 || k > EPPK_MAX_TOPK) return -1;
+  orc_scratch s;
+  if (scratch_init(&s, n_pods)) { scratch_free(&s); return -6; }
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  const size_t mw = (n_pods + 63u) / 64u;
+  int rc = 0;
+  for (uint32_t r = 0; r < n_reqs && rc == 0; ++r) {
+    int32_t pick; double sc; uint32_t nc = 0;
+    rc = schedule_one(chain, n_scorers, pods, n_pods, ix, (const uint8_t*)reqs + stride * r, max_blocks,
+                      cand_mask ? cand_mask + mw * r : NULL, &s, &pick, &sc, NULL, &nc);
+    if (rc) break;
+    /* the k best under (total desc, index asc): k selection passes over the candidates (naive on purpose) */
+    uint32_t top[EPPK_MAX_TOPK]; uint32_t n = 0;
+    for (uint32_t i = 0; i < k && i < nc; ++i) {
+      int best = -1;
+      for (uint32_t c = 0; c < nc; ++c) {
+        int taken = 0;
+        for (uint32_t t = 0; t < n; ++t) taken |= top[t] == c;
+        if (taken) continue;
+        if (best < 0 || s.total[c] > s.total[best]) best = (int)c;   /* candidates ascend by index: strict > keeps the lowest */
+      }
+      top[n++] = (uint32_t)best;
+    }
+    if (n == 0) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; continue; }
+    const uint64_t u = splitmix64_fin(seed + ((uint64_t)r + 1u) * 0x9E3779B97F4A7C15ULL);
+    const uint32_t j = (uint32_t)(u % (uint64_t)n);
+    out_pick[r] = (int32_t)s.cand[top[j]];
+    if (out_score) out_score[r] = s.total[top[j]];
+  }
+  scratch_free(&s);
+  return rc;
+}
+
 int orc_score_row(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
                   uint32_t n_pods, const orc_index* ix, const void* req, const uint64_t* mask_row,
                   double* out_total) {

@@ -54,6 +54,20 @@ int orc_pick_batch_mt(const eppk_weighted_scorer* chain, uint32_t n_scorers,
                       const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
                       int32_t* out_pick, double* out_score, int threads);
 
+/* SEMANTICS.md 2b: the batch in `epochs` sub-batches; after each, queue[pick] += 1 in `pods` (MUTATED: the caller keeps them
+ * for the next batch of the same snapshot).  epochs == 0: orc_pick_batch (no bump). */
+int orc_pick_batch_assumed(const eppk_weighted_scorer* chain, uint32_t n_scorers,
+                           eppk_pod_row* pods, uint32_t n_pods, const orc_index* ix,
+                           const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
+                           uint32_t epochs, int32_t* out_pick, double* out_score);
+
+/* SEMANTICS.md 3b: picker "random-top-k" -- entry (splitmix64(seed + (r+1)*golden) mod n) of the request's ordered fallback
+ * list of at most k (<= 8) candidates. */
+int orc_pick_random_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers,
+                         const eppk_pod_row* pods, uint32_t n_pods, const orc_index* ix,
+                         const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
+                         uint32_t k, uint64_t seed, int32_t* out_pick, double* out_score);
+
 /* Full weighted totals of ONE request over all pods (non-candidates get NaN); debugging aid. */
 int orc_score_row(const eppk_weighted_scorer* chain, uint32_t n_scorers,
                   const eppk_pod_row* pods, uint32_t n_pods, const orc_index* ix,
