@@ -429,4 +429,185 @@ inline eppk_cfg MakeCfg(const SchedulerProfile& profile, const GpuPickerOptions&
   return cfg;
 }
 
+// ---- the scheduling cycle with several profiles (interface.go:55-111, README.md:55-85) -------------------------------------
+//
+//   Scheduler.Schedule:  loop { profiles = ProfileHandler.Pick(request, profiles, results so far); run each: Filter* -> Score* ->
+//   Picker }  until Pick returns nothing;  then ProfileHandler.ProcessResults -> SchedulingResult{ProfileResults, PrimaryProfileName}.
+//
+// Batched here: a round asks the handler for every request of the batch, groups the requests by profile and runs each profile
+// ONCE over its group -- one libeppk context per profile (a context IS one SchedulerProfile: weighted scorer chain + picker), one
+// fused kernel per profile and round.  A profile's Filter plugins (`is-prefill`, `has-required-accelerator`, ... of
+// examples/example.yaml) depend on the endpoint only, so they are applied when the snapshot is published: endpoints a profile
+// filters out are HOLES of that profile's snapshot (EPPK_POD_INACTIVE) -- never candidates, at no per-request cost.
+// Request-dependent filtering (the subset hint) stays a per-request candidate mask (GpuPicker above).
+
+struct Request {  // interface.go:35-44
+  std::string request_id, target_model, prompt;
+  std::map<std::string, std::string> headers;
+};
+
+struct ScoredEndpoint {  // interface.go:50-53
+  const Endpoint* endpoint = nullptr;
+  double score = 0.0;
+};
+
+struct SchedulingResult {  // interface.go:81-84
+  std::map<std::string, std::vector<const Endpoint*>> profile_results;
+  std::string primary_profile_name;
+};
+
+enum class PickerKind { BestScore, RandomTopK };   // examples/example.yaml `selection: best-score | random-top-3`
+
+struct ProfileSpec {
+  std::string name;
+  std::function<bool(const Endpoint&)> filter;   // conjunction of the profile's Filter plugins (interface.go:113-118); empty = all
+  std::vector<WeightedScorer> scorers;           // interface.go:132-135, order = summation order
+  PickerKind picker = PickerKind::BestScore;     // interface.go:137-142
+  uint32_t k = 3;                                // random-top-k
+};
+
+class ProfileHandler {  // interface.go:91-111
+ public:
+  virtual ~ProfileHandler() = default;
+  // the profiles to run next for this request, given what has run already (empty = the cycle is over)
+  virtual std::vector<std::string> Pick(const Request& request, const std::vector<std::string>& profiles,
+                                        const std::map<std::string, std::vector<ScoredEndpoint>>& execution_results) = 0;
+  virtual SchedulingResult ProcessResults(const Request& request, const std::map<std::string, std::vector<ScoredEndpoint>>& profile_results) = 0;
+};
+
+// `profileSelection: disagg-token-length` of examples/example.yaml: every request runs the decode profile; a prompt of at least
+// `threshold` characters additionally runs the prefill profile (prefill / decode disaggregation); decode is primary.
+class DisaggTokenLengthHandler : public ProfileHandler {
+ public:
+  DisaggTokenLengthHandler(std::string prefill, std::string decode, size_t threshold) : prefill_(std::move(prefill)), decode_(std::move(decode)), threshold_(threshold) {}
+  std::vector<std::string> Pick(const Request& request, const std::vector<std::string>&, const std::map<std::string, std::vector<ScoredEndpoint>>& done) override {
+    if (!done.empty()) return {};
+    std::vector<std::string> run{decode_};
+    if (request.prompt.size() >= threshold_) run.push_back(prefill_);
+    return run;
+  }
+  SchedulingResult ProcessResults(const Request&, const std::map<std::string, std::vector<ScoredEndpoint>>& results) override {
+    SchedulingResult out;
+    for (const auto& kv : results) {
+      auto& v = out.profile_results[kv.first];
+      for (const ScoredEndpoint& e : kv.second) v.push_back(e.endpoint);
+    }
+    out.primary_profile_name = decode_;
+    return out;
+  }
+
+ private:
+  std::string prefill_, decode_;
+  size_t threshold_;
+};
+
+class Scheduler {  // interface.go:55-66
+ public:
+  struct Options { uint32_t max_pods = 4096, max_blocks = 32, max_batch = 4096, block_chars = 64, index_slots = 0; int device = 0; };
+
+  // one context per profile; the handler is borrowed
+  Status Configure(const std::vector<ProfileSpec>& profiles, ProfileHandler* handler, const Options& opt) {
+    opt_ = opt; handler_ = handler; profiles_.clear(); names_.clear();
+    for (const ProfileSpec& ps : profiles) {
+      SchedulerProfile sp; sp.scorers = ps.scorers;
+      GpuPickerOptions go; go.max_pods = opt.max_pods; go.max_blocks = opt.max_blocks; go.max_batch = opt.max_batch;
+      eppk_cfg cfg = MakeCfg(sp, go, opt.index_slots, opt.device);
+      eppk_ctx* c = nullptr;
+      if (eppk_create(&cfg, &c) != EPPK_OK) return {Code::Internal, std::string("profile ") + ps.name + ": " + eppk_last_error(nullptr)};
+      profiles_.push_back(Prof{ps, std::shared_ptr<eppk_ctx>(c, eppk_destroy)});
+      names_.push_back(ps.name);
+    }
+    return {};
+  }
+
+  // endpoints[i] is candidate index i in every profile; a profile's filter turns the endpoints it rejects into holes
+  Status PublishSnapshot(const std::vector<Endpoint>& endpoints, const std::vector<eppk_pod_row>& rows,
+                         const std::unordered_map<std::string, int32_t>& adapters, uint64_t epoch) {
+    if (endpoints.size() != rows.size()) return {Code::Internal, "endpoints/rows size mismatch"};
+    endpoints_ = endpoints; adapters_ = adapters;
+    for (Prof& p : profiles_) {
+      std::vector<eppk_pod_row> r = rows;
+      for (size_t i = 0; i < r.size(); ++i)
+        if (p.spec.filter && !p.spec.filter(endpoints_[i])) r[i].flags |= EPPK_POD_INACTIVE;
+      if (eppk_snapshot_publish(p.ctx.get(), r.data(), (uint32_t)r.size(), epoch) != EPPK_OK) return {Code::Internal, eppk_last_error(p.ctx.get())};
+    }
+    return {};
+  }
+
+  // "hash(chunk i): append server" for one profile's prefix index (0602-…/README.md:101-108)
+  Status IndexInsert(const std::string& profile, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
+    for (Prof& p : profiles_)
+      if (p.spec.name == profile) return eppk_index_insert(p.ctx.get(), hashes, pods, n) == EPPK_OK ? Status{} : Status{Code::Internal, eppk_last_error(p.ctx.get())};
+    return {Code::Internal, "unknown profile"};
+  }
+
+  // Scheduler.Schedule for a batch; statuses[r] = Unavailable when the primary profile left request r without an endpoint
+  // ("the framework will return an error ... if the endpoints are filtered to zero", interface.go:114-115).
+  Status ScheduleBatch(const std::vector<Request>& requests, uint64_t seed, std::vector<SchedulingResult>* out, std::vector<Status>* statuses) {
+    const size_t n = requests.size();
+    std::vector<std::map<std::string, std::vector<ScoredEndpoint>>> results(n);
+    const size_t stride = 8u + 8u * opt_.max_blocks;
+    for (int round = 0; round < 16; ++round) {        // (a handler that never stops is cut off)
+      std::map<std::string, std::vector<uint32_t>> group;
+      for (size_t r = 0; r < n; ++r)
+        for (const std::string& name : handler_->Pick(requests[r], names_, results[r]))
+          if (!results[r].count(name)) group[name].push_back((uint32_t)r);
+      if (group.empty()) break;
+      for (Prof& p : profiles_) {
+        auto g = group.find(p.spec.name);
+        if (g == group.end()) continue;
+        const std::vector<uint32_t>& idx = g->second;
+        for (size_t lo = 0; lo < idx.size(); lo += opt_.max_batch) {
+          const uint32_t m = (uint32_t)std::min<size_t>(opt_.max_batch, idx.size() - lo);
+          rows_.assign((size_t)m * stride, 0);
+          for (uint32_t i = 0; i < m; ++i) {
+            const Request& rq = requests[idx[lo + i]];
+            eppk_req_hdr hdr;
+            auto it = adapters_.find(rq.target_model);
+            hdr.adapter = it == adapters_.end() ? EPPK_ADAPTER_BASE : it->second;
+            const int nb = eppk_hash_prompt((const uint8_t*)rq.target_model.data(), rq.target_model.size(), (const uint8_t*)rq.prompt.data(), rq.prompt.size(),
+                                            opt_.block_chars, (uint64_t*)(rows_.data() + (size_t)i * stride + 8), opt_.max_blocks);
+            hdr.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
+            std::memcpy(rows_.data() + (size_t)i * stride, &hdr, sizeof hdr);
+          }
+          picks_.resize(m); scores_.resize(m);
+          // the random-top-k rule hashes a request's index in the batch handed to the library: this profile's group, in request order
+          const int rc = p.spec.picker == PickerKind::BestScore
+                             ? eppk_pick_batch(p.ctx.get(), rows_.data(), m, nullptr, picks_.data(), scores_.data())
+                             : eppk_pick_random_topk(p.ctx.get(), rows_.data(), m, nullptr, p.spec.k, seed + lo, picks_.data(), scores_.data());
+          if (rc != EPPK_OK) return {Code::Internal, eppk_last_error(p.ctx.get())};
+          for (uint32_t i = 0; i < m; ++i) {
+            auto& res = results[idx[lo + i]][p.spec.name];     // (present even when empty: the profile has run)
+            if (picks_[i] >= 0) res.push_back(ScoredEndpoint{&endpoints_[(size_t)picks_[i]], scores_[i]});
+          }
+        }
+      }
+    }
+    out->resize(n); statuses->assign(n, Status{});
+    for (size_t r = 0; r < n; ++r) {
+      (*out)[r] = handler_->ProcessResults(requests[r], results[r]);
+      auto pr = (*out)[r].profile_results.find((*out)[r].primary_profile_name);
+      if (pr == (*out)[r].profile_results.end() || pr->second.empty()) (*statuses)[r] = {Code::Unavailable, "no endpoints available"};
+    }
+    return {};
+  }
+
+  eppk_ctx* context(const std::string& profile) {
+    for (Prof& p : profiles_) if (p.spec.name == profile) return p.ctx.get();
+    return nullptr;
+  }
+
+ private:
+  struct Prof { ProfileSpec spec; std::shared_ptr<eppk_ctx> ctx; };
+  Options opt_;
+  ProfileHandler* handler_ = nullptr;
+  std::vector<Prof> profiles_;
+  std::vector<std::string> names_;
+  std::vector<Endpoint> endpoints_;
+  std::unordered_map<std::string, int32_t> adapters_;
+  std::vector<uint8_t> rows_;
+  std::vector<int32_t> picks_;
+  std::vector<double> scores_;
+};
+
 }  // namespace eppk_host
