@@ -1,0 +1,34 @@
+"""The Go side ships as a patch against the reference tree (integration/): it must apply cleanly to the reference's own files.
+(Uncompiled: no Go toolchain in this image.  Needs /root/reference, so it runs in the build container only.)"""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATCH = os.path.join(ROOT, "integration", "0001-lwepp-gpu-endpoint-picker.patch")
+REF = "/root/reference"
+FILES = ["pkg/lwepp/handlers/server.go", "pkg/lwepp/server/options.go", "pkg/lwepp/server/runserver.go", "cmd/lwepp/main.go", "lwepp.Dockerfile"]
+
+
+def test_patch_names_only_the_picker_seam():
+    text = open(PATCH).read()
+    touched = sorted({ln.split("\t")[0][len("+++ b/"):] for ln in text.splitlines() if ln.startswith("+++ b/")})
+    assert touched == sorted(FILES + ["pkg/lwepp/handlers/gpupicker.go", "pkg/lwepp/handlers/gpupicker_nocgo.go"])
+    assert "ctx.Done()" in text and "eppk_index_insert" in text and "runtime.LockOSThread()" in text
+
+
+def test_patch_applies_to_the_reference(tmp_path):
+    if not os.path.isdir(REF) or shutil.which("patch") is None:
+        pytest.skip("needs /root/reference and patch(1)")
+    for f in FILES:
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(REF, f), tmp_path / f)
+    out = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", PATCH], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Hunk" not in out.stdout            # no fuzz, no offsets
+    src = open(tmp_path / "pkg/lwepp/handlers/server.go").read()
+    assert "func NewStreamingServer(datastore Datastore) *StreamingServer" in src and "NewStreamingServerWithPicker" in src
+    # the reference's own tests keep compiling against the unchanged constructor
+    assert "NewStreamingServer(ds)" in open(os.path.join(REF, "pkg/lwepp/handlers/request_test.go")).read()
