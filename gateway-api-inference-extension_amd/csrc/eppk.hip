@@ -814,6 +814,40 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   return rc;
 }
 
+int eppk_index_trim_pods(eppk_ctx* c, uint32_t cap, uint64_t* n_removed) {
+  if (!c) return EPPK_ERR_ARG;
+  if (n_removed) *n_removed = 0;
+  if (!c->slots) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  // scratch: hist[4096][64] u32 | cutage[4096] u32 | over_t[64] u64 | removed u64
+  const size_t hist_b = 4096u * (size_t)eppk::kTrimBins * 4u, cut_b = 4096u * 4u, over_b = 64u * 8u;
+  int rc = ensure_tmp(c, hist_b + cut_b + over_b + 8u);
+  if (rc) return rc;
+  uint32_t* hist = (uint32_t*)c->d_tmp;
+  uint32_t* cutage = (uint32_t*)((uint8_t*)c->d_tmp + hist_b);
+  uint64_t* over_t = (uint64_t*)((uint8_t*)c->d_tmp + hist_b + cut_b);
+  unsigned long long* removed = (unsigned long long*)((uint8_t*)c->d_tmp + hist_b + cut_b + over_b);
+  HIPCHK(c, hipMemsetAsync(c->d_tmp, 0, hist_b + cut_b + over_b + 8u, c->stream));
+  const uint32_t rows = c->slots + 2u, threads = 256;
+  uint32_t grid = (rows * 64u + threads - 1) / threads;
+  if (grid > 4096u) grid = 4096u;
+  rc = by_lane_word(c, [&](auto tag) {
+    using LW = decltype(tag);
+    hipLaunchKernelGGL((index_pod_hist_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
+                       (const uint32_t*)c->stamps, c->slots, c->index_epoch, hist);
+    hipLaunchKernelGGL(index_pod_cut_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, c->cfg.max_pods, cap, cutage, over_t);
+    hipLaunchKernelGGL((index_pod_trim_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps,
+                       c->slots, c->index_epoch, (const uint32_t*)cutage, (const uint64_t*)over_t, c->ixc, removed);
+    return EPPK_OK;
+  });
+  HIPCHK(c, hipGetLastError());
+  unsigned long long rm = 0;
+  HIPCHK(c, hipMemcpyAsync(&rm, removed, sizeof rm, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_removed) *n_removed = (uint64_t)rm;
+  return rc;
+}
+
 int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream) {
   if (!c) return EPPK_ERR_ARG;
   if (!c->slots) return EPPK_OK;

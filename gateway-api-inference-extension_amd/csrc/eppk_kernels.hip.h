@@ -2091,6 +2091,98 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
   if (lane == 0 && gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
 }
 
+// ---- per-pod capacity (SEMANTICS.md §6c; 0602-…/README.md:82: the index mimics the model servers' own LRU-bounded caches) ----
+// A pod may be listed under at most `cap` hashes; what exceeds that goes oldest first, at epoch granularity: with
+// age(h) = min(63, epoch - stamp(h)) and cutage(p) = the smallest b >= 1 with #{h containing p : age(h) <= b} > cap, pod p is removed
+// from every hash of age >= cutage(p) (entries stamped in the current epoch always stay).  Three passes:
+//   (1) index_pod_hist_kernel   wave per row: hist[p][age] += 1 for every pod p of the row's set
+//   (2) index_pod_cut_kernel    thread per pod: cutage[p] (kNoCut = within capacity), then the lane-transposed set `over` of the pods to trim
+//   (3) index_pod_trim_kernel   wave per row: clears the bits of the pods with cutage <= age(row), rebuilds the list, tombstones empty rows
+constexpr uint32_t kTrimBins = 64u;
+constexpr uint32_t kNoCut = 0xFFFFFFFFu;
+
+template <typename LW>
+__global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* stamps, uint32_t slots, uint32_t epoch, uint32_t* hist) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
+    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
+    const uint64_t k = keys[row];
+    if (k == 0ull || (row < slots && k == kTomb)) continue;
+    const uint32_t st = stamps[row];
+    const uint32_t age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+    LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
+    while (v != 0) {
+      const uint32_t j = ctz_lw<LW>(v);
+      v = (LW)(v & (LW)(v - 1));
+      atomicAdd(&hist[(size_t)(j * 64u + lane) * kTrimBins + age], 1u);
+    }
+  }
+}
+
+#ifdef EPPK_MAIN_UNIT
+// one workgroup of 1024 threads; over_t: 64 u64 lane words (bit j of word l = pod j*64+l has a cut)
+__global__ __launch_bounds__(1024) void index_pod_cut_kernel(const uint32_t* hist, uint32_t max_pods, uint32_t cap, uint32_t* cutage, uint64_t* over_t) {
+  for (uint32_t p = threadIdx.x; p < 4096u; p += blockDim.x) {
+    uint32_t cut = kNoCut;
+    if (p < max_pods) {
+      uint64_t cum = 0;
+      for (uint32_t b = 0; b < kTrimBins; ++b) {
+        cum += hist[(size_t)p * kTrimBins + b];
+        if (cum > cap) { cut = b < 1u ? 1u : b; break; }      // (the current epoch's entries always stay)
+      }
+    }
+    cutage[p] = cut;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64u) {
+    uint64_t w = 0;
+    for (uint32_t j = 0; j < 64u; ++j)
+      if (cutage[j * 64u + threadIdx.x] != kNoCut) w |= 1ull << j;
+    over_t[threadIdx.x] = w;
+  }
+}
+#endif
+
+template <typename LW>
+__global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t epoch,
+                                      const uint32_t* cutage, const uint64_t* over_t, unsigned long long* ixc, unsigned long long* removed) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const LW over = (LW)over_t[lane];
+  uint32_t gone = 0, pairs = 0;
+  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
+    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
+    const uint64_t k = keys[row];
+    if (k == 0ull || (row < slots && k == kTomb)) continue;
+    LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
+    LW v = *w;
+    LW cand = (LW)(v & over);
+    if (!__any(cand != 0)) continue;
+    const uint32_t st = stamps[row];
+    const uint32_t age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+    LW rm = 0;
+    while (cand != 0) {
+      const uint32_t j = ctz_lw<LW>(cand);
+      cand = (LW)(cand & (LW)(cand - 1));
+      if (cutage[j * 64u + lane] <= age) rm |= (LW)((LW)1 << j);
+    }
+    const bool changed = rm != 0;
+    if (changed) { v = (LW)(v & (LW)~rm); *w = v; pairs += (uint32_t)__builtin_popcountll((unsigned long long)rm); }
+    if (!__any(changed)) continue;
+    if (lists) list_rebuild<LW>(lists, row, v, lane);
+    if (__ballot(v != 0) == 0ull) {
+      if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;
+      ++gone;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) pairs += (uint32_t)__shfl_xor((int)pairs, off);
+  if (lane == 0) {
+    if (gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
+    if (pairs) atomicAdd(removed, (unsigned long long)pairs);
+  }
+}
+
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
 // drop every key last stamped before min_epoch -- pod set emptied, key tombstoned (reusable by later inserts).
 // A wavefront scans 64 slots per step (lane = slot: keys and stamps stream in coalesced), then empties its victims one by one.

@@ -262,6 +262,12 @@ class BatchedPicker:
         """The same eviction, asynchronous on `stream` (hipStream_t as int), no count (include/eppk.h)."""
         self._check(self._lib.eppk_index_evict_older_device(self._ctx, min_epoch, stream or None), "index_evict_older_device")
 
+    def index_trim_pods(self, cap_per_pod: int) -> int:
+        """Per-pod capacity (include/eppk.h eppk_index_trim_pods; SEMANTICS.md §6c); returns the (hash, pod) pairs removed."""
+        n = C.c_uint64(0)
+        self._check(self._lib.eppk_index_trim_pods(self._ctx, int(cap_per_pod), C.byref(n)), "index_trim_pods")
+        return n.value
+
     def index_size(self) -> int:
         n = C.c_uint32(0)
         self._check(self._lib.eppk_index_size(self._ctx, C.byref(n)), "index_size")

@@ -171,6 +171,11 @@ int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
  * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches. */
 int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
 int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);
+/* Per-pod capacity (0602-…/README.md:82: the approximate index mimics the model servers' own LRU-bounded prefix caches; upstream
+ * bounds every pod's share of the index, SEMANTICS.md §6c).  A pod listed under more than `cap_per_pod` hashes is removed from
+ * its OLDEST ones, at epoch granularity (whole epochs, oldest first; entries stamped in the current epoch always stay), until it
+ * fits.  n_removed (nullable) = (hash, pod) pairs removed.  Synchronous; what a shim calls after a few epochs ticks. */
+int eppk_index_trim_pods(eppk_ctx* ctx, uint32_t cap_per_pod, uint64_t* n_removed);
 /* The same eviction, asynchronous on `stream` (a hipStream_t as void*; NULL = the context's stream) and without the count: what
  * a closed loop (pick -> eppk_index_insert_picks_device -> pick ...) issues on its own stream between two batches, ordered
  * behind the inserts and ahead of the next pick, without draining the pipeline.  eppk_index_size reports the effect. */

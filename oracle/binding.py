@@ -45,6 +45,8 @@ def load() -> C.CDLL:
     lib.orc_index_advance_epoch.restype = u32
     lib.orc_index_evict_older.argtypes = [vp, u32]
     lib.orc_index_evict_older.restype = u32
+    lib.orc_index_trim_pods.argtypes = [vp, u32, u32]
+    lib.orc_index_trim_pods.restype = u64
     lib.orc_index_size.argtypes = [vp]
     lib.orc_index_size.restype = u64
     lib.orc_index_lookup.argtypes = [vp, u64, vp, u32]
@@ -104,6 +106,10 @@ class OracleIndex:
 
     def evict_older(self, min_epoch: int) -> int:
         return int(self.lib.orc_index_evict_older(self.h, min_epoch))
+
+    def trim_pods(self, n_pods_max: int, cap: int) -> int:
+        """Per-pod capacity (SEMANTICS.md 6c); returns the (hash, pod) pairs removed."""
+        return int(self.lib.orc_index_trim_pods(self.h, n_pods_max, cap))
 
     def size(self) -> int:
         return int(self.lib.orc_index_size(self.h))

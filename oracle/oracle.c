@@ -228,6 +228,47 @@ uint32_t orc_index_evict_older(orc_index* ix, uint32_t min_epoch) {
   return gone;
 }
 
+/* SEMANTICS.md 6c.  age(h) = min(63, epoch - stamp(h)); cutage(p) = the smallest b >= 1 with #{h containing p : age(h) <= b} > cap;
+ * p leaves every hash of age >= cutage(p).  (Naive: one pass per pod.) */
+uint64_t orc_index_trim_pods(orc_index* ix, uint32_t n_pods_max, uint32_t cap) {
+  uint64_t removed = 0;
+  for (uint32_t p = 0; p < n_pods_max; ++p) {
+    uint64_t hist[64];
+    memset(hist, 0, sizeof hist);
+    for (uint64_t i = 0; i < ix->cap; ++i) {
+      const orc_entry* e = &ix->tab[i];
+      if (!e->used || e->n == 0) continue;
+      for (uint32_t j = 0; j < e->n; ++j)
+        if (e->pods[j] == p) {
+          uint32_t age = ix->epoch - e->stamp;
+          hist[age < 63u ? age : 63u]++;
+        }
+    }
+    uint64_t cum = 0;
+    int cut = -1;
+    for (int b = 0; b < 64; ++b) {
+      cum += hist[b];
+      if (cum > cap) { cut = b < 1 ? 1 : b; break; }
+    }
+    if (cut < 0) continue;
+    for (uint64_t i = 0; i < ix->cap; ++i) {
+      orc_entry* e = &ix->tab[i];
+      if (!e->used || e->n == 0) continue;
+      uint32_t age = ix->epoch - e->stamp;
+      if (age > 63u) age = 63u;
+      if ((int)age < cut) continue;
+      for (uint32_t j = 0; j < e->n; ++j)
+        if (e->pods[j] == p) {
+          memmove(e->pods + j, e->pods + j + 1, (e->n - j - 1) * sizeof(uint32_t));
+          e->n--;
+          removed++;
+          break;
+        }
+    }
+  }
+  return removed;
+}
+
 uint64_t orc_index_size(const orc_index* ix) {
   uint64_t n = 0;
   for (uint64_t i = 0; i < ix->cap; ++i) n += (ix->tab[i].used && ix->tab[i].n > 0);

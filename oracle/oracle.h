@@ -35,6 +35,8 @@ void       orc_index_scrub_inactive(orc_index* ix, const eppk_pod_row* pods, uin
 /* ageing: ++epoch (inserts stamp their hash with it); drop every hash last stamped before min_epoch -> number dropped */
 uint32_t   orc_index_advance_epoch(orc_index* ix);
 uint32_t   orc_index_evict_older(orc_index* ix, uint32_t min_epoch);
+/* SEMANTICS.md 6c: per-pod capacity, oldest epochs first; returns the (hash, pod) pairs removed */
+uint64_t   orc_index_trim_pods(orc_index* ix, uint32_t n_pods_max, uint32_t cap);
 /* number of hashes with a non-empty pod set */
 uint64_t   orc_index_size(const orc_index* ix);
 /* copy out the pod set of one hash (sorted ascending); returns its size */

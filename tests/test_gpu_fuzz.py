@@ -111,7 +111,7 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
         pk.publish(pods)
         oix = orc.OracleIndex()
         for step in range(14):
-            op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick_evict", "republish"])
+            op = rng.choice(["insert", "insert", "insert_picks", "remove_pod", "tick_evict", "republish", "trim"])
             if op == "insert":
                 ci = rng.integers(0, universe.shape[0], 3)
                 ih = np.concatenate([universe[c, : int(rng.integers(1, B + 1))] for c in ci])
@@ -132,6 +132,9 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
                 op_picks, _, _ = orc.pick_batch(chain, pods, oix, reqs, B)
                 assert np.array_equal(picks, op_picks)
                 oix.insert_picks(reqs, B, op_picks)
+            elif op == "trim":                              # per-pod capacity, oldest epochs first (SEMANTICS.md §6c)
+                cap = int(rng.integers(1, 12))
+                assert pk.index_trim_pods(cap) == oix.trim_pods(P, cap), f"seed {seed} step {step} trim {cap}"
             elif op == "remove_pod":
                 pod = int(rng.integers(0, P))
                 pk.index_remove_pod(pod); oix.remove_pod(pod)

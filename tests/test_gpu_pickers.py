@@ -111,3 +111,38 @@ def test_random_top_k_with_assumed_load_and_device_entry(pkg, orc):
         st.synchronize()
         _same(d_pick.cpu().numpy(), d_score.cpu().numpy(), *orc.pick_random_topk(chain, wl.pods, oix, wl.reqs, wl.B, 3, 77), "device entry")
         assert pk.launch_status() == 0
+
+
+@pytest.mark.parametrize("P", [300, 1500, 4096])
+def test_per_pod_capacity_trims_oldest_epochs_first(pkg, orc, P):
+    """eppk_index_trim_pods (SEMANTICS.md §6c): a pod listed under more hashes than its capacity loses its oldest epochs; the
+    entries of the current epoch stay; pair counts, index sizes and picks equal the oracle's after every step."""
+    rng = np.random.default_rng(P)
+    chain = [(KV, 1), (PF, 5)]
+    B = 8
+    pods = pkg.workload.make_pods(7, P, 128)
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=256, index_slots=1 << 15) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        hot = rng.choice(P, 6, replace=False)                  # a few pods that every epoch caches something on
+        universe = []
+        for epoch in range(6):
+            h = rng.integers(1, 2**63, 600, dtype=np.uint64)
+            p = np.where(rng.random(600) < 0.7, rng.choice(hot, 600), rng.integers(0, P, 600)).astype(np.uint32)
+            pk.index_insert(h, p); oix.insert(h, p)
+            universe.append(h)
+            if epoch % 2 == 1:                                  # some old hashes are touched again: their stamp moves up
+                again = universe[0][:100]
+                pa = rng.choice(hot, 100).astype(np.uint32)
+                pk.index_insert(again, pa); oix.insert(again, pa)
+            e = pk.index_advance_epoch()
+            assert e == oix.advance_epoch()
+        reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, 256), np.full(256, B), np.concatenate(universe)[rng.integers(0, 3600, (256, B))], B)
+        for cap in (2000, 700, 150, 10, 0):
+            got, want = pk.index_trim_pods(cap), oix.trim_pods(P, cap)
+            assert got == want, (cap, got, want)
+            assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0
+            picks, scores = pk.pick(reqs)
+            op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            _same(picks, scores, op, osc, f"cap {cap}")
+        assert pk.index_trim_pods(0) == 0                       # idempotent
