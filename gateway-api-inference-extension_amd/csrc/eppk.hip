@@ -221,6 +221,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       if (lds + hist <= c->max_lds) lds += hist;
       else ix.lists = nullptr;               // (interpreted tail at P = 4096: no room in the 160 KB -> dense rows only)
     }
+    // (ordered fallbacks use the uniform-lists route only: no histogram)
   } else {
     lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
   }

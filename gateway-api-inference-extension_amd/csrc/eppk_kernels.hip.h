@@ -745,7 +745,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   constexpr bool pterm_tab = HAS_P && NPL == 6;
   // SPARSE: requests whose hits all have a short pod list are counted from the lists (one 16-byte load per lane instead of
   // 64 * sizeof(LW) bytes per hit) in a per-wave byte histogram in LDS; everything else takes the dense rows as before.
-  constexpr bool SPARSE = HAS_P && NPL == 6 && !TOPK;
+  constexpr bool SPARSE = HAS_P && NPL == 6;      // (TOPK: the uniform-lists route only; anything else falls back to the dense rows)
   uint32_t* s_hist_all = (uint32_t*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);   // [waves][J * 16] dwords: one byte per pod
   const bool use_lists = SPARSE && ix.lists != nullptr;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
@@ -1010,6 +1010,54 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       tier = (uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1);
     }
     const double t = pod_total(p, v ? m0 : 0u, tier, s_pterm + (size_t)nb * sn.pterm_ld, (double)nb);
+    if constexpr (TOPK) {
+      // Ordered fallbacks from the lists: a k-way merge of the listed pods (totals in the lanes; the best remaining one by a DPP
+      // argmax per round) with the adapter's top table (already ordered; the cursor skips listed pods).  A table that runs out
+      // within its first 16 entries sends the request to the dense rows (return false: every round is rewritten there).
+      const uint32_t tk = topk;
+      unsigned long long tcm = ~0ull;
+      if (MASKED) tcm = __ballot(nat_bit(tb.cn, tb.top_p != kNoPod ? tb.top_p : 0u) && tb.top_p != kNoPod);
+      uint32_t e = 0;
+      bool table_end = false;
+      for (uint32_t round = 0; round < tk; ++round) {
+        double best = v ? t : -__builtin_inf();
+        uint32_t bidx = v ? p : kNoPod;
+        wave_argmax_dpp(best, bidx);
+        double cand_t = -__builtin_inf();
+        uint32_t cand_p = kNoPod;
+        if (!table_end) {
+          for (; e < 16u; ++e) {
+            const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tb.top_p, (int)e);
+            if (tp == kNoPod) { table_end = true; break; }
+            if (MASKED && !((tcm >> e) & 1ull)) continue;
+            if (!__any(listed && id == tp)) {
+              cand_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb.top_t), (int)e),
+                                        __builtin_amdgcn_readlane(__double2loint(tb.top_t), (int)e));
+              cand_p = tp;
+              break;
+            }
+          }
+          if (e == 16u && !table_end) {
+            if (sn.n_pods > 16u) return false;          // entries 16..63 would be needed
+            table_end = true;
+          }
+        }
+        const bool take_table = cand_t > best || (cand_t == best && cand_p < bidx);
+        if (take_table) { best = cand_t; bidx = cand_p; ++e; }
+        else if (v && p == bidx) v = false;             // the listed winner leaves the pool
+        const bool none = bidx == kNoPod || s.badm != 0u;
+        if (lane == 0) {
+          out_pick[(size_t)r * tk + round] = (none ? -1 : (int32_t)bidx) | (int32_t)s.badm;
+          if (out_score) out_score[(size_t)r * tk + round] = __longlong_as_double(__double_as_longlong(none ? 0.0 : best) & ~(long long)(int32_t)s.badm);
+        }
+        if (none) {
+          if (lane == 0)
+            for (uint32_t i = round + 1u; i < tk; ++i) { out_pick[(size_t)r * tk + i] = -1; if (out_score) out_score[(size_t)r * tk + i] = 0.0; }
+          break;
+        }
+      }
+      return true;
+    }
     double best = v ? t : -__builtin_inf();
     uint32_t bidx = v ? p : kNoPod;
     wave_argmax_dpp(best, bidx);
@@ -1349,7 +1397,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       // no candidate at all: fail closed right here; candidates that miss the snapshot-wide QUEUE extremes need the request's own
       // normalisers: the exact evaluation of the dense route
       if (!__any(tb.cn != 0ull)) {
-        if (lane == 0) { out_pick[r] = -1; if (out_score) out_score[r] = 0.0; }
+        const uint32_t tk = TOPK ? topk : 1u;
+        if (lane == 0)
+          for (uint32_t i = 0; i < tk; ++i) { out_pick[(size_t)r * tk + i] = -1; if (out_score) out_score[(size_t)r * tk + i] = 0.0; }
         return;
       }
       if (sn.lead_queue && !(__any((tb.cn & sn.nat[64 + lane]) != 0ull) && __any((tb.cn & sn.nat[128 + lane]) != 0ull))) {
@@ -1361,13 +1411,19 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
       sp = false;
       stage_rows(s, slot0, w);
     }
+    bool done = false;
     if (SPARSE && sp) {
-      if (stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < s.nb) ? s.hits + 1u : s.nb; }
 #ifndef EPPK_DBG_NO_UNIFORM
-      if (!stage_uniform(s, la, lb, tb))
+      done = stage_uniform(s, la, lb, tb);
 #endif
-        stage_sparse(s, la, lb, tb);
-    } else {
+      if constexpr (!TOPK) {
+        if (!done) { stage_sparse(s, la, lb, tb); done = true; }
+      } else {
+        if (!done) stage_rows(s, slot0, w);        // fallback lists from differing pod lists: the dense rows after all
+      }
+      if (done && stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < s.nb) ? s.hits + 1u : s.nb; }
+    }
+    if (!done) {
       LW c[NPL];
       stage_count(s, slot0, w, c);
       stage_eval(s, c, tb);

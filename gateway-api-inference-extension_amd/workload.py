@@ -152,14 +152,22 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
             hashes[r, :B] = out
         # index pre-population: each group's shared blocks cached on `pods_per_group` pods
         gp = (splitmix64(_sub(seed, 14), n_groups * pods_per_group) % np.uint64(max(P, 1))).astype(np.uint32).reshape(n_groups, pods_per_group)
-        gout = np.zeros(Bs, dtype=np.uint64)
+        gout = np.zeros((n_groups, Bs), dtype=np.uint64)
+        models = {}
+        stride = Bs * 8
+        base = gout.ctypes.data
+        gb = np.ascontiguousarray(gbytes)
+        plen = gb.shape[1] * 8
         for g in range(n_groups):
-            model = _model_name(int(group_adapter[g]))
-            prompt = gbytes[g].tobytes()
-            n = lib.eppk_hash_prompt(model, len(model), prompt, len(prompt), BLOCK_CHARS, gout.ctypes.data, Bs)
+            a = int(group_adapter[g])
+            model = models.get(a)
+            if model is None:
+                model = models[a] = _model_name(a)
+            n = lib.eppk_hash_prompt(model, len(model), gb.ctypes.data + g * plen, plen, BLOCK_CHARS, base + g * stride, Bs)
             assert n == Bs
-            idx_h.append(np.repeat(gout.copy(), pods_per_group))
-            idx_p.append(np.tile(gp[g], Bs))
+        # pair order: group-major, then block, then pod (what the per-group repeat / tile of the first version produced)
+        idx_h.append(np.repeat(gout.reshape(-1), pods_per_group))
+        idx_p.append(np.tile(gp[:, None, :], (1, Bs, 1)).reshape(-1))
     index_hashes = np.concatenate(idx_h) if idx_h else np.zeros(0, dtype=np.uint64)
     index_pods = np.concatenate(idx_p) if idx_p else np.zeros(0, dtype=np.uint32)
     n_keys = n_groups * Bs if B > 0 else 0
