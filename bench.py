@@ -296,6 +296,7 @@ def main() -> None:
     ap.add_argument("--no-cold-ref", action="store_true", help="skip the cold-index sub-run (roofline_cold)")
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold index)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
+    ap.add_argument("--pods-per-group", type=int, default=8, help="pods that hold each group's shared blocks in the pre-populated index")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
     ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
@@ -330,11 +331,11 @@ def main() -> None:
     t_gen = time.perf_counter()
     # replicated snapshot + index; the SAME batches on every rank (strong: a rank scores its slice of each; weak: ranks walk the
     # ring of batches at different offsets)
-    wl = pkg.workload.make_workload(args.config, R=args.requests, n_groups=args.groups, zipf_s=args.zipf)
+    wl = pkg.workload.make_workload(args.config, R=args.requests, n_groups=args.groups, zipf_s=args.zipf, pods_per_group=args.pods_per_group)
     R = wl.R
     batches = make_batches(pkg, wl, args, max(1, args.batches))
     log(f"[bench] rank {rank}: {len(batches)} batches of {R} requests generated in {time.perf_counter() - t_gen:.1f} s")
-    headline = args.config == 5 and args.requests is None and args.groups == 256 and args.zipf == 1.0 and not args.closed_loop
+    headline = args.config == 5 and args.requests is None and args.groups == 256 and args.zipf == 1.0 and args.pods_per_group == 8 and not args.closed_loop
 
     run = Runner(pkg, torch, dist, wl, batches, args, rank, world, local_rank,
                  index_slots=(args.cl_slots if args.closed_loop else None), closed_loop=args.closed_loop)
@@ -544,7 +545,11 @@ def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
     tj = stamped_json("pmc_traffic_cold.json", khash)
     if tj:
         roof["traffic"] = tj.get("hbm_bytes_per_launch")
-        roof["traffic_source"] = "profiles/pmc_traffic_cold.json"
+        roof["traffic_source"] = "profiles/pmc_traffic_cold.json (rocprofv3 TCC_EA0_RDREQ 32/64/128-byte request counters of this kernel build)"
+    # the ceiling of this access pattern, measured: random 64-byte line gathers reach 3.3 TB/s on this GPU whatever the depth
+    # (scripts/micro/linegather.hip -> profiles/r02_micro_linegather_hbm_ceiling.txt); 512-byte rows 6.2-6.9 TB/s (rowgather.hip)
+    roof["gather_ceiling_GBps"] = 3300.0
+    roof["frac_of_gather_ceiling"] = ach / 3300.0
     return roof
 
 

@@ -42,6 +42,10 @@
 #ifndef EPPK_LATE_HOOK
 #define EPPK_LATE_HOOK 0
 #endif
+#ifndef EPPK_ROW_PREFETCH
+#define EPPK_ROW_PREFETCH 10 // the request row of iteration r + this many is pulled into L2 by a throw-away load (0 = off): the rows
+#endif                      // stream from HBM (bench.py rotates > 256 MB of batches) and the pipeline's own row load, two iterations
+                            // ahead, has less slack than an HBM round trip
 #ifndef EPPK_MIN_WAVES
 #define EPPK_MIN_WAVES 1 // __launch_bounds__ minimum waves per SIMD for the fast kernel
 #endif
@@ -963,6 +967,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   auto issue_lists = [&](const ReqS& s, uint32_t slot_eff, u32x4_t& la, u32x4_t& lb) {
     const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
     const uint32_t sa = (uint32_t)__shfl((int)slot_eff, (int)(2u * (k < s.m0 ? k : 0u)));   // (lanes beyond the hits re-read hit 0: stage_uniform)
+#ifdef EPPK_DBG_NO_LISTS    // timing experiment only (wrong results): no list loads
+    la = (u32x4_t)(sa & 1u); lb = (u32x4_t)(0xFFFFFFFFu); return;
+#endif
     la = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sa * 64u + cch * 16u), 0, 0);
     lb = (u32x4_t)(0xFFFFFFFFu);
     if (s.m0 > 16u) {
@@ -988,6 +995,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (k < m0) diff = (la.x ^ shr1(la.x)) | (la.y ^ shr1(la.y)) | (la.z ^ shr1(la.z)) | (la.w ^ shr1(la.w));
     if (16u + k < m0) diff |= (lb.x ^ la.x) | (lb.y ^ la.y) | (lb.z ^ la.z) | (lb.w ^ la.w);
     if (__any(diff != 0u)) return false;
+#ifdef EPPK_DBG_SKIP_UNIFORM_EVAL   // timing experiment only (wrong results): no evaluation, no argmax, no table walk
+    if (lane == 0) { out_pick[r] = (int32_t)(la.x & 0xFFFu); if (out_score) out_score[r] = 0.0; }
+    return true;
+#endif
     // id k of this lane's chunk (positions 6..7 of chunk 0 are the count, of the other chunks unused)
     const uint32_t dw = (k & 4u) ? ((k & 2u) ? la.w : la.z) : ((k & 2u) ? la.y : la.x);
     uint32_t id = (k & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
@@ -1374,6 +1385,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     }
   };
 
+  uint32_t pf_sink = 0, pf_prev = 0;   // landing registers of the row prefetches (kept alive by the asm at the end, never read)
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + 1 (row in `nxt`) and stage 0 of
   // r + 2 (into `cur`, which is free once the probe of r is finished).
   auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
@@ -1392,6 +1404,16 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     else stage_rows(s, slot0, w);
     issue_keys(nxt);
     issue_row(r + 2u * nwaves, r, cur);
+#if EPPK_ROW_PREFETCH > 0
+    {   // L2 prefetch of a later row: five lanes touch its (at most five) 64-byte sectors; the value is never used
+      const uint32_t rp = r + (uint32_t)EPPK_ROW_PREFETCH * nwaves;
+      if (rp < n_reqs) {
+        const uint32_t off = (uint32_t)lane * 64u;
+        pf_sink ^= pf_prev;                 // (consumes the PREVIOUS iteration's prefetch, long landed: keeps every load alive without a wait)
+        pf_prev = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, (int)(off < stride - 4u ? off : stride - 4u), (int)(rp * stride), 0);
+      }
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (MASKED && SPARSE && sp) {
       // no candidate at all: fail closed right here; candidates that miss the snapshot-wide QUEUE extremes need the request's own
@@ -1445,6 +1467,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     process(r + nwaves, qb, qa);
   }
 
+#if EPPK_ROW_PREFETCH > 0
+  asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
+#endif
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
   if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {

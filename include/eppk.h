@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EPPK_ABI_VERSION 1u
+#define EPPK_ABI_VERSION 2u   /* 2: device groups, launch status, random-top-k, assumed load, holes, per-pod capacity, async eviction (additions only) */
 
 /* Limits of this build (SEMANTICS.md §limits). */
 #define EPPK_MAX_PODS      4096u /* candidate endpoints per snapshot                         */
