@@ -643,38 +643,15 @@ __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t
     return (LW)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0);
   }
 }
-// Structured buffer loads (index * stride + offset addressing).  This clang has no builtin for them; the LLVM intrinsics
-// are bound by name (the descriptor is passed as its four dwords).
-typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-extern "C" __device__ u32x2_t eppk_llvm_struct_buffer_load_v2i32(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
-extern "C" __device__ uint32_t eppk_llvm_struct_buffer_load_i32(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
-extern "C" __device__ uint16_t eppk_llvm_struct_buffer_load_i16(i32x4_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
-template <typename LW>
-__device__ __forceinline__ LW struct_buffer_load_lw(i32x4_t rs, uint32_t vindex, uint32_t voff) {
-  if constexpr (sizeof(LW) == 8) {
-    const u32x2_t v = eppk_llvm_struct_buffer_load_v2i32(rs, (int)vindex, (int)voff, 0, 0);
-    return ((uint64_t)v.y << 32) | v.x;
-  } else if constexpr (sizeof(LW) == 4) {
-    return (LW)eppk_llvm_struct_buffer_load_i32(rs, (int)vindex, (int)voff, 0, 0);
-  } else {
-    return (LW)eppk_llvm_struct_buffer_load_i16(rs, (int)vindex, (int)voff, 0, 0);
-  }
-}
-// Descriptor of a structured buffer: base (48 bits) | stride << 48, num_records, gfx9 word 3 (32-bit data format).
-__device__ __forceinline__ i32x4_t make_struct_rsrc(const void* base, uint32_t stride) {
-  const uint64_t b = (uint64_t)base;
-  i32x4_t r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-  r.y = __builtin_amdgcn_readfirstlane((int)(((uint32_t)(b >> 32) & 0xFFFFu) | (stride << 16)));
-  r.z = -1;
-  r.w = 0x00020000;
-  return r;
-}
-// BIG (index of 4 GiB and more, sized for the 288 GB of HBM): the descriptor is STRUCTURED (stride = one row), the row's slot
-// is the buffer index (32 bits x stride: 2 TiB of reach) -- one extra v_mov per row (the index must sit in a VGPR).
+// BIG (index of 4 GiB and more, sized for the 288 GB of HBM): a row's address is wave-uniform -- base + slot * row bytes, 64-bit
+// scalar arithmetic on the slot that v_readlane delivers -- so the row is read with a global load whose base sits in an SGPR pair
+// (saddr form) and whose lane offset is the 32-bit lane * sizeof(LW): still no per-lane 64-bit address arithmetic.
+// (Round 1 used a STRUCTURED buffer descriptor here, stride = one row, slot = buffer index.  Its index * stride product wraps at
+// 4 GiB on gfx950: rows beyond that offset read as garbage -- found in round 2 by the dense-rows-only run of the 8.6 GB
+// closed-loop test; the round-1 test stopped at exactly 4 GiB.)
 struct RowSrc {                  // how the fast kernel reaches the pod-set rows
   __amdgpu_buffer_rsrc_t raw;    // small index: raw descriptor over rows + keys, rows addressed by SGPR byte offsets
-  i32x4_t strided;               // BIG: structured descriptor over the rows (slot = buffer index)
+  const uint8_t* base;           // BIG: the rows' base address
 };
 template <typename LW, int N, bool BIG>
 __device__ __forceinline__ void load_rows(const RowSrc& src, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
@@ -683,8 +660,10 @@ __device__ __forceinline__ void load_rows(const RowSrc& src, uint32_t slot_eff, 
 #pragma unroll
     for (int u = 0; u < N; ++u) {
       const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
-      w[u] = struct_buffer_load_lw<LW>(src.strided, s, voff);
+      const LW* rowp = (const LW*)(src.base + (size_t)s * (size_t)(64u * sizeof(LW)));     // wave-uniform 64-bit base
+      w[u] = rowp[lane];
     }
+    (void)voff;
     return;
   }
   const __amdgpu_buffer_rsrc_t rs = src.raw;
@@ -773,7 +752,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   // hot-loop load is buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR/VGPR row selector) -- no 64-bit per-lane pointers.
   RowSrc rs;
   rs.raw = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, BIG ? 0 : (int)ix.table_bytes, 0x00020000);
-  rs.strided = make_struct_rsrc(ix.bitmaps, (uint32_t)(64u * sizeof(LW)));
+  rs.base = (const uint8_t*)ix.bitmaps;
   const __amdgpu_buffer_rsrc_t rk = BIG ? __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000) : rs.raw;
   const uint32_t keys_off = BIG ? 0u : ix.keys_off;
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);

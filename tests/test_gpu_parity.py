@@ -389,14 +389,18 @@ def test_index_ageing_and_word_reuse(pkg, orc):
             assert_same(picks, scores, op, osc)
 
 
-def test_index_of_4gib_and_more_uses_the_structured_descriptor(pkg, orc):
-    """An index whose rows + keys exceed 4 GiB (2^23 slots x 512 B at P = 4096) is served by the BIG instantiation of the fast
-    kernel (structured buffer descriptor, slot = buffer index) -- same picks, same scores."""
-    wl = pkg.workload.make_workload(5, R=512, P=4096)
-    wl.index_slots = 1 << 23
+@pytest.mark.parametrize("slots", [1 << 23, 1 << 24])
+@pytest.mark.parametrize("lists", ["1", "0"])
+def test_index_of_4gib_and_more(pkg, orc, monkeypatch, slots, lists):
+    """An index whose rows + keys reach 4 GiB (2^23 slots x 512 B at P = 4096) and beyond (2^24 slots: 8.6 GB, half of the rows past
+    the 4 GiB offset) is served by the BIG instantiation of the fast kernel (rows through wave-uniform 64-bit bases) -- same picks,
+    same scores, with the pod lists and with the dense rows alone (EPPK_LISTS=0: every hit reads its row)."""
+    monkeypatch.setenv("EPPK_LISTS", lists)
+    wl = pkg.workload.make_workload(5, R=2048, P=4096)
+    wl.index_slots = slots
     assert_same(*run_both(pkg, orc, wl))
     wm = pkg.workload.make_workload(5, R=256, P=4096, masked=True)
-    wm.index_slots = 1 << 23
+    wm.index_slots = slots
     assert_same(*run_both(pkg, orc, wm, mask=wm.mask))
 
 
