@@ -189,7 +189,7 @@ KIndex make_kindex(const eppk_ctx* c) {
 const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk) {
   eppk::PickVariant v{};
   v.fast = fast; v.masked = masked; v.topk = topk;
-  v.big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: structured row descriptor
+  v.big = c->slots != 0 && c->index_bytes >= (1ull << 32);   // index of 4 GiB and more: rows through wave-uniform 64-bit bases
   v.has_l = c->has_l; v.has_p = c->has_p; v.p_first = c->p_first; v.gen = c->gen;
   const bool six = c->npl == 6;
   switch (c->lw_bytes) {

@@ -18,7 +18,10 @@
 //     lists are identical (the blocks of a shared prefix are cached together) without any counting at all.
 //   * argmax across lanes: DPP max reduction on the score, ties to the lowest pod index.
 //   * no MFMA: this is integer/bit/f64-add work (north_star); the bound is instruction issue once the index bytes are
-//     lists (HBM for a cold index).
+//     lists (an index beyond the caches is bound by HBM gathers of 64-byte lines: DESIGN.md §3.1, §7).
+//   * candidate masks (MASKED) and ordered fallbacks (TOPK) take the list routes too: the mask row is used as it is
+//     (natural layout, one word per lane), fallbacks are a k-way merge of the listed pods with the adapter's top table.
+//   * holes of a snapshot (eppk_pod_row.flags & EPPK_POD_INACTIVE) are ANDed out of `valid` once per kernel.
 //   * "EPPK_DBG_NO_UNIFORM" (correct results, slower) sends every list request through the general histogram route: the
 //     GPU suite is run once with such a build whenever that route changes.
 //
@@ -747,9 +750,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
   const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
   // Buffer descriptors (gfx9 word 3: 32-bit data format).  Small index (< 4 GiB): ONE raw descriptor over rows + keys (one
-  // allocation, rows first), rows addressed by SGPR byte offsets.  BIG: a structured descriptor over the rows (stride = one
-  // row, the slot is the buffer index) and a raw one over the keys.  Plus the snapshot tables and the request rows: every
-  // hot-loop load is buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR/VGPR row selector) -- no 64-bit per-lane pointers.
+  // allocation, rows first), rows addressed by SGPR byte offsets.  BIG: the rows through wave-uniform 64-bit
+  // bases (RowSrc) and a raw descriptor over the keys.  Plus the snapshot tables and the request rows: every hot-loop load is
+  // buffer_load(descriptor SGPRs, 32-bit lane offset, SGPR row selector) or a saddr global load -- no 64-bit per-lane pointers.
   RowSrc rs;
   rs.raw = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, BIG ? 0 : (int)ix.table_bytes, 0x00020000);
   rs.base = (const uint8_t*)ix.bitmaps;

@@ -332,7 +332,8 @@ int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);
 
 /* Which kernel serves this context's chain: 1 = fused sparse kernel (chain = pod-only scorers, then LORA / PREFIX in either
  * order), 2 = the same kernel with an interpreted tail (at most two pod-only scorers behind the first LORA / PREFIX, e.g. the
- * reference example's `score: [prefix-cache: 3, kv-cache-util: 5]`, 0845-…/examples/example.yaml:21-25), 0 = generic
+ * scorer list of the reference example's decode profile, `score: [prefix-cache: 3, kv-cache-util: 5]`, 0845-…/examples/example.yaml:21-23
+ * -- that profile's picker is `random-top-3`, :25: eppk_pick_random_topk), 0 = generic
  * per-pair kernel (duplicated LORA / PREFIX scorers, more than two trailing pod-only scorers). */
 int eppk_chain_is_fused(const eppk_ctx* ctx);
 
