@@ -42,10 +42,29 @@ uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
 }
 
 // ---- subset filter helpers (request.go:104-133) ----
+// Go's strings.TrimSpace (request.go:58, :65, :109): leading and trailing Unicode White_Space, on UTF-8 --
+// U+0009..000D, U+0020, U+0085, U+00A0, U+1680, U+2000..200A, U+2028, U+2029, U+202F, U+205F, U+3000.
+// Length in bytes of the white-space rune that starts at s[i] (0: none).
+size_t space_at(std::string_view s, size_t i) {
+  const auto b = [&](size_t k) { return k < s.size() ? (unsigned char)s[k] : 0u; };
+  const unsigned c = b(i);
+  if (c == ' ' || (c >= '\t' && c <= '\r')) return 1;
+  if (c == 0xC2 && (b(i + 1) == 0x85 || b(i + 1) == 0xA0)) return 2;
+  if (c == 0xE1 && b(i + 1) == 0x9A && b(i + 2) == 0x80) return 3;
+  if (c == 0xE2 && b(i + 1) == 0x80 && ((b(i + 2) >= 0x80 && b(i + 2) <= 0x8A) || b(i + 2) == 0xA8 || b(i + 2) == 0xA9 || b(i + 2) == 0xAF)) return 3;
+  if (c == 0xE2 && b(i + 1) == 0x81 && b(i + 2) == 0x9F) return 3;
+  if (c == 0xE3 && b(i + 1) == 0x80 && b(i + 2) == 0x80) return 3;
+  return 0;
+}
 std::string_view trim(std::string_view s) {
-  auto ws = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
-  while (!s.empty() && ws(s.front())) s.remove_prefix(1);
-  while (!s.empty() && ws(s.back())) s.remove_suffix(1);
+  for (size_t n; !s.empty() && (n = space_at(s, 0)) != 0;) s.remove_prefix(n);
+  for (;;) {                         // the last rune: 1, 2 or 3 bytes back
+    size_t n = 0;
+    for (size_t back = 1; back <= 3 && back <= s.size(); ++back)
+      if (space_at(s, s.size() - back) == back) { n = back; break; }
+    if (!n) break;
+    s.remove_suffix(n);
+  }
   return s;
 }
 

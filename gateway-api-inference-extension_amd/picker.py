@@ -91,7 +91,7 @@ def subset_mask(endpoints: Sequence[Endpoint], filter_value: Optional[str]) -> T
 TEST_ENDPOINT_SELECTION_HEADER = "test-epp-endpoint-selection"          # request.go:84-97
 SUBSET_FILTER_NAMESPACE = "envoy.lb.subset_hint"                        # pkg/lwepp/metadata/consts.go:21
 SUBSET_FILTER_KEY = "x-gateway-destination-endpoint-subset"             # pkg/lwepp/metadata/consts.go:24
-_GO_SPACE = " \t\n\v\f\r\x85\xa0"                                        # strings.TrimSpace on Latin-1 (the ASCII set is what libeppk trims)
+_GO_SPACE = (" \t\n\v\f\r\x85\xa0\u1680" + "".join(chr(c) for c in range(0x2000, 0x200B)) + "\u2028\u2029\u202f\u205f\u3000")   # unicode.IsSpace (strings.TrimSpace)
 
 
 def resolve_subset_filter(headers: Sequence[Tuple[str, str]], request_metadata: Optional[dict]) -> Optional[str]:

@@ -592,7 +592,17 @@ int32_t orc_round_robin(uint64_t* counter, uint32_t n_candidates) {
   return (int32_t)(index % (uint64_t)n_candidates);        /* :96 */
 }
 
-static int is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+/* strings.TrimSpace trims Unicode White_Space; on UTF-8: bytes of the white-space rune at a[0..n), or 0 */
+static size_t space_len(const char* a, size_t n) {
+  const unsigned char* u = (const unsigned char*)a;
+  if (n >= 1 && (u[0] == ' ' || (u[0] >= 9 && u[0] <= 13))) return 1;
+  if (n >= 2 && u[0] == 0xC2 && (u[1] == 0x85 || u[1] == 0xA0)) return 2;                       /* NEL, NBSP */
+  if (n >= 3 && u[0] == 0xE1 && u[1] == 0x9A && u[2] == 0x80) return 3;                        /* U+1680 */
+  if (n >= 3 && u[0] == 0xE2 && u[1] == 0x80 && ((u[2] >= 0x80 && u[2] <= 0x8A) || u[2] == 0xA8 || u[2] == 0xA9 || u[2] == 0xAF)) return 3;
+  if (n >= 3 && u[0] == 0xE2 && u[1] == 0x81 && u[2] == 0x9F) return 3;                        /* U+205F */
+  if (n >= 3 && u[0] == 0xE3 && u[1] == 0x80 && u[2] == 0x80) return 3;                        /* U+3000 */
+  return 0;
+}
 
 /* Behaviour of Go's net.SplitHostPort as used at request.go:110: returns 1 and [host,port) spans on
  * success, 0 on any error (missing port, too many colons, bad brackets). */
@@ -641,8 +651,14 @@ int orc_subset_mask(const char* const* addrs, const char* const* ports, uint32_t
       const char* e = strchr(s, ',');
       size_t n = e ? (size_t)(e - s) : strlen(s);
       const char* a = s;
-      while (n && is_space(*a)) { ++a; --n; }
-      while (n && is_space(a[n - 1])) --n;
+      for (size_t k; n && (k = space_len(a, n)) != 0;) { a += k; n -= k; }
+      for (;;) {
+        size_t k = 0;
+        for (size_t back = 1; back <= 3 && back <= n; ++back)
+          if (space_len(a + n - back, back) == back) { k = back; break; }
+        if (!k) break;
+        n -= k;
+      }
       if (n) {
         size_t h0, h1, p0;
         if (split_host_port(a, n, &h0, &h1, &p0)) {

@@ -132,6 +132,9 @@ def _go_split_host_port(hp):
     return host, hp[i + 1:]
 
 
+_GO_SPACE = " \t\n\v\f\r\x85\xa0\u1680" + "".join(chr(c) for c in range(0x2000, 0x200B)) + "\u2028\u2029\u202f\u205f\u3000"   # unicode.IsSpace
+
+
 def _filter_restated(endpoints, value):
     """request.go:104-133 in Python: entries split on ',', trimmed; host:port entries allow that port, anything else is an
     address whose every port is allowed; returns candidate indices."""
@@ -139,7 +142,7 @@ def _filter_restated(endpoints, value):
         return list(range(len(endpoints)))
     allowed, allow_all = {}, set()
     for ep in value.split(","):
-        ep = ep.strip(" \t\r\n")
+        ep = ep.strip(_GO_SPACE)
         hp = _go_split_host_port(ep)
         if hp is not None:
             allowed.setdefault(hp[0], set()).add(hp[1])
@@ -154,7 +157,8 @@ def test_subset_filter_against_a_restatement_of_the_go_code(pkg, orc):
     rng = np.random.default_rng(2024)
     addrs = ["10.0.0.1", "10.0.0.2", "::1", "fe80::2", "host-a", "[::1]"]
     ports = ["80", "81", "8080", ""]
-    pieces = addrs + ports + [":", "::", "[", "]", " ", "\t", "x", "[::1]", "[fe80::2]", "10.0.0.1:80", "[::1]:81", "host-a:8080"]
+    pieces = addrs + ports + [":", "::", "[", "]", " ", "\t", "x", "[::1]", "[fe80::2]", "10.0.0.1:80", "[::1]:81", "host-a:8080",
+                              "\u00a0", "\u2003", "\u3000", "\x85", "\u200b"]     # Unicode spaces (U+200B is NOT one)
     for _ in range(400):
         n = int(rng.integers(1, 9))
         endpoints = [pkg.picker.Endpoint(str(rng.choice(addrs)), str(rng.choice(ports))) for _ in range(n)]
