@@ -423,13 +423,19 @@ def main() -> None:
         tj = stamped_json("pmc_traffic.json", khash)
         if tj and tj.get("workload") == wl.name and headline:
             roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel build, calibrated: profiles/r02_fetchcal.txt)"
+            roof["traffic_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of THIS kernel build (stamped with its source hash), exact bytes = "
+                                      "64 * RDREQ_64B + 128 * RDREQ_128B + WRITE_SIZE (every HBM read of this GPU is a 128-byte request; FETCH_SIZE tallies it at 64: profiles/r02_fetchcal.txt)")
         ij = stamped_json("pmc_issue.json", khash)
         if ij and headline:
             roof["issue"] = {k: ij[k] for k in ij if k not in ("kernel_src_sha16",)}
             if "valu_per_decision" in ij:      # wave-instructions issued per second / (SIMDs x clock / 4)
                 clk = ij.get("sclk_hz", 2.4e9)
                 roof["issue"]["valu_issue_frac_live"] = ij["valu_per_decision"] * res["per"] / (avg_ms * 1e-3) / (N_SIMD * clk / 4.0)
+        # the same bytes over the time of one STEP (with two launches in flight a launch lasts about twice as long as it does alone,
+        # while two of them finish per that time): the rate the whole GPU sustains
+        roof["step_GBps"] = bm["compulsory"] / (res["ms_per_step"] * 1e-3) / 1e9
+        roof["step_frac"] = roof["step_GBps"] / HBM_PEAK_GBS
         out["roofline"] = roof
         out["config"]["p99_step_ms"] = roof["kernel_p99_ms"]
         if cl_info:
@@ -545,7 +551,9 @@ def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
     tj = stamped_json("pmc_traffic_cold.json", khash)
     if tj:
         roof["traffic"] = tj.get("hbm_bytes_per_launch")
-        roof["traffic_source"] = "profiles/pmc_traffic_cold.json (rocprofv3 TCC_EA0_RDREQ 32/64/128-byte request counters of this kernel build)"
+        roof["traffic_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic_source"] = ("profiles/pmc_traffic_cold.json: rocprofv3 TCC_EA0_RDREQ 64/128-byte request counters + WRITE_SIZE of this kernel build; about twice "
+                                  "the algorithmic bytes because HBM is read in 128-byte requests and every gathered bucket / list is a 64-byte line")
     # the ceiling of this access pattern, measured: random 64-byte line gathers reach 3.3 TB/s on this GPU whatever the depth
     # (scripts/micro/linegather.hip -> profiles/r02_micro_linegather_hbm_ceiling.txt); 512-byte rows 6.2-6.9 TB/s (rowgather.hip)
     roof["gather_ceiling_GBps"] = 3300.0
