@@ -431,7 +431,8 @@ def main() -> None:
             roof["issue"] = {k: ij[k] for k in ij if k not in ("kernel_src_sha16",)}
             if "valu_per_decision" in ij:      # wave-instructions issued per second / (SIMDs x clock / 4)
                 clk = ij.get("sclk_hz", 2.4e9)
-                roof["issue"]["valu_issue_frac_live"] = ij["valu_per_decision"] * res["per"] / (avg_ms * 1e-3) / (N_SIMD * clk / 4.0)
+                # VALU wave-instructions per second over the whole step / (SIMDs x clock / 4 cycles per wave64 instruction)
+                roof["issue"]["valu_issue_frac_live"] = ij["valu_per_decision"] * res["per"] / (res["ms_per_step"] * 1e-3) / (N_SIMD * clk / 4.0)
         # the same bytes over the time of one STEP (with two launches in flight a launch lasts about twice as long as it does alone,
         # while two of them finish per that time): the rate the whole GPU sustains
         roof["step_GBps"] = bm["compulsory"] / (res["ms_per_step"] * 1e-3) / 1e9
