@@ -23,6 +23,8 @@ SYMBOLS = [
     "eppk_index_evict_older_device", "eppk_index_trim_pods",
     "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
+    "eppk_addr_fingerprint", "eppk_subset_entries", "eppk_snapshot_set_addresses", "eppk_subset_masks_device", "eppk_subset_masks",
+    "eppk_pick_batch_subset", "eppk_pick_batch_candidates_device",
     "eppk_launch_status", "eppk_pick_random_topk", "eppk_pick_random_topk_device", "eppk_set_assumed_load",
     "eppk_group_create", "eppk_group_destroy", "eppk_group_last_error", "eppk_group_size", "eppk_group_ctx", "eppk_group_ranks_seen",
     "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
@@ -105,6 +107,14 @@ def load_library() -> C.CDLL:
     lib.eppk_xxh64.argtypes = [vp, C.c_size_t, u64]
     lib.eppk_xxh64.restype = u64
     lib.eppk_subset_mask.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.c_char_p, vp]
+    lib.eppk_addr_fingerprint.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp]
+    lib.eppk_addr_fingerprint.restype = None
+    lib.eppk_subset_entries.argtypes = [C.c_char_p, vp, u32]
+    lib.eppk_snapshot_set_addresses.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32]
+    lib.eppk_subset_masks_device.argtypes = [vp, vp, vp, u32, vp, vp]
+    lib.eppk_subset_masks.argtypes = [vp, vp, vp, u32, vp]
+    lib.eppk_pick_batch_subset.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    lib.eppk_pick_batch_candidates_device.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp]
     lib.eppk_round_robin.argtypes = [C.POINTER(u64), u32]
     lib.eppk_round_robin.restype = i32
     lib.eppk_launch_status.argtypes = [vp, C.POINTER(u32)]

@@ -104,6 +104,10 @@ struct eppk_ctx {
   uint32_t* d_status = nullptr;         // sticky launch-status flags (eppk_launch_status)
   unsigned long long* ixc = nullptr;    // [kIxShards][8] sharded index counters: live keys, non-empty words, dropped inserts, evicted
 
+  // subset filter on the device: fingerprints of the published endpoints (eppk_snapshot_set_addresses), entry staging
+  uint64_t* d_at = nullptr; uint32_t* d_av = nullptr; uint32_t at_slots = 0; bool have_addrs = false; uint32_t addr_n = 0;
+  uint64_t* d_sk = nullptr; uint32_t* d_so = nullptr; size_t sk_cap = 0, so_cap = 0;
+
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
   void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
@@ -201,6 +205,8 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk
 
 // topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries): extra selection rounds of the
 // fast kernel for fused chains, the TOPK generic kernel otherwise
+template <typename F> int by_lane_word(const eppk_ctx* c, F&& f);
+
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st, uint32_t topk = 1) {
   const bool masked = d_mask != nullptr;
@@ -588,6 +594,7 @@ void eppk_destroy(eppk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
+  (void)hipFree(c->d_at); (void)hipFree(c->d_av); (void)hipFree(c->d_sk); (void)hipFree(c->d_so);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
@@ -937,11 +944,12 @@ int ensure_host_staging(eppk_ctx* c, bool need_mask) {
 
 // rows [lo, lo + n) of a batch of `full_n` rows starting at `base` (host memory; `pinned` = the device may DMA from it directly).
 // upload_all: rows [0, full_n) go to d_reqs (the shard is then d_reqs + lo * stride), else only the shard (at d_reqs).
+// mask_on_device: c->d_mask already holds the shard's mask rows (built by subset_masks_kernel on the context stream)
 int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full_n, uint32_t lo, uint32_t n, bool upload_all,
-                    const uint64_t* cand_mask_shard) {
+                    const uint64_t* cand_mask_shard, bool mask_on_device = false) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   const size_t J = (c->n_pods + 63u) / 64u;
-  int rc = ensure_host_staging(c, cand_mask_shard != nullptr);
+  int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
   if (rc) return rc;
   const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;
   const uint8_t* src = base + (size_t)up_lo * c->stride;
@@ -955,7 +963,7 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
     HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n * J * 8u, hipMemcpyHostToDevice, c->stream));
   }
   const uint8_t* d_shard = (const uint8_t*)c->d_reqs + (upload_all ? (size_t)lo * c->stride : 0u);
-  rc = run_pick(c, d_shard, n, (cand_mask_shard && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
+  rc = run_pick(c, d_shard, n, ((cand_mask_shard || mask_on_device) && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
                 c->d_score + (upload_all ? lo : 0u), c->stream, 1u, false, 0ull, 0u);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick + (upload_all ? lo : 0u), (size_t)n * 4u, hipMemcpyDeviceToHost, c->stream));
@@ -987,6 +995,190 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask);
   if (rc) return rc;
   return pick_host_end(c, n_reqs, cand_mask != nullptr, out_pick, out_score);
+}
+
+// ---- candidate-major pick (masked batches with few candidates) --------------------------------------------
+
+namespace {
+int launch_pick_cands(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, uint32_t k, int32_t* d_pick, double* d_score, hipStream_t st) {
+  KSnap sn = make_ksnap(c);
+  KIndex ix = make_kindex(c);
+  KChain ch = c->kchain;
+  bool any_prefix = false;                                         // (c->has_p is only meaningful for chains the fast kernel serves)
+  for (uint32_t i = 0; i < ch.n; ++i) any_prefix |= ch.kind[i] == 4u;
+  if (!any_prefix) ix.slots = 0u;                                  // no PREFIX scorer: nothing to look up
+  const uint8_t* reqs8 = (const uint8_t*)d_reqs;
+  uint32_t stride = c->stride;
+  uint32_t grid = (n_reqs + 3u) / 4u;
+  const uint32_t cap = (uint32_t)c->num_cu * 8u;
+  if (grid > cap) grid = cap;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof) {
+    if (c->ev_used + 2 > c->ev.size()) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c->ev.push_back(a);
+      c->ev.push_back(b);
+    }
+    e0 = c->ev[c->ev_used];
+    e1 = c->ev[c->ev_used + 1];
+    c->ev_used += 2;
+  }
+  const void* fn = nullptr;
+  (void)by_lane_word(c, [&](auto tag) { using LW = decltype(tag); fn = (const void*)eppk::pick_cands_kernel<LW>; return EPPK_OK; });
+  void* args[] = {&sn, &ix, &ch, &reqs8, &stride, &n_reqs, &d_mask, &d_pick, &d_score, &k};
+  HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(256), args, 0, st, e0, e1, 0));
+  c->last_done = e1;
+  c->last_stream = st;
+  if (c->prof) c->launches++;
+  return EPPK_OK;
+}
+}  // namespace
+
+int eppk_pick_batch_candidates_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
+                                      int32_t* d_out_pick, double* d_out_score, void* stream) {
+  if (!c || ((!d_reqs || !d_out_pick || !d_cand_mask) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_candidates_device: null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_candidates_device: k out of range (1..8)");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch_candidates_device: no snapshot published");
+  if (n_reqs == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (c->assumed_epochs)                                           // assumed load works in epochs of the general path (SEMANTICS.md §2b)
+    return k == 1 ? eppk_pick_batch_device(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream)
+                  : eppk_pick_topk_device(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, stream);
+  return launch_pick_cands(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, st);
+}
+
+// ---- subset filter on the device ------------------------------------------------------------------------
+
+int eppk_snapshot_set_addresses(eppk_ctx* c, const char* const* addrs, const char* const* ports, uint32_t n_pods) {
+  if (!c || ((!addrs || !ports) && n_pods)) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_set_addresses: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_snapshot_set_addresses: no snapshot published");
+  if (n_pods != c->n_pods) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_set_addresses: n_pods differs from the published snapshot");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  if (!c->d_at) {
+    uint32_t t = 64;
+    while (t < 8u * c->cfg.max_pods) t *= 2u;                      // two entries per pod, at most a quarter full
+    c->at_slots = t;
+    HIPCHK(c, hipMalloc((void**)&c->d_at, (size_t)t * 16u));
+    HIPCHK(c, hipMalloc((void**)&c->d_av, (size_t)t * 4u));
+  }
+  const uint32_t T = c->at_slots;
+  std::vector<uint64_t> at((size_t)T * 2u, 0ull);
+  std::vector<uint32_t> av(T, 0u);
+  auto put = [&](const uint64_t fp[2], uint32_t pod) {
+    uint32_t t = (uint32_t)fp[0] & (T - 1u);
+    while (av[t] != 0u) t = (t + 1u) & (T - 1u);
+    at[2 * (size_t)t] = fp[0]; at[2 * (size_t)t + 1] = fp[1]; av[t] = pod + 1u;
+  };
+  for (uint32_t p = 0; p < n_pods; ++p) {
+    if (!addrs[p]) continue;                                       // a hole of the snapshot: matches nothing
+    if (!ports[p]) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_set_addresses: pod " + std::to_string(p) + " has an address but no port");
+    uint64_t fp[2];
+    eppk_addr_fingerprint(addrs[p], std::strlen(addrs[p]), nullptr, 0, fp);
+    put(fp, p);
+    eppk_addr_fingerprint(addrs[p], std::strlen(addrs[p]), ports[p], std::strlen(ports[p]), fp);
+    put(fp, p);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));                      // (a subset kernel of an earlier batch may still read the table)
+  HIPCHK(c, hipMemcpy(c->d_at, at.data(), at.size() * 8u, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_av, av.data(), av.size() * 4u, hipMemcpyHostToDevice));
+  c->have_addrs = true;
+  c->addr_n = n_pods;
+  return EPPK_OK;
+}
+
+int eppk_subset_masks_device(eppk_ctx* c, const uint64_t* d_keys, const uint32_t* d_off, uint32_t n_reqs, uint64_t* d_mask_out, void* stream) {
+  if (!c || ((!d_off || !d_mask_out) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_subset_masks_device: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_subset_masks_device: no snapshot published");
+  if (!c->have_addrs || c->addr_n != c->n_pods)
+    return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_subset_masks_device: eppk_snapshot_set_addresses has not been called for the current snapshot");
+  if (n_reqs == 0 || c->n_pods == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  uint32_t grid = (n_reqs + 3u) / 4u;
+  const uint32_t cap = (uint32_t)c->num_cu * 8u;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(eppk::subset_masks_kernel, dim3(grid), dim3(256), 0, st, (const uint64_t*)c->d_at, (const uint32_t*)c->d_av, c->at_slots - 1u,
+                     d_keys, d_off, n_reqs, c->n_pods, d_mask_out);
+  HIPCHK(c, hipGetLastError());
+  return EPPK_OK;
+}
+
+namespace {
+// entries of a batch (host, CSR) -> device staging; returns the device pointers
+int stage_subset_entries(eppk_ctx* c, const char* who, const uint64_t* keys, const uint32_t* off, uint32_t n_reqs) {
+  for (uint32_t r = 0; r < n_reqs; ++r)
+    if (off[r + 1] < off[r]) return fail(c, EPPK_ERR_ARG, std::string(who) + ": off[] must be non-decreasing");
+  const size_t n_keys = off[n_reqs];
+  if (n_keys && !keys) return fail(c, EPPK_ERR_ARG, std::string(who) + ": null keys");
+  if (n_keys > c->sk_cap) {
+    (void)hipFree(c->d_sk); c->d_sk = nullptr; c->sk_cap = 0;
+    size_t cap = 1024; while (cap < n_keys) cap *= 2;
+    HIPCHK(c, hipMalloc((void**)&c->d_sk, cap * 16u));
+    c->sk_cap = cap;
+  }
+  if ((size_t)n_reqs + 1u > c->so_cap) {
+    (void)hipFree(c->d_so); c->d_so = nullptr; c->so_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_so, ((size_t)c->cfg.max_batch + 1u) * 4u));
+    c->so_cap = (size_t)c->cfg.max_batch + 1u;
+  }
+  if (n_keys) HIPCHK(c, hipMemcpyAsync(c->d_sk, keys, n_keys * 16u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_so, off, ((size_t)n_reqs + 1u) * 4u, hipMemcpyHostToDevice, c->stream));
+  return EPPK_OK;
+}
+}  // namespace
+
+int eppk_subset_masks(eppk_ctx* c, const uint64_t* keys, const uint32_t* off, uint32_t n_reqs, uint64_t* out_mask) {
+  if (!c || ((!off || !out_mask) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_subset_masks: null argument");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_subset_masks: n_reqs > max_batch");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_subset_masks: no snapshot published");
+  if (n_reqs == 0 || c->n_pods == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_host_staging(c, true);
+  if (rc) return rc;
+  rc = stage_subset_entries(c, "eppk_subset_masks", keys, off, n_reqs);
+  if (rc) return rc;
+  rc = eppk_subset_masks_device(c, c->d_sk, c->d_so, n_reqs, c->d_mask, c->stream);
+  if (rc) return rc;
+  const size_t J = (c->n_pods + 63u) / 64u;
+  HIPCHK(c, hipMemcpyAsync(out_mask, c->d_mask, (size_t)n_reqs * J * 8u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return EPPK_OK;
+}
+
+int eppk_pick_batch_subset(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_t* keys, const uint32_t* off,
+                           int32_t* out_pick, double* out_score) {
+  if (!c || ((!reqs || !out_pick || !off) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_subset: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch_subset: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_subset: n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  int rc = validate_rows(c, "eppk_pick_batch_subset", reqs, n_reqs);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  rc = ensure_host_staging(c, true);
+  if (rc) return rc;
+  if (c->n_pods) {
+    rc = stage_subset_entries(c, "eppk_pick_batch_subset", keys, off, n_reqs);
+    if (rc) return rc;
+    rc = eppk_subset_masks_device(c, c->d_sk, c->d_so, n_reqs, c->d_mask, c->stream);
+    if (rc) return rc;
+  }
+  // few entries per request (what a subset hint looks like): the candidate-major kernel, O(candidates) per request
+  const bool few = c->n_pods != 0u && c->assumed_epochs == 0u && (uint64_t)off[n_reqs] <= 32ull * n_reqs;
+  if (!few) {
+    rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, nullptr, true);
+    if (rc) return rc;
+    return pick_host_end(c, n_reqs, true, out_pick, out_score);
+  }
+  std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+  HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+  rc = launch_pick_cands(c, c->d_reqs, n_reqs, c->d_mask, 1u, c->d_pick, c->d_score, c->stream);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, c->stream));
+  return pick_host_end(c, n_reqs, false, out_pick, out_score);
 }
 
 // ---- ordered fallbacks ---------------------------------------------------------------------------------

@@ -148,6 +148,42 @@ int eppk_subset_mask(const char* const* addrs, const char* const* ports, uint32_
   return count;  // 0 => fail closed (request_test.go:335-369, :407-439)
 }
 
+// ---- subset filter on the device: the host half (tokenise + fingerprint) ------------------------------------------------
+// An address (or address + port) is represented by a 128-bit fingerprint: XXH64 of its bytes under two seeds.  Exact-port
+// entries hash host, a NUL byte, port -- no header value contains NUL, so an "all ports" entry can never alias one.
+void eppk_addr_fingerprint(const char* host, size_t host_len, const char* port, size_t port_len, uint64_t out[2]) {
+  std::string buf(host ? host : "", host ? host_len : 0);
+  if (port) { buf.push_back('\0'); buf.append(port, port_len); }
+  out[0] = xxh64((const uint8_t*)buf.data(), buf.size(), 0);
+  out[1] = xxh64((const uint8_t*)buf.data(), buf.size(), 0x9E3779B97F4A7C15ull);
+  if ((out[0] | out[1]) == 0ull) out[1] = 1ull;      // (0, 0) is the "no filter" entry
+}
+
+int eppk_subset_entries(const char* filter, uint64_t* out_keys, uint32_t cap) {
+  if (!out_keys && cap) return EPPK_ERR_ARG;
+  if (!filter) {                      // no subset filter: one entry that admits every pod (request.go:136-137)
+    if (cap >= 1) { out_keys[0] = 0; out_keys[1] = 0; }
+    return 1;
+  }
+  uint32_t n = 0;
+  std::string_view rest(filter);
+  for (;;) {
+    const size_t comma = rest.find(',');
+    const std::string_view e = trim(rest.substr(0, comma));
+    if (!e.empty()) {                 // (same entry rules as eppk_subset_mask: request.go:107-119)
+      std::string_view host, port;
+      uint64_t fp[2];
+      if (split_host_port(e, host, port)) eppk_addr_fingerprint(host.data(), host.size(), port.data(), port.size(), fp);
+      else eppk_addr_fingerprint(e.data(), e.size(), nullptr, 0, fp);
+      if (n < cap) { out_keys[2 * (size_t)n] = fp[0]; out_keys[2 * (size_t)n + 1] = fp[1]; }
+      ++n;
+    }
+    if (comma == std::string_view::npos) break;
+    rest.remove_prefix(comma + 1);
+  }
+  return (int)n;
+}
+
 int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates) {
   if (!counter || n_candidates == 0) return EPPK_NO_PICK;  // server.go:91-93
   const uint64_t idx = __atomic_add_fetch(counter, 1, __ATOMIC_SEQ_CST);  // server.go:95

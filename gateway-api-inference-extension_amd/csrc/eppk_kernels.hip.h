@@ -1460,6 +1460,184 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   }
 }
 
+// ---- CANDIDATE-MAJOR pick kernel (MASKED batches with few candidates: what a subset filter leaves, request.go:104-133) -----
+// The fast kernel's masked routes cost O(pods) per request (the mask row is transposed, every pod's counter planes are built, and
+// a candidate set that misses the snapshot-wide QUEUE extremes -- almost every small one -- takes the exact dense evaluation:
+// 291 us for 64k requests with ~30 candidates each).  This kernel costs O(candidates): one candidate per lane (64 at a time),
+// scored with the whole chain in chain order under the request's own QUEUE normalisers (SEMANTICS.md §2: they range over the
+// candidates); matched[p] is one word of the dense row per hit; no top tables, no LDS.  Same results as the fast / generic
+// kernels for any mask; the caller picks it when candidates are few (eppk_pick_batch_candidates_device, eppk_pick_batch_subset).
+// (Tried first as a route INSIDE the fast kernel: its registers -- two binary64 divisions on top of the pipeline's landing
+// registers -- spilled 60 VGPRs into the per-request loop and doubled the time of every masked batch; as a second loop of that
+// kernel +30..50 %; as a called function, or at 3 waves per SIMD, worse still; as a second launch behind every masked launch
+// +14 us even when it had nothing to do.  All measured, round 2.)
+template <typename LW>
+__global__ __launch_bounds__(256, 6) void pick_cands_kernel(KSnap sn, KIndex ix, KChain ch, const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n_reqs,
+                                                         const uint64_t* __restrict__ cand_mask, int32_t* __restrict__ out_pick,
+                                                         double* __restrict__ out_score, uint32_t tk) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t hwords = (stride - 8u) / 8u;
+  const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+  const __amdgpu_buffer_rsrc_t rk = ix.small ? __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
+  const uint32_t keys_off = ix.small ? ix.keys_off : 0u;
+  const LW* bm = (const LW*)ix.bitmaps;
+  bool has_q = false;
+  for (uint32_t i = 0; i < ch.n; ++i) has_q |= ch.kind[i] == 1u;
+  const uint32_t ki = (uint32_t)lane >> 1;
+  const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;
+  for (uint32_t r = wave0; r < n_reqs; r += nw) {
+    const uint8_t* row = reqs + (size_t)r * stride;
+    // everything that depends on r alone is requested first: header, the lane pair's hash, the candidate row
+    const uint64_t hdr = *(const uint64_t __attribute__((address_space(4)))*)row;
+    const uint64_t hraw = hw0 ? ((const uint64_t*)(row + 8))[ki < hw0 ? ki : hw0 - 1u] : 0ull;
+    const uint64_t cn = ((uint32_t)lane < sn.J) ? (cand_mask[(size_t)r * sn.J + (uint32_t)lane] & sn.nat[lane]) : 0ull;
+    int32_t adapter = (int32_t)(uint32_t)hdr;
+    uint32_t nb = (uint32_t)(hdr >> 32);
+    bool bad = false;
+    if (nb > hwords || adapter < -1 || adapter >= (int32_t)EPPK_MAX_ADAPTERS) {      // not scored + sticky flag (SEMANTICS.md §7)
+      bad = true; adapter = -1; nb = 0u;
+      if (lane == 0) atomicOr(sn.status, kStatusBadRow);
+    }
+    const uint32_t arow = adapter >= 0 ? (uint32_t)adapter : 128u;
+    // the request's leading hits: the pair probe of the fast kernel (32 keys at a time, two lanes per key)
+    const bool use_index = ix.slots != 0u && nb != 0u;
+    const uint32_t nchunk = nb < kKeysPerProbe ? nb : kKeysPerProbe;
+    ReqRegs q;
+    q.hdr = 0;
+    q.h = (use_index && ki < nchunk) ? hraw : 0ull;
+    q.kw[0] = q.kw[1] = make_uint4(0, 0, 0, 0);
+    q.bkt = 0;
+    if (use_index) {
+      pair_probe_prepare(ix, q);
+      pair_probe_issue(rk, keys_off, q, lane);
+    }
+    // candidates (while the keys are in flight): lane w holds word w of the row (pods 64w .. 64w+63), holes and pods beyond the
+    // snapshot already removed
+    const uint32_t pc = (uint32_t)__builtin_popcountll(cn);
+    uint32_t incl = pc;
+#pragma unroll
+    for (uint32_t dd = 1; dd < 64u; dd <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)dd);
+      if ((uint32_t)lane >= dd) incl += t;
+    }
+    const uint32_t excl = incl - pc;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t nchunks = (total + 63u) >> 6;
+    // candidate number g (in ascending pod order) -> pod: the lane whose prefix range holds g, then the (g - excl)-th set bit of its word
+    auto candidate = [&](uint32_t g, bool v) -> uint32_t {
+      uint32_t owner = 0;                                              // = the number of lanes whose inclusive count is <= g
+#pragma unroll
+      for (uint32_t step = 32u; step; step >>= 1) {                    // binary search: incl is non-decreasing over the lanes
+        const uint32_t probe_l = owner + step - 1u;
+        if ((uint32_t)__shfl((int)incl, (int)probe_l) <= g) owner += step;
+      }
+      const uint32_t ow = owner < 64u ? owner : 63u;
+      const uint32_t oex = (uint32_t)__shfl((int)excl, (int)ow);
+      uint64_t w = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(cn >> 32), (int)ow) << 32) | (uint32_t)__shfl((int)(uint32_t)cn, (int)ow);
+      if (!v) return 0u;
+      for (uint32_t n = g - oex; n; --n) w &= w - 1ull;
+      return ow * 64u + (uint32_t)__builtin_ctzll(w);
+    };
+    struct Facts { uint32_t p, q; bool v; double kvu; LW th, tl; };
+    auto facts_of = [&](uint32_t c) -> Facts {
+      Facts f;
+      const uint32_t g = c * 64u + (uint32_t)lane;
+      f.v = g < total;
+      f.p = candidate(g, f.v);
+      f.q = sn.queue[f.p];
+      f.kvu = sn.kv[f.p];
+      f.th = ((const LW*)sn.thi_t)[(size_t)arow * 64u + (f.p & 63u)];
+      f.tl = ((const LW*)sn.tlo_t)[(size_t)arow * 64u + (f.p & 63u)];
+      return f;
+    };
+    const Facts f0 = facts_of(0u);                                     // (the only pass when a request has at most 64 candidates)
+    uint32_t m0 = 0, slot_eff = ix.slots + 2u;
+    if (use_index) m0 = pair_probe_finish(ix, q, nchunk, lane, slot_eff);
+    // QUEUE normalisers over ALL candidates
+    uint32_t qmin = 0, qmax = 0;
+    if (has_q) {
+      uint32_t mn = f0.v ? f0.q : 0xFFFFFFFFu, mx = f0.v ? f0.q : 0u;
+      for (uint32_t c = 1; c < nchunks; ++c) {
+        const Facts f = facts_of(c);
+        if (f.v) { mn = f.q < mn ? f.q : mn; mx = f.q > mx ? f.q : mx; }
+      }
+      qmin = wave_min_u32(mn);
+      qmax = ~wave_min_u32(~mx);
+    }
+    const double qden = (double)(qmax - qmin);
+    uint32_t rep[EPPK_MAX_TOPK];                                       // pods already reported (ordered fallbacks)
+#pragma unroll
+    for (int i = 0; i < (int)EPPK_MAX_TOPK; ++i) rep[i] = kNoPod;
+    for (uint32_t round = 0; round < tk; ++round) {
+      double best = -__builtin_inf();
+      uint32_t bidx = kNoPod;
+      for (uint32_t c = 0; c < nchunks; ++c) {
+        const Facts f = c == 0u ? f0 : facts_of(c);
+        const uint32_t p = f.p;
+        bool v = f.v;
+#pragma unroll
+        for (int i = 0; i < (int)EPPK_MAX_TOPK; ++i) v = v && p != rep[i];
+        // matched[p]: one word of the dense row of every leading hit
+        uint32_t cnt = 0;
+        for (uint32_t k0 = 0; k0 < m0; k0 += 8u) {                     // 8 independent loads in flight (lane pairs beyond m0 hold the all-zero row)
+          LW wd[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t k = k0 + (uint32_t)u;
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k < kKeysPerProbe ? k : 0u)));
+            wd[u] = bm[(size_t)sk * 64u + (p & 63u)];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + (uint32_t)u < m0) cnt += (uint32_t)((wd[u] >> (p >> 6)) & 1);
+        }
+        if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {       // hashes beyond the first 32 (every earlier key hit)
+          bool stop = false;
+          for (uint32_t b0 = kKeysPerProbe; b0 < nb && !stop; b0 += 64u) {
+            const uint32_t i = b0 + (uint32_t)lane;
+            const bool act = i < nb;
+            const uint32_t slot = probe(ix, act ? ((const uint64_t*)(row + 8))[i] : 0ull, act);
+            const unsigned long long found = __ballot(slot != kNotFound);
+            const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
+            const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);
+            for (uint32_t k = 0; k < m; ++k) {
+              const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)k);
+              cnt += (uint32_t)((bm[(size_t)sk * 64u + (p & 63u)] >> (p >> 6)) & 1);
+            }
+            if (m < chunk) stop = true;
+          }
+        }
+        const uint32_t tier = (uint32_t)(((f.th >> (p >> 6)) & 1) << 1) | (uint32_t)((f.tl >> (p >> 6)) & 1);
+        double t = 0.0;
+        for (uint32_t i = 0; i < ch.n; ++i) {        // (the same expressions as masked_exact / the generic kernel: SEMANTICS.md §3)
+          double sc;
+          switch (ch.kind[i]) {
+            case 1u: sc = (qmax == qmin) ? 1.0 : (double)(qmax - f.q) / qden; break;
+            case 2u: sc = 1.0 - f.kvu; break;
+            case 3u: sc = tier == 3u ? 1.0 : tier == 2u ? 0.8 : tier == 1u ? 0.6 : 0.0; break;
+            default: sc = nb ? (double)cnt / (double)nb : 0.0; break;
+          }
+          t = t + clamp01(sc) * ch.w[i];
+        }
+        double cb = v ? t : -__builtin_inf();
+        uint32_t ci = v ? p : kNoPod;
+        wave_argmax_dpp(cb, ci);
+        if (cb > best || (cb == best && ci < bidx)) { best = cb; bidx = ci; }
+      }
+      const bool none = bidx == kNoPod || bad;
+      if (lane == 0) {
+        out_pick[(size_t)r * tk + round] = none ? -1 : (int32_t)bidx;
+        if (out_score) out_score[(size_t)r * tk + round] = none ? 0.0 : best;
+      }
+#pragma unroll
+      for (int i = 0; i < (int)EPPK_MAX_TOPK; ++i)        // (static indices: rep stays in registers)
+        if ((uint32_t)i == round) rep[i] = bidx;
+    }
+  }
+}
+
 // ---- GENERIC pick kernel -----------------------------------------------------------------------
 // Any chain order (duplicates allowed), optional candidate mask; every scorer evaluated per pair in
 // chain order.  Slower; it is both the fallback for non-canonical chains / masked batches and an
@@ -1686,6 +1864,53 @@ __global__ void hash_prompts_kernel(const uint8_t* __restrict__ prompts, uint64_
   }
   for (uint32_t b = nblk; b < max_blocks; ++b) out[1 + b] = 0ull;
   out[0] = (uint64_t)(uint32_t)adapters[r] | ((uint64_t)nblk << 32);
+}
+#endif
+
+// ---- subset filter for a batch (request.go:104-133; include/eppk.h "the subset filter for a whole batch") ---------------------
+// at / av: open-addressing table of the published endpoints' fingerprints (built on the host at eppk_snapshot_set_addresses:
+// two entries per pod -- address, address + port -- at most a quarter full; av = pod + 1, 0 = empty; equal fingerprints sit in
+// one probe run: several pods may share an address).  A wavefront per request: lane e looks entry e up and ORs the pods it
+// finds into the request's mask row in LDS; the row goes out with one coalesced store.
+#ifdef EPPK_MAIN_UNIT
+__global__ __launch_bounds__(256) void subset_masks_kernel(const uint64_t* __restrict__ at, const uint32_t* __restrict__ av, uint32_t tmask,
+                                                           const uint64_t* __restrict__ keys, const uint32_t* __restrict__ off, uint32_t n_reqs,
+                                                           uint32_t n_pods, uint64_t* __restrict__ out) {
+  __shared__ unsigned long long s_row[4][64];
+  const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t J = (n_pods + 63u) / 64u;
+  unsigned long long* row = s_row[wib];
+  for (uint32_t r = wave; r < n_reqs; r += nwaves) {
+    row[lane] = 0ull;
+    wave_lds_fence();
+    bool all = false;
+    const uint32_t e0 = off[r], e1 = off[r + 1];
+    for (uint32_t eb = e0; eb < e1; eb += 64u) {
+      const uint32_t e = eb + lane;
+      if (e < e1) {
+        const uint64_t lo = keys[2 * (size_t)e], hi = keys[2 * (size_t)e + 1];
+        if ((lo | hi) == 0ull) all = true;                       // the "no filter" entry
+        else {
+          uint32_t t = (uint32_t)lo & tmask;
+          for (uint32_t n = 0; n <= tmask; ++n) {
+            const uint32_t v = av[t];
+            if (v == 0u) break;
+            if (at[2 * (size_t)t] == lo && at[2 * (size_t)t + 1] == hi) atomicOr(&row[(v - 1u) >> 6], 1ull << ((v - 1u) & 63u));
+            t = (t + 1u) & tmask;
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+    const bool any_all = __any(all);
+    if (lane < J) {
+      unsigned long long w = any_all ? ~0ull : row[lane];
+      if (lane == J - 1u && (n_pods & 63u)) w &= (1ull << (n_pods & 63u)) - 1ull;     // no bits beyond the snapshot
+      out[(size_t)r * J + lane] = w;
+    }
+    wave_lds_fence();
+  }
 }
 #endif
 

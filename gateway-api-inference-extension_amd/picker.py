@@ -88,6 +88,31 @@ def subset_mask(endpoints: Sequence[Endpoint], filter_value: Optional[str]) -> T
     return mask[: (n + 63) // 64], rc
 
 
+def subset_entries(filter_value: Optional[str]) -> np.ndarray:
+    """Entries of one request's subset filter as 128-bit fingerprints, [n, 2] u64 (include/eppk.h eppk_subset_entries):
+    None (no filter) -> the single "every pod" entry (0, 0); "" -> no entries (fail closed)."""
+    lib = _lib.load_library()
+    raw = None if filter_value is None else filter_value.encode()
+    cap = 8
+    while True:
+        out = np.zeros((cap, 2), dtype=np.uint64)
+        n = lib.eppk_subset_entries(raw, out.ctypes.data, cap)
+        if n < 0:
+            raise EppkError(n, "eppk_subset_entries")
+        if n <= cap:
+            return out[:n]
+        cap = n
+
+
+def subset_entries_csr(filters: Sequence[Optional[str]]) -> Tuple[np.ndarray, np.ndarray]:
+    """Entry lists of a batch in the CSR form eppk_subset_masks / eppk_pick_batch_subset take: (keys [total, 2] u64, off [R + 1] u32)."""
+    per = [subset_entries(f) for f in filters]
+    off = np.zeros(len(per) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([e.shape[0] for e in per], dtype=np.uint64)
+    keys = np.concatenate(per) if per else np.zeros((0, 2), dtype=np.uint64)
+    return np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, 2), off
+
+
 TEST_ENDPOINT_SELECTION_HEADER = "test-epp-endpoint-selection"          # request.go:84-97
 SUBSET_FILTER_NAMESPACE = "envoy.lb.subset_hint"                        # pkg/lwepp/metadata/consts.go:21
 SUBSET_FILTER_KEY = "x-gateway-destination-endpoint-subset"             # pkg/lwepp/metadata/consts.go:24
@@ -289,6 +314,34 @@ class BatchedPicker:
         self._check(self._lib.eppk_pick_batch(self._ctx, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data), "pick_batch")
         return picks, scores
 
+    # -- subset filter resolved on the device (include/eppk.h "the subset filter for a whole batch") ------------------
+    def set_addresses(self, endpoints: Sequence[Optional[Endpoint]]) -> None:
+        """Address / port of every slot of the CURRENT snapshot (None = a hole)."""
+        n = len(endpoints)
+        addrs = (C.c_char_p * max(n, 1))(*[None if e is None else e.address.encode() for e in endpoints])
+        ports = (C.c_char_p * max(n, 1))(*[None if e is None else e.port.encode() for e in endpoints])
+        self._check(self._lib.eppk_snapshot_set_addresses(self._ctx, addrs, ports, n), "snapshot_set_addresses")
+
+    def subset_masks(self, filters: Sequence[Optional[str]]) -> np.ndarray:
+        """Mask rows [R, ceil(P/64)] of a batch of subset filters (None = no filter), built by the device."""
+        keys, off = subset_entries_csr(filters)
+        R = len(filters)
+        out = np.zeros((R, (self.n_pods + 63) // 64), dtype=np.uint64)
+        self._check(self._lib.eppk_subset_masks(self._ctx, keys.ctypes.data, off.ctypes.data, R, out.ctypes.data), "subset_masks")
+        return out
+
+    def pick_subset(self, reqs: np.ndarray, filters: Sequence[Optional[str]]) -> Tuple[np.ndarray, np.ndarray]:
+        """eppk_pick_batch_subset: the pick of a batch whose candidates are given as subset filters (request.go:104-133)."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words and len(filters) == R, "request rows / filters mismatch"
+        keys, off = subset_entries_csr(filters)
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        self._check(self._lib.eppk_pick_batch_subset(self._ctx, reqs.ctypes.data, R, keys.ctypes.data, off.ctypes.data, picks.ctypes.data,
+                                                     scores.ctypes.data), "pick_batch_subset")
+        return picks, scores
+
     def pick_topk(self, reqs: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Ordered fallbacks: ([R, k] candidate indices, [R, k] totals); column 0 is the pick (include/eppk.h eppk_pick_topk)."""
         if not 1 <= int(k) <= 8:
@@ -331,6 +384,29 @@ class BatchedPicker:
     def pick_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
+
+    def pick_candidates_device(self, d_reqs: int, n_reqs: int, d_mask: int, k: int, d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
+        """Candidate-major kernel for masked batches with few candidates (include/eppk.h eppk_pick_batch_candidates_device):
+        k = 1 the pick, k > 1 ordered fallbacks ([n_reqs, k] entries)."""
+        self._check(self._lib.eppk_pick_batch_candidates_device(self._ctx, d_reqs, n_reqs, d_mask, k, d_pick, d_score, stream or None),
+                    "pick_batch_candidates_device")
+
+    def pick_candidates(self, reqs: np.ndarray, mask: np.ndarray, k: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+        """Host-array convenience around pick_candidates_device (uses torch for the device buffers): ([R, k] picks, [R, k] scores)."""
+        import torch
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        R = reqs.shape[0]
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words and mask.shape == (R, (self.n_pods + 63) // 64)
+        dev = torch.device("cuda", self.device)
+        d_reqs = torch.from_numpy(reqs.view(np.int64)).to(dev)
+        d_mask = torch.from_numpy(mask.view(np.int64)).to(dev)
+        d_pick = torch.empty((R, k), dtype=torch.int32, device=dev)
+        d_score = torch.empty((R, k), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        self.pick_candidates_device(d_reqs.data_ptr(), R, d_mask.data_ptr(), k, d_pick.data_ptr(), d_score.data_ptr())
+        torch.cuda.synchronize(dev)      # (the launch went to the context's stream: device-wide sync)
+        return d_pick.cpu().numpy(), d_score.cpu().numpy()
 
     def launch_status(self) -> int:
         """Sticky flags of the *_device launches since the last call (include/eppk.h: EPPK_LAUNCH_BAD_REQUEST_ROW = 1,

@@ -324,6 +324,37 @@ int eppk_hash_prompts_device(eppk_ctx* ctx, const void* d_prompts, uint64_t prom
 int eppk_subset_mask(const char* const* addrs, const char* const* ports, uint32_t n_pods,
                      const char* filter, uint64_t* out_mask);
 
+/* ---- the subset filter for a whole batch, resolved on the device (SEMANTICS.md §8) -------------------
+ * request.go:104-133 walks every pod of the datastore per request (two map look-ups each): O(pods) host work per request,
+ * and a host-built mask costs pods/8 bytes of H2D per request.  Here the host only TOKENISES a request's filter into entries
+ * (trim, SplitHostPort -- string work stays on the host) and fingerprints each entry (128 bits: XXH64 under two seeds of
+ * "host" for an all-ports entry, of "host\0port" for an exact one); the device holds the fingerprints of the published
+ * endpoints in a hash table and turns a batch of entry lists into the candidate-mask rows the pick kernels read.
+ *
+ *   eppk_subset_entries          filter (NULL = the request has no filter: one entry (0,0) that admits every pod; "" = a filter
+ *                                that is present but empty: zero entries, zero candidates, fail closed) -> out_keys[cap][2].
+ *                                Returns the number of entries the filter has (write at most cap; retry when it exceeds cap).
+ *   eppk_snapshot_set_addresses  Endpoint.Address / Endpoint.Port (datastore.go:43-44) of the slots of the CURRENT snapshot
+ *                                (n_pods must match it; NULL address = a hole).  Call after every publish that changes them.
+ *   eppk_subset_masks[_device]   entries of n_reqs requests in CSR form (keys[off[r] .. off[r+1])) -> mask rows
+ *                                [n_reqs][ceil(n_pods/64)] u64, the layout of eppk_pick_batch*'s cand_mask.
+ *   eppk_pick_batch_subset       eppk_pick_batch with the masks built on the device from entry lists (host buffers in, picks out).
+ *   eppk_pick_batch_candidates_device   the results of eppk_pick_batch_device (k = 1) / eppk_pick_topk_device (k > 1) for a MASKED
+ *                                batch, from a kernel whose cost grows with the number of CANDIDATES of a request instead of the
+ *                                number of pods: the one to call when the masks leave a few dozen candidates (a subset hint);
+ *                                the general entry points stay better for dense masks.  eppk_pick_batch_subset chooses by itself.
+ * Two different addresses with the same 128-bit fingerprint would be confused (probability ~ 2^-100 per pair); the
+ * string-exact eppk_subset_mask stays available. */
+int eppk_pick_batch_candidates_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
+                                      int32_t* d_out_pick, double* d_out_score, void* stream);
+void eppk_addr_fingerprint(const char* host, size_t host_len, const char* port /* NULL = all ports */, size_t port_len, uint64_t out[2]);
+int eppk_subset_entries(const char* filter, uint64_t* out_keys, uint32_t cap);
+int eppk_snapshot_set_addresses(eppk_ctx* ctx, const char* const* addrs, const char* const* ports, uint32_t n_pods);
+int eppk_subset_masks_device(eppk_ctx* ctx, const uint64_t* d_keys, const uint32_t* d_off, uint32_t n_reqs, uint64_t* d_mask_out, void* stream);
+int eppk_subset_masks(eppk_ctx* ctx, const uint64_t* keys, const uint32_t* off, uint32_t n_reqs, uint64_t* out_mask);
+int eppk_pick_batch_subset(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* keys, const uint32_t* off,
+                           int32_t* out_pick, double* out_score);
+
 /* RoundRobinPicker.Pick (handlers/server.go:90-101): idx = atomic(++*counter) % n_candidates.
  * The fail-open fallback of the shim.  Returns the index, or EPPK_NO_PICK when n_candidates == 0. */
 int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);

@@ -171,3 +171,32 @@ def test_subset_filter_against_a_restatement_of_the_go_code(pkg, orc):
         mask, cnt = pkg.picker.subset_mask(endpoints, value)
         got = [i for i in range(n) if (int(mask[i >> 6]) >> (i & 63)) & 1]
         assert got == want and cnt == len(want), (value, [(e.address, e.port) for e in endpoints])
+
+
+def test_subset_entries_tokenise_like_the_string_filter(pkg):
+    """Host half of the on-device subset filter (include/eppk.h eppk_subset_entries; SEMANTICS.md §5a): the same entry rules as
+    eppk_subset_mask -- split on ',', Unicode trim, SplitHostPort decides between an exact and an all-ports entry."""
+    import ctypes as C
+    lib = pkg._lib.load_library()
+
+    def fp(host, port=None):
+        out = np.zeros(2, dtype=np.uint64)
+        h = host.encode()
+        p = None if port is None else port.encode()
+        lib.eppk_addr_fingerprint(h, len(h), p, 0 if p is None else len(p), out.ctypes.data)
+        return (int(out[0]), int(out[1]))
+
+    ent = pkg.picker.subset_entries
+    assert [tuple(int(x) for x in e) for e in ent(None)] == [(0, 0)]            # no filter: the "every pod" entry
+    assert ent("").shape == (0, 2) and ent(" , 　,").shape == (0, 2)         # present but empty: fail closed
+    got = [tuple(int(x) for x in e) for e in ent(" 10.0.0.1:80 ,10.0.0.2, [fd00::1]:8080\t,fd00::2,[fd00::3],host:")]
+    assert got == [fp("10.0.0.1", "80"), fp("10.0.0.2"), fp("fd00::1", "8080"), fp("fd00::2"), fp("[fd00::3]"), fp("host", "")]
+    assert fp("10.0.0.1", "80") != fp("10.0.0.1") and fp("a", "") != fp("a")      # an exact entry never aliases an all-ports one
+    # XXH64 under the two seeds of SEMANTICS.md §5a
+    assert fp("10.0.0.2") == (lib.eppk_xxh64(b"10.0.0.2", 8, 0), lib.eppk_xxh64(b"10.0.0.2", 8, 0x9E3779B97F4A7C15))
+    assert fp("h", "1") == (lib.eppk_xxh64(b"h\x001", 3, 0), lib.eppk_xxh64(b"h\x001", 3, 0x9E3779B97F4A7C15))
+    # a filter with more entries than the first buffer
+    many = ",".join(f"10.1.{i >> 8}.{i & 255}:{8000 + i}" for i in range(300))
+    assert ent(many).shape == (300, 2)
+    keys, off = pkg.picker.subset_entries_csr([None, "", many, "10.0.0.2"])
+    assert list(off) == [0, 1, 1, 301, 302] and keys.shape == (302, 2)
