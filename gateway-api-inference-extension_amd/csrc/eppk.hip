@@ -130,6 +130,17 @@ struct eppk_ctx {
   hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
+  // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>: kDeferBanks
+  // buffer sets, one per launch in flight (eppk_kernels.hip.h: KWork)
+  bool quad_on = true;            // EPPK_QUAD=0 switches it off (every request through pick_fast_kernel)
+  uint32_t quad_threads = 512;    // EPPK_QUAD_THREADS overrides (tuning knob; <= the kernel's launch bound)
+  uint32_t* d_defer[4] = {nullptr, nullptr, nullptr, nullptr};   // per bank: total[2] | cnt[segs] | list[segs][cap]
+  size_t defer_words = 0;         // capacity of one bank, in u32
+  uint32_t* h_defer_total = nullptr;   // pinned [kDeferBanks]: deferred count of the launch that last used the bank (written by the device)
+  uint32_t defer_bank = 0, quad_backoff = 0, quad_backoff_len = 0, defer_uses[4] = {0, 0, 0, 0};
+  uint64_t quad_launches = 0, quad_deferred_seen = 0;
+  const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
+  const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
   size_t max_lds = 65536;        // LDS a workgroup may use (160 KB on gfx950)
   int max_wg_per_cu = 0;         // EPPK_MAX_WG_PER_CU: cap on resident workgroups per CU (0 = what the occupancy query allows; tuning knob)
@@ -140,6 +151,7 @@ struct eppk_ctx {
 namespace {
 
 constexpr uint32_t kStatBanks = 4;
+constexpr uint32_t kDeferBanks = 4;     // work-list buffer sets: at most this many pick launches of one context in flight
 
 int fail(eppk_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -212,7 +224,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const bool masked = d_mask != nullptr;
   // masked batches use the fast kernel's MASKED instantiation, indexes of 4 GiB and more its BIG one
   const bool fast = c->canonical;   // (ordered fallbacks: extra selection rounds of the same kernel; generic TOPK kernel otherwise)
-  const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);
+  const void* fn = pick_kernel_ptr(c, fast, masked, topk > 1);   // (replaced by its work-list instantiation behind pick_quad_kernel)
   KSnap sn = make_ksnap(c);
   KIndex ix = make_kindex(c);
   const uint32_t threads = fast ? c->fast_threads : 512u, wpb = threads / 64;
@@ -246,6 +258,64 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (grid < 1) grid = 1;
 
   unsigned long long* stats = c->prof ? c->stats + (size_t)(c->stat_bank++ % kStatBanks) * 2u * kStatSlots : nullptr;
+  // pick_quad_kernel first (four requests per wavefront: the common shape of a request), then the fast kernel's work-list
+  // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
+  // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
+  bool quad = fast && c->quad_on && !masked && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
+              c->cfg.max_blocks >= 1 && n_reqs >= 4u;
+  if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
+  const void* quad_fn = nullptr;
+  uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0;
+  size_t quad_lds = 0;
+  uint32_t* dbank = nullptr;
+  const uint32_t bank = c->defer_bank % kDeferBanks;
+  if (quad) {
+    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first) : eppk::pick_quad_u64(c->has_l, c->p_first);
+    const uint32_t qwpb = c->quad_threads / 64u;
+    // LDS: base[] | lw[4] | pterm | one "listed" bit per pod for each of the 4 rows of each wavefront
+    quad_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 4u * sn.J * 8u;
+    if (quad_fn != c->quad_occ_fn || quad_lds != c->quad_occ_lds) {
+      HIPCHK(c, hipFuncSetAttribute(quad_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds));
+      int per_cu = 0;
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, quad_fn, (int)c->quad_threads, quad_lds));
+      if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
+      c->quad_occ_fn = quad_fn; c->quad_occ_lds = quad_lds; c->quad_per_cu = per_cu < 1 ? 1 : per_cu;
+    }
+    const uint32_t nblk = (n_reqs + 3u) / 4u;
+    quad_grid = (nblk + qwpb - 1) / qwpb;
+    const uint32_t qcap = (uint32_t)c->num_cu * (uint32_t)c->quad_per_cu;
+    if (quad_grid > qcap) quad_grid = qcap;
+    if (quad_grid > kStatSlots / qwpb) quad_grid = kStatSlots / qwpb;
+    if (quad_grid < 1) quad_grid = 1;
+    quad_segs = quad_grid * qwpb;
+    defer_cap = 4u * ((nblk + quad_segs - 1) / quad_segs);
+    const size_t words = 16u + (size_t)quad_segs + (size_t)quad_segs * defer_cap;
+    if (words > c->defer_words) {          // grow every bank (rare: the first launch, or a larger batch than ever before)
+      HIPCHK(c, hipDeviceSynchronize());
+      for (uint32_t b = 0; b < kDeferBanks; ++b) {
+        if (c->d_defer[b]) HIPCHK(c, hipFree(c->d_defer[b]));
+        c->d_defer[b] = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_defer[b], words * 4u));
+        HIPCHK(c, hipMemset(c->d_defer[b], 0, 64));     // the two total counters
+        c->defer_uses[b] = 0;
+        c->h_defer_total[b] = 0;
+      }
+      c->defer_words = words;
+    }
+    dbank = c->d_defer[bank];
+    // what the launch that used this bank last deferred (its report has long been written; a stale value only delays the decision)
+    const uint32_t seen = c->h_defer_total[bank];
+    if (c->quad_launches >= kDeferBanks && seen > n_reqs / 8u) {
+      c->quad_backoff_len = c->quad_backoff_len ? (c->quad_backoff_len < 4096u ? c->quad_backoff_len * 2u : 4096u) : 64u;
+      c->quad_backoff = c->quad_backoff_len;
+    } else if (c->quad_launches >= kDeferBanks && seen <= n_reqs / 64u) {
+      c->quad_backoff_len = 0;
+    }
+    c->quad_deferred_seen += seen;
+    c->h_defer_total[bank] = 0;
+    ++c->defer_bank;
+    ++c->quad_launches;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->ev_used + 2 > c->ev.size()) {
@@ -266,7 +336,35 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (fast) {
     KTail tl = c->tail;
     KChain chf = c->kchain;
-    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk};
+    eppk::KWork wk{};
+    if (quad) {
+      // two alternating total counters per bank: a launch adds to one and zeroes the other for the bank's next launch
+      uint32_t* d_total = dbank + (c->defer_uses[bank] & 1u);
+      uint32_t* d_total_next = dbank + ((c->defer_uses[bank] + 1u) & 1u);
+      ++c->defer_uses[bank];
+      uint32_t* d_cnt = dbank + 16;
+      uint32_t* d_list = dbank + 16 + quad_segs;
+      void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
+      HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, nullptr, 0));
+      e0 = nullptr;                         // (the pair is timed from the quad kernel's start to the work-list kernel's end)
+      wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = &c->h_defer_total[bank]; wk.cap = defer_cap; wk.n_segs = quad_segs;
+      // the work-list instantiation of the same fast kernel (same LDS, same geometry)
+      const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);
+      fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big)
+                                                                                                   : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big);
+      if (fn != c->wl_occ_fn || lds != c->wl_occ_lds) {
+        if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
+        if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
+        c->wl_occ_fn = fn; c->wl_occ_lds = lds; c->wl_per_cu = per_cu < 1 ? 1 : per_cu;
+      }
+      grid = (uint32_t)c->num_cu * (uint32_t)c->wl_per_cu;
+      if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
+      if (grid * wpb > quad_segs) grid = (quad_segs + wpb - 1) / wpb;      // one wavefront per segment at most
+      if (grid < 1) grid = 1;
+    }
+    void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk, &wk};
     HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(threads), args, lds, st, e0, e1, 0));
   } else {
     KChain ch = c->kchain;
@@ -466,6 +564,13 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->fast_threads = (uint32_t)v;
   }
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
+  if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
+  if (const char* qt = getenv("EPPK_QUAD_THREADS")) {
+    const int v = atoi(qt);
+    if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;
+  }
+  CHK(hipHostMalloc((void**)&c->h_defer_total, kDeferBanks * sizeof(uint32_t), hipHostMallocDefault));
+  std::memset(c->h_defer_total, 0, kDeferBanks * sizeof(uint32_t));
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;
@@ -526,6 +631,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.topi = off; off += 129u * 64u * 4u;
     L.thi = off; off += lora_bytes;
     L.tlo = off; off += lora_bytes;
+    off += 2u * lora_bytes;                    // the interleaved {hi, lo} copy of the two planes (SnapOff<LW>::thl; snap_planes_kernel writes it)
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
     L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes); L.nat = take(3u * 64u * 8u); L.qrange = take(8u);
@@ -599,6 +705,8 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
+  for (uint32_t b = 0; b < 4; ++b) (void)hipFree(c->d_defer[b]);
+  if (c->h_defer_total) (void)hipHostFree(c->h_defer_total);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);

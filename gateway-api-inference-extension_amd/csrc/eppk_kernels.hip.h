@@ -32,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/eppk.h"   // eppk_pod_row (the snapshot producer reads raw rows)
 
@@ -140,7 +141,9 @@ template <typename LW> struct SnapOff {
   static constexpr uint32_t topi = 129u * 64u * 8u;                      // u32 [129][64]
   static constexpr uint32_t thi = topi + 129u * 64u * 4u;                // LW  [129][64]
   static constexpr uint32_t tlo = thi + 129u * 64u * (uint32_t)sizeof(LW);
-  static constexpr uint32_t end = tlo + 129u * 64u * (uint32_t)sizeof(LW);
+  static constexpr uint32_t thl = tlo + 129u * 64u * (uint32_t)sizeof(LW);   // LW [129][64][2]: the same two planes, {hi, lo} of a lane word side by
+                                                                             // side (pick_quad_kernel: one load, one cache line per listed pod)
+  static constexpr uint32_t end = thl + 2u * 129u * 64u * (uint32_t)sizeof(LW);
 };
 
 struct KChain {            // the whole weighted chain (generic kernel)
@@ -536,6 +539,17 @@ __device__ __forceinline__ void wave_argmax_dpp(double& best, uint32_t& bidx) {
 // no probe chain.
 constexpr uint32_t kKeysPerProbe = 32u;
 
+// Work list of the fast kernel's WL instantiations.  pick_quad_kernel scores what it can and DEFERS the rest -- one private
+// segment per wavefront: list[seg * cap + j], j < cnt[seg] -- and pick_fast_kernel<..., WL = true> then runs over exactly those
+// requests (same stream, right behind it).
+struct KWork {
+  const uint32_t* cnt;      // [n_segs] requests in each segment
+  const uint32_t* list;     // [n_segs][cap] request indices
+  const uint32_t* total;    // sum of cnt[] (the quad kernel adds to it only from wavefronts that deferred something)
+  uint32_t* report;         // pinned HOST word: the kernel stores *total there (the library's "is the quad pass paying off" feedback)
+  uint32_t cap, n_segs;
+};
+
 struct ReqRegs {            // pipeline registers of one request
   uint64_t hdr, h;          // row header; the hash this lane pair probes (landing registers of the row prefetch)
   uint4 kw[2];              // this lane's half of the home bucket (landing registers of the key gather)
@@ -714,12 +728,23 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 //   stage 2  rows + tables of r, count, evaluate, pick.
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK>
+// WL (work-list) instantiations: the same kernel over the requests pick_quad_kernel deferred (KWork) instead of 0 .. n_reqs - 1.
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                         uint32_t stride, uint32_t n_reqs, uint32_t pwn,
                                                         const uint64_t* __restrict__ cand_mask, KChain ch,
                                                         int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                        unsigned long long* __restrict__ stats, uint32_t topk) {
+                                                        unsigned long long* __restrict__ stats, uint32_t topk, KWork wk) {
+  if constexpr (WL) {
+    const uint32_t total = *wk.total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *wk.report = total;
+    if (total == 0u) return;                               // nothing was deferred: done before any staging
+    // a workgroup none of whose wavefronts owns a segment with work leaves as well
+    uint32_t mine = 0;
+    const uint32_t nw_ = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); seg < wk.n_segs; seg += nw_) mine |= wk.cnt[seg];
+    if (!__syncthreads_or((int)mine)) return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
@@ -777,7 +802,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const uint32_t hidx8 = ((HAS_P && hw0) ? 1u + (ki < hw0 ? ki : hw0 - 1u) : 0u) * 8u;
   const bool use_index = HAS_P && ix.slots != 0u && hw0 != 0u;
 
-  if (gwave >= n_reqs) return;
+  if (!WL && gwave >= n_reqs) return;
 
   // Stage 0: request row.  The header is wave-uniform: a scalar load straight into SGPRs (constant address space); the
   // lane pair's hash is one buffer load.
@@ -1370,7 +1395,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   uint32_t pf_sink = 0, pf_prev = 0;   // landing registers of the row prefetches (kept alive by the asm at the end, never read)
   // Stage 2 of request r (its row in `cur`, keys gathered); issues stage 1 of r + 1 (row in `nxt`) and stage 0 of
   // r + 2 (into `cur`, which is free once the probe of r is finished).
-  auto process = [&](uint32_t r, ReqRegs& cur, ReqRegs& nxt) {
+  auto process = [&](uint32_t r, uint32_t r_next2, ReqRegs& cur, ReqRegs& nxt) {
     ReqS s;
     uint32_t slot0;
     stage_finish(r, cur, s, slot0);
@@ -1385,9 +1410,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     if (sp) issue_lists(s, slot0, la, lb);
     else stage_rows(s, slot0, w);
     issue_keys(nxt);
-    issue_row(r + 2u * nwaves, r, cur);
+    issue_row(r_next2, r, cur);
 #if EPPK_ROW_PREFETCH > 0
-    {   // L2 prefetch of a later row: five lanes touch its (at most five) 64-byte sectors; the value is never used
+    if constexpr (!WL) {   // L2 prefetch of a later row: five lanes touch its (at most five) 64-byte sectors; the value is never used
       const uint32_t rp = r + (uint32_t)EPPK_ROW_PREFETCH * nwaves;
       if (rp < n_reqs) {
         const uint32_t off = (uint32_t)lane * 64u;
@@ -1439,14 +1464,38 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   qa.kw[0] = qa.kw[1] = make_uint4(0, 0, 0, 0);
   qb.kw[0] = qb.kw[1] = make_uint4(0, 0, 0, 0);
   qa.bkt = qb.bkt = 0;
-  issue_row(gwave, gwave, qa);
-  issue_row(gwave + nwaves, gwave, qb);
-  prepare_keys(qa); issue_keys(qa);
+  if constexpr (WL) {
+    // the segments the quad kernel's wavefronts left behind: seg = gwave, gwave + nwaves, ...; the same pipeline inside a segment
+    for (uint32_t seg = gwave; seg < wk.n_segs; seg += nwaves) {
+      const uint32_t len = wk.cnt[seg];
+      if (len == 0u) continue;
+      const uint32_t* sl = wk.list + (size_t)seg * wk.cap;
+      auto req_at = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)sl[j < len ? j : len - 1u]); };   // (past the end: the last row again, never used)
+      uint32_t r0 = req_at(0u), r1 = req_at(1u);
+      issue_row(r0, r0, qa);
+      issue_row(r1, r1, qb);
+      prepare_keys(qa); issue_keys(qa);
+      for (uint32_t j = 0; j < len; j += 2u) {
+        const uint32_t r2 = req_at(j + 2u);
+        process(r0, r2, qa, qb);
+        if (j + 1u >= len) break;
+        const uint32_t r3 = req_at(j + 3u);
+        process(r1, r3, qb, qa);
+        r0 = r2; r1 = r3;
+      }
+    }
+  } else {
+    issue_row(gwave, gwave, qa);
+    issue_row(gwave + nwaves, gwave, qb);
+    prepare_keys(qa); issue_keys(qa);
+  }
   // ---- steady state, unrolled twice: the stage registers swap roles instead of being copied
-  for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
-    process(r, qa, qb);
-    if (r + nwaves >= n_reqs) break;
-    process(r + nwaves, qb, qa);
+  if constexpr (!WL) {
+    for (uint32_t r = gwave; r < n_reqs; r += 2u * nwaves) {
+      process(r, r + 2u * nwaves, qa, qb);
+      if (r + nwaves >= n_reqs) break;
+      process(r + nwaves, r + 3u * nwaves, qb, qa);
+    }
   }
 
 #if EPPK_ROW_PREFETCH > 0
@@ -1457,6 +1506,443 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
     stats[4 + 2 * gwave] += w_hits;
     stats[5 + 2 * gwave] += w_lookups;
+  }
+}
+
+// ---- QUAD pick kernel: FOUR requests per wavefront, every gather laid out for the vector memory pipe ------------------------
+// pick_fast_kernel spends a whole wavefront on one request (~180 vector + ~145 scalar instructions per decision).  The common
+// shape of a request -- no candidate mask, one pick, at most 32 blocks probed, every hit's pod set still in its short list, all
+// those lists IDENTICAL (the blocks of a shared prefix are cached together), the best pod without a prefix match among the first
+// 16 entries of the adapter's top table -- needs only 16 lanes: this kernel gives each DPP ROW (16 lanes) its own request, so one
+// instruction stream serves four requests.
+//
+// What bounds a pick on an L2-resident index is not instruction issue, though, but the vector memory pipe (measured, round 2:
+// scripts/micro/l2gather.hip, profiles/r02_g_*): a CU looks up about one (lane, 16 bytes) access per clock and the L2 delivers
+// about one 64-byte line per two clocks and CU -- whatever the instruction count.  A first version of this kernel (one lane per
+// key, the whole 64-byte bucket by four 16-byte loads per lane) executed 2.5 x fewer vector instructions than pick_fast_kernel
+// and took exactly as long: 19 M accesses per 64k batch, the texture-address unit 80 % busy.  Hence the layout below: the four
+// lanes of a QUAD read the four 16-byte pieces of ONE line, so a line costs one access instead of four.
+//   lane = (g, q, j): g = DPP row = request 4b + g of block b;  step i (0..7) of the probe serves key 4i + q of that request;
+//   j = which 16 bytes of the key's 64-byte home bucket (words 2j, 2j+1) / of a hit's 64-byte pod list this lane holds.
+//   * rows: lane k = 4q + j of a row loads hashes k and 16 + k (two 8-byte loads: 128 contiguous bytes per row) and computes
+//     their home buckets; step i gets hash and bucket of key 4i + q by ds_bpermute (the LDS crossbar is otherwise idle);
+//   * probe: 8 loads of 16 bytes; each lane compares its two words with the key; the slot is OR-reduced over the quad by DPP;
+//     found bits -> a 32-bit word per row (two DPP rotations) -> leading hits m = count of trailing ones;
+//   * lists: step i loads piece j of the list of hit 4i + q; "all lists identical" = every step equals step 0 (same lane) and
+//     every quad equals its neighbour quad at step 0 (DPP row_shr:4); lane (q, j) then evaluates id 4q + j of the common list
+//     (and id 16 + 4q + j when the list is that long) -- the ids sit in its own piece;
+//   * LoRA tier bits: the owning lane word of the adapter's two planes (one load each); base[] and the prefix terms from LDS;
+//     binary64 adds in chain order, exactly pick_fast_kernel's pod_total;
+//   * argmax: a DPP max reduction over the ROW (4 steps) + a row minimum of the pod index among the ties;
+//   * best pod outside the list: lane k holds entry k of the adapter's top table; "is entry k listed?" through a per-row bitmap
+//     in LDS (ds_or / ds_read / clear).
+// Anything else -- reserved hashes, an overflowed or differing list, a chain that continues past 32 hits, an exhausted table, an
+// out-of-range row, a looked-up key that was displaced from its home bucket -- is DEFERRED: the row's lane 0 appends the request
+// index to the wavefront's private segment of the work list and pick_fast_kernel<..., WL = true> scores exactly those requests
+// afterwards (same stream).  The FIRST missing key of a request whose home bucket has overflowed is followed through the next
+// buckets right here (0.03 % of the buckets at load 1/4: a 64k batch always has a few; confirmed absent = nothing to defer).
+// Software pipeline per wavefront: request rows two blocks ahead, key buckets one block ahead, lists / tables / tier words of
+// the current block; the loads of later blocks are queued BEHIND everything the current block waits for (loads retire in order).
+#ifndef EPPK_QUAD_MAX_THREADS
+#define EPPK_QUAD_MAX_THREADS 1024   // largest workgroup it may be launched with (the host launches 512: two workgroups per CU)
+#endif
+#ifndef EPPK_QUAD_PREFETCH
+#define EPPK_QUAD_PREFETCH 6    // the rows of the block this many iterations ahead are pulled into L2 (0 = off)
+#endif
+#ifndef EPPK_QUAD_PIPE_KEYS
+#define EPPK_QUAD_PIPE_KEYS 1   // 1: the key gather of the next block is in flight while this one is evaluated
+#endif
+#ifndef EPPK_QUAD_WAVES
+#define EPPK_QUAD_WAVES 4       // wavefronts per SIMD the register allocation aims at (<= 128 VGPRs)
+#endif
+template <typename LW, bool HAS_L, bool P_FIRST>
+__global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                                 int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                                                 unsigned long long* __restrict__ stats,
+                                                                 uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
+                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_base = (double*)smem;
+  double* s_lw = s_base + (size_t)sn.J * 64u;
+  double* s_pterm = s_lw + 4;
+  uint32_t* s_bits_all = (uint32_t*)(s_pterm + pwn);          // [waves][4 rows][J * 2] dwords: one bit per pod ("listed")
+  const uint32_t bits_dw = sn.J * 2u;
+#ifndef EPPK_DBGQ_NO_STAGE  // (defined: timing experiment only, wrong results: base[] is not staged)
+  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
+#endif
+  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
+  for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
+  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
+  __syncthreads();
+
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t k = (uint32_t)lane & 15u, g = (uint32_t)lane >> 4, gsh = (uint32_t)lane & 48u;
+  const uint32_t q = ((uint32_t)lane >> 2) & 3u, j = (uint32_t)lane & 3u, j16 = j * 16u;
+  const uint32_t wpb = blockDim.x >> 6;
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
+  const uint32_t nblk = (n_reqs + 3u) >> 2;                          // blocks of four requests
+  if (gwave >= nblk) {
+    if (lane == 0) defer_cnt[gwave] = 0u;
+    return;
+  }
+  uint32_t* bits = s_bits_all + ((threadIdx.x >> 6) * 4u + g) * bits_dw;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)ix.lists, 0, (int)((ix.slots + 4u) * 64u), 0x00020000);
+  const uint32_t hwords = (stride - 8u) / 8u;                        // hash words per request row (>= 1: the host checks)
+  const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;
+  // byte offsets inside a row of the two hashes this lane loads (clamped into the row; unused keys are masked by nb)
+  const uint32_t hoff0 = (1u + (k < hw0 ? k : hw0 - 1u)) * 8u, hoff1 = (1u + (16u + k < hw0 ? 16u + k : hw0 - 1u)) * 8u;
+  const uint32_t bp_addr = (gsh + q) * 4u;                           // ds_bpermute address of lane (g, k = q): key 4i + q sits 4 (i & 3) lanes on
+  const uint32_t bmask = (ix.slots / kBucket) - 1u;
+  uint32_t n_def = 0;                                                // requests this wavefront deferred (wave-uniform)
+  uint32_t acc_hits = 0, acc_look = 0;                               // probe statistics (lane 0 of each row)
+  uint32_t* my_list = defer_list + (size_t)gwave * defer_cap;
+  uint32_t pf_sink = 0, pf_prev = 0;                                 // landing registers of the row prefetches (never read)
+  const uint32_t pf_lim = n_reqs * stride - 4u;
+  const uint32_t pf_lane = (uint32_t)lane * 64u < 4u * stride ? (uint32_t)lane * 64u : 4u * stride - 4u;
+
+  struct Row { uint64_t hdr, h0, h1; };                              // landing registers of a block's request rows (lane k: hashes k, 16 + k)
+  struct Probe {                                                     // the key gather of a block, quad-transposed: step i = key 4i + q
+    uint32_t hlo[8], hhi[8], bkt[8];                                 //   the key and its home bucket
+    u32x4_t w[8];                                                    //   landing registers: words 2j, 2j + 1 of that bucket
+  };
+  auto issue_row = [&](uint32_t blk, Row& r_) {
+    uint32_t r = (blk < nblk ? blk : nblk - 1u) * 4u + g;
+    r = r < n_reqs ? r : n_reqs - 1u;
+    const uint32_t roff = r * stride;
+    r_.hdr = buffer_load_u64(rq, roff, 0u);
+    r_.h0 = buffer_load_u64(rq, roff + hoff0, 0u);
+    r_.h1 = buffer_load_u64(rq, roff + hoff1, 0u);
+  };
+  // hash + home bucket of step i's key from the lanes that loaded them, then the 16-byte piece of that bucket
+  auto fetch_step = [&](const Row& r_, uint32_t b0, uint32_t b1, Probe& pb, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int a = (int)(bp_addr + 16u * (uint32_t)(i & 3));
+    pb.hlo[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(i < 4 ? r_.h0 : r_.h1));
+    pb.hhi[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)((i < 4 ? r_.h0 : r_.h1) >> 32));
+    pb.bkt[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(i < 4 ? b0 : b1));
+  };
+  // The pipelined gather covers the first kAhead steps (20 keys): the walk ends at the first miss, and a request whose first 20
+  // blocks are all cached is the exception -- it fetches steps 5..7 on demand (one more round trip) instead of every request
+  // paying 12 bucket lines it never looks at.
+  constexpr int kAhead = 5;
+  auto issue_keys = [&](const Row& r_, Probe& pb) {
+    const uint32_t b0 = home_bucket(r_.h0, ix.shift), b1 = home_bucket(r_.h1, ix.shift);
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 0>{});
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 1>{});
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 2>{});
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 3>{});
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 4>{});
+#ifdef EPPK_DBGQ_NO_BKT     // timing experiment only (wrong results): no key-bucket loads, every key a miss
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) pb.w[i] = (u32x4_t)(0u);
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
+  };
+  // a key absent from its overflowed home bucket: the following buckets (rare; plain loads)
+  auto walk = [&](uint64_t h, uint32_t b) -> uint32_t {
+#pragma unroll 1
+    for (uint32_t n = 0; n < bmask; ++n) {
+      b = (b + 1u) & bmask;
+      const uint64_t* kb = ix.keys + (size_t)b * kBucket;
+#pragma unroll 1
+      for (uint32_t i = 1; i < kBucket; ++i)
+        if (kb[i] == h) return b * kBucket + i;
+      if (!(kb[0] & 1ull)) break;
+    }
+    return kNotFound;
+  };
+  // {hi, lo} LoRA tier lane words of pod p for adapter row `arow`: ONE load out of the interleaved planes
+  auto load_tier_pair = [&](uint32_t arow, uint32_t p, LW& th, LW& tl_) {
+    const uint32_t woff = (arow * 64u + (p & 63u)) * 2u * (uint32_t)sizeof(LW);
+    if constexpr (sizeof(LW) == 8) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)woff, (int)SnapOff<LW>::thl, 0);
+      th = u64_of(v.x, v.y); tl_ = u64_of(v.z, v.w);
+    } else if constexpr (sizeof(LW) == 4) {
+      const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsn, (int)woff, (int)SnapOff<LW>::thl, 0);
+      th = v.x; tl_ = v.y;
+    } else {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)woff, (int)SnapOff<LW>::thl, 0);
+      th = (LW)(v & 0xFFFFu); tl_ = (LW)(v >> 16);
+    }
+  };
+  auto row16 = [&](unsigned long long m_) -> uint32_t { return (uint32_t)(m_ >> gsh) & 0xFFFFu; };   // this row's slice of a wavefront mask
+  // v | (v of another lane): DPP controls quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_ror:4 = 0x124, row_ror:8 = 0x128
+  auto or_dpp = [](uint32_t v, auto ctrl) { return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true); };
+  // (inline asm: written with the builtin, the compiler turns "(a ^ a') | (b ^ b') | ... != 0" into a chain of v_mov_dpp + v_cmp + s_or)
+  auto xshr4 = [](uint32_t v) {   // v ^ (v of the lane 4 below in the row); the first quad gets v ^ 0 (its result is not used)
+    uint32_t x;
+    asm("v_xor_b32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(x) : "v"(v));
+    return x;
+  };
+
+  // Block `blk`: its rows in `cur`, its key gather in `pb`; issues the key gather of blk + nwaves (rows in `nxt`, into `pb`) and
+  // the rows of blk + 2 nwaves (into `cur`).
+  auto process = [&](uint32_t blk, Row& cur, Row& nxt, Probe& pb) {
+    const uint32_t r = blk * 4u + g;
+    const bool live = r < n_reqs;
+    int32_t adapter = (int32_t)(uint32_t)cur.hdr;
+    uint32_t nb = (uint32_t)(cur.hdr >> 32);
+    const bool badh = nb > hwords || adapter < -1 || adapter >= (int32_t)EPPK_MAX_ADAPTERS;   // pick_fast_kernel reports the row
+    if (badh) { adapter = -1; nb = 0u; }
+    const uint32_t arow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+    const uint32_t nbc = nb < kKeysPerProbe ? nb : kKeysPerProbe;
+    // reserved hashes 0 / ~0 among the probed keys: deferred (lane k looks at keys k and 16 + k)
+    const bool rsv = (k < nbc && (cur.h0 + 1ull) <= 1ull) || (16u + k < nbc && (cur.h1 + 1ull) <= 1ull);
+#if !EPPK_QUAD_PIPE_KEYS
+    issue_keys(cur, pb);      // (not pipelined: gathered and consumed right here; fewer live registers, more wavefronts per SIMD)
+#endif
+    // ---- finish the probe: slot of key 4i + q (0 = absent) in all four lanes of its quad
+    uint32_t slot[8];
+    uint32_t W = 0u, ovf = 0u;
+    const uint32_t j2 = 2u * j;
+    auto finish_step = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const uint64_t h = u64_of(pb.hlo[i], pb.hhi[i]);
+      const bool c0 = j != 0u && u64_of(pb.w[i].x, pb.w[i].y) == h;  // (word 0 of a bucket is its header)
+      const bool c1 = u64_of(pb.w[i].z, pb.w[i].w) == h;
+      const uint32_t base = pb.bkt[i] * kBucket + j2;
+      uint32_t s = c1 ? base + 1u : (c0 ? base : 0u);
+      s = or_dpp(s, std::integral_constant<int, 0xB1>{});
+      s = or_dpp(s, std::integral_constant<int, 0x4E>{});
+      slot[i] = s;
+      W |= (s != 0u ? 1u : 0u) << (4 * i + 0);
+      ovf |= (pb.w[i].x & 1u) << i;                                   // header bit 0 ("a key of this bucket lives further on"): lanes j == 0
+    };
+    finish_step(std::integral_constant<int, 0>{});
+    finish_step(std::integral_constant<int, 1>{});
+    finish_step(std::integral_constant<int, 2>{});
+    finish_step(std::integral_constant<int, 3>{});
+    finish_step(std::integral_constant<int, 4>{});
+    slot[5] = slot[6] = slot[7] = 0u;
+    // bit 4i + q = key 4i + q found; then the whole row's keys in every lane; m = leading hits of this row's request
+    auto row_found = [&](uint32_t w_) {
+      w_ <<= q;
+      w_ = or_dpp(w_, std::integral_constant<int, 0x124>{});
+      w_ = or_dpp(w_, std::integral_constant<int, 0x128>{});
+      return w_ & (nbc >= 32u ? 0xFFFFFFFFu : ((1u << nbc) - 1u));
+    };
+    uint32_t Wq = W;                                                  // (this quad's bits, before the row-wide OR)
+    W = row_found(Wq);
+    uint32_t m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);   // (<= nbc)
+    if (__builtin_expect(__any(m == 4u * (uint32_t)kAhead && nbc > 4u * (uint32_t)kAhead), 0)) {   // steps 5..7 on demand
+      const uint32_t b1 = home_bucket(cur.h1, ix.shift);
+      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 5>{});
+      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 6>{});
+      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 7>{});
+#pragma unroll
+      for (int i = kAhead; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
+      W = Wq;
+      finish_step(std::integral_constant<int, 5>{});
+      finish_step(std::integral_constant<int, 6>{});
+      finish_step(std::integral_constant<int, 7>{});
+      W = row_found(W);
+      m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
+    }
+    {   // the first missing key sits in an OVERFLOWED bucket: it may live in a later bucket (rare: 0.03 % of the buckets at load
+        // 1/4, but a displaced key of a popular prefix is looked up by every request of its group).  Lane (q = m & 3, j = 0) walks
+        // the chain; a key found there is a hit like any other: its slot goes to its quad, its bit into W, and the next first
+        // miss is examined in turn.
+      bool pend = m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
+      if (__builtin_expect(__any(pend), 0)) do {
+        uint32_t sf = 0u;
+        if (pend) {
+          const uint64_t hh = *(const uint64_t*)(reqs + (size_t)(r < n_reqs ? r : n_reqs - 1u) * stride + 8u + (size_t)m * 8u);
+          const uint32_t s = walk(hh, home_bucket(hh, ix.shift));
+          sf = s != kNotFound ? s : 0u;
+        }
+        sf = or_dpp(sf, std::integral_constant<int, 0xB1>{});           // to the four lanes of the key's quad
+        sf = or_dpp(sf, std::integral_constant<int, 0x4E>{});
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (sf != 0u && (m >> 2) == (uint32_t)i) slot[i] = sf;
+        uint32_t add = sf != 0u ? 1u << (m & 31u) : 0u;                  // to the whole row
+        add = or_dpp(add, std::integral_constant<int, 0x124>{});
+        add = or_dpp(add, std::integral_constant<int, 0x128>{});
+        W |= add;
+        m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
+        pend = add != 0u && m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
+      } while (__any(pend));
+    }
+    unsigned long long badm = __ballot(badh || rsv || (m == kKeysPerProbe && nb > kKeysPerProbe));
+    // ---- lists of the hits: step i = piece j of the list of hit 4i + q (lanes without that hit: the list of step 0 again)
+    const bool any_hit = m > 0u;
+    uint32_t sl0 = slot[0];
+    {   // quads whose step-0 key is no hit (m < 4): the list of hit 0 -- quad 0's slot, broadcast along the row
+      uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)sl0, (int)sl0, 0x114, 0xf, 0xE, false);   // row_shr:4 into quads 1..3
+      t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x118, 0xf, 0xC, false);               // row_shr:8 into quads 2..3
+      sl0 = q < m ? sl0 : t;
+    }
+    if (!any_hit) sl0 = 0u;
+    u32x4_t L[4];
+#ifdef EPPK_DBGQ_NO_LISTS   // timing experiment only (wrong results): no list loads, six pseudo pods per piece
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { L[i].x = 0x00020001u + (sl0 & 1u); L[i].y = 0x00040003u; L[i].z = 0xFFFFFFFFu; L[i].w = 8u; }
+#else
+    L[0] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sl0 * 64u + j16), 0, 0);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const uint32_t s = (4u * (uint32_t)i + q < m) ? slot[i] : sl0;
+      L[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(s * 64u + j16), 0, 0);
+    }
+#endif
+#ifdef EPPK_DBGQ_NO_TOP     // timing experiment only (wrong results): no top-table loads
+    const double top_t = -1.0 - (double)arow;
+    const uint32_t top_p = k + arow;
+#else
+    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, arow * 512u + k * 8u, SnapOff<LW>::topv));
+    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)(arow * 256u + k * 4u), (int)SnapOff<LW>::topi, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the listed pods (as soon as step 0's list is there): lane (q, j) takes id 4q + j, and id 16 + 4q + j when the list is
+    //      that long; the LoRA tier words of pod A are requested before the other steps' lists are compared
+    const uint32_t idsh = 16u * (q & 1u);
+    const uint32_t idA = (((q & 2u) ? L[0].y : L[0].x) >> idsh) & 0xFFFFu;
+    const uint32_t idB = q < 2u ? (L[0].z >> idsh) & 0xFFFFu : kListNone;
+    const bool lsA = any_hit && idA < sn.n_pods, lsB = any_hit && idB < sn.n_pods;
+    const uint32_t pA = lsA ? idA : 0u, pB = lsB ? idB : 0u;
+    LW thA = 0, tlA = 0;
+#ifndef EPPK_DBGQ_NO_TIER   // (defined: timing experiment only, wrong results: no tier-word loads)
+    if (HAS_L) load_tier_pair(arow, pA, thA, tlA);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- all hits list the same pods?  every step against step 0, every quad against its neighbour quad
+    uint32_t diff = xshr4(L[0].x) | xshr4(L[0].y) | xshr4(L[0].z) | xshr4(L[0].w);
+    if (q == 0u) diff = 0u;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) diff |= (L[i].x ^ L[0].x) | (L[i].y ^ L[0].y) | (L[i].z ^ L[0].z) | (L[i].w ^ L[0].w);
+    if (j == 0u && L[0].w > kListCap) diff = 1u;                      // an overflowed list (count > capacity): the dense rows
+    if (__any(m > 16u)) {                                             // hits 16..31: loaded and consumed here
+#pragma unroll
+      for (int i2 = 0; i2 < 4; i2 += 2) {                              // (two at a time: the registers of four more lists would spill)
+        u32x4_t M[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t s = (16u + 4u * (uint32_t)(i2 + i) + q < m) ? slot[4 + i2 + i] : sl0;
+          M[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(s * 64u + j16), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) diff |= (M[i].x ^ L[0].x) | (M[i].y ^ L[0].y) | (M[i].z ^ L[0].z) | (M[i].w ^ L[0].w);
+      }
+    }
+    badm |= __ballot(any_hit && diff != 0u);
+    // ---- next stages, queued BEHIND everything this block still waits for: key gather of the next block, rows of the one
+    //      after, L2 prefetch of a later one
+#if EPPK_QUAD_PIPE_KEYS
+    issue_keys(nxt, pb);
+#endif
+    issue_row(blk + 2u * nwaves, cur);
+#if EPPK_QUAD_PREFETCH > 0
+    {   // one lane per 64-byte sector of the four (contiguous) rows; the value is never used.  Branch-free (past the end: the
+        // last block again; lanes beyond the rows: their last sector again): a conditional landing register would need a copy,
+        // and a copy of a landing register waits for every load in flight
+      const uint32_t bp = blk + (uint32_t)EPPK_QUAD_PREFETCH * nwaves;
+      const uint32_t off = (bp < nblk ? bp : nblk - 1u) * 4u * stride + pf_lane;
+      pf_sink ^= pf_prev;                   // (consumes the PREVIOUS iteration's prefetch, long landed: keeps every load alive without a wait)
+      pf_prev = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, (int)(off < pf_lim ? off : pf_lim), 0, 0);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- evaluate: binary64 adds in chain order (pick_fast_kernel: pod_total)
+    const double pterm = s_pterm[(size_t)nb * sn.pterm_ld + m];
+    auto total_of = [&](uint32_t p, LW th, LW tl_) -> double {
+      double lterm = 0.0;
+      if (HAS_L) {
+        const uint32_t jb = p >> 6;
+        lterm = s_lw[(uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1)];
+      }
+      return eval_total<HAS_L, true, P_FIRST>(s_base[p], lterm, pterm);
+    };
+    const double tA = total_of(pA, thA, tlA);
+    double best = lsA ? tA : -__builtin_inf();
+    uint32_t bidx = lsA ? pA : kNoPod;
+    const bool anyB = __any(lsB);
+    if (anyB) {                                                       // a list of more than 16 pods
+      LW thB = 0, tlB = 0;
+      if (HAS_L) load_tier_pair(arow, pB, thB, tlB);
+      const double tB = total_of(pB, thB, tlB);
+      if (lsB && (tB > best || (tB == best && pB < bidx))) { best = tB; bidx = pB; }
+    }
+    // ---- "listed" bitmap of the row (LDS): set, look the table entries up, clear
+    if (lsA) atomicOr(&bits[pA >> 5], 1u << (pA & 31u));
+    if (anyB && lsB) atomicOr(&bits[pB >> 5], 1u << (pB & 31u));
+    wave_lds_fence();
+    const bool tpv = top_p != kNoPod;
+    const uint32_t tq = tpv ? top_p : 0u;
+    const bool tok = tpv && !((bits[tq >> 5] >> (tq & 31u)) & 1u);   // entry k exists and is not listed
+    wave_lds_fence();
+    if (lsA) bits[pA >> 5] = 0u;
+    if (anyB && lsB) bits[pB >> 5] = 0u;
+    // ---- argmax over the row: (total desc, pod asc)
+    double wmax = best;
+    wmax = vmax_f64(wmax, dpp_f64<0xB1, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x4E, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x141, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x140, 0xf>(wmax));
+    uint32_t widx = best == wmax ? bidx : kNoPod;
+    widx = dpp_min_u32<0xB1, 0xf>(widx);
+    widx = dpp_min_u32<0x4E, 0xf>(widx);
+    widx = dpp_min_u32<0x141, 0xf>(widx);
+    widx = dpp_min_u32<0x140, 0xf>(widx);
+    // ---- best pod outside the list: the first table entry that is not listed
+    const uint32_t okr = row16(__ballot(tok)), tvr = row16(__ballot(tpv));
+    const uint32_t e = (uint32_t)__builtin_ctz(okr | 0x10000u);       // 16: none among the 16 entries
+    badm |= __ballot(e == 16u && tvr == 0xFFFFu);                     // all 16 exist and are listed: the rest of the table is needed
+    const uint32_t src = gsh + (e & 15u);
+    double cand_t = __hiloint2double(__shfl(__double2hiint(top_t), (int)src), __shfl(__double2loint(top_t), (int)src));
+    uint32_t cand_p = (uint32_t)__shfl((int)top_p, (int)src);
+    if (e == 16u) { cand_t = -__builtin_inf(); cand_p = kNoPod; }
+    if (cand_t > wmax || (cand_t == wmax && cand_p < widx)) { wmax = cand_t; widx = cand_p; }
+    // ---- store, or defer
+    const bool gbad = row16(badm) != 0u;
+    const bool lead = k == 0u && live;
+    const unsigned long long dm = __ballot(lead && gbad);
+    if (lead) {
+      if (!gbad) {
+        const bool none = widx == kNoPod;
+        out_pick[r] = none ? -1 : (int32_t)widx;
+        if (out_score) out_score[r] = none ? 0.0 : wmax;
+        acc_hits += m;
+        acc_look += (m + 1u < nb) ? m + 1u : nb;
+      } else {
+        my_list[n_def + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull))] = r;
+      }
+    }
+    n_def += (uint32_t)__builtin_popcountll(dm);
+  };
+
+  Row qa, qb;
+  Probe pb;
+  issue_row(gwave, qa);
+  issue_row(gwave + nwaves, qb);
+#if EPPK_QUAD_PIPE_KEYS
+  issue_keys(qa, pb);
+#endif
+  for (uint32_t blk = gwave; blk < nblk; blk += 2u * nwaves) {
+    process(blk, qa, qb, pb);
+    if (blk + nwaves >= nblk) break;
+    process(blk + nwaves, qb, qa, pb);
+  }
+#if EPPK_QUAD_PREFETCH > 0
+  asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
+#endif
+  if (lane == 0) {
+    defer_cnt[gwave] = n_def;
+    if (n_def) atomicAdd(defer_total, n_def);
+  }
+  if (stats && gwave < kStatSlots) {
+    const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 0) + (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 16) +
+                        (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 48);
+    const uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 0) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 16) +
+                        (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 48);
+    if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
   }
 }
 
@@ -2038,7 +2524,11 @@ __global__ void snap_planes_kernel(const eppk_pod_row* __restrict__ rows, uint32
     }
   }
   if (a == 129u) { qmin_t[l] = hi; qmax_t[l] = lo; act_t[l] = ac; }
-  else { thi[(size_t)a * 64u + l] = hi; tlo[(size_t)a * 64u + l] = lo; }
+  else {
+    thi[(size_t)a * 64u + l] = hi; tlo[(size_t)a * 64u + l] = lo;
+    LW* thl = tlo + 129u * 64u;                     // the interleaved copy right behind the lo planes (SnapOff<LW>::thl)
+    thl[((size_t)a * 64u + l) * 2u] = hi; thl[((size_t)a * 64u + l) * 2u + 1u] = lo;
+  }
 }
 
 // (3) workgroup per adapter row: the 64 best pods by T_a[p] = base[p] (+ lw[tier(a,p)]) under (T desc, p asc) -- the exact

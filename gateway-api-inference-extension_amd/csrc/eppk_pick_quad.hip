@@ -1,0 +1,16 @@
+// pick_quad_kernel instantiations (four requests per wavefront; see eppk_kernels.hip.h).
+#include "eppk_kernels.hip.h"
+#include "eppk_pick_inst.hip.h"
+
+namespace eppk {
+
+template <typename LW>
+static const void* quad_ptr(bool has_l, bool p_first) {
+  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true> : (const void*)pick_quad_kernel<LW, true, false>;
+  return (const void*)pick_quad_kernel<LW, false, false>;
+}
+const void* pick_quad_u16(bool has_l, bool p_first) { return quad_ptr<uint16_t>(has_l, p_first); }
+const void* pick_quad_u32(bool has_l, bool p_first) { return quad_ptr<uint32_t>(has_l, p_first); }
+const void* pick_quad_u64(bool has_l, bool p_first) { return quad_ptr<uint64_t>(has_l, p_first); }
+
+}  // namespace eppk
