@@ -252,7 +252,11 @@ class Runner:
         self.pk.close()
 
 
-def byte_models(wl, R, kern_stats, khash, lists_on=True):
+L2_GATHER_PEAK_GBS = 16900.0   # measured ceiling of 64-byte line gathers out of an L2-resident table, one quad per line (the quad kernel's
+                               # access pattern): 0.515 lines / clock / CU (profiles/r02_g_micro_l2gather.txt)
+
+
+def byte_models(wl, R, kern_stats, khash, lists_on=True, quad=False):
     """Per-launch byte counts from the device-counted probe statistics: (SURVEY model, layout L2-side bytes, compulsory HBM bytes)."""
     abytes, lookups, launches = kern_stats
     launches = max(launches, 1)
@@ -267,14 +271,20 @@ def byte_models(wl, R, kern_stats, khash, lists_on=True):
     tables = 129 * 64 * (12 + 2 * lw_bytes) + wl.P * 8 + (wl.B + 1) ** 2 * 8   # per-adapter tables + base[] + pterm (read through L2 by every workgroup)
     # L2-side: what the layout requests per launch (all of a request's first 32 key buckets are gathered, one list or row per hit)
     per_hit = 64 if lists_on else 64 * lw_bytes
-    l2_side = R * stride + out_bytes + (R * min(wl.B, 32) * 64 + hits * per_hit if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
+    if quad:      # pick_quad_kernel: 20 key buckets gathered ahead (the rest only behind 20 hits), a list per hit, one 64-byte line of
+        # interleaved tier planes per listed pod (~8), 16 table entries
+        probed = min(wl.B, 20) if hits <= 20 * R else min(wl.B, 32)
+        l2_side = R * stride + out_bytes + (R * probed * 64 + hits * 64 if wl.B else 0) + R * (16 * 12 + 8 * 64)
+    else:
+        l2_side = R * stride + out_bytes + (R * min(wl.B, 32) * 64 + hits * per_hit if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
     # compulsory HBM: streams (rows in, picks/scores out) + every DISTINCT index line once + the tables once
     n_keys = int(np.unique(wl.index_hashes).size) if wl.B else 0
     distinct_buckets = min(R * min(wl.B, 32), wl.index_slots // 8) if wl.B else 0
     distinct_lists = min(hits, n_keys)
     compulsory = R * stride + out_bytes + distinct_buckets * 64 + distinct_lists * per_hit + tables
     # an index far beyond the caches: every gathered bucket and every list comes from HBM, the adapter tables do not
-    cold_hbm = R * stride + out_bytes + (R * min(wl.B, 32) * 64 + hits * per_hit if wl.B else 0)
+    probed_cold = (min(wl.B, 20) if hits <= 20 * R else min(wl.B, 32)) if quad else min(wl.B, 32)
+    cold_hbm = R * stride + out_bytes + (R * probed_cold * 64 + hits * per_hit if wl.B else 0)
     return dict(model=model, lookups=lk, hits=hits, l2_side=l2_side, compulsory=compulsory, cold_hbm=cold_hbm)
 
 
@@ -404,8 +414,12 @@ def main() -> None:
         k_timed = res["kern_ms"]
         k_all = np.concatenate([k_timed, extra_ms]) if extra_ms.size else k_timed
         avg_ms = float(k_timed.mean()) if k_timed.size else float("nan")
-        bm = byte_models(wl, res["per"], res["stats"], khash, lists_on=os.environ.get("EPPK_LISTS", "1") != "0")
-        kname = ("pick_fast_kernel" if run.pk.chain_is_fused() else "pick_generic_kernel")
+        q_launches, q_deferred = run.pk.quad_stats()
+        quad = q_launches > 0
+        bm = byte_models(wl, res["per"], res["stats"], khash, lists_on=os.environ.get("EPPK_LISTS", "1") != "0", quad=quad)
+        kname = ("pick_quad_kernel" if quad else "pick_fast_kernel" if run.pk.chain_is_fused() else "pick_generic_kernel")
+        out["config"]["quad_route"] = {"launches": q_launches, "requests_deferred_to_pick_fast_kernel": q_deferred,
+                                       "note": "four requests per wavefront; a launch = pick_quad_kernel + the work-list pass of pick_fast_kernel over what it deferred (both inside kernel_*_ms)"}
         achieved = bm["compulsory"] / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": kname, "kernel_avg_ms": avg_ms,
@@ -416,7 +430,9 @@ def main() -> None:
                 "bytes_definition": "compulsory HBM bytes of one launch under libeppk's layout: request rows in + picks/scores out + each distinct key bucket / pod list / table touched, once",
                 "l2_side_bytes_per_launch": bm["l2_side"], "l2_side_GBps": bm["l2_side"] / (avg_ms * 1e-3) / 1e9,
                 "index_lookups_per_launch": bm["lookups"],
-                "limiter": "valu-issue (not HBM): see `issue`; the HBM-bound case is `roofline_cold`",
+                "l2_frac_of_gather_ceiling": bm["l2_side"] / (avg_ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
+                "limiter": ("not HBM: the L2-resident index is gathered line by line -- vector memory pipe (one access per 16-byte piece and clock and CU, "
+                            "an L2 line per two clocks and CU: DESIGN.md 3.1) plus VALU issue of the per-request skeleton; see `issue`; the HBM-bound case is `roofline_cold`"),
                 "model_bytes_per_launch": bm["model"], "model_frac": bm["model"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "model_note": "SURVEY 8(d) byte model (u64 key + P/8-byte bitmap per index entry, the reference-shaped index): NOT what this kernel moves; reference figure only, may exceed 1",
                 "kernel_src_sha16": khash}
@@ -539,7 +555,8 @@ def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
     run.setup("single", 1)
     elapsed, kern_ms, stats = run.timed(steps, warmup)
     run.pk.profile(False)
-    bm = byte_models(wl, wl.R, stats, khash)
+    quad = run.pk.quad_stats()[0] > 0
+    bm = byte_models(wl, wl.R, stats, khash, quad=quad)
     run.close()
     avg_ms = float(kern_ms.mean())
     ach = bm["cold_hbm"] / (avg_ms * 1e-3) / 1e9
@@ -547,7 +564,10 @@ def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
             "workload": f"{wl.name}, cold index: {a.groups} prefix groups, uniform ({int(np.unique(wl.index_hashes).size)} distinct hashes, {wl.index_slots} slots)",
             "value": wl.R * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_avg_ms": avg_ms, "kernel_p99_ms": float(np.percentile(kern_ms, 99)),
             "bytes_per_launch": bm["cold_hbm"],
-            "bytes_definition": "what the layout reads from HBM per launch: request rows + outputs + one 64-byte key bucket per gathered hash (32 per request) + one 64-byte pod list per hit (adapter tables stay in L2)",
+            "kernel": "pick_quad_kernel" if quad else "pick_fast_kernel",
+            "bytes_definition": ("what the layout reads from HBM per launch: request rows + outputs + one 64-byte key bucket per gathered hash (" +
+                                 ("20 per request: pick_quad_kernel gathers the first 20 ahead, the rest only behind 20 hits" if quad else "32 per request") +
+                                 ") + one 64-byte pod list per hit (adapter tables stay in L2)"),
             "launches_in_flight": len(run.streams), "steps": steps, "generate_seconds": gen_s, "kernel_src_sha16": khash}
     tj = stamped_json("pmc_traffic_cold.json", khash)
     if tj:

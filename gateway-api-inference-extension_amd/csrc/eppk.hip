@@ -1443,6 +1443,17 @@ int eppk_chain_is_fused(const eppk_ctx* c) {
   return c->canonical ? (c->gen ? 2 : 1) : 0;
 }
 
+int eppk_quad_stats(eppk_ctx* c, uint64_t* launches, uint64_t* deferred) {
+  if (!c) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipDeviceSynchronize());
+  uint64_t d = c->quad_deferred_seen;
+  for (uint32_t b = 0; b < kDeferBanks; ++b) d += c->h_defer_total[b];     // (reports of the launches whose bank has not been reused yet)
+  if (launches) *launches = c->quad_launches;
+  if (deferred) *deferred = d;
+  return EPPK_OK;
+}
+
 int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));

@@ -1547,7 +1547,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 #define EPPK_QUAD_MAX_THREADS 1024   // largest workgroup it may be launched with (the host launches 512: two workgroups per CU)
 #endif
 #ifndef EPPK_QUAD_PREFETCH
-#define EPPK_QUAD_PREFETCH 6    // the rows of the block this many iterations ahead are pulled into L2 (0 = off)
+#define EPPK_QUAD_PREFETCH 0    // > 0: the rows of the block this many iterations ahead are pulled into L2 (measured: a wavefront
+                                // walks only ~4 blocks of a 64k batch; 6 ahead cost 0.4 us, profiles/r02_g_quad_ablations.txt)
 #endif
 #ifndef EPPK_QUAD_PIPE_KEYS
 #define EPPK_QUAD_PIPE_KEYS 1   // 1: the key gather of the next block is in flight while this one is evaluated
@@ -1602,9 +1603,11 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   uint32_t n_def = 0;                                                // requests this wavefront deferred (wave-uniform)
   uint32_t acc_hits = 0, acc_look = 0;                               // probe statistics (lane 0 of each row)
   uint32_t* my_list = defer_list + (size_t)gwave * defer_cap;
+#if EPPK_QUAD_PREFETCH > 0
   uint32_t pf_sink = 0, pf_prev = 0;                                 // landing registers of the row prefetches (never read)
   const uint32_t pf_lim = n_reqs * stride - 4u;
   const uint32_t pf_lane = (uint32_t)lane * 64u < 4u * stride ? (uint32_t)lane * 64u : 4u * stride - 4u;
+#endif
 
   struct Row { uint64_t hdr, h0, h1; };                              // landing registers of a block's request rows (lane k: hashes k, 16 + k)
   struct Probe {                                                     // the key gather of a block, quad-transposed: step i = key 4i + q
@@ -1700,38 +1703,52 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     issue_keys(cur, pb);      // (not pipelined: gathered and consumed right here; fewer live registers, more wavefronts per SIMD)
 #endif
     // ---- finish the probe: slot of key 4i + q (0 = absent) in all four lanes of its quad
+    // Per step a lane produces a 4-bit CODE: 0 = its piece does not hold the key, else the key's word index in the bucket (2j or
+    // 2j + 1: 1..7).  The codes of all steps are packed into one register and OR-reduced over the quad ONCE (two DPP ops for the
+    // whole probe instead of two per step); slot = bucket * 8 + code, found = code != 0.
     uint32_t slot[8];
-    uint32_t W = 0u, ovf = 0u;
+    uint32_t codes = 0u, hdr = 0u;
     const uint32_t j2 = 2u * j;
-    auto finish_step = [&](auto ic) {
+    auto match_step = [&](auto ic, uint32_t& cd) {
       constexpr int i = decltype(ic)::value;
       const uint64_t h = u64_of(pb.hlo[i], pb.hhi[i]);
       const bool c0 = j != 0u && u64_of(pb.w[i].x, pb.w[i].y) == h;  // (word 0 of a bucket is its header)
       const bool c1 = u64_of(pb.w[i].z, pb.w[i].w) == h;
-      const uint32_t base = pb.bkt[i] * kBucket + j2;
-      uint32_t s = c1 ? base + 1u : (c0 ? base : 0u);
-      s = or_dpp(s, std::integral_constant<int, 0xB1>{});
-      s = or_dpp(s, std::integral_constant<int, 0x4E>{});
-      slot[i] = s;
-      W |= (s != 0u ? 1u : 0u) << (4 * i + 0);
-      ovf |= (pb.w[i].x & 1u) << i;                                   // header bit 0 ("a key of this bucket lives further on"): lanes j == 0
+      const uint32_t code = c1 ? j2 + 1u : (c0 ? j2 : 0u);
+      cd |= code << (4 * i);
+      hdr |= pb.w[i].x;                                               // header bit 0 ("a key of this bucket lives further on"): lanes j == 0
     };
-    finish_step(std::integral_constant<int, 0>{});
-    finish_step(std::integral_constant<int, 1>{});
-    finish_step(std::integral_constant<int, 2>{});
-    finish_step(std::integral_constant<int, 3>{});
-    finish_step(std::integral_constant<int, 4>{});
-    slot[5] = slot[6] = slot[7] = 0u;
-    // bit 4i + q = key 4i + q found; then the whole row's keys in every lane; m = leading hits of this row's request
-    auto row_found = [&](uint32_t w_) {
+    auto quad_or = [&](uint32_t v) {
+      v = or_dpp(v, std::integral_constant<int, 0xB1>{});
+      return or_dpp(v, std::integral_constant<int, 0x4E>{});
+    };
+    auto slot_of = [&](auto ic) {                                     // (unspecified where the key is absent: only hits are used)
+      constexpr int i = decltype(ic)::value;
+      slot[i] = pb.bkt[i] * kBucket + ((codes >> (4 * i)) & 15u);
+    };
+    // found bits of this quad's keys (bit 4i = step i) -> bit 4i + q = key 4i + q -> the whole row's keys in every lane
+    auto row_found = [&](uint32_t cd) {
+      uint32_t w_ = (cd | (cd >> 1) | (cd >> 2)) & 0x11111111u;
       w_ <<= q;
       w_ = or_dpp(w_, std::integral_constant<int, 0x124>{});
       w_ = or_dpp(w_, std::integral_constant<int, 0x128>{});
       return w_ & (nbc >= 32u ? 0xFFFFFFFFu : ((1u << nbc) - 1u));
     };
-    uint32_t Wq = W;                                                  // (this quad's bits, before the row-wide OR)
-    W = row_found(Wq);
-    uint32_t m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);   // (<= nbc)
+    match_step(std::integral_constant<int, 0>{}, codes);
+    match_step(std::integral_constant<int, 1>{}, codes);
+    match_step(std::integral_constant<int, 2>{}, codes);
+    match_step(std::integral_constant<int, 3>{}, codes);
+    match_step(std::integral_constant<int, 4>{}, codes);
+    codes = quad_or(codes);
+    slot_of(std::integral_constant<int, 0>{});
+    slot_of(std::integral_constant<int, 1>{});
+    slot_of(std::integral_constant<int, 2>{});
+    slot_of(std::integral_constant<int, 3>{});
+    slot_of(std::integral_constant<int, 4>{});
+    slot[5] = slot[6] = slot[7] = 0u;
+    uint32_t W = row_found(codes);
+    uint32_t m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);   // leading hits of this row's request (<= nbc)
+    bool all8 = false;
     if (__builtin_expect(__any(m == 4u * (uint32_t)kAhead && nbc > 4u * (uint32_t)kAhead), 0)) {   // steps 5..7 on demand
       const uint32_t b1 = home_bucket(cur.h1, ix.shift);
       fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 5>{});
@@ -1739,27 +1756,36 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
       fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 7>{});
 #pragma unroll
       for (int i = kAhead; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
-      W = Wq;
-      finish_step(std::integral_constant<int, 5>{});
-      finish_step(std::integral_constant<int, 6>{});
-      finish_step(std::integral_constant<int, 7>{});
-      W = row_found(W);
+      uint32_t cd2 = 0u;
+      match_step(std::integral_constant<int, 5>{}, cd2);
+      match_step(std::integral_constant<int, 6>{}, cd2);
+      match_step(std::integral_constant<int, 7>{}, cd2);
+      codes |= quad_or(cd2);
+      slot_of(std::integral_constant<int, 5>{});
+      slot_of(std::integral_constant<int, 6>{});
+      slot_of(std::integral_constant<int, 7>{});
+      W = row_found(codes);
       m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
+      all8 = true;
     }
-    {   // the first missing key sits in an OVERFLOWED bucket: it may live in a later bucket (rare: 0.03 % of the buckets at load
-        // 1/4, but a displaced key of a popular prefix is looked up by every request of its group).  Lane (q = m & 3, j = 0) walks
-        // the chain; a key found there is a hit like any other: its slot goes to its quad, its bit into W, and the next first
-        // miss is examined in turn.
+    if (__builtin_expect(__any(j == 0u && (hdr & 1u)), 0)) {
+      // The first missing key sits in an OVERFLOWED bucket: it may live in a later bucket (rare: 0.03 % of the buckets at load
+      // 1/4, but a displaced key of a popular prefix is looked up by every request of its group).  Lane (q = m & 3, j = 0) walks
+      // the chain; a key found there is a hit like any other: its slot goes to its quad, its bit into W, and the next first
+      // miss is examined in turn.
+      uint32_t ovf = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < kAhead || all8) ovf |= (pb.w[i].x & 1u) << i;
       bool pend = m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
-      if (__builtin_expect(__any(pend), 0)) do {
+      while (__any(pend)) {
         uint32_t sf = 0u;
         if (pend) {
           const uint64_t hh = *(const uint64_t*)(reqs + (size_t)(r < n_reqs ? r : n_reqs - 1u) * stride + 8u + (size_t)m * 8u);
           const uint32_t s = walk(hh, home_bucket(hh, ix.shift));
           sf = s != kNotFound ? s : 0u;
         }
-        sf = or_dpp(sf, std::integral_constant<int, 0xB1>{});           // to the four lanes of the key's quad
-        sf = or_dpp(sf, std::integral_constant<int, 0x4E>{});
+        sf = quad_or(sf);                                               // to the four lanes of the key's quad
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (sf != 0u && (m >> 2) == (uint32_t)i) slot[i] = sf;
@@ -1769,7 +1795,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
         W |= add;
         m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
         pend = add != 0u && m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
-      } while (__any(pend));
+      }
     }
     unsigned long long badm = __ballot(badh || rsv || (m == kKeysPerProbe && nb > kKeysPerProbe));
     // ---- lists of the hits: step i = piece j of the list of hit 4i + q (lanes without that hit: the list of step 0 again)
@@ -1810,7 +1836,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const uint32_t pA = lsA ? idA : 0u, pB = lsB ? idB : 0u;
     LW thA = 0, tlA = 0;
 #ifndef EPPK_DBGQ_NO_TIER   // (defined: timing experiment only, wrong results: no tier-word loads)
-    if (HAS_L) load_tier_pair(arow, pA, thA, tlA);
+    if (HAS_L && lsA) load_tier_pair(arow, pA, thA, tlA);             // (lanes without a listed pod stay out of the gather)
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- all hits list the same pods?  every step against step 0, every quad against its neighbour quad

@@ -451,6 +451,13 @@ class BatchedPicker:
         """0 = generic per-pair kernel, 1 = fused sparse kernel, 2 = fused with an interpreted tail (include/eppk.h)."""
         return int(self._lib.eppk_chain_is_fused(self._ctx))
 
+    def quad_stats(self) -> Tuple[int, int]:
+        """(pick launches that went through the four-requests-per-wavefront kernel, requests those launches deferred to the
+        general kernel); synchronises the device (include/eppk.h eppk_quad_stats)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.eppk_quad_stats(self._ctx, C.byref(a), C.byref(b)), "quad_stats")
+        return int(a.value), int(b.value)
+
     # -- measurement ------------------------------------------------------------------------
     def profile(self, on: bool) -> None:
         self._check(self._lib.eppk_profile_enable(self._ctx, 1 if on else 0), "profile_enable")

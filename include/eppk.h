@@ -368,6 +368,14 @@ int32_t eppk_round_robin(uint64_t* counter, uint32_t n_candidates);
  * per-pair kernel (duplicated LORA / PREFIX scorers, more than two trailing pod-only scorers). */
 int eppk_chain_is_fused(const eppk_ctx* ctx);
 
+/* Diagnostic.  Unmasked single-pick batches of a fused chain with a PREFIX scorer (max_blocks <= 63) go through the
+ * four-requests-per-wavefront kernel first (csrc/eppk_kernels.hip.h: pick_quad_kernel); a request outside its common shape
+ * (differing or overflowed pod lists, more than 32 cached blocks, reserved hashes, an out-of-range row ...) is DEFERRED to the general
+ * kernel, launched right behind it on the same stream -- same picks and scores either way.  Synchronises the device and returns
+ * how many pick launches took that route and how many requests they deferred.  (Environment: EPPK_QUAD=0 switches the route off.
+ * A workload that keeps deferring a large part of its batches pauses it by itself.) */
+int eppk_quad_stats(eppk_ctx* ctx, uint64_t* launches, uint64_t* deferred);
+
 /* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,
  * every pick launch is bracketed by HIP events recorded on the launch stream and accumulates its
  * index-probe counts on device (one atomic per wavefront). */

@@ -8,12 +8,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_hash)
 
 root, pat, workload, out = sys.argv[1:5]
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
+acc = collections.defaultdict(lambda: collections.defaultdict(float))   # (pattern index, counter) -> dispatch -> value
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if pat in row["Kernel_Name"]:
-            acc[row["Counter_Name"]][(f, row["Dispatch_Id"])] += float(row["Counter_Value"])
-mean = {c: sum(v.values()) / len(v) for c, v in acc.items()}
+        for pi, one in enumerate(pat.split("+")):      # "a+b": a launch is one dispatch of kernel a AND one of kernel b (means are added)
+            if one in row["Kernel_Name"]:
+                acc[(pi, row["Counter_Name"])][(f, row["Dispatch_Id"])] += float(row["Counter_Value"])
+                break
+mean = collections.defaultdict(float)
+for (pi, c), v in acc.items():
+    mean[c] += sum(v.values()) / len(v)
+mean = dict(mean)
 kh = bench.kernel_source_hash()
 n32, n64, n128, nall = (mean.get(k, 0.0) for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_sum"))
 if n64 == 0.0 and nall:      # (no 64B counter in this pass set: the rest of the requests)

@@ -118,6 +118,9 @@ def _fake_picker_class(pkg, orc, log):
             n, self.launches = self.launches, 0
             return [0.05] * n
 
+        def quad_stats(self):
+            return 0, 0
+
         def profile_bytes(self):
             return 1000 * max(self.launches, 1), 17 * max(self.launches, 1), max(self.launches, 1)
 

@@ -1,0 +1,203 @@
+"""pick_quad_kernel (four requests per wavefront, csrc/eppk_kernels.hip.h) against the oracle: the shapes of a request it scores
+itself, the ones it defers to pick_fast_kernel's work-list instantiation, and the bookkeeping between the two launches.
+
+Every case also runs with the route switched off (EPPK_QUAD=0): same picks, same scores, same probe statistics.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(picks, scores, opicks, oscores):
+    bad = np.nonzero(picks != opicks)[0]
+    assert bad.size == 0, f"{bad.size} picks differ, first at {bad[:5]}: gpu {picks[bad[:5]]} oracle {opicks[bad[:5]]}"
+    sb = np.nonzero(scores.view(np.uint64) != oscores.view(np.uint64))[0]
+    assert sb.size == 0, f"{sb.size} scores differ bitwise, first {sb[:5]}: {scores[sb[:5]]} vs {oscores[sb[:5]]}"
+
+
+class quad_env:
+    """EPPK_QUAD is read when a context is created."""
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("EPPK_QUAD")
+        os.environ["EPPK_QUAD"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("EPPK_QUAD", None)
+        else:
+            os.environ["EPPK_QUAD"] = self.old
+
+
+def pairs_by_pod(sets):
+    """[(hashes, pods)] insert calls, one per pod in ascending order: every hash's list then holds its pods in ascending order, so
+    hashes with the same pod set have bitwise identical lists (a single call appends in whatever order the device gets to them)."""
+    by_pod = {}
+    for h, pods in sets.items():
+        for p in pods:
+            by_pod.setdefault(int(p), []).append(h)
+    return [(np.array(hs, dtype=np.uint64), np.full(len(hs), p, dtype=np.uint32)) for p, hs in sorted(by_pod.items())]
+
+
+def run(pkg, orc, wl, sets, reqs=None, slots=None, launches=1, expect_quad=True):
+    """Index = {hash: pods} built pod by pod; `launches` picks of the same batch; returns (quad launches, deferred requests)."""
+    reqs = wl.reqs if reqs is None else reqs
+    if slots is None:                                        # load <= 1/4, libeppk's recommended sizing
+        slots = max(wl.index_slots, 64)
+        while slots < 4 * len(sets):
+            slots *= 2
+    calls = pairs_by_pod(sets)
+    oix = orc.OracleIndex()
+    for h, p in calls:
+        oix.insert(h, p)
+    opicks, oscores, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B)
+    out = {}
+    for on in (True, False):
+        with quad_env(on):
+            with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=max(reqs.shape[0], 1),
+                                   index_slots=slots) as pk:
+                pk.publish(wl.pods)
+                for h, p in calls:
+                    pk.index_insert(h, p)
+                pk.profile(True)
+                for _ in range(launches):
+                    picks, scores = pk.pick(reqs)
+                    assert_same(picks, scores, opicks, oscores)
+                stats = pk.profile_bytes()
+                out[on] = (pk.quad_stats(), stats)
+                assert pk.index_selfcheck() == 0
+    (ql, qd), st_on = out[True]
+    (zl, zd), st_off = out[False]
+    assert (zl, zd) == (0, 0), "EPPK_QUAD=0 must keep every launch on the fast kernel"
+    assert st_on == st_off, f"probe statistics differ between the routes: {st_on} vs {st_off}"
+    if expect_quad:
+        assert ql >= 1, "the quad route was not taken"
+    return ql, qd
+
+
+def group_sets(wl, n_pods=None):
+    """{hash: pod tuple} of the workload's pre-populated index (make_workload: every shared block of a group on the group's pods)."""
+    sets = {}
+    for h, p in zip(wl.index_hashes.tolist(), wl.index_pods.tolist()):
+        sets.setdefault(h, []).append(p)
+    return {h: tuple(sorted(set(ps)))[:n_pods] for h, ps in sets.items()}
+
+
+def hashes_of(wl, reqs=None):
+    reqs = wl.reqs if reqs is None else reqs
+    return reqs[:, 1:1 + wl.B]
+
+
+@pytest.mark.parametrize("R,P", [(1024, 4096), (1023, 4096), (5, 4096), (4, 64), (777, 1000), (2050, 2048), (96, 700)])
+def test_common_shape_is_scored_by_the_quad_kernel(pkg, orc, R, P):
+    wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=32)
+    ql, qd = run(pkg, orc, wl, group_sets(wl))
+    assert ql == 1 and qd == 0, f"{qd} of {R} requests deferred although every request has the common shape"
+
+
+@pytest.mark.parametrize("chain", [[(4, 3)], [(4, 3), (3, 1)], [(3, 1), (4, 3)], [(1, 2), (2, 2), (4, 3)], [(2, 1), (3, 2), (4, -3)]])
+def test_chains(pkg, orc, chain):
+    wl = pkg.workload.make_workload(3, R=640, P=900, n_groups=24)
+    wl.chain = [(int(k), int(w)) for k, w in chain]
+    ql, qd = run(pkg, orc, wl, group_sets(wl))
+    assert ql == 1 and qd == 0
+
+
+def test_long_matches_and_ragged_block_counts(pkg, orc):
+    """Requests whose cached prefix is 0, 1, 5, 16, 17, 19, 20, 21, 24, 31 or all 32 blocks long (steps 5..7 of the probe are fetched on
+    demand, lists of hits 16..31 are compared), with n_blocks from 0 to 32."""
+    wl = pkg.workload.make_workload(5, R=704, P=4096, n_groups=16)
+    sets = group_sets(wl)
+    hs = hashes_of(wl)
+    reqs = wl.reqs.copy()
+    want = [0, 1, 5, 16, 17, 19, 20, 21, 24, 31, 32]
+    half = wl.B // 2
+    gp = {}
+    for r in range(wl.R):
+        n_hit = want[r % len(want)]
+        pods = sets[int(hs[r, 0])]                       # the group's pods: the tail blocks are cached on the same ones
+        for b in range(half, n_hit):
+            sets[int(hs[r, b])] = pods
+        gp[r] = n_hit
+    # ragged n_blocks (the header's high half): some rows end before their cached prefix does
+    nbs = [32, 32, 31, 17, 16, 5, 1, 0, 20, 21, 24]
+    hdr = reqs[:, 0].copy()
+    for r in range(wl.R):
+        nb = nbs[(r // len(want)) % len(nbs)]
+        hdr[r] = (hdr[r] & np.uint64(0xFFFFFFFF)) | (np.uint64(nb) << np.uint64(32))
+    reqs[:, 0] = hdr
+    # requests with n_hit < 16 miss INSIDE the shared prefix: drop those blocks from the index for a few groups' worth of rows
+    for r in range(wl.R):
+        if gp[r] < half:
+            # a private copy of the row's hashes: flip a bit from block n_hit on so that the walk ends there
+            reqs[r, 1 + gp[r]:] ^= np.uint64(0x9E3779B97F4A7C15)
+    ql, qd = run(pkg, orc, wl, sets, reqs=reqs)
+    assert ql == 1 and qd == 0
+
+
+def test_lists_of_up_to_24_pods_and_overflowed_ones(pkg, orc):
+    wl = pkg.workload.make_workload(5, R=512, P=4096, n_groups=8)
+    base = group_sets(wl)
+    rng = np.random.default_rng(7)
+    sizes = {}
+    sets = {}
+    for h, pods in base.items():
+        g = pods                                             # (the group is identified by its pod tuple)
+        if g not in sizes:
+            sizes[g] = (1, 7, 16, 17, 23, 24, 25, 40)[len(sizes) % 8]
+        extra = rng.choice(wl.P, size=64, replace=False).tolist()
+        rng2 = np.random.default_rng(hash(g) & 0xFFFF)       # the same pods for every block of the group
+        more = rng2.choice(wl.P, size=64, replace=False).tolist()
+        allp = list(dict.fromkeys(list(pods) + more))[:sizes[g]]
+        sets[h] = tuple(sorted(allp))
+    ql, qd = run(pkg, orc, wl, sets)
+    assert ql == 1
+    assert qd > 0, "lists of 25 and 40 pods have overflowed: those requests belong to the dense rows"
+    assert qd < wl.R, "lists of up to 24 pods are the quad kernel's"
+
+
+def test_differing_lists_are_deferred(pkg, orc):
+    wl = pkg.workload.make_workload(5, R=384, P=4096, n_groups=8)
+    sets = group_sets(wl)
+    keys = sorted(sets)
+    for n, h in enumerate(keys):
+        if n % 5 == 0:                                       # one block in five is cached on one more pod
+            sets[h] = tuple(sorted(set(sets[h]) | {(n * 37) % wl.P}))
+    ql, qd = run(pkg, orc, wl, sets)
+    assert ql == 1 and qd > 0
+
+
+def test_reserved_hashes_are_deferred(pkg, orc):
+    wl = pkg.workload.make_workload(5, R=256, P=4096, n_groups=8)
+    sets = group_sets(wl)
+    reqs = wl.reqs.copy()
+    reqs[3, 1 + 2] = np.uint64(0)                            # reserved: presence words behind the table
+    reqs[70, 1 + 20] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    reqs[71, 1] = np.uint64(0)
+    sets[0] = (5, 9)
+    ql, qd = run(pkg, orc, wl, sets, reqs=reqs)
+    assert ql == 1 and 3 <= qd <= 8
+
+
+def test_displaced_keys_in_a_crowded_table(pkg, orc):
+    """A table near its load limit: buckets overflow, keys live in later buckets; the first missing key of a request may have to be
+    followed through the chain (and is found there, or confirmed absent)."""
+    wl = pkg.workload.make_workload(5, R=1024, P=4096, n_groups=120)       # 1920 keys
+    ql, qd = run(pkg, orc, wl, group_sets(wl), slots=4096)                 # 512 buckets x 7 words: load 0.54
+    assert ql == 1 and qd == 0
+
+
+def test_backoff_on_a_workload_of_differing_lists(pkg, orc):
+    """Every request defers: after a few launches the library stops trying (and tries again later); results never change."""
+    wl = pkg.workload.make_workload(5, R=256, P=4096, n_groups=4)
+    sets = group_sets(wl)
+    for n, h in enumerate(sorted(sets)):
+        sets[h] = tuple(sorted(set(sets[h]) | {(n * 131 + 1) % wl.P}))     # a different extra pod on every block
+    ql, qd = run(pkg, orc, wl, sets, launches=40)
+    assert 4 <= ql < 40, f"{ql} of 40 launches went through the quad kernel"
+    assert qd == ql * wl.R
