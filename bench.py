@@ -308,7 +308,7 @@ def main() -> None:
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
     ap.add_argument("--pods-per-group", type=int, default=8, help="pods that hold each group's shared blocks in the pre-populated index")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
-    ap.add_argument("--inflight", type=int, default=2, choices=(1, 2), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
+    ap.add_argument("--inflight", type=int, default=2, choices=(1, 2, 3, 4), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
     ap.add_argument("--p99-samples", type=int, default=1000, help="kernel durations collected for the p99 (beyond the timed region if it has fewer launches)")
     ap.add_argument("--host-path", type=int, default=1000, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the pick latency a host caller observes; 0 = skip")

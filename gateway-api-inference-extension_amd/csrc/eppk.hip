@@ -632,6 +632,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     L.thi = off; off += lora_bytes;
     L.tlo = off; off += lora_bytes;
     off += 2u * lora_bytes;                    // the interleaved {hi, lo} copy of the two planes (SnapOff<LW>::thl; snap_planes_kernel writes it)
+    off += 129u * 16u * 16u;                   // the first 16 entries of every top table as {T, pod} pairs (SnapOff<LW>::top16; snap_top_kernel)
     off = (off + 255u) & ~(size_t)255u;
     L.base = take(np64 * 8u); L.post0 = take(np64 * 8u); L.post1 = take(np64 * 8u); L.queue = take(np64 * 4u); L.kv = take(np64 * 8u);
     L.qmin = take(64u * (size_t)c->lw_bytes); L.qmax = take(64u * (size_t)c->lw_bytes); L.act = take(64u * (size_t)c->lw_bytes); L.nat = take(3u * 64u * 8u); L.qrange = take(8u);

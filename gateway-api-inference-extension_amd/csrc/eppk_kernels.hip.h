@@ -143,8 +143,12 @@ template <typename LW> struct SnapOff {
   static constexpr uint32_t tlo = thi + 129u * 64u * (uint32_t)sizeof(LW);
   static constexpr uint32_t thl = tlo + 129u * 64u * (uint32_t)sizeof(LW);   // LW [129][64][2]: the same two planes, {hi, lo} of a lane word side by
                                                                              // side (pick_quad_kernel: one load, one cache line per listed pod)
-  static constexpr uint32_t end = thl + 2u * 129u * 64u * (uint32_t)sizeof(LW);
+  static constexpr uint32_t top16 = thl + 2u * 129u * 64u * (uint32_t)sizeof(LW);   // {f64 T, u32 pod, u32 0} [129][16]: the first 16 entries of
+                                                                                     // every top table again, value and pod side by side
+                                                                                     // (pick_quad_kernel: one 16-byte load per lane)
+  static constexpr uint32_t end = top16 + 129u * 16u * 16u;
 };
+struct TopEntry { double t; uint32_t p, pad; };
 
 struct KChain {            // the whole weighted chain (generic kernel)
   uint32_t n;
@@ -1569,14 +1573,6 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   double* s_pterm = s_lw + 4;
   uint32_t* s_bits_all = (uint32_t*)(s_pterm + pwn);          // [waves][4 rows][J * 2] dwords: one bit per pod ("listed")
   const uint32_t bits_dw = sn.J * 2u;
-#ifndef EPPK_DBGQ_NO_STAGE  // (defined: timing experiment only, wrong results: base[] is not staged)
-  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
-#endif
-  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
-  for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
-  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
-  __syncthreads();
-
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t k = (uint32_t)lane & 15u, g = (uint32_t)lane >> 4, gsh = (uint32_t)lane & 48u;
   const uint32_t q = ((uint32_t)lane >> 2) & 3u, j = (uint32_t)lane & 3u, j16 = j * 16u;
@@ -1585,10 +1581,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
   if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
   const uint32_t nblk = (n_reqs + 3u) >> 2;                          // blocks of four requests
-  if (gwave >= nblk) {
-    if (lane == 0) defer_cnt[gwave] = 0u;
-    return;
-  }
+  const bool idle = gwave >= nblk;                                   // (more wavefronts than blocks: it still helps staging the tables)
   uint32_t* bits = s_bits_all + ((threadIdx.x >> 6) * 4u + g) * bits_dw;
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
@@ -1823,8 +1816,9 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const double top_t = -1.0 - (double)arow;
     const uint32_t top_p = k + arow;
 #else
-    const double top_t = __longlong_as_double((long long)buffer_load_u64(rsn, arow * 512u + k * 8u, SnapOff<LW>::topv));
-    const uint32_t top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)(arow * 256u + k * 4u), (int)SnapOff<LW>::topi, 0);
+    const u32x4_t te = __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)(arow * 256u + k * 16u), (int)SnapOff<LW>::top16, 0);   // entry k: {T, pod}
+    const double top_t = __hiloint2double((int)te.y, (int)te.x);
+    const uint32_t top_p = te.z;
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // ---- the listed pods (as soon as step 0's list is there): lane (q, j) takes id 4q + j, and id 16 + 4q + j when the list is
@@ -1930,7 +1924,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const bool gbad = row16(badm) != 0u;
     const bool lead = k == 0u && live;
     const unsigned long long dm = __ballot(lead && gbad);
-    if (lead) {
+    if (lead) {      // (one store instruction for pick and score -- lanes 0 / 1 / 2 of a row writing pick / score halves -- was measured: no gain)
       if (!gbad) {
         const bool none = widx == kNoPod;
         out_pick[r] = none ? -1 : (int32_t)widx;
@@ -1946,8 +1940,21 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
 
   Row qa, qb;
   Probe pb;
-  issue_row(gwave, qa);
+  issue_row(gwave, qa);                                              // the first rows come from HBM: in flight while the tables are staged
   issue_row(gwave + nwaves, qb);
+#ifndef EPPK_DBGQ_NO_STAGE  // (defined: timing experiment only, wrong results: base[] is not staged)
+  for (uint32_t i = threadIdx.x; i < sn.J * 32u; i += blockDim.x) ((double2*)s_base)[i] = ((const double2*)sn.base)[i];   // (16 bytes per load: every
+                                                                     // vector memory instruction costs the CU's address unit ~16 clocks)
+#endif
+  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
+  for (uint32_t i = threadIdx.x; i < pwn / 2u; i += blockDim.x) ((double2*)s_pterm)[i] = ((const double2*)sn.pterm)[i];
+  if ((pwn & 1u) && threadIdx.x == 0u) s_pterm[pwn - 1u] = sn.pterm[pwn - 1u];
+  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
+  __syncthreads();
+  if (idle) {
+    if (lane == 0) defer_cnt[gwave] = 0u;
+    return;
+  }
 #if EPPK_QUAD_PIPE_KEYS
   issue_keys(qa, pb);
 #endif
@@ -2569,8 +2576,10 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
   __shared__ double red_t[4];
   __shared__ uint32_t red_p[4];
   const uint32_t a = blockIdx.x, tid = threadIdx.x;
+  TopEntry* top16 = (TopEntry*)((uint8_t*)topv + SnapOff<LW>::top16);   // (topv is the head of the snapshot blob: SnapOff<LW>::topv == 0)
   if ((!has_l && a != 128u) || n_pods == 0u) {        // without a LoRA scorer only the base row is read
     if (tid < 64u) { topv[(size_t)a * 64u + tid] = -__builtin_inf(); topi[(size_t)a * 64u + tid] = kNoPod; }
+    if (tid < 16u) top16[(size_t)a * 16u + tid] = TopEntry{-__builtin_inf(), kNoPod, 0u};
     return;
   }
   for (uint32_t p = tid; p < np64; p += blockDim.x) {
@@ -2599,7 +2608,10 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
   const uint32_t K = n_act < 64u ? n_act : 64u;
   for (uint32_t k = 0; k < 64u; ++k) {
     if (k >= K) {                                     // fewer than 64 active pods: pad
-      if (tid == 0) { topv[(size_t)a * 64u + k] = -__builtin_inf(); topi[(size_t)a * 64u + k] = kNoPod; }
+      if (tid == 0) {
+        topv[(size_t)a * 64u + k] = -__builtin_inf(); topi[(size_t)a * 64u + k] = kNoPod;
+        if (k < 16u) top16[(size_t)a * 16u + k] = TopEntry{-__builtin_inf(), kNoPod, 0u};
+      }
       continue;
     }
     double best = -__builtin_inf();
@@ -2618,6 +2630,7 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
         if (red_t[w] > bt || (red_t[w] == bt && red_p[w] < bp)) { bt = red_t[w]; bp = red_p[w]; }
       topv[(size_t)a * 64u + k] = bt;
       topi[(size_t)a * 64u + k] = bp;
+      if (k < 16u) top16[(size_t)a * 16u + k] = TopEntry{bt, bp, 0u};
       sT[bp] = -__builtin_inf();                      // taken
     }
     __syncthreads();
