@@ -114,7 +114,10 @@ class Runner:
         self.R, self.NB = wl.R, len(batches)
         self.h_batches = batches
         slots = wl.index_slots if index_slots is None else index_slots
-        self.pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=wl.R, index_slots=slots, device=local_rank)
+        # strong scaling scores a rank's shards of a whole gather bucket with ONE launch (setup()): up to gather_every x R/world rows
+        per_strong = (wl.R + world - 1) // world
+        max_batch = max(wl.R, args.gather_every * per_strong) if self.use_dist else wl.R
+        self.pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=max_batch, index_slots=slots, device=local_rank)
         self.pk.publish(wl.pods)
         if slots:
             self.pk.index_insert(wl.index_hashes, wl.index_pods)
@@ -141,11 +144,31 @@ class Runner:
         self.per = (R + W - 1) // W if mode == "strong" else R          # requests this rank scores per step
         self.lo = min(self.rank * self.per, R) if mode == "strong" else 0
         self.n_mine = max(0, min(self.lo + self.per, R) - self.lo) if mode == "strong" else R
-        self.ring = self.pkg.distributed.GatherRing(nbuf=16 if mode == "strong" else 8, gather_every=gather_every)
+        # (strong scaling with launch groups: four buckets, so that launches run ahead of the collectives that free their buckets)
+        want_groups = (mode == "strong" and self.use_dist and not self.closed_loop and gather_every > 1 and self.NB % gather_every == 0
+                       and self.n_mine > 0 and not getattr(self.args, "no_launch_groups", False))
+        self.ring = self.pkg.distributed.GatherRing(nbuf=(4 * gather_every if want_groups else 16) if mode == "strong" else 8, gather_every=gather_every)
         NBUF, G = self.ring.nbuf, self.ring.gather_every
         self.d_picks_all = torch.full((NBUF * self.per,), -1, dtype=torch.int32, device=self.dev)
         self.d_picks = [self.d_picks_all[i * self.per:(i + 1) * self.per] for i in range(NBUF)]
-        self.d_scores = [torch.empty(self.per, dtype=torch.float64, device=self.dev) for _ in range(NBUF)]
+        self.d_scores_all = torch.empty(NBUF * self.per, dtype=torch.float64, device=self.dev)
+        self.d_scores = [self.d_scores_all[i * self.per:(i + 1) * self.per] for i in range(NBUF)]
+        # Strong scaling: a rank's shard of one batch (R / world rows: 8192 at 8 GPUs) is a launch-bound kernel, and the host's enqueue
+        # cost per launch then caps the rate.  The batches are independent and a bucket of G of them is all-gathered by one collective
+        # anyway, so the rank keeps ITS rows of every batch contiguous (d_shards[b]) and scores the G shards of a bucket with ONE
+        # launch over G x R/world contiguous rows (8 x 8192 = one 64k launch at 8 GPUs) right before the bucket's collective.
+        self.grouped = want_groups and G == gather_every
+        self.ev_bucket = [None] * (NBUF // G)        # grouped: the event behind the collective that last read bucket k (its slots are free again)
+        if self.grouped:
+            rows = self.stride // 8
+            self.d_shards = torch.empty((self.NB, self.per, rows), dtype=torch.int64, device=self.dev)
+            for b, t in enumerate(self.d_batches):
+                v = t.view(-1, rows)
+                self.d_shards[b, : self.n_mine] = v[self.lo:self.lo + self.n_mine]
+                if self.n_mine < self.per:                       # a ragged last shard: valid filler rows (their picks are never looked at)
+                    self.d_shards[b, self.n_mine:] = v[self.lo:self.lo + 1]
+            self.p_shards = self.d_shards.data_ptr()
+        self.launch_requests = (G * self.per) if self.grouped else self.n_mine
         self.p_picks = [t.data_ptr() for t in self.d_picks]
         self.p_scores = [t.data_ptr() for t in self.d_scores]
         self.d_alls = [torch.empty(W * G * self.per, dtype=torch.int32, device=self.dev) for _ in range(NBUF // G)] if self.use_dist else None
@@ -161,7 +184,12 @@ class Runner:
         out = self.d_alls[self.ring.bucket_of(b0)][: self.world * n * self.per]
         self.dist.all_gather_into_tensor(out, self.d_picks_all[b0 * self.per:(b0 + n) * self.per])     # on `comm`, the current stream
         self.last_gather = (out, n)
-        if closes_trip:
+        if self.grouped:
+            k = self.ring.bucket_of(b0)
+            if self.ev_bucket[k] is None:
+                self.ev_bucket[k] = self.torch.cuda.Event()
+            self.ev_bucket[k].record(self.comm)
+        elif closes_trip:
             self.ev_gather.record(self.comm)
 
     def batch_of(self, step: int) -> int:
@@ -171,26 +199,44 @@ class Runner:
 
     def step(self):
         ring = self.ring
-        if self.use_dist and ring.begins_trip():
+        if self.use_dist and not self.grouped and ring.begins_trip():
             for c in self.computes:
                 c.wait_event(self.ev_gather)                 # every all-gather of the previous trip is done: the ring is free again
         slot = ring.next_slot()
         b = self.batch_of(self.step_no)
         st = self.streams[slot % len(self.streams)]
-        if self.n_mine:
+        if self.n_mine and not self.grouped:
             self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
             if self.closed_loop:                              # post-route index update on the same stream: the next pick sees it
                 self.pk.index_insert_picks_device(self.p_batches[b] + self.lo * self.stride, self.p_picks[slot], self.n_mine, st)
         due = ring.after_batch()
+        if self.grouped and due is not None:
+            self._launch_group(due, b)
         if self.use_dist:
-            if self.n_mine:
+            if self.n_mine and (not self.grouped or due is not None):
                 self.pk.stream_wait_pick(self.comm_handle)   # comm waits for the kernel's own completion event
             self._gather(due)
         self.last_batch, self.last_slot = b, slot
         self.step_no += 1
 
+    def _launch_group(self, due, last_b):
+        """One launch over this rank's shards of the `n` batches of a bucket (slots first .. first + n - 1; batches last_b - n + 1 ..
+        last_b: buckets never wrap the ring, and NB is a multiple of the bucket size, so both ranges are contiguous)."""
+        first, n, _ = due
+        b0 = last_b - n + 1
+        assert b0 >= 0 and b0 + n <= self.NB
+        k = self.ring.bucket_of(first)
+        cs = self.computes[k % len(self.computes)]
+        st = cs.cuda_stream
+        if self.ev_bucket[k] is not None:
+            cs.wait_event(self.ev_bucket[k])                 # the collective that read this bucket on its previous trip is done
+        self.pk.pick_device(self.p_shards + b0 * self.per * self.stride, n * self.per, None, self.p_picks[first], self.p_scores[first], st)
+
     def fence(self):
         due = self.ring.flush()
+        if self.grouped and due is not None:
+            self._launch_group(due, self.last_batch)
+            self.pk.stream_wait_pick(self.comm_handle)
         if self.use_dist:
             self._gather(due)                                # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
         self.torch.cuda.synchronize()
@@ -309,7 +355,8 @@ def main() -> None:
     ap.add_argument("--pods-per-group", type=int, default=8, help="pods that hold each group's shared blocks in the pre-populated index")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1 (exercises the N>1 code path on one GPU)")
     ap.add_argument("--inflight", type=int, default=2, choices=(1, 2, 3, 4), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
-    ap.add_argument("--gather-every", type=int, default=8, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
+    ap.add_argument("--no-launch-groups", action="store_true", help="N>1 strong scaling: one launch per batch shard instead of one per gather bucket")
+    ap.add_argument("--gather-every", type=int, default=16, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
     ap.add_argument("--p99-samples", type=int, default=1000, help="kernel durations collected for the p99 (beyond the timed region if it has fewer launches)")
     ap.add_argument("--host-path", type=int, default=1000, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the pick latency a host caller observes; 0 = skip")
     args = ap.parse_args()
@@ -365,7 +412,7 @@ def main() -> None:
                     if state["epoch"] > args.keep_epochs:
                         run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, run.streams[0])
         elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
-        results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per,
+        results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per, launch_requests=run.launch_requests, grouped=run.grouped,
                              value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
         if mode == modes[0]:
             extra_ms = run.more_kernel_samples(len(kern_ms), args.p99_samples) if not args.closed_loop else np.zeros(0)
@@ -383,7 +430,8 @@ def main() -> None:
         res = results[main_mode]
         G = run.ring.gather_every
         sharding = {"single": "single GPU",
-                    "strong": f"each 64k batch split R/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels",
+                    "strong": (f"each 64k batch split R/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels" +
+                               (f"; a rank scores its {G} shards of a bucket with ONE launch ({G} x {run.per} contiguous rows)" if res.get("grouped") else "")),
                     "weak": f"one whole batch per rank per step, RCCL all-gather of picks (buckets of {G} batches)"}[main_mode]
         out = {
             "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if headline else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf}{', closed loop' if args.closed_loop else ''})",
@@ -416,7 +464,8 @@ def main() -> None:
         avg_ms = float(k_timed.mean()) if k_timed.size else float("nan")
         q_launches, q_deferred = run.pk.quad_stats()
         quad = q_launches > 0
-        bm = byte_models(wl, res["per"], res["stats"], khash, lists_on=os.environ.get("EPPK_LISTS", "1") != "0", quad=quad)
+        bm = byte_models(wl, res["launch_requests"], res["stats"], khash, lists_on=os.environ.get("EPPK_LISTS", "1") != "0", quad=quad)
+        out["config"]["requests_per_launch"] = int(res["launch_requests"])
         kname = ("pick_quad_kernel" if quad else "pick_fast_kernel" if run.pk.chain_is_fused() else "pick_generic_kernel")
         out["config"]["quad_route"] = {"launches": q_launches, "requests_deferred_to_pick_fast_kernel": q_deferred,
                                        "note": "four requests per wavefront; a launch = pick_quad_kernel + the work-list pass of pick_fast_kernel over what it deferred (both inside kernel_*_ms)"}

@@ -133,6 +133,8 @@ struct eppk_ctx {
   // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>: kDeferBanks
   // buffer sets, one per launch in flight (eppk_kernels.hip.h: KWork)
   bool quad_on = true;            // EPPK_QUAD=0 switches it off (every request through pick_fast_kernel)
+  uint32_t quad_min = 24576;      // smallest batch that takes the route (EPPK_QUAD_MIN overrides): below ~20k requests the second launch
+                                  // costs more than the leaner kernel saves (8k x 1024: 16.7 vs 10.5 us per step, measured)
   uint32_t quad_threads = 512;    // EPPK_QUAD_THREADS overrides (tuning knob; <= the kernel's launch bound)
   uint32_t* d_defer[4] = {nullptr, nullptr, nullptr, nullptr};   // per bank: total[2] | cnt[segs] | list[segs][cap]
   size_t defer_words = 0;         // capacity of one bank, in u32
@@ -262,7 +264,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
   bool quad = fast && c->quad_on && !masked && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
-              c->cfg.max_blocks >= 1 && n_reqs >= 4u;
+              c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
   if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
   const void* quad_fn = nullptr;
   uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0;
@@ -565,6 +567,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   }
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
+  if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_THREADS")) {
     const int v = atoi(qt);
     if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;

@@ -372,8 +372,9 @@ int eppk_chain_is_fused(const eppk_ctx* ctx);
  * four-requests-per-wavefront kernel first (csrc/eppk_kernels.hip.h: pick_quad_kernel); a request outside its common shape
  * (differing or overflowed pod lists, more than 32 cached blocks, reserved hashes, an out-of-range row ...) is DEFERRED to the general
  * kernel, launched right behind it on the same stream -- same picks and scores either way.  Synchronises the device and returns
- * how many pick launches took that route and how many requests they deferred.  (Environment: EPPK_QUAD=0 switches the route off.
- * A workload that keeps deferring a large part of its batches pauses it by itself.) */
+ * how many pick launches took that route and how many requests they deferred.  (Environment: EPPK_QUAD=0 switches the route off;
+ * EPPK_QUAD_MIN = smallest batch that takes it, default 24576 requests -- below that the second launch costs more than the leaner
+ * kernel saves.  A workload that keeps deferring a large part of its batches pauses it by itself.) */
 int eppk_quad_stats(eppk_ctx* ctx, uint64_t* launches, uint64_t* deferred);
 
 /* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,

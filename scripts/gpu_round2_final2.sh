@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 2, final measurement session with pick_quad_kernel in front (run on the GPU box via gpurun): the GPU suite in four modes,
+# Round 2, final measurement session with pick_quad_kernel in front (run on the GPU box via gpurun): the GPU suite in five modes,
 # the bench line and its variants, rocprofv3 kernel stats, PMC passes of the headline and of the cold reference.
 # Everything -> gpurun_out/r2final2/; scripts/make_pmc_json.py turns the passes into the stamped profiles/*.json.
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -9,6 +9,7 @@ rm -rf $OUT; mkdir -p $OUT/pmc $OUT/pmc_cold $OUT/prof
 T0=$(date +%s)
 lap() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $OUT/pytest.txt; lap pytest
+EPPK_QUAD_MIN=4 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest_quad_everywhere.txt; lap pytest-quad-everywhere
 EPPK_QUAD=0 timeout 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_quad.py 2>&1 | tail -3 | tee $OUT/pytest_quad_off.txt; lap pytest-quad-off
 EPPK_LISTS=0 timeout 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_quad.py 2>&1 | tail -3 | tee $OUT/pytest_lists_off.txt; lap pytest-lists-off
 if [ -f ab/libeppk_nouniform.so ]; then EPPK_LIB=$PWD/ab/libeppk_nouniform.so EPPK_QUAD=0 timeout 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_quad.py 2>&1 | tail -3 | tee $OUT/pytest_no_uniform.txt; lap pytest-no-uniform; fi

@@ -191,10 +191,15 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
         both = "--scaling" not in argv
         assert d["scaling"] == ("strong" if both else "weak") and d["config"]["ranks_seen"] == 1
         assert ("weak" in d) == both
-        regions = 2 if both else 1
         extra = max(0, 40 - d["steps"]) if "--p99-samples" in argv else 0
-        assert n_picks >= regions * (d["steps"] + d["warmup"]) + extra
-        assert sum(1 for e in log if e[0] == "wait") == n_picks                          # one cross-stream dependency per batch
+        steps = d["steps"] + d["warmup"]
+        if both:
+            # strong scaling scores the shards of a whole gather bucket (16 batches) with ONE launch; weak scaling one launch per batch
+            assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 16 * 96
+            assert n_picks >= (steps + 15) // 16 + steps + extra                              # (extra = launches beyond the timed region: samples)
+        else:
+            assert n_picks >= steps + extra
+        assert sum(1 for e in log if e[0] == "wait") == n_picks                          # one cross-stream dependency per launch
         if extra:
             assert d["roofline"]["kernel_samples"] >= 40
     else:
@@ -203,7 +208,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
             assert d["config"]["distinct_batches"] == 3
 
 
-def _bench_worker(rank, world, port, outdir):
+def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5")):
     """One rank of a world-size-2 dry run: the same stand-ins, patched by hand (no pytest fixtures in a spawned process)."""
     sys.path.insert(0, ROOT)
     import torch
@@ -221,7 +226,7 @@ def _bench_worker(rank, world, port, outdir):
     log = []
     pkg.BatchedPicker = _fake_picker_class(pkg, orc, log)
     sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", "64", "--steps", "10", "--warmup", "3", "--p99-samples", "0",
-                "--batches", "5"]
+                *extra_args]
     out = io.StringIO()
     with redirect_stdout(out):
         bench.main()
@@ -229,11 +234,13 @@ def _bench_worker(rank, world, port, outdir):
         f.write(out.getvalue())
 
 
-def test_bench_two_ranks_on_cpu(tmp_path):
+@pytest.mark.parametrize("extra,grouped", [(("--batches", "5"), False),                        # 5 batches do not tile into buckets: a launch per shard
+                                           (("--batches", "8", "--gather-every", "4"), True)])  # one launch per bucket of 4 shards
+def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     """World size 2 over gloo: both ranks run bench.py's N>1 path to the end, rank 0 alone prints the JSON line, with the
     whole-job aggregate (requests of BOTH ranks) in it."""
     world = 2
-    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), extra), nprocs=world, join=True)
     out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
     out1 = [ln for ln in open(tmp_path / "bench_rank1.out").read().splitlines() if ln.strip()]
     assert not any(ln.lstrip().startswith("{") for ln in out1)
@@ -243,6 +250,7 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     assert d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 32 and d["config"]["requests_per_step"] == 64
     assert "cpu_baseline" not in d and "split R/2 per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
     assert d["parity"]["gathered_picks_equal_oracle"] is True
+    assert ("ONE launch" in d["config"]["sharding"]) == grouped and d["config"]["requests_per_launch"] == (4 * 32 if grouped else 32)
     assert abs(d["value"] - 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
     # weak scaling timed beside it: a whole batch per rank and step, the aggregate counts BOTH ranks
     w = d["weak"]

@@ -19,19 +19,21 @@ def assert_same(picks, scores, opicks, oscores):
 
 
 class quad_env:
-    """EPPK_QUAD is read when a context is created."""
+    """EPPK_QUAD / EPPK_QUAD_MIN are read when a context is created."""
     def __init__(self, on):
         self.on = on
 
     def __enter__(self):
-        self.old = os.environ.get("EPPK_QUAD")
+        self.old = {k: os.environ.get(k) for k in ("EPPK_QUAD", "EPPK_QUAD_MIN")}
         os.environ["EPPK_QUAD"] = "1" if self.on else "0"
+        os.environ["EPPK_QUAD_MIN"] = "4"                    # (by default only batches of 24576 requests and more take the route)
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("EPPK_QUAD", None)
-        else:
-            os.environ["EPPK_QUAD"] = self.old
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def pairs_by_pod(sets):
