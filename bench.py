@@ -413,6 +413,7 @@ def main() -> None:
                         run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, run.streams[0])
         elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
         results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per, launch_requests=run.launch_requests, grouped=run.grouped,
+                             bucket=run.ring.gather_every,
                              value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
         if mode == modes[0]:
             extra_ms = run.more_kernel_samples(len(kern_ms), args.p99_samples) if not args.closed_loop else np.zeros(0)
@@ -428,7 +429,7 @@ def main() -> None:
     if rank == 0:
         main_mode = modes[0]
         res = results[main_mode]
-        G = run.ring.gather_every
+        G = res["bucket"]
         sharding = {"single": "single GPU",
                     "strong": (f"each 64k batch split R/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels" +
                                (f"; a rank scores its {G} shards of a bucket with ONE launch ({G} x {run.per} contiguous rows)" if res.get("grouped") else "")),

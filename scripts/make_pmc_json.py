@@ -42,6 +42,10 @@ if "--issue" in sys.argv:
          "vmem_rd_per_decision": mean.get("SQ_INSTS_VMEM_RD", 0) / reqs, "smem_per_decision": mean.get("SQ_INSTS_SMEM", 0) / reqs,
          "wave_cycles_quad": mean.get("SQ_WAVE_CYCLES"), "active_inst_any_quad": mean.get("SQ_ACTIVE_INST_ANY"), "wait_any_quad": mean.get("SQ_WAIT_ANY"),
          "wait_inst_any_quad": mean.get("SQ_WAIT_INST_ANY"),
+         # the vector memory pipe: address-unit busy cycles (average over the CUs) against the kernel's length in L2 clocks, tag look-ups, L2 requests
+         "ta_busy_cycles_avg": mean.get("TA_BUSY_avr"), "kernel_cycles_tcc_busy_avg": mean.get("TCC_BUSY_avr"),
+         "tcp_accesses_per_decision": (mean.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / reqs) or None,
+         "l2_requests_per_decision": (mean.get("TCC_REQ_sum", 0) / reqs) or None,
          "note": "SQ counters, mean per dispatch; *_quad in 4-cycle units summed over wavefronts; sclk 2.0 GHz measured for 40-us kernels (profiles/r02_clockcal.txt)"}
     json.dump(d, open(iout, "w"), indent=1)
     print(json.dumps(d))
