@@ -130,16 +130,23 @@ struct eppk_ctx {
   hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
 
   const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
-  // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>: kDeferBanks
-  // buffer sets, one per launch in flight (eppk_kernels.hip.h: KWork)
+  // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>
+  // (eppk_kernels.hip.h: KWork)
   bool quad_on = true;            // EPPK_QUAD=0 switches it off (every request through pick_fast_kernel)
   uint32_t quad_min = 24576;      // smallest batch that takes the route (EPPK_QUAD_MIN overrides): below ~20k requests the second launch
                                   // costs more than the leaner kernel saves (8k x 1024: 16.7 vs 10.5 us per step, measured)
   uint32_t quad_threads = 512;    // EPPK_QUAD_THREADS overrides (tuning knob; <= the kernel's launch bound)
-  uint32_t* d_defer[4] = {nullptr, nullptr, nullptr, nullptr};   // per bank: total[2] | cnt[segs] | list[segs][cap]
-  size_t defer_words = 0;         // capacity of one bank, in u32
-  uint32_t* h_defer_total = nullptr;   // pinned [kDeferBanks]: deferred count of the launch that last used the bank (written by the device)
-  uint32_t defer_bank = 0, quad_backoff = 0, quad_backoff_len = 0, defer_uses[4] = {0, 0, 0, 0};
+  // One work-list buffer per STREAM that has launched picks (launches of one stream are ordered, so a buffer is never written
+  // while an earlier launch still reads it; launches of different streams never share one).  More than kDeferSets distinct streams:
+  // the later ones stay on pick_fast_kernel.
+  struct DeferSet { hipStream_t st = nullptr; bool used = false; uint32_t* d = nullptr; size_t words = 0; uint32_t uses = 0; };   // d: total[2] | cnt[segs] | list[segs][cap]
+  DeferSet dsets[8];
+  // Reports: every quad launch owns the next slot of a ring of pinned host words; the work-list kernel stores the launch's deferred
+  // count there (kReportPending until then); the host consumes the slots in order, whenever it passes by.
+  volatile uint32_t* h_reports = nullptr;      // pinned [kReportRing]
+  uint32_t rep_n[4096] = {0};                  // requests of the launch that owns the slot (kReportRing entries)
+  uint64_t rep_unread = 0;                     // first launch whose report has not been consumed
+  uint32_t quad_backoff = 0, quad_backoff_len = 0;
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
   const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
   const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
@@ -153,7 +160,31 @@ struct eppk_ctx {
 namespace {
 
 constexpr uint32_t kStatBanks = 4;
-constexpr uint32_t kDeferBanks = 4;     // work-list buffer sets: at most this many pick launches of one context in flight
+constexpr uint32_t kDeferSets = 8;       // streams with a work-list buffer of their own (eppk_ctx::dsets)
+constexpr uint32_t kReportRing = 4096;   // quad launches whose deferred-count report may be outstanding (a host that enqueues far ahead of
+                                         // the device: bench.py is a few hundred launches ahead; a full ring = the fast kernel for that launch)
+constexpr uint32_t kReportPending = 0xFFFFFFFFu;
+
+// Consume the reports that have arrived, in launch order; steer the back-off: a launch that deferred more than 1/8 of its batch
+// pauses the route (the pause doubles while that keeps happening), one that deferred (almost) nothing resets the pause length.
+void quad_consume_reports(eppk_ctx* c) {
+  while (c->rep_unread < c->quad_launches) {
+    const uint32_t slot = (uint32_t)(c->rep_unread % kReportRing);
+    const uint32_t v = c->h_reports[slot];
+    if (v == kReportPending) break;
+    c->quad_deferred_seen += v;
+    const uint32_t n = c->rep_n[slot];
+    if (v > n / 8u) {
+      if (c->quad_backoff == 0) {
+        c->quad_backoff_len = c->quad_backoff_len ? (c->quad_backoff_len < 4096u ? c->quad_backoff_len * 2u : 4096u) : 64u;
+        c->quad_backoff = c->quad_backoff_len;
+      }
+    } else if (v <= n / 64u) {
+      c->quad_backoff_len = 0;
+    }
+    ++c->rep_unread;
+  }
+}
 
 int fail(eppk_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -265,12 +296,19 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
   bool quad = fast && c->quad_on && !masked && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
               c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
+  if (quad) quad_consume_reports(c);
   if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
+  eppk_ctx::DeferSet* dset = nullptr;
+  if (quad) {                              // this stream's work-list buffer, a free report slot
+    for (uint32_t i = 0; i < kDeferSets && !dset; ++i)
+      if (c->dsets[i].used && c->dsets[i].st == st) dset = &c->dsets[i];
+    for (uint32_t i = 0; i < kDeferSets && !dset; ++i)
+      if (!c->dsets[i].used) { dset = &c->dsets[i]; dset->used = true; dset->st = st; }
+    if (!dset || c->quad_launches - c->rep_unread >= kReportRing) quad = false;     // (a ninth stream; a full ring of launches without a report: the fast kernel)
+  }
   const void* quad_fn = nullptr;
-  uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0;
+  uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0, rep_slot = 0;
   size_t quad_lds = 0;
-  uint32_t* dbank = nullptr;
-  const uint32_t bank = c->defer_bank % kDeferBanks;
   if (quad) {
     quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first) : eppk::pick_quad_u64(c->has_l, c->p_first);
     const uint32_t qwpb = c->quad_threads / 64u;
@@ -292,30 +330,17 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     quad_segs = quad_grid * qwpb;
     defer_cap = 4u * ((nblk + quad_segs - 1) / quad_segs);
     const size_t words = 16u + (size_t)quad_segs + (size_t)quad_segs * defer_cap;
-    if (words > c->defer_words) {          // grow every bank (rare: the first launch, or a larger batch than ever before)
-      HIPCHK(c, hipDeviceSynchronize());
-      for (uint32_t b = 0; b < kDeferBanks; ++b) {
-        if (c->d_defer[b]) HIPCHK(c, hipFree(c->d_defer[b]));
-        c->d_defer[b] = nullptr;
-        HIPCHK(c, hipMalloc((void**)&c->d_defer[b], words * 4u));
-        HIPCHK(c, hipMemset(c->d_defer[b], 0, 64));     // the two total counters
-        c->defer_uses[b] = 0;
-        c->h_defer_total[b] = 0;
-      }
-      c->defer_words = words;
+    if (words > dset->words) {             // grow this stream's buffer (rare: its first launch, or a larger batch than ever before)
+      HIPCHK(c, hipStreamSynchronize(st));
+      if (dset->d) HIPCHK(c, hipFree(dset->d));
+      dset->d = nullptr; dset->words = 0;
+      HIPCHK(c, hipMalloc((void**)&dset->d, words * 4u));
+      HIPCHK(c, hipMemset(dset->d, 0, 64));          // the two total counters
+      dset->words = words; dset->uses = 0;
     }
-    dbank = c->d_defer[bank];
-    // what the launch that used this bank last deferred (its report has long been written; a stale value only delays the decision)
-    const uint32_t seen = c->h_defer_total[bank];
-    if (c->quad_launches >= kDeferBanks && seen > n_reqs / 8u) {
-      c->quad_backoff_len = c->quad_backoff_len ? (c->quad_backoff_len < 4096u ? c->quad_backoff_len * 2u : 4096u) : 64u;
-      c->quad_backoff = c->quad_backoff_len;
-    } else if (c->quad_launches >= kDeferBanks && seen <= n_reqs / 64u) {
-      c->quad_backoff_len = 0;
-    }
-    c->quad_deferred_seen += seen;
-    c->h_defer_total[bank] = 0;
-    ++c->defer_bank;
+    rep_slot = (uint32_t)(c->quad_launches % kReportRing);
+    c->h_reports[rep_slot] = kReportPending;
+    c->rep_n[rep_slot] = n_reqs;
     ++c->quad_launches;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -340,16 +365,16 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     KChain chf = c->kchain;
     eppk::KWork wk{};
     if (quad) {
-      // two alternating total counters per bank: a launch adds to one and zeroes the other for the bank's next launch
-      uint32_t* d_total = dbank + (c->defer_uses[bank] & 1u);
-      uint32_t* d_total_next = dbank + ((c->defer_uses[bank] + 1u) & 1u);
-      ++c->defer_uses[bank];
-      uint32_t* d_cnt = dbank + 16;
-      uint32_t* d_list = dbank + 16 + quad_segs;
+      // two alternating total counters per buffer: a launch adds to one and zeroes the other for the buffer's next launch
+      uint32_t* d_total = dset->d + (dset->uses & 1u);
+      uint32_t* d_total_next = dset->d + ((dset->uses + 1u) & 1u);
+      ++dset->uses;
+      uint32_t* d_cnt = dset->d + 16;
+      uint32_t* d_list = dset->d + 16 + quad_segs;
       void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
       HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, nullptr, 0));
       e0 = nullptr;                         // (the pair is timed from the quad kernel's start to the work-list kernel's end)
-      wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = &c->h_defer_total[bank]; wk.cap = defer_cap; wk.n_segs = quad_segs;
+      wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = (uint32_t*)&c->h_reports[rep_slot]; wk.cap = defer_cap; wk.n_segs = quad_segs;
       // the work-list instantiation of the same fast kernel (same LDS, same geometry)
       const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);
       fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big)
@@ -572,8 +597,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     const int v = atoi(qt);
     if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;
   }
-  CHK(hipHostMalloc((void**)&c->h_defer_total, kDeferBanks * sizeof(uint32_t), hipHostMallocDefault));
-  std::memset(c->h_defer_total, 0, kDeferBanks * sizeof(uint32_t));
+  CHK(hipHostMalloc((void**)&c->h_reports, kReportRing * sizeof(uint32_t), hipHostMallocDefault));
+  for (uint32_t i = 0; i < kReportRing; ++i) c->h_reports[i] = 0u;
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;
@@ -709,8 +734,8 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
-  for (uint32_t b = 0; b < 4; ++b) (void)hipFree(c->d_defer[b]);
-  if (c->h_defer_total) (void)hipHostFree(c->h_defer_total);
+  for (uint32_t b = 0; b < 8; ++b) (void)hipFree(c->dsets[b].d);
+  if (c->h_reports) (void)hipHostFree((void*)c->h_reports);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
@@ -1451,10 +1476,9 @@ int eppk_quad_stats(eppk_ctx* c, uint64_t* launches, uint64_t* deferred) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());
-  uint64_t d = c->quad_deferred_seen;
-  for (uint32_t b = 0; b < kDeferBanks; ++b) d += c->h_defer_total[b];     // (reports of the launches whose bank has not been reused yet)
+  quad_consume_reports(c);                 // (every launch has finished: every report is there)
   if (launches) *launches = c->quad_launches;
-  if (deferred) *deferred = d;
+  if (deferred) *deferred = c->quad_deferred_seen;
   return EPPK_OK;
 }
 
