@@ -145,6 +145,7 @@ struct eppk_ctx {
   // count there (kReportPending until then); the host consumes the slots in order, whenever it passes by.
   volatile uint32_t* h_reports = nullptr;      // pinned [kReportRing]
   uint32_t rep_n[4096] = {0};                  // requests of the launch that owns the slot (kReportRing entries)
+  uint8_t rep_masked[4096] = {0};              // ... and whether it was a masked batch
   uint64_t rep_unread = 0;                     // first launch whose report has not been consumed
   uint32_t quad_backoff = 0, quad_backoff_len = 0;
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
@@ -165,8 +166,9 @@ constexpr uint32_t kReportRing = 4096;   // quad launches whose deferred-count r
                                          // the device: bench.py is a few hundred launches ahead; a full ring = the fast kernel for that launch)
 constexpr uint32_t kReportPending = 0xFFFFFFFFu;
 
-// Consume the reports that have arrived, in launch order; steer the back-off: a launch that deferred more than 1/8 of its batch
-// pauses the route (the pause doubles while that keeps happening), one that deferred (almost) nothing resets the pause length.
+// Consume the reports that have arrived, in launch order; steer the back-off: a launch that deferred more than 1/4 of its batch
+// (quad pass + a work-list pass over a quarter of the batch costs about what the fast kernel alone does; 1/8 for a masked batch, whose
+// deferred requests are the ones that need the exact dense evaluation: 110 vs 80 us at 1/8-density masks, measured) pauses the route (the pause doubles while that keeps happening), one that deferred (almost) nothing resets the pause length.
 void quad_consume_reports(eppk_ctx* c) {
   while (c->rep_unread < c->quad_launches) {
     const uint32_t slot = (uint32_t)(c->rep_unread % kReportRing);
@@ -174,7 +176,7 @@ void quad_consume_reports(eppk_ctx* c) {
     if (v == kReportPending) break;
     c->quad_deferred_seen += v;
     const uint32_t n = c->rep_n[slot];
-    if (v > n / 8u) {
+    if (v > (c->rep_masked[slot] ? n / 8u : n / 4u)) {
       if (c->quad_backoff == 0) {
         c->quad_backoff_len = c->quad_backoff_len ? (c->quad_backoff_len < 4096u ? c->quad_backoff_len * 2u : 4096u) : 64u;
         c->quad_backoff = c->quad_backoff_len;
@@ -294,7 +296,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   // pick_quad_kernel first (four requests per wavefront: the common shape of a request), then the fast kernel's work-list
   // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
-  bool quad = fast && c->quad_on && !masked && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
+  bool quad = fast && c->quad_on && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
               c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
   if (quad) quad_consume_reports(c);
   if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
@@ -310,10 +312,12 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0, rep_slot = 0;
   size_t quad_lds = 0;
   if (quad) {
-    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first) : eppk::pick_quad_u64(c->has_l, c->p_first);
+    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked)
+                                                                                                     : eppk::pick_quad_u64(c->has_l, c->p_first, masked);
     const uint32_t qwpb = c->quad_threads / 64u;
     // LDS: base[] | lw[4] | pterm | one "listed" bit per pod for each of the 4 rows of each wavefront
-    quad_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 4u * sn.J * 8u;
+    //      (masked: + the snapshot's three natural-layout sets + the candidate words of each row)
+    quad_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 4u * sn.J * 8u + (masked ? 192u * 8u + (size_t)qwpb * 4u * sn.J * 8u : 0u);
     if (quad_fn != c->quad_occ_fn || quad_lds != c->quad_occ_lds) {
       HIPCHK(c, hipFuncSetAttribute(quad_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds));
       int per_cu = 0;
@@ -341,6 +345,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     rep_slot = (uint32_t)(c->quad_launches % kReportRing);
     c->h_reports[rep_slot] = kReportPending;
     c->rep_n[rep_slot] = n_reqs;
+    c->rep_masked[rep_slot] = masked ? 1 : 0;
     ++c->quad_launches;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -371,14 +376,14 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       ++dset->uses;
       uint32_t* d_cnt = dset->d + 16;
       uint32_t* d_list = dset->d + 16 + quad_segs;
-      void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
+      void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
       HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, nullptr, 0));
       e0 = nullptr;                         // (the pair is timed from the quad kernel's start to the work-list kernel's end)
       wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = (uint32_t*)&c->h_reports[rep_slot]; wk.cap = defer_cap; wk.n_segs = quad_segs;
       // the work-list instantiation of the same fast kernel (same LDS, same geometry)
       const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);
-      fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big)
-                                                                                                   : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big);
+      fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big, masked) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big, masked)
+                                                                                                           : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big, masked);
       if (fn != c->wl_occ_fn || lds != c->wl_occ_lds) {
         if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;

@@ -1560,9 +1560,14 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 #ifndef EPPK_QUAD_WAVES
 #define EPPK_QUAD_WAVES 4       // wavefronts per SIMD the register allocation aims at (<= 128 VGPRs)
 #endif
-template <typename LW, bool HAS_L, bool P_FIRST>
+// MASKED: a candidate row per request (natural layout, [J] u64: request.go:104-133 as a bitmask).  Lane k of a row loads words 4k .. 4k+3
+// (32 contiguous bytes), ANDs them with the active pods and parks them in the row's LDS area, where "is pod p a candidate?" is one
+// ds_read_b64 for a listed pod or a table entry.  No candidate at all: EPPK_NO_PICK right here.  Candidates that miss the snapshot-wide
+// QUEUE extremes need the request's own normalisers: deferred (pick_fast_kernel's exact evaluation), like a request whose first 16 table
+// entries hold no candidate outside its list.
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false>
 __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
-                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                                  int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                                  unsigned long long* __restrict__ stats,
                                                                  uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
@@ -1573,6 +1578,10 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   double* s_pterm = s_lw + 4;
   uint32_t* s_bits_all = (uint32_t*)(s_pterm + pwn);          // [waves][4 rows][J * 2] dwords: one bit per pod ("listed")
   const uint32_t bits_dw = sn.J * 2u;
+  // MASKED: the three natural-layout sets of the snapshot (active pods, pods at the minimum / maximum queue depth: [3][64] u64) and,
+  // per row, the request's candidates (mask & active: [J] u64)
+  uint64_t* s_nat = (uint64_t*)(s_bits_all + (blockDim.x >> 4) * bits_dw);
+  uint64_t* s_cn_all = s_nat + 192;
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t k = (uint32_t)lane & 15u, g = (uint32_t)lane >> 4, gsh = (uint32_t)lane & 48u;
   const uint32_t q = ((uint32_t)lane >> 2) & 3u, j = (uint32_t)lane & 3u, j16 = j * 16u;
@@ -1583,6 +1592,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   const uint32_t nblk = (n_reqs + 3u) >> 2;                          // blocks of four requests
   const bool idle = gwave >= nblk;                                   // (more wavefronts than blocks: it still helps staging the tables)
   uint32_t* bits = s_bits_all + ((threadIdx.x >> 6) * 4u + g) * bits_dw;
+  uint64_t* s_cn = s_cn_all + ((threadIdx.x >> 6) * 4u + g) * sn.J;
+  const __amdgpu_buffer_rsrc_t rmk = __builtin_amdgcn_make_buffer_rsrc((void*)cand_mask, 0, MASKED ? (int)((size_t)n_reqs * sn.J * 8u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
@@ -1820,13 +1831,19 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const double top_t = __hiloint2double((int)te.y, (int)te.x);
     const uint32_t top_p = te.z;
 #endif
+    u32x4_t mk0 = (u32x4_t)(0u), mk1 = (u32x4_t)(0u);
+    if (MASKED) {     // words 4k .. 4k+3 of the request's candidate row (a read past the last row returns zeros: buffer range)
+      const uint32_t mo = ((r < n_reqs ? r : n_reqs - 1u) * sn.J + 4u * k) * 8u;
+      mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0);
+      mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- the listed pods (as soon as step 0's list is there): lane (q, j) takes id 4q + j, and id 16 + 4q + j when the list is
     //      that long; the LoRA tier words of pod A are requested before the other steps' lists are compared
     const uint32_t idsh = 16u * (q & 1u);
     const uint32_t idA = (((q & 2u) ? L[0].y : L[0].x) >> idsh) & 0xFFFFu;
     const uint32_t idB = q < 2u ? (L[0].z >> idsh) & 0xFFFFu : kListNone;
-    const bool lsA = any_hit && idA < sn.n_pods, lsB = any_hit && idB < sn.n_pods;
+    bool lsA = any_hit && idA < sn.n_pods, lsB = any_hit && idB < sn.n_pods;
     const uint32_t pA = lsA ? idA : 0u, pB = lsB ? idB : 0u;
     LW thA = 0, tlA = 0;
 #ifndef EPPK_DBGQ_NO_TIER   // (defined: timing experiment only, wrong results: no tier-word loads)
@@ -1870,6 +1887,29 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
+    bool no_cand = false;
+    if (MASKED) {
+      // this lane's four candidate words: mask & active (words beyond J are no pods)
+      uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
+      bool anyc = false, hmin = false, hmax = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t w = 4u * k + (uint32_t)i;
+        cw[i] = w < sn.J ? cw[i] & s_nat[w] : 0ull;
+        anyc = anyc || cw[i] != 0ull;
+        hmin = hmin || (cw[i] & s_nat[64u + (w & 63u)]) != 0ull;
+        hmax = hmax || (cw[i] & s_nat[128u + (w & 63u)]) != 0ull;
+        if (w < sn.J) s_cn[w] = cw[i];
+      }
+      no_cand = row16(__ballot(anyc)) == 0u;                          // fail closed: EPPK_NO_PICK (stored below)
+      // base[] and the top tables embed the snapshot-wide QUEUE normalisers: they apply iff the candidates contain a pod at the
+      // minimum and one at the maximum queue depth; otherwise the request's own normalisers are needed (exact evaluation: deferred)
+      if (sn.lead_queue) badm |= __ballot(!no_cand && (row16(__ballot(hmin)) == 0u || row16(__ballot(hmax)) == 0u));
+      wave_lds_fence();
+      auto is_cand = [&](uint32_t p_) -> bool { return (s_cn[p_ >> 6] >> (p_ & 63u)) & 1ull; };
+      lsA = lsA && is_cand(pA);
+      lsB = lsB && is_cand(pB);
+    }
     // ---- evaluate: binary64 adds in chain order (pick_fast_kernel: pod_total)
     const double pterm = s_pterm[(size_t)nb * sn.pterm_ld + m];
     auto total_of = [&](uint32_t p, LW th, LW tl_) -> double {
@@ -1896,7 +1936,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     wave_lds_fence();
     const bool tpv = top_p != kNoPod;
     const uint32_t tq = tpv ? top_p : 0u;
-    const bool tok = tpv && !((bits[tq >> 5] >> (tq & 31u)) & 1u);   // entry k exists and is not listed
+    bool tok = tpv && !((bits[tq >> 5] >> (tq & 31u)) & 1u);         // entry k exists and is not listed
+    if (MASKED) tok = tok && ((s_cn[tq >> 6] >> (tq & 63u)) & 1ull);  // ... and is a candidate of this request
     wave_lds_fence();
     if (lsA) bits[pA >> 5] = 0u;
     if (anyB && lsB) bits[pB >> 5] = 0u;
@@ -1914,7 +1955,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     // ---- best pod outside the list: the first table entry that is not listed
     const uint32_t okr = row16(__ballot(tok)), tvr = row16(__ballot(tpv));
     const uint32_t e = (uint32_t)__builtin_ctz(okr | 0x10000u);       // 16: none among the 16 entries
-    badm |= __ballot(e == 16u && tvr == 0xFFFFu);                     // all 16 exist and are listed: the rest of the table is needed
+    badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand);         // all 16 exist and are listed (or no candidates): the rest of the table is needed
     const uint32_t src = gsh + (e & 15u);
     double cand_t = __hiloint2double(__shfl(__double2hiint(top_t), (int)src), __shfl(__double2loint(top_t), (int)src));
     uint32_t cand_p = (uint32_t)__shfl((int)top_p, (int)src);
@@ -1926,11 +1967,13 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const unsigned long long dm = __ballot(lead && gbad);
     if (lead) {      // (one store instruction for pick and score -- lanes 0 / 1 / 2 of a row writing pick / score halves -- was measured: no gain)
       if (!gbad) {
-        const bool none = widx == kNoPod;
+        const bool none = widx == kNoPod || no_cand;
         out_pick[r] = none ? -1 : (int32_t)widx;
         if (out_score) out_score[r] = none ? 0.0 : wmax;
-        acc_hits += m;
-        acc_look += (m + 1u < nb) ? m + 1u : nb;
+        if (!no_cand) {                                                 // (like pick_fast_kernel: a request without candidates is not counted)
+          acc_hits += m;
+          acc_look += (m + 1u < nb) ? m + 1u : nb;
+        }
       } else {
         my_list[n_def + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull))] = r;
       }
@@ -1950,6 +1993,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   for (uint32_t i = threadIdx.x; i < pwn / 2u; i += blockDim.x) ((double2*)s_pterm)[i] = ((const double2*)sn.pterm)[i];
   if ((pwn & 1u) && threadIdx.x == 0u) s_pterm[pwn - 1u] = sn.pterm[pwn - 1u];
   for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
+  if (MASKED)
+    for (uint32_t i = threadIdx.x; i < 192u; i += blockDim.x) s_nat[i] = sn.nat[i];
   __syncthreads();
   if (idle) {
     if (lane == 0) defer_cnt[gwave] = 0u;

@@ -4,13 +4,17 @@
 
 namespace eppk {
 
-template <typename LW>
+template <typename LW, bool MASKED>
 static const void* quad_ptr(bool has_l, bool p_first) {
-  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true> : (const void*)pick_quad_kernel<LW, true, false>;
-  return (const void*)pick_quad_kernel<LW, false, false>;
+  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true, MASKED> : (const void*)pick_quad_kernel<LW, true, false, MASKED>;
+  return (const void*)pick_quad_kernel<LW, false, false, MASKED>;
 }
-const void* pick_quad_u16(bool has_l, bool p_first) { return quad_ptr<uint16_t>(has_l, p_first); }
-const void* pick_quad_u32(bool has_l, bool p_first) { return quad_ptr<uint32_t>(has_l, p_first); }
-const void* pick_quad_u64(bool has_l, bool p_first) { return quad_ptr<uint64_t>(has_l, p_first); }
+template <typename LW>
+static const void* quad_ptr(bool has_l, bool p_first, bool masked) {
+  return masked ? quad_ptr<LW, true>(has_l, p_first) : quad_ptr<LW, false>(has_l, p_first);
+}
+const void* pick_quad_u16(bool has_l, bool p_first, bool masked) { return quad_ptr<uint16_t>(has_l, p_first, masked); }
+const void* pick_quad_u32(bool has_l, bool p_first, bool masked) { return quad_ptr<uint32_t>(has_l, p_first, masked); }
+const void* pick_quad_u64(bool has_l, bool p_first, bool masked) { return quad_ptr<uint64_t>(has_l, p_first, masked); }
 
 }  // namespace eppk

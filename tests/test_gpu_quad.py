@@ -46,7 +46,7 @@ def pairs_by_pod(sets):
     return [(np.array(hs, dtype=np.uint64), np.full(len(hs), p, dtype=np.uint32)) for p, hs in sorted(by_pod.items())]
 
 
-def run(pkg, orc, wl, sets, reqs=None, slots=None, launches=1, expect_quad=True):
+def run(pkg, orc, wl, sets, reqs=None, slots=None, launches=1, expect_quad=True, mask=None):
     """Index = {hash: pods} built pod by pod; `launches` picks of the same batch; returns (quad launches, deferred requests)."""
     reqs = wl.reqs if reqs is None else reqs
     if slots is None:                                        # load <= 1/4, libeppk's recommended sizing
@@ -57,7 +57,7 @@ def run(pkg, orc, wl, sets, reqs=None, slots=None, launches=1, expect_quad=True)
     oix = orc.OracleIndex()
     for h, p in calls:
         oix.insert(h, p)
-    opicks, oscores, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B)
+    opicks, oscores, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B, mask)
     out = {}
     for on in (True, False):
         with quad_env(on):
@@ -68,7 +68,7 @@ def run(pkg, orc, wl, sets, reqs=None, slots=None, launches=1, expect_quad=True)
                     pk.index_insert(h, p)
                 pk.profile(True)
                 for _ in range(launches):
-                    picks, scores = pk.pick(reqs)
+                    picks, scores = pk.pick(reqs, mask)
                     assert_same(picks, scores, opicks, oscores)
                 stats = pk.profile_bytes()
                 out[on] = (pk.quad_stats(), stats)
@@ -245,3 +245,29 @@ def test_many_launches_in_flight_on_several_streams(pkg, orc, n_streams):
             ql, qd = pk.quad_stats()
             assert ql == (n_launch if n_streams <= 8 else 6 * 8) and qd > 0
             assert pk.launch_status() == 0
+
+
+@pytest.mark.parametrize("R,P,density", [(1024, 4096, 0.5), (1000, 4096, 0.12), (640, 1000, 0.5), (512, 777, 0.3), (256, 2048, 0.5), (96, 64, 0.5)])
+def test_candidate_masks(pkg, orc, R, P, density):
+    """Masked batches on the quad route: random subsets, rows without any candidate, rows whose candidates miss the snapshot-wide QUEUE
+    extremes (deferred: the request's own normalisers), rows whose listed pods are no candidates."""
+    wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=24, masked=True)
+    rng = np.random.default_rng(R + P)
+    W = (P + 63) // 64
+    mask = wl.mask.copy()
+    if density < 0.5:
+        for _ in range(2):
+            mask &= rng.integers(0, 2**63, (R, W), dtype=np.uint64) | (rng.integers(0, 2, (R, W), dtype=np.uint64) << np.uint64(63))
+    mask[5] = 0                                              # no candidate at all: EPPK_NO_PICK
+    mask[R // 2] = 0
+    if P % 64:
+        mask[:, -1] &= np.uint64((1 << (P % 64)) - 1)
+    # a few rows with very few candidates (they almost surely miss a pod at the minimum / maximum queue depth)
+    for r in range(7, R, 97):
+        keep = rng.choice(P, size=3, replace=False)
+        mask[r] = 0
+        for p in keep:
+            mask[r, p // 64] |= np.uint64(1) << np.uint64(p % 64)
+    ql, qd = run(pkg, orc, wl, group_sets(wl), mask=mask)
+    assert ql == 1
+    assert 0 < qd < (R // 4 if density >= 0.5 and P >= 1000 else R), f"{qd} of {R} masked requests deferred"
