@@ -1057,12 +1057,12 @@ int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
 // every device) and the shard starts at row `lo` of them.
 namespace {
 
-int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs) {
+int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row = 0) {
   for (uint32_t r = 0; r < n_reqs; ++r) {
     eppk_req_hdr h;
     std::memcpy(&h, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof h);
     if (h.n_blocks > c->cfg.max_blocks || h.adapter < -1 || h.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
-      return fail(c, EPPK_ERR_ARG, std::string(who) + ": request row " + std::to_string(r) + " out of range");
+      return fail(c, EPPK_ERR_ARG, std::string(who) + ": request row " + std::to_string(first_row + r) + " out of range");
   }
   return EPPK_OK;
 }
@@ -1087,8 +1087,9 @@ int ensure_host_staging(eppk_ctx* c, bool need_mask) {
 // rows [lo, lo + n) of a batch of `full_n` rows starting at `base` (host memory; `pinned` = the device may DMA from it directly).
 // upload_all: rows [0, full_n) go to d_reqs (the shard is then d_reqs + lo * stride), else only the shard (at d_reqs).
 // mask_on_device: c->d_mask already holds the shard's mask rows (built by subset_masks_kernel on the context stream)
+// validate_as != nullptr: the rows are validated on the way (chunk by chunk, while the previous chunk is on the PCIe link), under that name
 int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full_n, uint32_t lo, uint32_t n, bool upload_all,
-                    const uint64_t* cand_mask_shard, bool mask_on_device = false) {
+                    const uint64_t* cand_mask_shard, bool mask_on_device = false, const char* validate_as = nullptr) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   const size_t J = (c->n_pods + 63u) / 64u;
   int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
@@ -1096,13 +1097,35 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
   const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;
   const uint8_t* src = base + (size_t)up_lo * c->stride;
   if (up_n) {
-    if (!pinned) { std::memcpy(c->h_reqs, src, (size_t)up_n * c->stride); src = (const uint8_t*)c->h_reqs; }
-    HIPCHK(c, hipMemcpyAsync(c->d_reqs, src, (size_t)up_n * c->stride, hipMemcpyHostToDevice, c->stream));
+    if (pinned && !validate_as) {
+      HIPCHK(c, hipMemcpyAsync(c->d_reqs, src, (size_t)up_n * c->stride, hipMemcpyHostToDevice, c->stream));
+    } else {
+      // In chunks of whole rows: pageable caller memory goes through the pinned staging buffer, and the copy (and the validation) of
+      // chunk i + 1 runs while chunk i is on its way over PCIe (one pass over 17 MB followed by one DMA of 17 MB was 1.2 ms per
+      // 64k-request batch).  A row out of range: nothing is launched (the chunks already uploaded are simply not used).
+      const uint32_t rows_per_chunk = (uint32_t)(((size_t)2 << 20) / c->stride) ? (uint32_t)(((size_t)2 << 20) / c->stride) : 1u;
+      for (uint32_t r0 = 0; r0 < up_n; r0 += rows_per_chunk) {
+        const uint32_t nr = up_n - r0 < rows_per_chunk ? up_n - r0 : rows_per_chunk;
+        const size_t off = (size_t)r0 * c->stride, len = (size_t)nr * c->stride;
+        const uint8_t* from = src + off;
+        if (!pinned) { std::memcpy((uint8_t*)c->h_reqs + off, from, len); from = (const uint8_t*)c->h_reqs + off; }
+        if (validate_as) { rc = validate_rows(c, validate_as, from, nr, up_lo + r0); if (rc) return rc; }
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_reqs + off, from, len, hipMemcpyHostToDevice, c->stream));
+      }
+    }
   }
   if (n == 0) return EPPK_OK;
   if (cand_mask_shard && J) {
-    std::memcpy(c->h_mask, cand_mask_shard, (size_t)n * J * 8u);
-    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n * J * 8u, hipMemcpyHostToDevice, c->stream));
+    const size_t total = (size_t)n * J * 8u, chunk = (size_t)2 << 20;
+    if (cand_mask_shard == c->h_mask) {            // (eppk_pick_batch_staged: the rows are in the staging buffer already)
+      HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, total, hipMemcpyHostToDevice, c->stream));
+    } else {
+      for (size_t off = 0; off < total; off += chunk) {
+        const size_t len = total - off < chunk ? total - off : chunk;
+        std::memcpy((uint8_t*)c->h_mask + off, (const uint8_t*)cand_mask_shard + off, len);
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_mask + off, (const uint8_t*)c->h_mask + off, len, hipMemcpyHostToDevice, c->stream));
+      }
+    }
   }
   const uint8_t* d_shard = (const uint8_t*)c->d_reqs + (upload_all ? (size_t)lo * c->stride : 0u);
   rc = run_pick(c, d_shard, n, ((cand_mask_shard || mask_on_device) && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
@@ -1131,12 +1154,31 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
-  // validate rows on the host: never hand the kernel an out-of-range adapter / block count
-  int rc = validate_rows(c, "eppk_pick_batch", reqs, n_reqs);
-  if (rc) return rc;
-  rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask);
+  // (rows are validated on the host, chunk by chunk on their way to the device: never hand the kernel an out-of-range adapter / block count)
+  int rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask, false, "eppk_pick_batch");
   if (rc) return rc;
   return pick_host_end(c, n_reqs, cand_mask != nullptr, out_pick, out_score);
+}
+
+int eppk_host_staging(eppk_ctx* c, void** reqs, uint64_t** cand_mask) {
+  if (!c) return EPPK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_host_staging(c, cand_mask != nullptr);
+  if (rc) return rc;
+  if (reqs) *reqs = c->h_reqs;
+  if (cand_mask) *cand_mask = c->h_mask;
+  return EPPK_OK;
+}
+
+int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* out_pick, double* out_score) {
+  if (!c || (!out_pick && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch_staged: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_staged: n_reqs > max_batch");
+  if (!c->h_reqs || (use_mask && !c->h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: eppk_host_staging was not called for these buffers");
+  if (n_reqs == 0) return EPPK_OK;
+  int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged");
+  if (rc) return rc;
+  return pick_host_end(c, n_reqs, use_mask != 0, out_pick, out_score);
 }
 
 // ---- candidate-major pick (masked batches with few candidates) --------------------------------------------

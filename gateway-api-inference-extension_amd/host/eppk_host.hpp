@@ -559,22 +559,32 @@ class Scheduler {  // interface.go:55-66
         const std::vector<uint32_t>& idx = g->second;
         for (size_t lo = 0; lo < idx.size(); lo += opt_.max_batch) {
           const uint32_t m = (uint32_t)std::min<size_t>(opt_.max_batch, idx.size() - lo);
-          rows_.assign((size_t)m * stride, 0);
+          // best-score profiles build their rows straight in the context's pinned staging buffer (eppk_host_staging: no host copy
+          // between here and the DMA); the other pickers take a plain buffer
+          uint8_t* rows = nullptr;
+          bool staged = false;
+          if (p.spec.picker == PickerKind::BestScore) {
+            void* st = nullptr;
+            staged = eppk_host_staging(p.ctx.get(), &st, nullptr) == EPPK_OK && st != nullptr;
+            if (staged) { rows = (uint8_t*)st; std::memset(rows, 0, (size_t)m * stride); }
+          }
+          if (!staged) { rows_.assign((size_t)m * stride, 0); rows = rows_.data(); }
           for (uint32_t i = 0; i < m; ++i) {
             const Request& rq = requests[idx[lo + i]];
             eppk_req_hdr hdr;
             auto it = adapters_.find(rq.target_model);
             hdr.adapter = it == adapters_.end() ? EPPK_ADAPTER_BASE : it->second;
             const int nb = eppk_hash_prompt((const uint8_t*)rq.target_model.data(), rq.target_model.size(), (const uint8_t*)rq.prompt.data(), rq.prompt.size(),
-                                            opt_.block_chars, (uint64_t*)(rows_.data() + (size_t)i * stride + 8), opt_.max_blocks);
+                                            opt_.block_chars, (uint64_t*)(rows + (size_t)i * stride + 8), opt_.max_blocks);
             hdr.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
-            std::memcpy(rows_.data() + (size_t)i * stride, &hdr, sizeof hdr);
+            std::memcpy(rows + (size_t)i * stride, &hdr, sizeof hdr);
           }
           picks_.resize(m); scores_.resize(m);
           // the random-top-k rule hashes a request's index in the batch handed to the library: this profile's group, in request order
-          const int rc = p.spec.picker == PickerKind::BestScore
-                             ? eppk_pick_batch(p.ctx.get(), rows_.data(), m, nullptr, picks_.data(), scores_.data())
-                             : eppk_pick_random_topk(p.ctx.get(), rows_.data(), m, nullptr, p.spec.k, seed + lo, picks_.data(), scores_.data());
+          const int rc = staged ? eppk_pick_batch_staged(p.ctx.get(), m, 0, picks_.data(), scores_.data())
+                         : p.spec.picker == PickerKind::BestScore
+                             ? eppk_pick_batch(p.ctx.get(), rows, m, nullptr, picks_.data(), scores_.data())
+                             : eppk_pick_random_topk(p.ctx.get(), rows, m, nullptr, p.spec.k, seed + lo, picks_.data(), scores_.data());
           if (rc != EPPK_OK) return {Code::Internal, eppk_last_error(p.ctx.get())};
           for (uint32_t i = 0; i < m; ++i) {
             auto& res = results[idx[lo + i]][p.spec.name];     // (present even when empty: the profile has run)

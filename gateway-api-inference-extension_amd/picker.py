@@ -314,6 +314,26 @@ class BatchedPicker:
         self._check(self._lib.eppk_pick_batch(self._ctx, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data), "pick_batch")
         return picks, scores
 
+    def staging(self, with_mask: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """The context's pinned staging buffers as numpy arrays: [max_batch, row_words] u64 request rows and a FLAT u64 array for the
+        mask rows (pack them [R, ceil(n_pods / 64)] at its start): fill the first R rows in place, then `pick_staged(R)`
+        (include/eppk.h eppk_host_staging)."""
+        rp, mp = C.c_void_p(0), C.c_void_p(0)
+        self._check(self._lib.eppk_host_staging(self._ctx, C.byref(rp), C.byref(mp) if with_mask else None), "host_staging")
+        reqs = np.frombuffer((C.c_uint64 * (self.max_batch * self.row_words)).from_address(rp.value), dtype=np.uint64).reshape(self.max_batch, self.row_words)
+        mask = None
+        if with_mask:
+            jmax = (self.max_pods + 63) // 64
+            mask = np.frombuffer((C.c_uint64 * (self.max_batch * jmax)).from_address(mp.value), dtype=np.uint64)
+        return reqs, mask
+
+    def pick_staged(self, R: int, use_mask: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """`pick` over the first R rows of the staging buffers (mask rows: [R, ceil(n_pods/64)] packed at the START of the mask buffer)."""
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        self._check(self._lib.eppk_pick_batch_staged(self._ctx, R, 1 if use_mask else 0, picks.ctypes.data, scores.ctypes.data), "pick_batch_staged")
+        return picks, scores
+
     # -- subset filter resolved on the device (include/eppk.h "the subset filter for a whole batch") ------------------
     def set_addresses(self, endpoints: Sequence[Optional[Endpoint]]) -> None:
         """Address / port of every slot of the CURRENT snapshot (None = a hole)."""

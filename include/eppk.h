@@ -195,6 +195,15 @@ int eppk_index_evict_older_device(eppk_ctx* ctx, uint32_t min_epoch, void* strea
 int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask,
                     int32_t* out_pick, double* out_score);
 
+/* The context's pinned staging buffers (allocated on first use, max_batch rows each; *cand_mask only when asked for): a caller that
+ * BUILDS its request rows -- and candidate mask rows, [n][ceil(n_pods / 64)] u64 -- right there saves the copy eppk_pick_batch makes of
+ * pageable caller memory (that copy, not PCIe, is most of a 64k-request batch's 1.2 ms; INTEGRATION.md: the cgo dispatcher fills
+ * C memory anyway).  Valid until eppk_destroy; not to be written while a eppk_pick_batch* call of this context is running. */
+int eppk_host_staging(eppk_ctx* ctx, void** reqs, uint64_t** cand_mask);
+/* eppk_pick_batch over the first n_reqs rows (and, with use_mask != 0, mask rows) of the staging buffers: same validation, same
+ * results, no host copy. */
+int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t* out_pick, double* out_score);
+
 /* Same, with every buffer already resident in this device's HBM; asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the context's own NON-BLOCKING stream, which is not ordered against the
  * legacy default stream — callers that mix this with other GPU work pass their own stream).  No n_reqs limit. */
