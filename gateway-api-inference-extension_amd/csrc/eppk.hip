@@ -296,8 +296,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   // pick_quad_kernel first (four requests per wavefront: the common shape of a request), then the fast kernel's work-list
   // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
-  bool quad = fast && c->quad_on && topk == 1 && c->has_p && c->npl == 6 && !c->gen && c->pterm && ix.lists && ix.slots != 0u &&
-              c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
+  bool quad = fast && c->quad_on && (topk == 1 || !masked) /* ordered fallbacks: unmasked batches only */ && c->has_p && c->npl == 6 && !c->gen &&
+              c->pterm && ix.lists && ix.slots != 0u && c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
   if (quad) quad_consume_reports(c);
   if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
   eppk_ctx::DeferSet* dset = nullptr;
@@ -312,8 +312,9 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0, rep_slot = 0;
   size_t quad_lds = 0;
   if (quad) {
-    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked)
-                                                                                                     : eppk::pick_quad_u64(c->has_l, c->p_first, masked);
+    const bool tkq = topk > 1;
+    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked, tkq)
+                                                                                                          : eppk::pick_quad_u64(c->has_l, c->p_first, masked, tkq);
     const uint32_t qwpb = c->quad_threads / 64u;
     // LDS: base[] | lw[4] | pterm | one "listed" bit per pod for each of the 4 rows of each wavefront
     //      (masked: + the snapshot's three natural-layout sets + the candidate words of each row)
@@ -376,14 +377,19 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       ++dset->uses;
       uint32_t* d_cnt = dset->d + 16;
       uint32_t* d_list = dset->d + 16 + quad_segs;
-      void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next};
+      void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next,
+                       &topk};
       HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, nullptr, 0));
       e0 = nullptr;                         // (the pair is timed from the quad kernel's start to the work-list kernel's end)
       wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = (uint32_t*)&c->h_reports[rep_slot]; wk.cap = defer_cap; wk.n_segs = quad_segs;
       // the work-list instantiation of the same fast kernel (same LDS, same geometry)
       const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);
-      fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big, masked) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big, masked)
-                                                                                                           : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big, masked);
+      if (topk > 1)
+        fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_topk_u16(c->has_l, c->p_first, big) : c->lw_bytes == 4 ? eppk::pick_fast_wl_topk_u32(c->has_l, c->p_first, big)
+                                                                                                          : eppk::pick_fast_wl_topk_u64(c->has_l, c->p_first, big);
+      else
+        fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big, masked) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big, masked)
+                                                                                                             : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big, masked);
       if (fn != c->wl_occ_fn || lds != c->wl_occ_lds) {
         if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;

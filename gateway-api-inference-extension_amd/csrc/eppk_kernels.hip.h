@@ -1565,13 +1565,17 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 // ds_read_b64 for a listed pod or a table entry.  No candidate at all: EPPK_NO_PICK right here.  Candidates that miss the snapshot-wide
 // QUEUE extremes need the request's own normalisers: deferred (pick_fast_kernel's exact evaluation), like a request whose first 16 table
 // entries hold no candidate outside its list.
-template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false>
+// TOPK: ordered fallbacks (eppk_pick_topk: out_pick / out_score hold topk entries per request).  The candidates of a row sit in its
+// lanes -- the listed pods' totals (ids 4q + j and 16 + 4q + j) and the 16 table entries that are not listed -- so round i of the
+// merge is one more row argmax over each lane's best remaining candidate; the winner leaves the pool.  A round that finds the table's
+// pool empty although the table goes on beyond its 16th entry cannot know the next value: deferred.
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false>
 __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                                  uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                                  int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                                  unsigned long long* __restrict__ stats,
                                                                  uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next) {
+                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -1923,11 +1927,13 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const double tA = total_of(pA, thA, tlA);
     double best = lsA ? tA : -__builtin_inf();
     uint32_t bidx = lsA ? pA : kNoPod;
+    double tB_keep = -__builtin_inf();                                // (TOPK: the second listed pod of the lane stays a candidate of its own)
     const bool anyB = __any(lsB);
     if (anyB) {                                                       // a list of more than 16 pods
       LW thB = 0, tlB = 0;
       if (HAS_L) load_tier_pair(arow, pB, thB, tlB);
       const double tB = total_of(pB, thB, tlB);
+      tB_keep = tB;
       if (lsB && (tB > best || (tB == best && pB < bidx))) { best = tB; bidx = pB; }
     }
     // ---- "listed" bitmap of the row (LDS): set, look the table entries up, clear
@@ -1941,19 +1947,53 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     wave_lds_fence();
     if (lsA) bits[pA >> 5] = 0u;
     if (anyB && lsB) bits[pB >> 5] = 0u;
-    // ---- argmax over the row: (total desc, pod asc)
+    const uint32_t tvr = row16(__ballot(tpv));
+    if constexpr (TOPK) {
+      // ---- ordered fallbacks: topk rounds of a row argmax over every lane's best remaining candidate
+      bool vA = lsA, vB = lsB, vT = tok;
+      const uint32_t tk = topk;
+      for (uint32_t round = 0; round < tk; ++round) {
+        badm |= __ballot(row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand);   // the table's pool is empty but the table goes on: entry 17.. is unknown
+        double lb = vA ? tA : -__builtin_inf();
+        uint32_t lp = vA ? pA : kNoPod;
+        if (vB && (tB_keep > lb || (tB_keep == lb && pB < lp))) { lb = tB_keep; lp = pB; }
+        if (vT && (top_t > lb || (top_t == lb && top_p < lp))) { lb = top_t; lp = top_p; }
+        double wm = lb;
+        wm = vmax_f64(wm, dpp_f64<0xB1, 0xf>(wm));
+        wm = vmax_f64(wm, dpp_f64<0x4E, 0xf>(wm));
+        wm = vmax_f64(wm, dpp_f64<0x141, 0xf>(wm));
+        wm = vmax_f64(wm, dpp_f64<0x140, 0xf>(wm));
+        uint32_t wi = lb == wm ? lp : kNoPod;
+        wi = dpp_min_u32<0xB1, 0xf>(wi);
+        wi = dpp_min_u32<0x4E, 0xf>(wi);
+        wi = dpp_min_u32<0x141, 0xf>(wi);
+        wi = dpp_min_u32<0x140, 0xf>(wi);
+        const bool none = wi == kNoPod || no_cand;
+        if (k == 0u && live) {                                        // (stored right away; a row that ends up deferred is rewritten by the work-list pass)
+          out_pick[(size_t)r * tk + round] = none ? -1 : (int32_t)wi;
+          if (out_score) out_score[(size_t)r * tk + round] = none ? 0.0 : wm;
+        }
+        if (vA && pA == wi) vA = false;                               // the winner leaves the pool
+        if (vB && pB == wi) vB = false;
+        if (vT && top_p == wi) vT = false;
+      }
+    }
     double wmax = best;
+    uint32_t widx = kNoPod;
+    if constexpr (!TOPK) {
+    // ---- argmax over the row: (total desc, pod asc)
+    wmax = best;
     wmax = vmax_f64(wmax, dpp_f64<0xB1, 0xf>(wmax));
     wmax = vmax_f64(wmax, dpp_f64<0x4E, 0xf>(wmax));
     wmax = vmax_f64(wmax, dpp_f64<0x141, 0xf>(wmax));
     wmax = vmax_f64(wmax, dpp_f64<0x140, 0xf>(wmax));
-    uint32_t widx = best == wmax ? bidx : kNoPod;
+    widx = best == wmax ? bidx : kNoPod;
     widx = dpp_min_u32<0xB1, 0xf>(widx);
     widx = dpp_min_u32<0x4E, 0xf>(widx);
     widx = dpp_min_u32<0x141, 0xf>(widx);
     widx = dpp_min_u32<0x140, 0xf>(widx);
     // ---- best pod outside the list: the first table entry that is not listed
-    const uint32_t okr = row16(__ballot(tok)), tvr = row16(__ballot(tpv));
+    const uint32_t okr = row16(__ballot(tok));
     const uint32_t e = (uint32_t)__builtin_ctz(okr | 0x10000u);       // 16: none among the 16 entries
     badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand);         // all 16 exist and are listed (or no candidates): the rest of the table is needed
     const uint32_t src = gsh + (e & 15u);
@@ -1961,15 +2001,18 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     uint32_t cand_p = (uint32_t)__shfl((int)top_p, (int)src);
     if (e == 16u) { cand_t = -__builtin_inf(); cand_p = kNoPod; }
     if (cand_t > wmax || (cand_t == wmax && cand_p < widx)) { wmax = cand_t; widx = cand_p; }
+    }
     // ---- store, or defer
     const bool gbad = row16(badm) != 0u;
     const bool lead = k == 0u && live;
     const unsigned long long dm = __ballot(lead && gbad);
     if (lead) {      // (one store instruction for pick and score -- lanes 0 / 1 / 2 of a row writing pick / score halves -- was measured: no gain)
       if (!gbad) {
-        const bool none = widx == kNoPod || no_cand;
-        out_pick[r] = none ? -1 : (int32_t)widx;
-        if (out_score) out_score[r] = none ? 0.0 : wmax;
+        if constexpr (!TOPK) {
+          const bool none = widx == kNoPod || no_cand;
+          out_pick[r] = none ? -1 : (int32_t)widx;
+          if (out_score) out_score[r] = none ? 0.0 : wmax;
+        }
         if (!no_cand) {                                                 // (like pick_fast_kernel: a request without candidates is not counted)
           acc_hits += m;
           acc_look += (m + 1u < nb) ? m + 1u : nb;

@@ -271,3 +271,33 @@ def test_candidate_masks(pkg, orc, R, P, density):
     ql, qd = run(pkg, orc, wl, group_sets(wl), mask=mask)
     assert ql == 1
     assert 0 < qd < (R // 4 if density >= 0.5 and P >= 1000 else R), f"{qd} of {R} masked requests deferred"
+
+
+@pytest.mark.parametrize("R,P,k", [(512, 4096, 2), (777, 4096, 8), (300, 1000, 3), (256, 64, 8), (128, 12, 8)])
+def test_ordered_fallbacks(pkg, orc, R, P, k):
+    """eppk_pick_topk on the quad route: the k best candidates in order (listed pods and top-table entries merged in the row); lists of
+    up to 24 pods, tables that run out (few pods), requests with long matches."""
+    wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=12)
+    sets = group_sets(wl)
+    rng = np.random.default_rng(R * k)
+    grown = {}
+    for h, pods in list(sets.items()):                       # some groups cached on many pods (the second id of a lane comes into play)
+        if pods not in grown:
+            extra = rng.choice(P, size=min(P, 14), replace=False).tolist() if len(grown) % 3 == 0 else []
+            grown[pods] = tuple(sorted(set(pods) | set(extra)))[:24]
+        sets[h] = grown[pods]
+    calls = pairs_by_pod(sets)
+    oix = orc.OracleIndex()
+    for h, p in calls:
+        oix.insert(h, p)
+    want_p, want_s = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, k)
+    with quad_env(True):
+        with pkg.BatchedPicker(wl.chain, max_pods=max(P, 64), max_blocks=wl.B, max_batch=R, index_slots=max(wl.index_slots, 1024)) as pk:
+            pk.publish(wl.pods)
+            for h, p in calls:
+                pk.index_insert(h, p)
+            got_p, got_s = pk.pick_topk(wl.reqs, k)
+            ql, qd = pk.quad_stats()
+    assert np.array_equal(got_p, want_p), f"{np.count_nonzero(got_p != want_p)} entries differ"
+    assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64))
+    assert ql == 1 and qd < R
