@@ -208,7 +208,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
             assert d["config"]["distinct_batches"] == 3
 
 
-def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5")):
+def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5"), requests=64):
     """One rank of a world-size-2 dry run: the same stand-ins, patched by hand (no pytest fixtures in a spawned process)."""
     sys.path.insert(0, ROOT)
     import torch
@@ -225,7 +225,7 @@ def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5")):
     dist.init_process_group = lambda backend=None, device_id=None, **k: real_init("gloo", rank=rank, world_size=world)
     log = []
     pkg.BatchedPicker = _fake_picker_class(pkg, orc, log)
-    sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", "64", "--steps", "10", "--warmup", "3", "--p99-samples", "0",
+    sys.argv = ["bench.py", "--gpus", str(world), "--config", "3", "--requests", str(requests), "--steps", "10", "--warmup", "3", "--p99-samples", "0",
                 *extra_args]
     out = io.StringIO()
     with redirect_stdout(out):
@@ -255,3 +255,15 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     # weak scaling timed beside it: a whole batch per rank and step, the aggregate counts BOTH ranks
     w = d["weak"]
     assert w["requests_per_gpu"] == 64 and abs(w["value"] - 2 * 64 * 10 / (w["ms_per_step"] * 1e-3 * 10)) < 1e-6 * w["value"]
+
+
+def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
+    """71 requests over 2 ranks: shards of 36 and 35 rows; the short shard is padded with filler rows inside the grouped launches and
+    the gathered batch still equals the oracle's."""
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), ("--batches", "8", "--gather-every", "4"), 71), nprocs=world, join=True)
+    out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
+    d = json.loads(out0[-1])
+    assert d["n_gpus"] == 2 and d["config"]["requests_per_gpu"] == 36 and d["config"]["requests_per_step"] == 71
+    assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 4 * 36
+    assert d["parity"]["gathered_picks_equal_oracle"] is True
