@@ -168,6 +168,12 @@ class Runner:
                 if self.n_mine < self.per:                       # a ragged last shard: valid filler rows (their picks are never looked at)
                     self.d_shards[b, self.n_mine:] = v[self.lo:self.lo + 1]
             self.p_shards = self.d_shards.data_ptr()
+            # one full-size launch per compute stream now: the library sizes a stream's work-list buffer at its first launch of that size
+            # (a hipMalloc behind a stream synchronize), and with 16 steps per launch the second stream's first launch would otherwise
+            # fall into the timed region
+            for c in self.computes:
+                self.pk.pick_device(self.p_shards, G * self.per, None, self.d_picks[0].data_ptr(), self.d_scores[0].data_ptr(), c.cuda_stream)
+            torch.cuda.synchronize()
         self.launch_requests = (G * self.per) if self.grouped else self.n_mine
         self.p_picks = [t.data_ptr() for t in self.d_picks]
         self.p_scores = [t.data_ptr() for t in self.d_scores]

@@ -199,7 +199,8 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
             assert n_picks >= (steps + 15) // 16 + steps + extra                              # (extra = launches beyond the timed region: samples)
         else:
             assert n_picks >= steps + extra
-        assert sum(1 for e in log if e[0] == "wait") == n_picks                          # one cross-stream dependency per launch
+        warm = 2 if both else 0                                                            # (grouped mode: one sizing launch per compute stream in setup)
+        assert sum(1 for e in log if e[0] == "wait") == n_picks - warm                   # one cross-stream dependency per launch
         if extra:
             assert d["roofline"]["kernel_samples"] >= 40
     else:
