@@ -103,6 +103,11 @@ class Backend {
   virtual ~Backend() = default;
   virtual int Publish(const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) = 0;
   virtual int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) = 0;
+  // Optional: a buffer of the backend's own (pinned, DMA-able) in which the caller may BUILD up to max_batch request rows, and the
+  // pick over the first n rows in it without candidate masks (eppk_host_staging / eppk_pick_batch_staged: no host copy on the way
+  // to the device).  nullptr = not offered.
+  virtual void* StagingRows() { return nullptr; }
+  virtual int PickStaged(uint32_t, int32_t*, double*) { return EPPK_ERR_ARG; }
   // k ordered candidates per request (pick + fallbacks), picks/scores hold n*k entries (eppk_pick_topk)
   virtual int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) = 0;
   // prefix index: pods[i] has cached the block with hash hashes[i] ("hash(chunk i): append server", 0602-…/README.md:101-108)
@@ -127,6 +132,11 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
     return eppk_pick_batch(ctx_, reqs, n, mask, picks, scores);
   }
+  void* StagingRows() override {
+    if (!staging_ && eppk_host_staging(ctx_, &staging_, nullptr) != EPPK_OK) staging_ = nullptr;
+    return staging_;
+  }
+  int PickStaged(uint32_t n, int32_t* picks, double* scores) override { return eppk_pick_batch_staged(ctx_, n, 0, picks, scores); }
   int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
     return eppk_pick_topk(ctx_, reqs, n, mask, k, picks, scores);
   }
@@ -140,6 +150,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
  private:
   explicit LibEppkBackend(eppk_ctx* c) : ctx_(c) {}
   eppk_ctx* ctx_;
+  void* staging_ = nullptr;       // the context's pinned request-row buffer (eppk_host_staging), fetched on first use
 };
 
 // ---- GpuPicker: EndpointPicker over batched picks -------------------------------------------------------
@@ -322,7 +333,12 @@ class GpuPicker : public EndpointPicker {
         failed = !snap;
         if (!failed) {
           const uint32_t P = (uint32_t)snap->endpoints.size(), W = (P + 63u) / 64u;
-          rows.assign(n * stride_, 0);
+          // rows are built in the backend's pinned staging buffer when it offers one: a batch without candidate masks then goes to
+          // the device without another host copy (eppk_pick_batch_staged)
+          uint8_t* rowp = (uint8_t*)be_->StagingRows();
+          const bool staged = rowp != nullptr;
+          if (staged) std::memset(rowp, 0, n * stride_);
+          else { rows.assign(n * stride_, 0); rowp = rows.data(); }
           bool any_mask = false;
           mask.assign(n * (size_t)(W ? W : 1), 0);
           for (size_t i = 0; i < n; ++i) {
@@ -331,9 +347,9 @@ class GpuPicker : public EndpointPicker {
             auto it = snap->adapters.find(rq.model);
             hdr.adapter = it == snap->adapters.end() ? EPPK_ADAPTER_BASE : it->second;
             int nb = eppk_hash_prompt((const uint8_t*)rq.model.data(), rq.model.size(), (const uint8_t*)rq.body.data(), rq.body.size(),
-                                      opt_.block_chars, (uint64_t*)(rows.data() + i * stride_ + 8), opt_.max_blocks);
+                                      opt_.block_chars, (uint64_t*)(rowp + i * stride_ + 8), opt_.max_blocks);
             hdr.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
-            std::memcpy(rows.data() + i * stride_, &hdr, sizeof hdr);
+            std::memcpy(rowp + i * stride_, &hdr, sizeof hdr);
             // candidate slice -> bitmask over snapshot indices (the subset filter already ran: request.go:104-133)
             uint32_t found = 0;
             for (const Endpoint* e : *batch[i]->cands) {
@@ -348,8 +364,14 @@ class GpuPicker : public EndpointPicker {
           const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
           picks.resize(n * k);
           scores.resize(n * k);
-          const int rc = k == 1 ? be_->PickBatch(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data())
-                                : be_->PickTopK(rows.data(), (uint32_t)n, any_mask ? mask.data() : nullptr, k, picks.data(), scores.data());
+          int rc;
+          if (staged && k == 1 && !any_mask) {
+            rc = be_->PickStaged((uint32_t)n, picks.data(), scores.data());
+          } else {
+            if (staged) { rows.assign(rowp, rowp + n * stride_); rowp = rows.data(); }     // (the other entry points copy FROM caller memory INTO that buffer)
+            rc = k == 1 ? be_->PickBatch(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data())
+                        : be_->PickTopK(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, k, picks.data(), scores.data());
+          }
           failed = rc != EPPK_OK;
           if (!failed)
             for (size_t i = 0; i < n; ++i) {
@@ -370,8 +392,8 @@ class GpuPicker : public EndpointPicker {
               const int32_t p = picks[i * k];
               if (p < 0) continue;
               eppk_req_hdr hdr;
-              std::memcpy(&hdr, rows.data() + i * stride_, sizeof hdr);
-              const uint64_t* h = (const uint64_t*)(rows.data() + i * stride_ + 8);
+              std::memcpy(&hdr, rowp + i * stride_, sizeof hdr);
+              const uint64_t* h = (const uint64_t*)(rowp + i * stride_ + 8);
               for (uint32_t b = 0; b < hdr.n_blocks; ++b) { learn_h.push_back(h[b]); learn_p.push_back((uint32_t)p); }
             }
             if (!learn_h.empty() && be_->IndexInsert(learn_h.data(), learn_p.data(), (uint32_t)learn_h.size()) != EPPK_OK)
