@@ -1,0 +1,85 @@
+// host/eppk_metrics.hpp on CPU: Prometheus text -> eppk_pod_row (the model-server protocol of docs/proposals/003-…/README.md).
+#include <cassert>
+#include <cstdio>
+#include <cmath>
+#include <map>
+#include <string>
+
+#include "../../gateway-api-inference-extension_amd/host/eppk_metrics.hpp"
+
+using namespace eppk_host;
+
+#define CHECK(x) do { if (!(x)) { std::fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #x); return 1; } } while (0)
+
+int main() {
+  const std::map<std::string, int32_t> ids = {{"adapter1", 0}, {"adapter2", 1}, {"sql-lora", 64}, {"big", 127}, {"out-of-range", 200}};
+
+  // --- a vLLM-shaped body: comments, labels, timestamps, two lora series (the later one counts)
+  const std::string vllm =
+      "# HELP vllm:num_requests_waiting Number of requests waiting to be processed.\n"
+      "# TYPE vllm:num_requests_waiting gauge\n"
+      "vllm:num_requests_waiting{model_name=\"meta-llama/Llama-3.1-8B\"} 7.0\n"
+      "vllm:num_requests_running{model_name=\"meta-llama/Llama-3.1-8B\"} 3 1712345678000\n"
+      "vllm:kv_cache_usage_perc{model_name=\"meta-llama/Llama-3.1-8B\"} 0.4375\n"
+      "vllm:cache_config_info{block_size=\"16\",cache_dtype=\"auto\",num_gpu_blocks=\"27000\"} 1.0\n"
+      "vllm:lora_requests_info{max_lora=\"4\",running_lora_adapters=\"adapter1\",waiting_lora_adapters=\"\"} 1.7123e+09\n"
+      "vllm:lora_requests_info{max_lora=\"8\",running_lora_adapters=\"adapter2, sql-lora\",waiting_lora_adapters=\"big,unknown-one , out-of-range\"} 1.7124e+09\n"
+      "vllm:some_histogram_bucket{le=\"+Inf\"} 12\n"
+      "this line is not a sample\n"
+      "\n";
+  ScrapeResult r = ParseModelServerMetrics(vllm, ids);
+  CHECK(r.complete() && r.has_running && r.has_lora);
+  CHECK(r.row.queue == 7 && r.row.running == 3 && r.row.kv_util == 0.4375 && r.row.flags == 0);
+  CHECK(r.row.max_lora == 8);
+  CHECK(r.row.active[0] == 2ull && r.row.active[1] == 1ull);            // adapter2 (id 1), sql-lora (id 64)
+  CHECK(r.row.waiting[0] == 0ull && r.row.waiting[1] == (1ull << 63));  // big (id 127)
+  CHECK(r.unknown_adapters.size() == 2 && r.unknown_adapters[0] == "unknown-one" && r.unknown_adapters[1] == "out-of-range");
+  CHECK(r.block_size == 16 && r.num_gpu_blocks == 27000);
+  CHECK(r.malformed_lines == 1);
+
+  // --- Triton-shaped names: one metric name, the series picked by a label (README.md:30-32)
+  MetricNames tr;
+  tr.queued = MetricSpec::Parse("nv_trt_llm_request_metrics{request_type=waiting}");
+  tr.running = MetricSpec::Parse("nv_trt_llm_request_metrics{request_type=\"scheduled\"}");
+  tr.kv_util = MetricSpec::Parse("nv_trt_llm_kv_cache_block_metrics{kv_cache_block_type=fraction}");
+  const std::string triton =
+      "nv_trt_llm_request_metrics{model=\"m\",request_type=\"waiting\",version=\"1\"} 11\n"
+      "nv_trt_llm_request_metrics{model=\"m\",request_type=\"scheduled\",version=\"1\"} 5\n"
+      "nv_trt_llm_request_metrics{model=\"m\",request_type=\"max\",version=\"1\"} 512\n"
+      "nv_trt_llm_kv_cache_block_metrics{kv_cache_block_type=\"fraction\",model=\"m\"} 0.25\n"
+      "nv_trt_llm_kv_cache_block_metrics{kv_cache_block_type=\"max\",model=\"m\"} 4096\n";
+  ScrapeResult t = ParseModelServerMetrics(triton, ids, tr);
+  CHECK(t.complete() && !t.has_lora && t.row.queue == 11 && t.row.running == 5 && t.row.kv_util == 0.25 && t.row.max_lora == 0);
+
+  // --- several series of one gauge (a server with two models): counts add up, utilisation takes the maximum
+  const std::string two =
+      "vllm:num_requests_waiting{model_name=\"a\"} 2\nvllm:num_requests_waiting{model_name=\"b\"} 3\n"
+      "vllm:kv_cache_usage_perc{model_name=\"a\"} 0.5\nvllm:kv_cache_usage_perc{model_name=\"b\"} 0.125\n";
+  ScrapeResult w = ParseModelServerMetrics(two, ids);
+  CHECK(w.row.queue == 5 && w.row.kv_util == 0.5 && !w.has_running);
+
+  // --- label escapes, NaN, negative and huge values
+  Sample s;
+  bool bad = false;
+  CHECK(ParseSample("m{a=\"x\\\"y\\\\z\\nq\",b=\"\"} -1.5e3 17", &s, &bad) && !bad);
+  CHECK(s.name == "m" && s.labels.size() == 2 && *s.Label("a") == "x\"y\\z\nq" && *s.Label("b") == "" && s.value == -1500.0);
+  CHECK(ParseSample("plain 42", &s) && s.labels.empty() && s.value == 42.0);
+  CHECK(ParseSample("g NaN", &s) && std::isnan(s.value));
+  CHECK(ParseSample("g +Inf", &s) && std::isinf(s.value));
+  CHECK(!ParseSample("# TYPE g gauge", &s, &bad) && !bad);
+  CHECK(!ParseSample("g{a=\"unterminated} 1", &s, &bad) && bad);
+  CHECK(!ParseSample("g{a=1} 1", &s, &bad) && bad);
+  CHECK(!ParseSample("g notanumber", &s, &bad) && bad);
+  const std::string odd = "vllm:num_requests_waiting -4\nvllm:kv_cache_usage_perc NaN\nvllm:num_requests_running 1e12\n";
+  ScrapeResult o = ParseModelServerMetrics(odd, ids);
+  CHECK(o.row.queue == 0 && o.row.running == 0xFFFFFFFFu && !o.has_kv && !o.complete());
+
+  // --- a snapshot: an endpoint without a usable scrape becomes a hole
+  std::vector<ScrapeResult> det;
+  std::vector<eppk_pod_row> rows = BuildPodRows({vllm, "", two, "garbage only\n"}, ids, MetricNames(), &det);
+  CHECK(rows.size() == 4 && det.size() == 4);
+  CHECK(rows[0].flags == 0 && rows[0].queue == 7 && rows[2].flags == 0 && rows[2].queue == 5);
+  CHECK(rows[1].flags == EPPK_POD_INACTIVE && rows[3].flags == EPPK_POD_INACTIVE && rows[3].queue == 0);
+  std::printf("metrics ok\n");
+  return 0;
+}
