@@ -1,15 +1,85 @@
-"""host/eppk_metrics.hpp (the extractor half of the metrics scraper: Prometheus text of a model server -> eppk_pod_row, after
-docs/proposals/003-model-server-protocol/README.md) compiled with g++ and run on the CPU: tests/cpp/test_metrics.cpp."""
+"""The snapshot producer's input side, compiled with g++ and run on the CPU (no GPU, no libeppk):
+  * host/eppk_metrics.hpp — extractor: Prometheus text of a model server -> eppk_pod_row (docs/proposals/003-model-server-protocol);
+  * host/eppk_scrape.hpp  — data source: HTTP GET of every endpoint's /metrics + the collector that keeps the latest row per endpoint
+    (the DataSource / DataCollection interfaces of docs/proposals/1023-data-layer-architecture), against fixture servers started here."""
+import http.server
 import os
+import socket
 import subprocess
+import threading
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "cpp", "test_metrics.cpp")
-EXE = os.path.join(ROOT, "tests", "cpp", "test_metrics")
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _build(name, extra=()):
+    exe = os.path.join(CPP, name)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", exe + ".cpp", "-o", exe, *extra], check=True)
+    return exe
 
 
 def test_metrics_extractor():
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", SRC, "-o", EXE], check=True)
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([_build("test_metrics")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "metrics ok" in out.stdout
+
+
+BODY_A = (b"# TYPE vllm:num_requests_waiting gauge\n"
+          b"vllm:num_requests_waiting{model_name=\"m\"} 7.0\n"
+          b"vllm:num_requests_running{model_name=\"m\"} 3.0\n"
+          b"vllm:kv_cache_usage_perc{model_name=\"m\"} 0.4375\n"
+          b"vllm:lora_requests_info{max_lora=\"4\",running_lora_adapters=\"adapter1,adapter2\",waiting_lora_adapters=\"\"} 1.7e+09\n")
+BODY_B = b"vllm:num_requests_waiting 5\nvllm:kv_cache_usage_perc 0.5\n" + b"# padding\n" * 3000      # > one chunk, > one recv
+
+
+def _handler(kind):
+    class H(http.server.BaseHTTPRequestHandler):
+        protocol_version = "HTTP/1.1"
+
+        def log_message(self, *a):
+            pass
+
+        def do_GET(self):
+            if self.path != "/metrics" or kind == "503":
+                self.send_response(503 if kind == "503" else 404)
+                self.send_header("Content-Length", "0")
+                self.end_headers()
+                return
+            self.send_response(200)
+            self.send_header("Content-Type", "text/plain; version=0.0.4")
+            if kind == "len":
+                self.send_header("Content-Length", str(len(BODY_A)))
+                self.end_headers()
+                self.wfile.write(BODY_A)
+            else:
+                self.send_header("Transfer-Encoding", "chunked")
+                self.end_headers()
+                for i in range(0, len(BODY_B), 4093):
+                    part = BODY_B[i:i + 4093]
+                    self.wfile.write(b"%x\r\n" % len(part) + part + b"\r\n")
+                self.wfile.write(b"0\r\n\r\n")
+    return H
+
+
+def test_metrics_data_source():
+    exe = _build("test_scrape", ["-pthread"])
+    servers = [http.server.ThreadingHTTPServer(("127.0.0.1", 0), _handler(k)) for k in ("len", "chunked", "503")]
+    for s in servers:
+        threading.Thread(target=s.serve_forever, daemon=True).start()
+    silent = socket.socket()                 # accepts (backlog) and never answers
+    silent.bind(("127.0.0.1", 0))
+    silent.listen(64)
+    closed = socket.socket()                 # a port nobody listens on
+    closed.bind(("127.0.0.1", 0))
+    closed_port = closed.getsockname()[1]
+    closed.close()
+    try:
+        ports = [str(s.server_address[1]) for s in servers] + [str(silent.getsockname()[1]), str(closed_port)]
+        out = subprocess.run([exe, *ports], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr + out.stdout
+        assert "scrape ok" in out.stdout
+    finally:
+        for s in servers:
+            s.shutdown()
+            s.server_close()
+        silent.close()
