@@ -57,6 +57,11 @@ def load() -> C.CDLL:
     lib.orc_pick_batch_assumed.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, vp, vp]
     lib.orc_pick_random_topk.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, u64, vp, vp]
     lib.orc_index_insert_picks.argtypes = [vp, vp, u32, u32, vp]
+    lib.orc_tables_new.argtypes = [vp, u32, vp, u32]
+    lib.orc_tables_new.restype = vp
+    lib.orc_tables_free.argtypes = [vp]
+    lib.orc_tables_free.restype = None
+    lib.orc_pick_batch_sparse.argtypes = [vp, vp, vp, u32, u32, vp, vp, C.c_int]
     lib.orc_index_insert_picks.restype = None
     lib.orc_xxh64.argtypes = [vp, C.c_size_t, u64]
     lib.orc_xxh64.restype = u64
@@ -158,6 +163,40 @@ def pick_batch(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.n
     if rc != 0:
         raise RuntimeError(f"oracle rc={rc}")
     return picks, scores, probes
+
+
+class OracleTables:
+    """Per (chain, snapshot) tables of the second CPU algorithm (oracle.c: orc_pick_batch_sparse); keeps `pods` alive."""
+
+    def __init__(self, chain, pods: np.ndarray) -> None:
+        self._lib = load()
+        self._chain = _chain_array(chain)
+        self._pods = np.ascontiguousarray(pods)
+        assert self._pods.dtype.itemsize == 64
+        self.h = self._lib.orc_tables_new(self._chain.ctypes.data, len(chain), self._pods.ctypes.data, self._pods.shape[0])
+        if not self.h:
+            raise RuntimeError("orc_tables_new failed")
+
+    def pick_batch(self, index: Optional[OracleIndex], reqs: np.ndarray, max_blocks: int, threads: int = 1):
+        """Unmasked batch -> (picks i32, scores f64); bit-identical to pick_batch() by construction, held so by the tests."""
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        R = reqs.shape[0]
+        assert reqs.shape[1] == 1 + max_blocks
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        rc = self._lib.orc_pick_batch_sparse(self.h, index.h if index is not None else None, reqs.ctypes.data, max_blocks, R,
+                                             picks.ctypes.data, scores.ctypes.data, int(threads))
+        if rc != 0:
+            raise RuntimeError(f"oracle rc={rc}")
+        return picks, scores
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.orc_tables_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 def score_row(chain, pods: np.ndarray, index: Optional[OracleIndex], req_row: np.ndarray, mask_row: Optional[np.ndarray] = None) -> np.ndarray:

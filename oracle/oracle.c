@@ -489,6 +489,225 @@ int orc_pick_batch_mt(const eppk_weighted_scorer* chain, uint32_t n_scorers, con
   return rc;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* The same decisions by a second algorithm: snapshot tables + the pods a request's prefix walk names.
+ * Nothing of the reference is restated here beyond schedule_one() above; this is what a careful CPU implementation of a whole batch
+ * would do, and it is what bench.py times as `cpu_baseline` (the O(R x P) loop above is the shape of the reference's per-request
+ * Schedule(), not a fair CPU competitor).  Per (chain, snapshot): the clamped per-pod scores of the request-independent scorers,
+ * and per adapter class a the totals T_a[p] of a pod WITHOUT any prefix match (x + 0.0 * w == x, so the prefix terms drop out)
+ * with the candidates ordered by (T_a descending, index ascending).  Per request: walk the hashes, count matches per named pod,
+ * score the named candidates through the whole chain in chain order (same expression as schedule_one, -ffp-contract=off), take the
+ * best of them, take the first pod of the class order that the walk did not name, and keep the higher total, the lower index on a
+ * tie: the first maximum in snapshot order.  Unmasked batches only (a mask changes the QUEUE extremes per request).
+ * tests/test_oracle_golden.py holds it bit-exact against orc_pick_batch. */
+
+struct orc_tables {
+  eppk_weighted_scorer chain[EPPK_MAX_SCORERS];
+  uint32_t n_scorers, n_pods, nc, has_prefix, has_lora;
+  uint32_t* cand;            /* active slots, ascending */
+  uint8_t*  is_cand;         /* [n_pods] */
+  double*   qs;              /* [n_pods] clamp01(queue score) among all candidates */
+  double*   ks;              /* [n_pods] clamp01(1 - kv_util) */
+  const eppk_pod_row* pods;  /* borrowed: must outlive the tables */
+  double*   T[EPPK_MAX_ADAPTERS + 1];      /* class a + 1 -> [n_pods] totals without prefix matches */
+  uint32_t* order[EPPK_MAX_ADAPTERS + 1];  /* class a + 1 -> [nc] candidates by (T desc, index asc) */
+};
+
+static double lora_score_one(const eppk_pod_row* r, int32_t adapter) {
+  int in_active = adapter >= 0 && bit128(r->active, adapter);
+  int in_waiting = adapter >= 0 && bit128(r->waiting, adapter);
+  uint32_t loaded = pop128(r->active) + pop128(r->waiting);
+  if (in_active) return 1.0;
+  if (loaded < r->max_lora) return 0.8;
+  if (in_waiting) return 0.6;
+  return 0.0;
+}
+
+void orc_tables_free(orc_tables* tb) {
+  if (!tb) return;
+  for (uint32_t a = 0; a <= EPPK_MAX_ADAPTERS; ++a) { free(tb->T[a]); free(tb->order[a]); }
+  free(tb->cand); free(tb->is_cand); free(tb->qs); free(tb->ks);
+  free(tb);
+}
+
+orc_tables* orc_tables_new(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods, uint32_t n_pods) {
+  if (n_scorers > EPPK_MAX_SCORERS || (!chain && n_scorers) || (!pods && n_pods)) return NULL;
+  orc_tables* tb = (orc_tables*)calloc(1, sizeof(*tb));
+  if (!tb) return NULL;
+  size_t n = n_pods ? n_pods : 1;
+  tb->n_scorers = n_scorers; tb->n_pods = n_pods; tb->pods = pods;
+  tb->cand = (uint32_t*)malloc(n * sizeof(uint32_t));
+  tb->is_cand = (uint8_t*)calloc(n, 1);
+  tb->qs = (double*)calloc(n, sizeof(double));
+  tb->ks = (double*)calloc(n, sizeof(double));
+  if (!tb->cand || !tb->is_cand || !tb->qs || !tb->ks) { orc_tables_free(tb); return NULL; }
+  for (uint32_t k = 0; k < n_scorers; ++k) {
+    tb->chain[k] = chain[k];
+    if (chain[k].kind == EPPK_SCORER_PREFIX) tb->has_prefix = 1;
+    else if (chain[k].kind == EPPK_SCORER_LORA) tb->has_lora = 1;
+    else if (chain[k].kind != EPPK_SCORER_QUEUE && chain[k].kind != EPPK_SCORER_KV) { orc_tables_free(tb); return NULL; }
+  }
+  for (uint32_t p = 0; p < n_pods; ++p)
+    if (!(pods[p].flags & EPPK_POD_INACTIVE)) { tb->cand[tb->nc++] = p; tb->is_cand[p] = 1; }
+  if (tb->nc) {
+    double* sc = (double*)malloc(tb->nc * sizeof(double));
+    if (!sc) { orc_tables_free(tb); return NULL; }
+    score_queue(pods, tb->cand, tb->nc, sc);
+    for (uint32_t c = 0; c < tb->nc; ++c) tb->qs[tb->cand[c]] = clamp01(sc[c]);
+    score_kv(pods, tb->cand, tb->nc, sc);
+    for (uint32_t c = 0; c < tb->nc; ++c) tb->ks[tb->cand[c]] = clamp01(sc[c]);
+    free(sc);
+  }
+  return tb;
+}
+
+static const double* g_sort_T; /* qsort has no context argument; classes are built by one thread before the workers start */
+static int cmp_order(const void* a, const void* b) {
+  uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  if (g_sort_T[x] > g_sort_T[y]) return -1;
+  if (g_sort_T[x] < g_sort_T[y]) return 1;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+static int tables_build_class(orc_tables* tb, int32_t adapter) {
+  const uint32_t a = (uint32_t)(adapter + 1);
+  if (tb->T[a]) return 0;
+  size_t n = tb->n_pods ? tb->n_pods : 1;
+  double* T = (double*)calloc(n, sizeof(double));
+  uint32_t* ord = (uint32_t*)malloc((tb->nc ? tb->nc : 1) * sizeof(uint32_t));
+  if (!T || !ord) { free(T); free(ord); return -6; }
+  for (uint32_t c = 0; c < tb->nc; ++c) {
+    const uint32_t p = tb->cand[c];
+    double total = 0.0;
+    for (uint32_t k = 0; k < tb->n_scorers; ++k) {
+      double sc;
+      switch (tb->chain[k].kind) {
+        case EPPK_SCORER_QUEUE: sc = tb->qs[p]; break;
+        case EPPK_SCORER_KV: sc = tb->ks[p]; break;
+        case EPPK_SCORER_LORA: sc = clamp01(lora_score_one(&tb->pods[p], adapter)); break;
+        default: sc = 0.0; break; /* PREFIX without a match */
+      }
+      total = total + sc * (double)tb->chain[k].weight;
+    }
+    T[p] = total;
+    ord[c] = p;
+  }
+  g_sort_T = T;
+  qsort(ord, tb->nc, sizeof(uint32_t), cmp_order);
+  tb->T[a] = T; tb->order[a] = ord;
+  return 0;
+}
+
+typedef struct { uint32_t* stamp; uint32_t* cnt; uint32_t* named; uint32_t tick; } sparse_scratch;
+
+static int sparse_range(const orc_tables* tb, const orc_index* ix, const uint8_t* reqs, uint32_t max_blocks, uint32_t r0,
+                        uint32_t r1, int32_t* out_pick, double* out_score) {
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  size_t n = tb->n_pods ? tb->n_pods : 1;
+  sparse_scratch s;
+  s.stamp = (uint32_t*)calloc(n, sizeof(uint32_t));
+  s.cnt = (uint32_t*)malloc(n * sizeof(uint32_t));
+  s.named = (uint32_t*)malloc(n * sizeof(uint32_t));
+  s.tick = 0;
+  int rc = (s.stamp && s.cnt && s.named) ? 0 : -6;
+  for (uint32_t r = r0; r < r1 && rc == 0; ++r) {
+    const uint8_t* req = reqs + stride * r;
+    eppk_req_hdr hdr;
+    memcpy(&hdr, req, sizeof hdr);
+    const uint64_t* hashes = (const uint64_t*)(req + sizeof hdr);
+    if (hdr.n_blocks > max_blocks || hdr.adapter < -1 || hdr.adapter >= (int32_t)EPPK_MAX_ADAPTERS) { rc = -1; break; }
+    if (tb->nc == 0) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; continue; }
+    const int32_t cls = tb->has_lora ? hdr.adapter : -1;
+    const double* T = tb->T[cls + 1];
+    const uint32_t* ord = tb->order[cls + 1];
+    uint32_t nn = 0;
+    ++s.tick;
+    if (tb->has_prefix && ix) {
+      for (uint32_t i = 0; i < hdr.n_blocks; ++i) {
+        const orc_entry* e = ix_find(ix, hashes[i], 0);
+        if (!e || e->n == 0) break;
+        for (uint32_t j = 0; j < e->n; ++j) {
+          const uint32_t p = e->pods[j];
+          if (p >= tb->n_pods) continue;
+          if (s.stamp[p] != s.tick) { s.stamp[p] = s.tick; s.cnt[p] = 1; s.named[nn++] = p; }
+          else s.cnt[p]++;
+        }
+      }
+    }
+    /* the named candidates, through the whole chain */
+    int32_t best = -1;
+    double best_t = 0.0;
+    for (uint32_t j = 0; j < nn; ++j) {
+      const uint32_t p = s.named[j];
+      if (!tb->is_cand[p]) continue;
+      double total = 0.0;
+      for (uint32_t k = 0; k < tb->n_scorers; ++k) {
+        double sc;
+        switch (tb->chain[k].kind) {
+          case EPPK_SCORER_QUEUE: sc = tb->qs[p]; break;
+          case EPPK_SCORER_KV: sc = tb->ks[p]; break;
+          case EPPK_SCORER_LORA: sc = clamp01(lora_score_one(&tb->pods[p], hdr.adapter)); break;
+          default: sc = clamp01((double)s.cnt[p] / (double)hdr.n_blocks); break;
+        }
+        total = total + sc * (double)tb->chain[k].weight;
+      }
+      if (best < 0 || total > best_t || (total == best_t && (int32_t)p < best)) { best = (int32_t)p; best_t = total; }
+    }
+    /* the best candidate the walk did not name */
+    for (uint32_t c = 0; c < tb->nc; ++c) {
+      const uint32_t p = ord[c];
+      if (s.stamp[p] == s.tick) continue;
+      if (best < 0 || T[p] > best_t || (T[p] == best_t && (int32_t)p < best)) { best = (int32_t)p; best_t = T[p]; }
+      break;
+    }
+    out_pick[r] = best;
+    if (out_score) out_score[r] = best_t;
+  }
+  free(s.stamp); free(s.cnt); free(s.named);
+  return rc;
+}
+
+typedef struct { const orc_tables* tb; const orc_index* ix; const uint8_t* reqs; uint32_t max_blocks, r0, r1; int32_t* pick; double* score; int rc; } sparse_job;
+static void* sparse_main(void* arg) {
+  sparse_job* j = (sparse_job*)arg;
+  j->rc = sparse_range(j->tb, j->ix, j->reqs, j->max_blocks, j->r0, j->r1, j->pick, j->score);
+  return NULL;
+}
+
+int orc_pick_batch_sparse(orc_tables* tb, const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
+                          int32_t* out_pick, double* out_score, int threads) {
+  if (!tb || (!reqs && n_reqs) || (!out_pick && n_reqs)) return -1;
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  /* classes this batch needs (kept in the tables for the next batch of the snapshot) */
+  if (tb->nc) {
+    if (!tb->has_lora) { if (tables_build_class(tb, -1)) return -6; }
+    else for (uint32_t r = 0; r < n_reqs; ++r) {
+      eppk_req_hdr hdr;
+      memcpy(&hdr, (const uint8_t*)reqs + stride * r, sizeof hdr);
+      if (hdr.adapter < -1 || hdr.adapter >= (int32_t)EPPK_MAX_ADAPTERS) return -1;
+      if (!tb->T[hdr.adapter + 1] && tables_build_class(tb, hdr.adapter)) return -6;
+    }
+  }
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if ((uint32_t)threads > n_reqs) threads = n_reqs ? (int)n_reqs : 1;
+  pthread_t tid[256];
+  sparse_job job[256];
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    sparse_job* j = &job[t];
+    j->tb = tb; j->ix = ix; j->reqs = (const uint8_t*)reqs; j->max_blocks = max_blocks; j->pick = out_pick; j->score = out_score; j->rc = 0;
+    j->r0 = (uint32_t)((uint64_t)n_reqs * (uint64_t)t / (uint64_t)threads);
+    j->r1 = (uint32_t)((uint64_t)n_reqs * (uint64_t)(t + 1) / (uint64_t)threads);
+    if (threads == 1 || pthread_create(&tid[t], NULL, sparse_main, j)) { sparse_main(j); tid[t] = 0; }
+  }
+  for (int t = 0; t < threads; ++t) {
+    if (tid[t]) pthread_join(tid[t], NULL);
+    if (job[t].rc) rc = job[t].rc;
+  }
+  return rc;
+}
+
 int orc_pick_batch_assumed(const eppk_weighted_scorer* chain, uint32_t n_scorers, eppk_pod_row* pods, uint32_t n_pods,
                            const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
                            const uint64_t* cand_mask, uint32_t epochs, int32_t* out_pick, double* out_score) {

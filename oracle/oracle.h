@@ -56,6 +56,15 @@ int orc_pick_batch_mt(const eppk_weighted_scorer* chain, uint32_t n_scorers,
                       const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
                       int32_t* out_pick, double* out_score, int threads);
 
+/* The same decisions by a second algorithm (snapshot tables + the pods each request's prefix walk names): what bench.py times as
+ * the CPU baseline.  Unmasked batches.  `pods` is borrowed by the tables and must outlive them; the tables cache per-adapter classes
+ * across batches of one snapshot.  Bit-exact against orc_pick_batch (tests/test_oracle_golden.py). */
+typedef struct orc_tables orc_tables;
+orc_tables* orc_tables_new(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods, uint32_t n_pods);
+void        orc_tables_free(orc_tables* tb);
+int orc_pick_batch_sparse(orc_tables* tb, const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs,
+                          int32_t* out_pick, double* out_score, int threads);
+
 /* SEMANTICS.md 2b: the batch in `epochs` sub-batches; after each, queue[pick] += 1 in `pods` (MUTATED: the caller keeps them
  * for the next batch of the same snapshot).  epochs == 0: orc_pick_batch (no bump). */
 int orc_pick_batch_assumed(const eppk_weighted_scorer* chain, uint32_t n_scorers,

@@ -184,7 +184,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
         assert d["closed_loop"]["generations_verified"] == 3 and d["config"]["closed_loop"] is True
         assert sum(1 for e in log if e[0] == "learn") == n_picks == 3 + d["steps"] + d["warmup"]    # every pick is followed by its index update
         return
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "algorithm", "single_thread_value", "per_request_loop_value"):
         assert key in d["cpu_baseline"], key
     assert d["parity"]["picks_equal_oracle"] and d["parity"]["scores_bitwise_equal_oracle"]
     if "--force-dist" in argv:

@@ -48,6 +48,33 @@ def test_oracle_matches_numpy_restatement_bitwise(gold, pkg, orc):
         assert np.array_equal(scores.view(np.uint64), c["score"].view(np.uint64)), name
 
 
+def test_sparse_cpu_algorithm_equals_the_per_request_loop(pkg, orc):
+    """orc_pick_batch_sparse (snapshot tables + the pods each prefix walk names) against orc_pick_batch on the bench workloads'
+    shapes (C1..C3 here; C5 in bench.py's `parity` of every run): picks equal, scores bitwise equal, tables reused across batches,
+    holes and an empty snapshot."""
+    for cfg in (1, 2, 3):
+        wl = pkg.workload.make_workload(cfg)
+        oix = orc.OracleIndex()
+        oix.insert(wl.index_hashes, wl.index_pods)
+        tb = orc.OracleTables(wl.chain, wl.pods)
+        for b in range(2):
+            reqs = wl.reqs if b == 0 else pkg.workload.make_requests(wl, 1234 + cfg)
+            n = min(reqs.shape[0], 2048)
+            p0, s0, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs[:n], wl.B, threads=4)
+            p1, s1 = tb.pick_batch(oix, reqs[:n], wl.B, threads=4)
+            assert np.array_equal(p0, p1), (cfg, b)
+            assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)), (cfg, b)
+    pods = wl.pods.copy()
+    pods["flags"][::3] = 1                      # EPPK_POD_INACTIVE
+    oix.scrub_inactive(pods)
+    p0, s0, _ = orc.pick_batch(wl.chain, pods, oix, wl.reqs[:512], wl.B)
+    p1, s1 = orc.OracleTables(wl.chain, pods).pick_batch(oix, wl.reqs[:512], wl.B, threads=2)
+    assert np.array_equal(p0, p1) and np.array_equal(s0.view(np.uint64), s1.view(np.uint64))
+    pods["flags"][:] = 1
+    p1, s1 = orc.OracleTables(wl.chain, pods).pick_batch(oix, wl.reqs[:64], wl.B)
+    assert (p1 == -1).all() and (s1 == 0.0).all()
+
+
 def test_oracle_mt_equals_sequential(gold, pkg, orc):
     c = load_case(gold, "full_masked")
     reqs, B = rows_of(pkg, c)
@@ -194,6 +221,11 @@ def test_oracle_vs_numpy_restatement_random(pkg, orc, seed):
     picks, scores, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, mask)
     assert np.array_equal(picks, c["pick"]), (seed, chain, P, B)
     assert np.array_equal(scores.view(np.uint64), c["score"].view(np.uint64)), (seed, chain, P, B)
+    # the second CPU algorithm (tables + named pods; what bench.py times as the CPU baseline) on the unmasked form of the case
+    p0, s0, _ = orc.pick_batch(chain, c["pods"], oix, reqs, B, None)
+    for th in (1, 3):
+        p1, s1 = orc.OracleTables(chain, c["pods"]).pick_batch(oix, reqs, B, threads=th)
+        assert np.array_equal(p0, p1) and np.array_equal(s0.view(np.uint64), s1.view(np.uint64)), (seed, chain, P, B, th)
     # ordered fallbacks (SEMANTICS.md §3a): the oracle's list against the matrix form's stable sort
     index = {}
     for h, p_ in zip(c["index_hashes"].tolist(), c["index_pods"].tolist()):
