@@ -7,7 +7,7 @@
 //     worker pool, every `interval`; a failed or timed-out scrape is delivered as an error, not dropped (the collector decides);
 //   * PodRowCollector: Extract = eppk_metrics.hpp's ParseModelServerMetrics; keeps the latest row per endpoint and the time it was
 //     taken; Rows(ids, max_age) returns them in candidate-index order, a stale or missing one as a hole (EPPK_POD_INACTIVE).
-// What consumes the rows is eppk_publish_snapshot (GpuPicker::PublishSnapshot in eppk_host.hpp).  Plain POSIX sockets: no TLS (the
+// What consumes the rows is eppk_snapshot_publish (GpuPicker::PublishSnapshot in eppk_host.hpp).  Plain POSIX sockets: no TLS (the
 // model-server protocol's metrics endpoint is plain HTTP inside the cluster), no redirects, no keep-alive (one short GET per scrape).
 #pragma once
 

@@ -15,8 +15,23 @@ FILES = ["pkg/lwepp/handlers/server.go", "pkg/lwepp/server/options.go", "pkg/lwe
 def test_patch_names_only_the_picker_seam():
     text = open(PATCH).read()
     touched = sorted({ln.split("\t")[0][len("+++ b/"):] for ln in text.splitlines() if ln.startswith("+++ b/")})
-    assert touched == sorted(FILES + ["pkg/lwepp/handlers/gpupicker.go", "pkg/lwepp/handlers/gpupicker_nocgo.go"])
+    assert touched == sorted(FILES + ["pkg/lwepp/handlers/gpupicker.go", "pkg/lwepp/handlers/gpupicker_nocgo.go", "pkg/lwepp/handlers/gpusnapshot.go"])
     assert "ctx.Done()" in text and "eppk_index_insert" in text and "runtime.LockOSThread()" in text
+    # the picker is fed: main.go starts the snapshot producer (scrape -> pod rows -> PublishSnapshot), in both build modes
+    assert "go sp.Run(ctx)" in text and text.count("func (p *GPUPicker) PublishSnapshot(") == 2
+
+
+def test_go_pod_row_matches_the_c_struct():
+    """PodRow of gpusnapshot.go is copied over eppk_pod_row byte for byte: same fields, same order, 64 bytes (the Go file asserts the
+    size at compile time; this checks the field order against include/eppk.h here, where no Go toolchain exists)."""
+    import re
+    text = open(PATCH).read()
+    go = re.search(r"type PodRow struct \{(.*?)\n\+\}", text, re.S).group(1)
+    go_fields = [ln.lstrip("+").split()[0].lower() for ln in go.splitlines() if ln.lstrip("+").strip() and not ln.lstrip("+").strip().startswith("//")]
+    hdr = open(os.path.join(ROOT, "include", "eppk.h")).read()
+    c = re.search(r"typedef struct eppk_pod_row \{(.*?)\} eppk_pod_row;", hdr, re.S).group(1)
+    c_fields = [re.sub(r"\[.*", "", ln.split(";")[0].split()[-1]).replace("_", "") for ln in c.splitlines() if ";" in ln]
+    assert go_fields == c_fields == ["queue", "running", "kvutil", "maxlora", "flags", "active", "waiting", "reserved"]
 
 
 def test_patch_applies_to_the_reference(tmp_path):
