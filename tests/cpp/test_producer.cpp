@@ -1,0 +1,126 @@
+// host/eppk_producer.hpp end to end on the CPU: fixture model servers (tests/test_metrics_cpp.py) -> scrape -> pod rows ->
+// GpuPicker::PublishSnapshot -> Pick().  The backend is a stand-in that picks the shortest queue among the candidates, so the test
+// is about the host path (who is in the snapshot, with which gauges, at which candidate index), not about the scorers.
+//   argv: p_len (queue 7, adapters adapter1+adapter2)  p_chunked (queue 5)  p_503  p_silent  p_closed
+#include <cstdio>
+#include <string>
+
+#include "../../gateway-api-inference-extension_amd/host/eppk_producer.hpp"
+
+using namespace eppk_host;
+
+#define CHECK(x) do { if (!(x)) { std::fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #x); return 1; } } while (0)
+
+class ShortestQueueBackend : public Backend {
+ public:
+  int Publish(const eppk_pod_row* rows, uint32_t n, uint64_t epoch) override {
+    std::lock_guard<std::mutex> g(mu);
+    rows_.assign(rows, rows + n);
+    last_epoch = epoch;
+    ++publishes;
+    return EPPK_OK;
+  }
+  int PickBatch(const void*, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
+    std::lock_guard<std::mutex> g(mu);
+    const uint32_t P = (uint32_t)rows_.size(), W = (P + 63u) / 64u;
+    for (uint32_t r = 0; r < n; ++r) {
+      int32_t best = -1;
+      for (uint32_t p = 0; p < P; ++p) {
+        if (rows_[p].flags & EPPK_POD_INACTIVE) continue;
+        if (mask && !((mask[(size_t)r * W + (p >> 6)] >> (p & 63u)) & 1u)) continue;
+        if (best < 0 || rows_[p].queue < rows_[(size_t)best].queue) best = (int32_t)p;
+      }
+      picks[r] = best;
+      if (scores) scores[r] = 0.0;
+    }
+    return EPPK_OK;
+  }
+  int PickTopK(const void*, uint32_t, const uint64_t*, uint32_t, int32_t*, double*) override { return EPPK_ERR_ARG; }
+  int IndexInsert(const uint64_t*, const uint32_t*, uint32_t) override { return EPPK_OK; }
+  int IndexRemovePod(uint32_t pod) override { std::lock_guard<std::mutex> g(mu); removed.push_back(pod); return EPPK_OK; }
+  int IndexAdvanceEpoch(uint32_t* e) override { *e = 1; return EPPK_OK; }
+  int IndexEvictOlder(uint32_t, uint32_t* n) override { *n = 0; return EPPK_OK; }
+  std::string LastError() const override { return "stand-in"; }
+  std::mutex mu;
+  std::vector<eppk_pod_row> rows_;
+  std::vector<uint32_t> removed;
+  uint64_t last_epoch = 0;
+  int publishes = 0;
+};
+
+int main(int argc, char** argv) {
+  if (argc != 6) { std::fprintf(stderr, "usage: test_producer p_len p_chunked p_503 p_silent p_closed\n"); return 2; }
+  auto* be = new ShortestQueueBackend();
+  GpuPickerOptions po;
+  po.max_pods = 16;
+  po.max_blocks = 4;
+  po.max_batch = 8;
+  po.stable_slots = true;
+  po.window = std::chrono::microseconds(500);
+  GpuPicker picker(std::unique_ptr<Backend>(be), po);
+
+  std::mutex pool_mu;
+  std::vector<Endpoint> pool;
+  for (int i = 1; i <= 5; ++i) {
+    Endpoint e;
+    e.pod_name = "pod-" + std::to_string(i);
+    e.address = "127.0.0.1";
+    e.port = argv[i];
+    pool.push_back(e);
+  }
+  SnapshotProducer::Options o;
+  o.scrape.interval_ms = 20;
+  o.scrape.timeout_ms = 300;
+  o.scrape.workers = 4;
+  o.max_age_ms = 2000;     // (a round lasts as long as its slowest scrape: 300 ms for the silent server)
+  o.adapters = {{"adapter2", 5}};            // a fixed id for one adapter; adapter1 is assigned the lowest free id (0)
+  SnapshotProducer prod(&picker, [&] { std::lock_guard<std::mutex> g(pool_mu); return pool; }, o);
+
+  const std::vector<Endpoint> first_pool = pool;
+  std::vector<const Endpoint*> cands;
+  for (const Endpoint& e : first_pool) cands.push_back(&e);
+  PickResult pr;
+  CHECK(picker.Pick({}, cands, &pr).ok() && picker.fail_opens() == 1);       // nothing published yet: round robin
+
+  size_t n = 0;
+  { Status st = prod.RefreshOnce(&n); if (!st.ok() || n != 2) std::fprintf(stderr, "refresh: %s n=%zu failed_scrapes=%llu\n", st.message.c_str(), n, (unsigned long long)prod.failed_scrapes()); CHECK(st.ok() && n == 2); }
+  //                                 // two of the five servers answer usefully
+  {
+    std::lock_guard<std::mutex> g(be->mu);
+    CHECK(be->rows_.size() == 2 && be->last_epoch == 1);
+    CHECK(be->rows_[0].queue == 7 && be->rows_[0].max_lora == 4 && be->rows_[0].active[0] == ((1ull << 0) | (1ull << 5)));
+    CHECK(be->rows_[1].queue == 5 && be->rows_[1].kv_util == 0.5);
+  }
+  CHECK(prod.adapters().at("adapter1") == 0 && prod.adapters().at("adapter2") == 5);
+  CHECK(prod.failed_scrapes() == 3);
+  // the pick goes to the shorter queue (pod-2, the chunked server), whatever the candidates' order
+  CHECK(picker.Pick({}, cands, &pr).ok() && pr.endpoint == std::string("127.0.0.1:") + argv[2]);
+  // a candidate list without it: the other one; only endpoints outside the snapshot: nothing scoreable -> Unavailable
+  std::vector<const Endpoint*> only1{&first_pool[0], &first_pool[2]};
+  CHECK(picker.Pick({}, only1, &pr).ok() && pr.endpoint == std::string("127.0.0.1:") + argv[1]);
+  std::vector<const Endpoint*> none{&first_pool[2], &first_pool[3]};
+  CHECK(picker.Pick({}, none, &pr).code == Code::Unavailable);
+
+  // churn: pod-1 leaves the pool -> its slot becomes a hole (stable slots: pod-2 keeps candidate index 1)
+  { std::lock_guard<std::mutex> g(pool_mu); pool.erase(pool.begin()); }
+  CHECK(prod.RefreshOnce(&n).ok() && n == 1);
+  {
+    std::lock_guard<std::mutex> g(be->mu);
+    CHECK(be->rows_.size() == 2 && (be->rows_[0].flags & EPPK_POD_INACTIVE) && be->rows_[1].queue == 5 && be->rows_[1].flags == 0);
+  }
+  CHECK(picker.SlotOf(std::string("127.0.0.1:") + argv[2]) == 1 && picker.SlotOf(std::string("127.0.0.1:") + argv[1]) == -1);
+  std::vector<Endpoint> now_pool;
+  { std::lock_guard<std::mutex> g(pool_mu); now_pool = pool; }
+  std::vector<const Endpoint*> left;
+  for (const Endpoint& e : now_pool) left.push_back(&e);
+  CHECK(picker.Pick({}, left, &pr).ok() && pr.endpoint == std::string("127.0.0.1:") + argv[2]);
+
+  // the timer loop keeps publishing; epochs grow
+  prod.Start();
+  for (int i = 0; i < 300 && prod.rounds() < 4; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  prod.Stop();
+  CHECK(prod.rounds() >= 4 && prod.failed_publishes() == 0);
+  { std::lock_guard<std::mutex> g(be->mu); CHECK(be->last_epoch >= 6 && be->publishes >= 6); }
+  std::printf("producer ok\n");
+  return 0;
+}

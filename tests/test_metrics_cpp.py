@@ -61,8 +61,7 @@ def _handler(kind):
     return H
 
 
-def test_metrics_data_source():
-    exe = _build("test_scrape", ["-pthread"])
+def _with_fixture_servers(exe):
     servers = [http.server.ThreadingHTTPServer(("127.0.0.1", 0), _handler(k)) for k in ("len", "chunked", "503")]
     for s in servers:
         threading.Thread(target=s.serve_forever, daemon=True).start()
@@ -77,9 +76,21 @@ def test_metrics_data_source():
         ports = [str(s.server_address[1]) for s in servers] + [str(silent.getsockname()[1]), str(closed_port)]
         out = subprocess.run([exe, *ports], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr + out.stdout
-        assert "scrape ok" in out.stdout
+        return out.stdout
     finally:
         for s in servers:
             s.shutdown()
             s.server_close()
         silent.close()
+
+
+def test_metrics_data_source():
+    assert "scrape ok" in _with_fixture_servers(_build("test_scrape", ["-pthread"]))
+
+
+def test_snapshot_producer_end_to_end():
+    """list the pool -> scrape -> pod rows -> GpuPicker::PublishSnapshot -> Pick(), with a stand-in backend (host/eppk_producer.hpp)."""
+    import __graft_entry__ as g
+    g.build()                        # GpuPicker calls the library's host-side helpers (eppk_round_robin, eppk_hash_prompt): link libeppk
+    pkg = os.path.join(ROOT, "gateway-api-inference-extension_amd")
+    assert "producer ok" in _with_fixture_servers(_build("test_producer", ["-pthread", f"-L{pkg}", "-leppk", f"-Wl,-rpath,{pkg}"]))
