@@ -11,6 +11,7 @@
  * Data structures are deliberately the naive ones (per-pod rows, hash -> sorted pod list), NOT the
  * device layouts, so that agreement with the kernel is evidence and not a tautology.
  */
+#define _GNU_SOURCE /* qsort_r */
 #include "oracle.h"
 
 #include <math.h>
@@ -561,11 +562,11 @@ orc_tables* orc_tables_new(const eppk_weighted_scorer* chain, uint32_t n_scorers
   return tb;
 }
 
-static const double* g_sort_T; /* qsort has no context argument; classes are built by one thread before the workers start */
-static int cmp_order(const void* a, const void* b) {
+static int cmp_order(const void* a, const void* b, void* ctx) {
+  const double* T = (const double*)ctx;
   uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
-  if (g_sort_T[x] > g_sort_T[y]) return -1;
-  if (g_sort_T[x] < g_sort_T[y]) return 1;
+  if (T[x] > T[y]) return -1;
+  if (T[x] < T[y]) return 1;
   return x < y ? -1 : (x > y ? 1 : 0);
 }
 
@@ -592,8 +593,7 @@ static int tables_build_class(orc_tables* tb, int32_t adapter) {
     T[p] = total;
     ord[c] = p;
   }
-  g_sort_T = T;
-  qsort(ord, tb->nc, sizeof(uint32_t), cmp_order);
+  qsort_r(ord, tb->nc, sizeof(uint32_t), cmp_order, T);
   tb->T[a] = T; tb->order[a] = ord;
   return 0;
 }
