@@ -11,7 +11,41 @@ using namespace eppk_host;
 
 #define CHECK(x) do { if (!(x)) { std::fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
-int main() {
+// --dump: the samples of the exposition on stdin, one per line, every string hex-encoded (name, then label name / value pairs)
+// and the value as the bits of the double -- read back by tests/test_metrics_cpp.py and compared with prometheus_client's parser.
+static std::string hex(const std::string& s) {
+  static const char* d = "0123456789abcdef";
+  std::string o = "x";
+  for (unsigned char c : s) { o.push_back(d[c >> 4]); o.push_back(d[c & 15]); }
+  return o;
+}
+static int dump() {
+  std::string text, line;
+  char buf[65536];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, stdin)) > 0) text.append(buf, n);
+  size_t pos = 0;
+  while (pos <= text.size()) {
+    size_t nl = text.find('\n', pos);
+    if (nl == std::string::npos) nl = text.size();
+    Sample s;
+    bool bad = false;
+    if (ParseSample(std::string_view(text).substr(pos, nl - pos), &s, &bad)) {
+      uint64_t bits;
+      std::memcpy(&bits, &s.value, 8);
+      std::printf("%s", hex(s.name).c_str());
+      for (const auto& kv : s.labels) std::printf(" %s %s", hex(kv.first).c_str(), hex(kv.second).c_str());
+      std::printf(" = %016llx\n", (unsigned long long)bits);
+    } else if (bad) {
+      std::printf("MALFORMED\n");
+    }
+    pos = nl + 1;
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "--dump") return dump();
   const std::map<std::string, int32_t> ids = {{"adapter1", 0}, {"adapter2", 1}, {"sql-lora", 64}, {"big", 127}, {"out-of-range", 200}};
 
   // --- a vLLM-shaped body: comments, labels, timestamps, two lora series (the later one counts)

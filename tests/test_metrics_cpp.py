@@ -24,6 +24,64 @@ def test_metrics_extractor():
     assert "metrics ok" in out.stdout
 
 
+def test_sample_parser_against_prometheus_client():
+    """Differential test of ParseSample (the C++ extractor's line parser) against prometheus_client's text parser -- an independent
+    implementation of the exposition format -- on random expositions: metric names with colons, label values with every escape,
+    odd spacing, timestamps, NaN / +Inf / -Inf / exponents, comment and blank lines."""
+    import math
+    import random
+    import struct
+    from prometheus_client.parser import text_string_to_metric_families
+    exe = _build("test_metrics")
+    rnd = random.Random(20260923)
+    alphabet = 'abcXYZ019 _-:/.,{}=#\u00e9'
+
+    def esc(v):
+        return v.replace("\\", "\\\\").replace('"', '\\"').replace("\n", "\\n")
+
+    total = escaped = 0
+    for round_ in range(30):
+        lines, want = [], []
+        for i in range(rnd.randrange(1, 40)):
+            kind = rnd.random()
+            if kind < 0.1:
+                lines.append(rnd.choice(["", "# HELP m_%d some text {with} \"quotes\"" % i, "# TYPE m_%d gauge" % i, "   "]))
+                continue
+            name = rnd.choice(["vllm:num_requests_waiting", "vllm:kv_cache_usage_perc", "nv_trt_llm_request_metrics", "m_%d" % i, "a:b:c_%d" % i])
+            labels = {}
+            for j in range(rnd.choice([0, 0, 1, 2, 5])):
+                val = "".join(rnd.choice(alphabet + '"\\\n') for _ in range(rnd.randrange(0, 12)))
+                labels["l%d_%s" % (j, rnd.choice(["x", "model_name", "le"]))] = val
+            value = rnd.choice([0.0, 1.0, -1.5, 7, 1.7123e9, 0.4375, 1e-300, 1e300, math.inf, -math.inf, math.nan, rnd.uniform(-1e6, 1e6)])
+            vtxt = {math.inf: "+Inf", -math.inf: "-Inf"}.get(value, "NaN" if isinstance(value, float) and math.isnan(value) else repr(value))
+            lab = ""
+            if labels or rnd.random() < 0.1:
+                sep = rnd.choice([",", ", ", " ,"])
+                lab = "{" + sep.join('%s="%s"' % (k, esc(v)) for k, v in labels.items()) + rnd.choice(["", ","] if labels else [""]) + "}"
+            ts = rnd.choice(["", "", " 1712345678000", " -5"])
+            lines.append(name + lab + rnd.choice([" ", "  ", "\t"]) + vtxt + ts)
+            want.append((name, labels, value))
+        body = "\n".join(lines) + "\n"
+        ref = [(s_.name, dict(s_.labels), s_.value) for fam in text_string_to_metric_families(body) for s_ in fam.samples]
+        assert len(ref) == len(want)                                           # the generator and the reference parser agree first
+        out = subprocess.run([exe, "--dump"], input=body.encode(), capture_output=True, timeout=60)
+        assert out.returncode == 0
+        got = []
+        for ln in out.stdout.decode().splitlines():
+            assert ln != "MALFORMED", body
+            f = ln.split(" ")
+            eq = f.index("=")
+            strs = [bytes.fromhex(x[1:]).decode() for x in f[:eq]]
+            got.append((strs[0], dict(zip(strs[1::2], strs[2::2])), struct.unpack("<d", struct.pack("<Q", int(f[eq + 1], 16)))[0]))
+        assert len(got) == len(ref), body
+        for g_, r_ in zip(got, ref):
+            assert g_[0] == r_[0] and g_[1] == r_[1], (g_, r_)
+            assert (math.isnan(g_[2]) and math.isnan(r_[2])) or g_[2] == r_[2], (g_, r_)
+            total += 1
+            escaped += any(c in v for v in g_[1].values() for c in '"\\\n')
+    assert total > 300 and escaped > 30, (total, escaped)
+
+
 BODY_A = (b"# TYPE vllm:num_requests_waiting gauge\n"
           b"vllm:num_requests_waiting{model_name=\"m\"} 7.0\n"
           b"vllm:num_requests_running{model_name=\"m\"} 3.0\n"
