@@ -20,7 +20,7 @@ namespace eppk_host {
 class SnapshotProducer {
  public:
   struct Options {
-    MetricsDataSource::Options scrape;        // interval 50 ms, timeout 1 s, 8 workers
+    MetricsDataSource::Options scrape;        // interval 50 ms, timeout 1 s, 512 exchanges in flight
     int max_age_ms = 2000;                    // a row older than this is not published (its endpoint leaves the snapshot)
     MetricNames names;
     std::map<std::string, int32_t> adapters;  // fixed name -> id table; names beyond it are assigned the next free id

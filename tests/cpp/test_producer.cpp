@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
   SnapshotProducer::Options o;
   o.scrape.interval_ms = 20;
   o.scrape.timeout_ms = 300;
-  o.scrape.workers = 4;
+  o.scrape.max_inflight = 3;          // fewer sockets than endpoints: the engine refills as exchanges finish
   o.max_age_ms = 2000;     // (a round lasts as long as its slowest scrape: 300 ms for the silent server)
   o.adapters = {{"adapter2", 5}};            // a fixed id for one adapter; adapter1 is assigned the lowest free id (0)
   SnapshotProducer prod(&picker, [&] { std::lock_guard<std::mutex> g(pool_mu); return pool; }, o);

@@ -25,11 +25,29 @@ int main(int argc, char** argv) {
   CHECK(!HttpGet("127.0.0.1", argv[5], "/metrics", 500, &body, &err) && err.find("connect") != std::string::npos);
   CHECK(!HttpGet("no-such-host.invalid", "80", "/metrics", 500, &body, &err) && err.find("resolve") != std::string::npos);
 
+  // many exchanges on one thread: 400 GETs, every fourth to the closed port, 64 sockets at a time
+  {
+    std::vector<HttpRequest> reqs;
+    for (int i = 0; i < 400; ++i) reqs.push_back({"127.0.0.1", argv[i % 4 == 3 ? 5 : 1 + (i & 1)], "/metrics"});
+    const auto m0 = SteadyClock::now();
+    std::vector<HttpResult> res = HttpGetMany(reqs, 3000, 64);
+    const auto mms = std::chrono::duration_cast<std::chrono::milliseconds>(SteadyClock::now() - m0).count();
+    CHECK(res.size() == 400);
+    size_t ok = 0, refused = 0;
+    for (int i = 0; i < 400; ++i) {
+      if (i % 4 == 3) { CHECK(!res[(size_t)i].ok && res[(size_t)i].error.find("connect") != std::string::npos); ++refused; }
+      else { CHECK(res[(size_t)i].ok && res[(size_t)i].body.find(i & 1 ? "vllm:kv_cache_usage_perc 0.5" : "vllm:num_requests_waiting{model_name=\"m\"} 7.0") != std::string::npos); ++ok; }
+    }
+    CHECK(ok == 300 && refused == 100);
+    std::fprintf(stderr, "400 exchanges, 64 in flight: %lld ms\n", (long long)mms);
+    CHECK(mms < 20000);
+  }
+
   // the data source + the collector: five endpoints, two usable
   MetricsDataSource::Options o;
   o.interval_ms = 20;
   o.timeout_ms = 300;
-  o.workers = 4;
+  o.max_inflight = 4;
   MetricsDataSource src(o);
   auto rows = std::make_shared<PodRowCollector>(std::map<std::string, int32_t>{{"adapter1", 0}, {"adapter2", 1}});
   src.Subscribe(rows);

@@ -120,7 +120,11 @@ def _handler(kind):
 
 
 def _with_fixture_servers(exe):
-    servers = [http.server.ThreadingHTTPServer(("127.0.0.1", 0), _handler(k)) for k in ("len", "chunked", "503")]
+    class Server(http.server.ThreadingHTTPServer):
+        request_queue_size = 256                 # the engine opens dozens of connections at once
+        daemon_threads = True
+
+    servers = [Server(("127.0.0.1", 0), _handler(k)) for k in ("len", "chunked", "503")]
     for s in servers:
         threading.Thread(target=s.serve_forever, daemon=True).start()
     silent = socket.socket()                 # accepts (backlog) and never answers
