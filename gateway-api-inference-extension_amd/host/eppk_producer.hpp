@@ -12,6 +12,8 @@
 // LoRA adapter names are given ids 0..127 in the order the model servers first report them (or take a fixed table).
 #pragma once
 
+#include <unordered_set>
+
 #include "eppk_host.hpp"
 #include "eppk_scrape.hpp"
 
@@ -56,9 +58,9 @@ class SnapshotProducer {
         usable.push_back(eps[i]);
         rows.push_back(it->second.row);
       }
-      for (auto it = latest_.begin(); it != latest_.end();)        // endpoints that left the pool
-        it = std::find_if(targets.begin(), targets.end(), [&](const ScrapeTarget& t) { return t.id == it->first; }) == targets.end()
-                 ? latest_.erase(it) : std::next(it);
+      std::unordered_set<std::string> listed;
+      for (const ScrapeTarget& t : targets) listed.insert(t.id);
+      for (auto it = latest_.begin(); it != latest_.end();) it = listed.count(it->first) ? std::next(it) : latest_.erase(it);   // endpoints that left the pool
       adapters.insert(adapters_.begin(), adapters_.end());
     }
     if (published) *published = usable.size();
