@@ -6,6 +6,8 @@ scripts/micro/insertbreak.hip (the product sources are not touched).  Output: sc
   v2  v1 + the bucket is read with four 16-byte coherent loads (sc0 sc1) instead of eight 8-byte atomic loads
   f1  v2 + the live / words / dropped counters bumped once per WORKGROUP (LDS) instead of once per wavefront
   f2  f1 with 64 counter shards instead of 32          f3  the library's insert with only the per-workgroup counters
+  f4  f1 with 256 counter shards (ix_budget sums four per lane) + the evict kernel's counters once per workgroup
+  d4  f4 where a claimed key does not write its row (diagnostic for "rows only for overflowed sets": wrong table)
   d1  v2 without the live / words / dropped counters      d2  d1 without the stamp / row / list updates (claim only)
   d3  v2 counting lost claims (a CAS that found the word taken by another key) in the "evicted" counter
   (d1-d3 are diagnostics: they partition the time and give wrong tables)"""
@@ -105,6 +107,41 @@ SH_OLD = "constexpr uint32_t kIxShards = 32u;"
 SH_NEW = "constexpr uint32_t kIxShards = 64u;"
 
 
+EVICT_OLD = """  if (lane == 0 && gone) {
+    const uint32_t shard = (wave & (kIxShards - 1u)) * 8u;
+    atomicAdd(&ixc[shard + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
+    atomicAdd(&ixc[shard + kIxEvicted], (unsigned long long)gone);   // evicted by this launch (the synchronous entry point zeroes it first)
+  }
+}"""
+EVICT_NEW = """  __shared__ unsigned int s_gone;
+  if (threadIdx.x == 0u) s_gone = 0u;
+  __syncthreads();
+  if (lane == 0 && gone) atomicAdd(&s_gone, gone);
+  __syncthreads();
+  if (threadIdx.x == 0u && s_gone) {
+    const uint32_t shard = (blockIdx.x & (kIxShards - 1u)) * 8u;
+    atomicAdd(&ixc[shard + kIxLive], (unsigned long long)(0ull - (unsigned long long)s_gone));
+    atomicAdd(&ixc[shard + kIxEvicted], (unsigned long long)s_gone);
+  }
+}"""
+# 256 shards: ix_budget sums four shards per lane
+BUD_OLD = """    unsigned long long lv = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    unsigned long long wd = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long lv0 = __shfl((long long)lv, 0), wd0 = __shfl((long long)wd, 0);"""
+BUD_NEW = """    unsigned long long lv = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    unsigned long long wd = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long lv0 = __shfl((long long)lv, 0), wd0 = __shfl((long long)wd, 0);
+    for (uint32_t sh = l + 64u; sh < kIxShards; sh += 64u) {
+      lv += __hip_atomic_load(&ixc[sh * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wd += __hip_atomic_load(&ixc[sh * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }"""
+SH256_NEW = "constexpr uint32_t kIxShards = 256u;"
+# diagnostic: a claimed key does not write its row (what "rows only for overflowed sets" would save); wrong table
+ROW_OLD = """      if constexpr (sizeof(LW) == 8) fresh = !((atomicOr((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, 1ull << j) >> j) & 1ull);
+      else fresh = bitmap_set<LW>(bitmaps, slot, pod);"""
+ROW_NEW = """      fresh = true; (void)lane; (void)j;"""
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     src = open(SRC).read()
@@ -114,6 +151,8 @@ def main():
                         ("f1", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW)]),
                         ("f2", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH_NEW)]),
                         ("f3", [(AGG_OLD, AGG_NEW)]),
+                        ("f4", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH256_NEW), (BUD_OLD, BUD_NEW), (EVICT_OLD, EVICT_NEW)]),
+                        ("d4", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH256_NEW), (BUD_OLD, BUD_NEW), (EVICT_OLD, EVICT_NEW), (ROW_OLD, ROW_NEW)]),
                         ("d3", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (RETRY_OLD, RETRY_NEW)])):
         s = src
         for a, b in edits:

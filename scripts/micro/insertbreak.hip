@@ -20,6 +20,8 @@
 #include "_gen/eppk_kernels_f1.hip.h"
 #include "_gen/eppk_kernels_f2.hip.h"
 #include "_gen/eppk_kernels_f3.hip.h"
+#include "_gen/eppk_kernels_f4.hip.h"
+#include "_gen/eppk_kernels_d4.hip.h"
 #define HAVE_VARIANTS 1
 #endif
 
@@ -58,7 +60,7 @@ int main() {
   const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
   CK(hipMalloc((void**)&lists, nd * 4u));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
-  CK(hipMalloc((void**)&ixc, 64 * 64)); CK(hipMemset(ixc, 0, 64 * 64));   // (room for the 64-shard variant)
+  CK(hipMalloc((void**)&ixc, 256 * 64)); CK(hipMemset(ixc, 0, 256 * 64));   // (room for the 256-shard variant)
   CK(hipMalloc((void**)&status, 8)); CK(hipMemset(status, 0, 8));
 
   // batches (host): kind 0 = new, 1 = known, 2 = step; `gen` makes the unique hashes of different batches differ
@@ -94,34 +96,47 @@ int main() {
     return 0;
   };
   unsigned long long* d_dig; CK(hipMalloc((void**)&d_dig, 8));
-  struct V { const char* name; Kern k; };
-  std::vector<V> variants{{"library", eppk::index_insert_picks_kernel<LW>}};
+  using EvictKern = void (*)(uint64_t*, void*, uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*);
+  struct V { const char* name; Kern k; EvictKern ev; };
+  std::vector<V> variants{{"library", eppk::index_insert_picks_kernel<LW>, eppk::index_evict_kernel<LW>}};
 #ifdef HAVE_VARIANTS
-  variants.push_back({"v1 (claimed key: no loads before the atomics)", eppk_v1::index_insert_picks_kernel<LW>});
-  variants.push_back({"v2 (v1 + bucket by four 16-byte loads)", eppk_v2::index_insert_picks_kernel<LW>});
-  variants.push_back({"f1 (v2 + counters once per workgroup)", eppk_f1::index_insert_picks_kernel<LW>});
-  variants.push_back({"f2 (f1 + 64 counter shards)", eppk_f2::index_insert_picks_kernel<LW>});
-  variants.push_back({"f3 (library + counters once per workgroup, nothing else)", eppk_f3::index_insert_picks_kernel<LW>});
-  variants.push_back({"d1 (diagnostic: v2 without the counters)", eppk_d1::index_insert_picks_kernel<LW>});
-  variants.push_back({"d2 (diagnostic: claim only)", eppk_d2::index_insert_picks_kernel<LW>});
-  variants.push_back({"d3 (diagnostic: v2 counting lost claims)", eppk_d3::index_insert_picks_kernel<LW>});
+  variants.push_back({"v1 (claimed key: no loads before the atomics)", eppk_v1::index_insert_picks_kernel<LW>, eppk_v1::index_evict_kernel<LW>});
+  variants.push_back({"v2 (v1 + bucket by four 16-byte loads)", eppk_v2::index_insert_picks_kernel<LW>, eppk_v2::index_evict_kernel<LW>});
+  variants.push_back({"f1 (v2 + counters once per workgroup)", eppk_f1::index_insert_picks_kernel<LW>, eppk_f1::index_evict_kernel<LW>});
+  variants.push_back({"f2 (f1 + 64 counter shards)", eppk_f2::index_insert_picks_kernel<LW>, eppk_f2::index_evict_kernel<LW>});
+  variants.push_back({"f3 (library + counters once per workgroup, nothing else)", eppk_f3::index_insert_picks_kernel<LW>, eppk_f3::index_evict_kernel<LW>});
+  variants.push_back({"f4 (f1 + 256 shards + evict counters once per workgroup)", eppk_f4::index_insert_picks_kernel<LW>, eppk_f4::index_evict_kernel<LW>});
+  variants.push_back({"d4 (diagnostic: f4, a claimed key does not write its row)", eppk_d4::index_insert_picks_kernel<LW>, eppk_d4::index_evict_kernel<LW>});
+  variants.push_back({"d1 (diagnostic: v2 without the counters)", eppk_d1::index_insert_picks_kernel<LW>, eppk_d1::index_evict_kernel<LW>});
+  variants.push_back({"d2 (diagnostic: claim only)", eppk_d2::index_insert_picks_kernel<LW>, eppk_d2::index_evict_kernel<LW>});
+  variants.push_back({"d3 (diagnostic: v2 counting lost claims)", eppk_d3::index_insert_picks_kernel<LW>, eppk_d3::index_evict_kernel<LW>});
 #endif
   for (const V& v : variants) {
     printf("--- %s\n", v.name);
     kern = v.k;
-    CK(hipMemset(bitmaps, 0, index_bytes)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u)); CK(hipMemset(ixc, 0, 64 * 64));
+    CK(hipMemset(bitmaps, 0, index_bytes)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u)); CK(hipMemset(ixc, 0, 256 * 64));
     hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
     if (run("warm", 1, 0, 2, false)) return 1;                 // the hot prefixes enter the index
     if (run("new", 0, 10, 2, true)) return 1;
     if (run("known", 1, 0, 2, true)) return 1;
     if (run("known+", 1, 0, 3, true)) return 1;
     if (run("step", 2, 20, 3, true)) return 1;               // (2.1 Mi + 2 Mi pairs stays below the 4 Mi limit: no exact-capacity mode)
-    unsigned long long h[64 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
-    unsigned long long live = 0, dropped = 0, lost = 0; for (uint32_t s2 = 0; s2 < 64u; ++s2) { live += h[s2 * 8 + eppk::kIxLive]; dropped += h[s2 * 8 + eppk::kIxDropped]; lost += h[s2 * 8 + eppk::kIxEvicted]; }
+    unsigned long long h[256 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long live = 0, dropped = 0, lost = 0; for (uint32_t s2 = 0; s2 < 256u; ++s2) { live += h[s2 * 8 + eppk::kIxLive]; dropped += h[s2 * 8 + eppk::kIxDropped]; lost += h[s2 * 8 + eppk::kIxEvicted]; }
     CK(hipMemset(d_dig, 0, 8));
     hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, stamps, lists, slots, d_dig);
     unsigned long long dig; CK(hipMemcpy(&dig, d_dig, 8, hipMemcpyDeviceToHost));
     printf("live keys %llu (expected %u), dropped %llu, lost claims %llu, digest %016llx\n", live, 4096u + 2u * 1048576u, dropped, lost, dig);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(v.ev, dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, 3u, ixc);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ems; CK(hipEventElapsedTime(&ems, e0, e1));
+    CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long live2 = 0, ev = 0; for (uint32_t s2 = 0; s2 < 256u; ++s2) { live2 += h[s2 * 8 + eppk::kIxLive]; ev += h[s2 * 8 + eppk::kIxEvicted]; }
+    CK(hipMemset(d_dig, 0, 8));
+    hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, stamps, lists, slots, d_dig);
+    CK(hipMemcpy(&dig, d_dig, 8, hipMemcpyDeviceToHost));
+    printf("evict    < epoch 3: %8.1f us   live keys after %llu, evicted %llu, digest %016llx\n", ems * 1e3, live2, ev - lost, dig);
   }
   return 0;
 }
