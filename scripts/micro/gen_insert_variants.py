@@ -7,6 +7,8 @@ scripts/micro/insertbreak.hip (the product sources are not touched).  Output: sc
   f1  v2 + the live / words / dropped counters bumped once per WORKGROUP (LDS) instead of once per wavefront
   f2  f1 with 64 counter shards instead of 32          f3  the library's insert with only the per-workgroup counters
   f4  f1 with 256 counter shards (ix_budget sums four per lane) + the evict kernel's counters once per workgroup
+  e1  f2 + eviction with a LANE per victim (all victims of a wave step in flight) instead of the wavefront walking them one by one
+  e2  e1 + the stamp loaded beside the key (not behind the key test); the harness launches it with a wavefront per 64 slots (no grid cap)
   d4  f4 where a claimed key does not write its row (diagnostic for "rows only for overflowed sets": wrong table)
   d1  v2 without the live / words / dropped counters      d2  d1 without the stamp / row / list updates (claim only)
   d3  v2 counting lost claims (a CAS that found the word taken by another key) in the "evicted" counter
@@ -142,6 +144,49 @@ ROW_OLD = """      if constexpr (sizeof(LW) == 8) fresh = !((atomicOr((unsigned 
 ROW_NEW = """      fresh = true; (void)lane; (void)j;"""
 
 
+# eviction with every victim of a wave step in flight at once: a LANE per victim (its list by four 16-byte loads, a store per listed
+# pod, the list reset by four 16-byte stores) instead of the wavefront walking its victims one after the other
+EV_OLD = """    unsigned long long vm = __ballot(victim);
+    gone += (uint32_t)__builtin_popcountll(vm);
+    while (vm) {
+      const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
+      vm &= vm - 1ull;
+      bool whole = true;
+      if (lists) {"""
+EV_NEW = """    unsigned long long vm = __ballot(victim);
+    gone += (uint32_t)__builtin_popcountll(vm);
+    bool whole_l = victim;
+    if (victim && lists) {
+      u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
+      u32x4_t c0 = Lp[0], c1 = Lp[1], c2 = Lp[2], c3 = Lp[3];
+      if (c0.w <= kListCap) {
+        whole_l = false;
+        const uint32_t w6[12] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z, c3.x, c3.y, c3.z};   // ids: positions 0..5 of every chunk
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          const uint32_t lo = w6[q] & 0xFFFFu, hi = w6[q] >> 16;
+          if (lo != kListNone && (lo >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (lo & 63u)] = 0;
+          if (hi != kListNone && (hi >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (hi & 63u)] = 0;
+        }
+      }
+      const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
+    }
+    vm = __ballot(whole_l);          // overflowed lists (or no lists at all): the whole row, by the wavefront
+    while (vm) {
+      const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
+      vm &= vm - 1ull;
+      bool whole = true;
+      if (false) {"""
+
+
+ST_OLD = """      const uint64_t k = keys[row];
+      victim = k != 0ull && !(row < slots && k == kTomb) && stamps[row] < min_epoch;"""
+ST_NEW = """      const uint64_t k = keys[row];
+      const uint32_t st = stamps[row];                 // (not behind the key test: the two loads travel together)
+      victim = k != 0ull && !(row < slots && k == kTomb) && st < min_epoch;"""
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     src = open(SRC).read()
@@ -152,6 +197,8 @@ def main():
                         ("f2", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH_NEW)]),
                         ("f3", [(AGG_OLD, AGG_NEW)]),
                         ("f4", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH256_NEW), (BUD_OLD, BUD_NEW), (EVICT_OLD, EVICT_NEW)]),
+                        ("e1", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH_NEW), (EV_OLD, EV_NEW)]),
+                        ("e2", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH_NEW), (EV_OLD, EV_NEW), (ST_OLD, ST_NEW)]),
                         ("d4", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (AGG_OLD, AGG_NEW), (SH_OLD, SH256_NEW), (BUD_OLD, BUD_NEW), (EVICT_OLD, EVICT_NEW), (ROW_OLD, ROW_NEW)]),
                         ("d3", [(HEAD_OLD, HEAD_NEW), (TAIL_OLD, TAIL_NEW), (LOAD_OLD, LOAD_NEW), (RETRY_OLD, RETRY_NEW)])):
         s = src

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #define EPPK_MAIN_UNIT 1
@@ -22,6 +23,8 @@
 #include "_gen/eppk_kernels_f3.hip.h"
 #include "_gen/eppk_kernels_f4.hip.h"
 #include "_gen/eppk_kernels_d4.hip.h"
+#include "_gen/eppk_kernels_e1.hip.h"
+#include "_gen/eppk_kernels_e2.hip.h"
 #define HAVE_VARIANTS 1
 #endif
 
@@ -47,7 +50,7 @@ __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const 
   atomicAdd(out, acc);
 }
 
-int main() {
+int main(int argc, char** argv) {
   using LW = uint64_t;
   const uint32_t slots = 8u << 20, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
   uint32_t lg = 0; while ((1u << lg) < slots / eppk::kBucket) ++lg;
@@ -97,7 +100,7 @@ int main() {
   };
   unsigned long long* d_dig; CK(hipMalloc((void**)&d_dig, 8));
   using EvictKern = void (*)(uint64_t*, void*, uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*);
-  struct V { const char* name; Kern k; EvictKern ev; };
+  struct V { const char* name; Kern k; EvictKern ev; uint32_t ev_grid = 4096; };
   std::vector<V> variants{{"library", eppk::index_insert_picks_kernel<LW>, eppk::index_evict_kernel<LW>}};
 #ifdef HAVE_VARIANTS
   variants.push_back({"v1 (claimed key: no loads before the atomics)", eppk_v1::index_insert_picks_kernel<LW>, eppk_v1::index_evict_kernel<LW>});
@@ -106,12 +109,17 @@ int main() {
   variants.push_back({"f2 (f1 + 64 counter shards)", eppk_f2::index_insert_picks_kernel<LW>, eppk_f2::index_evict_kernel<LW>});
   variants.push_back({"f3 (library + counters once per workgroup, nothing else)", eppk_f3::index_insert_picks_kernel<LW>, eppk_f3::index_evict_kernel<LW>});
   variants.push_back({"f4 (f1 + 256 shards + evict counters once per workgroup)", eppk_f4::index_insert_picks_kernel<LW>, eppk_f4::index_evict_kernel<LW>});
+  variants.push_back({"e1 (f2 + eviction with a lane per victim)", eppk_e1::index_insert_picks_kernel<LW>, eppk_e1::index_evict_kernel<LW>});
+  variants.push_back({"e2 (e1 + stamp beside key, grid 4096)", eppk_e2::index_insert_picks_kernel<LW>, eppk_e2::index_evict_kernel<LW>});
+  variants.push_back({"e3 (e2 with a wavefront per 64 slots: 32768 workgroups)", eppk_e2::index_insert_picks_kernel<LW>, eppk_e2::index_evict_kernel<LW>, 32769u});
+  variants.push_back({"e4 (e1 with 32768 workgroups)", eppk_e1::index_insert_picks_kernel<LW>, eppk_e1::index_evict_kernel<LW>, 32769u});
   variants.push_back({"d4 (diagnostic: f4, a claimed key does not write its row)", eppk_d4::index_insert_picks_kernel<LW>, eppk_d4::index_evict_kernel<LW>});
   variants.push_back({"d1 (diagnostic: v2 without the counters)", eppk_d1::index_insert_picks_kernel<LW>, eppk_d1::index_evict_kernel<LW>});
   variants.push_back({"d2 (diagnostic: claim only)", eppk_d2::index_insert_picks_kernel<LW>, eppk_d2::index_evict_kernel<LW>});
   variants.push_back({"d3 (diagnostic: v2 counting lost claims)", eppk_d3::index_insert_picks_kernel<LW>, eppk_d3::index_evict_kernel<LW>});
 #endif
   for (const V& v : variants) {
+    if (argc > 1) { bool want = false; for (int a = 1; a < argc; ++a) want = want || std::string(v.name).rfind(argv[a], 0) == 0; if (!want) continue; }
     printf("--- %s\n", v.name);
     kern = v.k;
     CK(hipMemset(bitmaps, 0, index_bytes)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u)); CK(hipMemset(ixc, 0, 256 * 64));
@@ -128,7 +136,7 @@ int main() {
     unsigned long long dig; CK(hipMemcpy(&dig, d_dig, 8, hipMemcpyDeviceToHost));
     printf("live keys %llu (expected %u), dropped %llu, lost claims %llu, digest %016llx\n", live, 4096u + 2u * 1048576u, dropped, lost, dig);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(v.ev, dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, 3u, ixc);
+    hipLaunchKernelGGL(v.ev, dim3(v.ev_grid), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, 3u, ixc);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ems; CK(hipEventElapsedTime(&ems, e0, e1));
     CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
