@@ -1,5 +1,5 @@
 // Measurement tool (not product code): bench.py's timed region without Python or torch, for A/B runs that cost seconds of GPU budget.
-//   pickbench <workload dir> <libeppk.so> [more libeppk.so ...] [--steps N] [--inflight 1|2] [--closed-loop] [--cl-slots N]
+//   pickbench <workload dir> <libeppk.so> [more libeppk.so ...] [--steps N] [--inflight 1|2] [--closed-loop] [--cl-slots N] [--profile]
 // Every library named is dlopen()ed in turn (scripts/abq.sh leaves one per variant under ab/<name>/), run on the same workload
 // (scripts/dump_workload.py), timed like bench.py (16 rotating batches resident in HBM, two in flight on two streams; closed loop:
 // pick -> eppk_index_insert_picks_device -> next batch with fresh tail hashes, ageing every 2 steps, keep 2 epochs) and compared
@@ -54,7 +54,7 @@ struct Api {
   decltype(&eppk_create) create; decltype(&eppk_destroy) destroy; decltype(&eppk_last_error) last_error;
   decltype(&eppk_snapshot_publish) publish; decltype(&eppk_index_insert) index_insert; decltype(&eppk_pick_batch_device) pick_device;
   decltype(&eppk_index_insert_picks_device) insert_picks; decltype(&eppk_index_advance_epoch) advance; decltype(&eppk_index_evict_older_device) evict_device;
-  decltype(&eppk_quad_stats) quad_stats; decltype(&eppk_index_size) index_size; decltype(&eppk_index_dropped) index_dropped;
+  decltype(&eppk_quad_stats) quad_stats; decltype(&eppk_profile_enable) profile_enable; decltype(&eppk_index_size) index_size; decltype(&eppk_index_dropped) index_dropped;
   bool load(const char* path) {
     h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!h) { std::printf("dlopen %s: %s\n", path, dlerror()); return false; }
@@ -64,6 +64,7 @@ struct Api {
     SYM(advance, eppk_index_advance_epoch) SYM(evict_device, eppk_index_evict_older_device) SYM(index_size, eppk_index_size) SYM(index_dropped, eppk_index_dropped)
 #undef SYM
     quad_stats = (decltype(quad_stats))dlsym(h, "eppk_quad_stats");       // (optional: older builds)
+    profile_enable = (decltype(profile_enable))dlsym(h, "eppk_profile_enable");
     return true;
   }
 };
@@ -72,7 +73,7 @@ int main(int argc, char** argv) {
   std::vector<std::string> libs;
   std::string dir;
   int steps = 200, warmup = 20, inflight = 2;
-  bool closed = false;
+  bool closed = false, profile = false;
   uint32_t cl_slots = 1u << 24;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -80,6 +81,7 @@ int main(int argc, char** argv) {
     else if (a == "--warmup") warmup = std::atoi(argv[++i]);
     else if (a == "--inflight") inflight = std::atoi(argv[++i]);
     else if (a == "--closed-loop") closed = true;
+    else if (a == "--profile") profile = true;          // completion events on every pick launch, as bench.py runs (eppk_profile_enable)
     else if (a == "--cl-slots") cl_slots = (uint32_t)std::strtoul(argv[++i], nullptr, 0);
     else if (dir.empty()) dir = a;
     else libs.push_back(a);
@@ -130,6 +132,7 @@ int main(int argc, char** argv) {
       for (uint32_t r = 0; r < R; ++r) d += (unsigned long long)(uint32_t)hp[r] * (0x9E3779B97F4A7C15ull * (r + 1u) | 1ull);
       digest.push_back(d);
     }
+    if (profile && api.profile_enable) api.profile_enable(ctx, 1);
     uint64_t gen = 1;
     uint32_t epoch = 1;
     auto step = [&](int i) -> int {
