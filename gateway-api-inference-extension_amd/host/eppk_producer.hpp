@@ -85,9 +85,10 @@ class SnapshotProducer {
     });
   }
   void Stop() {
-    { std::lock_guard<std::mutex> g(run_mu_); stop_ = true; }
+    std::thread t;
+    { std::lock_guard<std::mutex> g(run_mu_); stop_ = true; t = std::move(th_); }
     cv_.notify_all();
-    if (th_.joinable()) th_.join();
+    if (t.joinable()) t.join();
   }
   uint64_t rounds() const { return rounds_.load(); }
   uint64_t failed_publishes() const { return failed_publishes_.load(); }

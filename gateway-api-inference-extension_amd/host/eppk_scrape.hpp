@@ -303,9 +303,10 @@ class MetricsDataSource {      // 1023-…/README.md:143-163 (DataSource)
     });
   }
   void Stop() {
-    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    std::thread t;
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; t = std::move(th_); }
     cv_.notify_all();
-    if (th_.joinable()) th_.join();
+    if (t.joinable()) t.join();
   }
   uint64_t rounds() const { return rounds_.load(); }
 
