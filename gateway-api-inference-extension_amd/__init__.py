@@ -12,10 +12,11 @@ Only the hot path lives here: ``csrc/`` holds the HIP kernels an
 * ``picker.subset_mask``    — candidate filter of handleRequestHeaders (request.go:104-133)
 * ``distributed``           — request sharding + the all-gather of picks
 * ``workload``              — synthetic snapshot/request tables of SURVEY.md §8(d)
+* ``metrics``               — snapshot producer: model-server /metrics -> pod rows -> ``BatchedPicker.publish`` (§8(f)-2)
 
 There is no CPU implementation of the pick in this package: without ``libeppk.so`` and a HIP device
 every pick raises.
 """
-from . import _lib, distributed, picker, workload  # noqa: F401
+from . import _lib, distributed, metrics, picker, workload  # noqa: F401
 from ._lib import EppkError, lib_path, load_library  # noqa: F401
 from .picker import BatchedPicker, DeviceGroup, Endpoint, PickResult, RoundRobinPicker, ScorerKind, Unavailable, subset_mask  # noqa: F401
