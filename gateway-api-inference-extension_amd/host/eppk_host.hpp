@@ -267,6 +267,18 @@ class GpuPicker : public EndpointPicker {
     Slot slot;
     slot.req = &req;
     slot.cands = &endpoints;
+    // The per-request work that does not need the device runs HERE, on the request's own thread: hashing the prompt (2 KiB of XXH64
+    // per request) and turning the candidate slice into a bitmask (one look-up per candidate: O(pods) when nothing was filtered --
+    // what the reference's PodList costs per request too, request.go:99).  The dispatcher thread only copies rows and masks.
+    slot.hashes.resize(opt_.max_blocks);
+    const int nb = eppk_hash_prompt((const uint8_t*)req.model.data(), req.model.size(), (const uint8_t*)req.body.data(), req.body.size(), opt_.block_chars,
+                                    slot.hashes.data(), opt_.max_blocks);
+    slot.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
+    {
+      std::shared_ptr<Snapshot> snap;
+      { std::lock_guard<std::mutex> sg(mu_); snap = snap_; }
+      if (snap) { BuildMask(*snap, endpoints, &slot.mask, &slot.found); slot.mask_snap = std::move(snap); }
+    }
     std::unique_lock<std::mutex> g(mu_);
     queue_.push_back(&slot);
     cv_.notify_all();
@@ -298,11 +310,31 @@ class GpuPicker : public EndpointPicker {
   struct Slot {
     const PickRequest* req = nullptr;
     const std::vector<const Endpoint*>* cands = nullptr;
+    // prepared by the CALLER's thread in Pick() (every request thread works on its own request; the dispatcher only copies):
+    std::vector<uint64_t> hashes;             // the block-hash chain of the prompt
+    uint32_t n_blocks = 0;
+    std::shared_ptr<Snapshot> mask_snap;      // the snapshot `mask` was built against (the dispatcher rebuilds it if a publish came between)
+    std::vector<uint64_t> mask;               // candidate bitmask over that snapshot's indices
+    uint32_t found = 0;                       // distinct candidates known to that snapshot
     bool done = false, fail_open = false;
     int32_t pick = -1;
     std::string endpoint;
     std::vector<std::string> fallbacks;
   };
+
+  // candidate slice -> bitmask over the snapshot's indices (the subset filter already ran: request.go:104-133)
+  static void BuildMask(const Snapshot& snap, const std::vector<const Endpoint*>& cands, std::vector<uint64_t>* mask, uint32_t* found) {
+    const uint32_t P = (uint32_t)snap.endpoints.size(), W = (P + 63u) / 64u;
+    mask->assign(W ? W : 1, 0);
+    *found = 0;
+    for (const Endpoint* e : cands) {
+      auto a = snap.by_addr.find(JoinHostPort(e->address, e->port));
+      if (a == snap.by_addr.end()) continue;  // candidate unknown to this snapshot: not scoreable
+      const uint64_t bit = 1ull << (a->second & 63u);
+      if (!((*mask)[a->second >> 6] & bit)) ++*found;
+      (*mask)[a->second >> 6] |= bit;
+    }
+  }
 
   void Loop() {
     std::vector<Slot*> batch;
@@ -342,23 +374,16 @@ class GpuPicker : public EndpointPicker {
           bool any_mask = false;
           mask.assign(n * (size_t)(W ? W : 1), 0);
           for (size_t i = 0; i < n; ++i) {
-            const PickRequest& rq = *batch[i]->req;
+            Slot& sl = *batch[i];
             eppk_req_hdr hdr;
-            auto it = snap->adapters.find(rq.model);
+            auto it = snap->adapters.find(sl.req->model);
             hdr.adapter = it == snap->adapters.end() ? EPPK_ADAPTER_BASE : it->second;
-            int nb = eppk_hash_prompt((const uint8_t*)rq.model.data(), rq.model.size(), (const uint8_t*)rq.body.data(), rq.body.size(),
-                                      opt_.block_chars, (uint64_t*)(rowp + i * stride_ + 8), opt_.max_blocks);
-            hdr.n_blocks = nb < 0 ? 0u : (uint32_t)nb;
+            hdr.n_blocks = sl.n_blocks;
             std::memcpy(rowp + i * stride_, &hdr, sizeof hdr);
-            // candidate slice -> bitmask over snapshot indices (the subset filter already ran: request.go:104-133)
-            uint32_t found = 0;
-            for (const Endpoint* e : *batch[i]->cands) {
-              auto a = snap->by_addr.find(JoinHostPort(e->address, e->port));
-              if (a == snap->by_addr.end()) continue;  // candidate unknown to this snapshot: not scoreable
-              const uint64_t bit = 1ull << (a->second & 63u);
-              if (!(mask[i * W + (a->second >> 6)] & bit)) ++found;
-              mask[i * W + (a->second >> 6)] |= bit;
-            }
+            std::memcpy(rowp + i * stride_ + 8, sl.hashes.data(), (size_t)sl.n_blocks * 8u);
+            if (sl.mask_snap != snap) BuildMask(*snap, *sl.cands, &sl.mask, &sl.found);     // a publish came between Pick() and this batch
+            std::memcpy(mask.data() + i * (size_t)(W ? W : 1), sl.mask.data(), (size_t)(W ? W : 1) * 8u);
+            const uint32_t found = sl.found;
             if (found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
           }
           const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);

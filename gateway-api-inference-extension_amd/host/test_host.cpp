@@ -159,6 +159,48 @@ static int run_cpu() {
   CHECK(gp.Pick({}, all, &pr).ok() && !pr.endpoint.empty() && gp.fail_opens() == fo + 1);
   fake->fail = false;
   CHECK(gp.Pick({}, all, &pr).ok() && pr.endpoint == "10.0.0.4:8080");
+  {  // snapshots published WHILE requests are in flight: a request prepares its candidate mask on its own thread against the snapshot
+     // it saw in Pick(); when another one is current by the time its batch is built, the dispatcher rebuilds the mask -- every pick
+     // must still be a candidate of its request and an endpoint of one of the two snapshots, whatever the interleaving.
+    auto eps_b = make_endpoints(5);
+    std::vector<Endpoint> snap_b{eps_b[4], eps_b[2], eps_b[0]};          // other order, other size: every index means another endpoint
+    std::vector<eppk_pod_row> rows_b(3);
+    std::memset(rows_b.data(), 0, rows_b.size() * sizeof(eppk_pod_row));
+    rows_b[0].queue = 2; rows_b[1].queue = 1; rows_b[2].queue = 3;        // shortest queue: 10.0.0.3
+    std::atomic<bool> stop_pub{false};
+    std::atomic<int> wrong{0}, served{0};
+    std::thread publisher([&] {
+      for (uint64_t e = 10; !stop_pub.load(); ++e) {
+        if (!(e & 1 ? gp.PublishSnapshot(snap_b, rows_b, {}, e) : gp.PublishSnapshot(eps, rows, {{"adapter-a", 3}}, e)).ok()) wrong++;
+        std::this_thread::sleep_for(std::chrono::microseconds(300));
+      }
+    });
+    std::vector<std::thread> callers;
+    for (int t = 0; t < 8; ++t)
+      callers.emplace_back([&, t] {
+        std::vector<const Endpoint*> mine;                                   // thread t may use every endpoint but number t % 5
+        for (int i = 0; i < 5; ++i) if (i != t % 5) mine.push_back(&eps[(size_t)i]);
+        for (int i = 0; i < 300; ++i) {
+          PickRequest rq;
+          rq.body = std::string(200 + (size_t)i, (char)('a' + t));
+          PickResult r;
+          const Status st = gp.Pick(rq, mine, &r);
+          if (!st.ok()) { wrong++; continue; }
+          bool is_cand = false;
+          for (const Endpoint* e : mine) is_cand = is_cand || JoinHostPort(e->address, e->port) == r.endpoint;
+          if (!is_cand) wrong++;
+          // the shortest queue among this thread's candidates, under either snapshot
+          const std::string a = t % 5 == 3 ? "10.0.0.2:8080" : "10.0.0.4:8080", b = t % 5 == 2 ? "10.0.0.5:8080" : "10.0.0.3:8080";
+          if (r.endpoint != a && r.endpoint != b) wrong++;
+          served++;
+        }
+      });
+    for (auto& c : callers) c.join();
+    stop_pub = true;
+    publisher.join();
+    CHECK(wrong.load() == 0 && served.load() == 2400);
+    CHECK(gp.PublishSnapshot(eps, rows, {{"adapter-a", 3}}, 999).ok());
+  }
   std::printf("host cpu ok: %d backend calls for 3200 concurrent picks, largest batch %llu\n", calls,
               (unsigned long long)gp.largest_batch());
   {  // ordered fallbacks (PickResult.Fallbacks, server.go:74) through the micro-batcher
