@@ -15,7 +15,7 @@ FILES = ["pkg/lwepp/handlers/server.go", "pkg/lwepp/server/options.go", "pkg/lwe
 def test_patch_names_only_the_picker_seam():
     text = open(PATCH).read()
     touched = sorted({ln.split("\t")[0][len("+++ b/"):] for ln in text.splitlines() if ln.startswith("+++ b/")})
-    assert touched == sorted(FILES + ["pkg/lwepp/handlers/gpupicker.go", "pkg/lwepp/handlers/gpupicker_nocgo.go", "pkg/lwepp/handlers/gpusnapshot.go"])
+    assert touched == sorted(FILES + ["pkg/lwepp/handlers/gpupicker.go", "pkg/lwepp/handlers/gpupicker_nocgo.go", "pkg/lwepp/handlers/gpusnapshot.go", "pkg/lwepp/handlers/gpusnapshot_test.go"])
     assert "ctx.Done()" in text and "eppk_index_insert" in text and "runtime.LockOSThread()" in text
     # the picker is fed: main.go starts the snapshot producer (scrape -> pod rows -> PublishSnapshot), in both build modes
     assert "go sp.Run(ctx)" in text and text.count("func (p *GPUPicker) PublishSnapshot(") == 2
