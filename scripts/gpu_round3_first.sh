@@ -6,6 +6,8 @@ OUT=$PWD/gpurun_out/r3first
 rm -rf $OUT; mkdir -p $OUT
 T0=$(date +%s)
 lap() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
+# 0. seconds: open-loop and closed-loop parity of C5 against the oracle in a Python-free binary
+timeout 300 python -m pytest tests/test_zz_parity_quick_gpu.py -m gpu -x -q > $OUT/parity_quick.txt 2>&1; tail -3 $OUT/parity_quick.txt; lap parity-quick
 # 1. the index maintenance and closed-loop tests first: they are what the change can break
 timeout 900 python -m pytest tests/test_gpu_closed_loop.py tests/test_gpu_fuzz.py tests/test_gpu_holes.py -m gpu -x -q > $OUT/pytest_index.txt 2>&1; tail -3 $OUT/pytest_index.txt; lap index-tests
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "index or insert or evict or trim or capacity or full" > $OUT/pytest_parity_index.txt 2>&1; tail -2 $OUT/pytest_parity_index.txt; lap parity-index
