@@ -4,7 +4,9 @@
 //   2. the closed loop: G generations of  pick -> index_insert_picks -> (every 2nd: advance epoch, evict older than epoch - 1)  with
 //      fresh tail hashes per generation; picks, scores and the number of live hashes after every generation.
 // What the full pytest suite checks in minutes, for the two things a kernel edit breaks first.   parity_quick <workload dir> [G]
+#ifndef PARITY_QUICK_SELFTEST
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +18,35 @@
 
 #include "../../include/eppk.h"
 #include "../../oracle/oracle.h"
+
+#ifdef PARITY_QUICK_SELFTEST
+// Self-test of THIS harness on a box without a GPU (tests/test_zz_parity_quick_gpu.py::test_parity_quick_selftest): the library's entry
+// points and the HIP calls are replaced by stand-ins backed by a second oracle instance, so that the control flow -- file parsing,
+// fresh tails, epochs, the eviction, the index-size bookkeeping -- is exercised end to end.  It says nothing about the library.
+#include <map>
+typedef int hipError_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+static const char* hipGetErrorString(hipError_t) { return "stand-in"; }
+static hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
+static hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
+struct eppk_ctx { eppk_cfg cfg; std::vector<eppk_pod_row> pods; orc_index* ix; };
+extern "C" {
+int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) { *out = new eppk_ctx{*cfg, {}, orc_index_new()}; return EPPK_OK; }
+void eppk_destroy(eppk_ctx* c) { orc_index_free(c->ix); delete c; }
+const char* eppk_last_error(const eppk_ctx*) { return "stand-in"; }
+int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n, uint64_t) { c->pods.assign(rows, rows + n); return EPPK_OK; }
+int eppk_index_insert(eppk_ctx* c, const uint64_t* h, const uint32_t* p, uint32_t n) { for (uint32_t i = 0; i < n; ++i) orc_index_insert(c->ix, h[i], p[i]); return EPPK_OK; }
+int eppk_pick_batch_device(eppk_ctx* c, const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores, void*) {
+  return orc_pick_batch_mt(c->cfg.chain, c->cfg.n_scorers, c->pods.data(), (uint32_t)c->pods.size(), c->ix, reqs, c->cfg.max_blocks, n, mask, picks, scores, 4) ? EPPK_ERR_ARG : EPPK_OK;
+}
+int eppk_index_insert_picks_device(eppk_ctx* c, const void* reqs, const int32_t* picks, uint32_t n, void*) { orc_index_insert_picks(c->ix, reqs, c->cfg.max_blocks, n, picks); return EPPK_OK; }
+int eppk_launch_status(eppk_ctx*, uint32_t* flags) { *flags = 0; return EPPK_OK; }
+int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* e) { *e = orc_index_advance_epoch(c->ix); return EPPK_OK; }
+int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n) { *n = orc_index_evict_older(c->ix, min_epoch); return EPPK_OK; }
+int eppk_index_size(eppk_ctx* c, uint32_t* n) { *n = (uint32_t)orc_index_size(c->ix); return EPPK_OK; }
+int eppk_index_dropped(eppk_ctx*, uint64_t* n) { *n = 0; return EPPK_OK; }
+}
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 #define EK(x) do { int rc_ = (x); if (rc_ != EPPK_OK) { std::printf("%s -> %d: %s\n", #x, rc_, eppk_last_error(ctx)); return 1; } } while (0)
@@ -64,7 +95,7 @@ int main(int argc, char** argv) {
   };
 
   for (int pass = 0; pass < 2; ++pass) {           // pass 0: open loop on the workload's own index; pass 1: closed loop on a large one
-    cfg.index_slots = pass == 0 ? slots : (1u << 24);
+    cfg.index_slots = pass == 0 ? slots : (1u << 24);     // (the stand-ins of the self-test ignore it)
     eppk_ctx* ctx = nullptr;
     if (eppk_create(&cfg, &ctx) != EPPK_OK) { std::printf("eppk_create: %s\n", eppk_last_error(nullptr)); return 1; }
     EK(eppk_snapshot_publish(ctx, (const eppk_pod_row*)pods.data(), P, 1));

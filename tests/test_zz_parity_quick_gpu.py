@@ -28,6 +28,22 @@ def test_parity_quick_compiles():
     build()
 
 
+def test_parity_quick_selftest(tmp_path):
+    """The harness itself, on the CPU: the library and HIP replaced by stand-ins over a second oracle instance (-DPARITY_QUICK_SELFTEST) --
+    file parsing, fresh tails per generation, epoch ticks, a real eviction and the index-size bookkeeping run end to end on C3."""
+    import __graft_entry__ as g
+    g.load_oracle().build()
+    exe = str(tmp_path / "parity_quick_selftest")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-x", "c++", "-DPARITY_QUICK_SELFTEST", SRC, "-o", exe, f"-L{os.path.join(ROOT, 'oracle')}", "-loracle",
+                    f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-pthread"], check=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dump_workload.py"), "--config", "3", "--out", str(tmp_path / "c3")], check=True, timeout=300)
+    out = subprocess.run([exe, str(tmp_path / "c3"), "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "parity_quick ok" in out.stdout and "closed loop, generation 3:" in out.stdout
+    evicted = [ln for ln in out.stdout.splitlines() if "evicted" in ln]
+    assert evicted and int(evicted[-1].split()[1]) > 0, out.stdout          # the eviction really dropped something
+
+
 @pytest.mark.gpu
 def test_parity_quick(tmp_path):
     exe = build()
