@@ -282,7 +282,7 @@ class GpuPicker : public EndpointPicker {
     std::unique_lock<std::mutex> g(mu_);
     queue_.push_back(&slot);
     cv_.notify_all();
-    done_cv_.wait(g, [&] { return slot.done; });
+    slot.cv.wait(g, [&] { return slot.done; });   // (its own condition variable: a finished batch wakes its requests, not every waiter)
     g.unlock();
     if (slot.fail_open) {  // backend error: never take the stream down, fall back to the reference picker
       fail_open_count_.fetch_add(1, std::memory_order_relaxed);
@@ -317,6 +317,7 @@ class GpuPicker : public EndpointPicker {
     std::vector<uint64_t> mask;               // candidate bitmask over that snapshot's indices
     uint32_t found = 0;                       // distinct candidates known to that snapshot
     bool done = false, fail_open = false;
+    std::condition_variable cv;               // signalled under mu_ when `done` is set
     int32_t pick = -1;
     std::string endpoint;
     std::vector<std::string> fallbacks;
@@ -434,10 +435,9 @@ class GpuPicker : public EndpointPicker {
         }
       }
       g.lock();
-      for (Slot* s : batch) { s->fail_open = failed; s->done = true; }
+      for (Slot* s : batch) { s->fail_open = failed; s->done = true; s->cv.notify_one(); }   // under mu_: the Slot outlives the call
       batches_.fetch_add(1);
       if (n > largest_batch_.load()) largest_batch_.store(n);
-      done_cv_.notify_all();
     }
   }
 
@@ -447,7 +447,7 @@ class GpuPicker : public EndpointPicker {
   RoundRobinPicker rr_;
   std::mutex mu_;     // queue + snap_ pointer
   std::mutex be_mu_;  // backend context + snapshot consistency; always taken BEFORE mu_
-  std::condition_variable cv_, done_cv_;
+  std::condition_variable cv_;
   std::vector<Slot*> queue_;
   std::shared_ptr<Snapshot> snap_;
   // stable_slots (guarded by be_mu_): "ip:port" -> slot across snapshots, freed slots, high-water mark
