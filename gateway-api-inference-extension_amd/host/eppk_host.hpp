@@ -198,7 +198,7 @@ class GpuPicker : public EndpointPicker {
     if (!opt_.stable_slots) {
       snap->endpoints = endpoints;
       snap->n_active = (uint32_t)endpoints.size();
-      for (size_t i = 0; i < endpoints.size(); ++i) snap->by_addr[JoinHostPort(endpoints[i].address, endpoints[i].port)] = (uint32_t)i;
+      for (size_t i = 0; i < endpoints.size(); ++i) snap->Index(JoinHostPort(endpoints[i].address, endpoints[i].port), endpoints[i], (uint32_t)i);
       if (be_->Publish(rows.data(), (uint32_t)rows.size(), epoch) != EPPK_OK) return {Code::Internal, be_->LastError()};
     } else {
       // 1. endpoints that left free their slots (lowest slot first is reused first: the table stays as dense as the churn allows)
@@ -241,7 +241,7 @@ class GpuPicker : public EndpointPicker {
         by_slot[slot] = rows[i];
         active[slot] = true;
         snap->endpoints[slot] = endpoints[i];
-        snap->by_addr[key] = slot;
+        snap->Index(key, endpoints[i], slot);
       }
       snap->n_active = (uint32_t)endpoints.size();
       for (uint32_t sidx = 0; sidx < n_slots_; ++sidx)
@@ -305,6 +305,33 @@ class GpuPicker : public EndpointPicker {
     std::vector<Endpoint> endpoints;  // by candidate index (stable_slots: by slot, holes are default-constructed)
     uint32_t n_active = 0;            // endpoints that are candidates (== endpoints.size() unless there are holes)
     std::unordered_map<std::string, uint32_t> by_addr;
+    // the same map keyed by a 64-bit fingerprint of (address, port): the per-candidate look-up of BuildMask without building the
+    // "ip:port" string (an allocation per candidate and request).  A hit is verified against the endpoint's strings; two endpoints
+    // with one fingerprint make it ambiguous (kAmbiguous) and fall back to by_addr.
+    static constexpr uint32_t kAmbiguous = 0xFFFFFFFFu;
+    std::unordered_map<uint64_t, uint32_t> by_fp;
+    static uint64_t Fingerprint(const std::string& address, const std::string& port) {
+      uint64_t h = 0xCBF29CE484222325ull;                                        // FNV-1a over address, a separator, port
+      for (unsigned char c : address) { h ^= c; h *= 0x100000001B3ull; }
+      h ^= 0xFFu; h *= 0x100000001B3ull;
+      for (unsigned char c : port) { h ^= c; h *= 0x100000001B3ull; }
+      return h;
+    }
+    void Index(const std::string& key, const Endpoint& e, uint32_t slot) {
+      by_addr[key] = slot;
+      auto ins = by_fp.emplace(Fingerprint(e.address, e.port), slot);
+      if (!ins.second && ins.first->second != slot) ins.first->second = kAmbiguous;
+    }
+    // candidate index of an endpoint, or -1
+    int64_t Find(const Endpoint& e) const {
+      auto f = by_fp.find(Fingerprint(e.address, e.port));
+      if (f != by_fp.end() && f->second != kAmbiguous) {
+        const Endpoint& mine = endpoints[f->second];
+        if (mine.address == e.address && mine.port == e.port) return f->second;
+      }
+      auto a = by_addr.find(JoinHostPort(e.address, e.port));                   // ambiguous or colliding fingerprint, or unknown
+      return a == by_addr.end() ? -1 : (int64_t)a->second;
+    }
     std::unordered_map<std::string, int32_t> adapters;
   };
   struct Slot {
@@ -329,11 +356,11 @@ class GpuPicker : public EndpointPicker {
     mask->assign(W ? W : 1, 0);
     *found = 0;
     for (const Endpoint* e : cands) {
-      auto a = snap.by_addr.find(JoinHostPort(e->address, e->port));
-      if (a == snap.by_addr.end()) continue;  // candidate unknown to this snapshot: not scoreable
-      const uint64_t bit = 1ull << (a->second & 63u);
-      if (!((*mask)[a->second >> 6] & bit)) ++*found;
-      (*mask)[a->second >> 6] |= bit;
+      const int64_t idx = snap.Find(*e);
+      if (idx < 0) continue;  // candidate unknown to this snapshot: not scoreable
+      const uint64_t bit = 1ull << (idx & 63);
+      if (!((*mask)[(size_t)idx >> 6] & bit)) ++*found;
+      (*mask)[(size_t)idx >> 6] |= bit;
     }
   }
 
