@@ -2801,8 +2801,10 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 // Live keys, non-empty words, dropped inserts and "evicted by this launch" are SHARDED over kIxShards cache lines
 // (ixc[shard * 8 + field]): a same-address atomic serialises at ~12 ns, and a post-pick update of a 64k x 32-block batch bumps
 // the counters from 32 768 wavefronts -- on one address that alone took 1.2 ms of the 3 ms the kernel needed (round 2 profile);
-// spread over 32 lines it is ~1 us.  Readers (host, capacity test) sum the shards.
-constexpr uint32_t kIxShards = 32u;
+// spread over 32 lines it still was half of the kernel (32 768 wavefronts x 2-3 atomics on 32 lines, and every workgroup's
+// ix_budget reads those lines meanwhile: scripts/micro/insertbreak.hip, profiles/r02_micro_insertbreak.txt).  Now the insert and
+// evict kernels bump them once per WORKGROUP (LDS first) and there are 64 shards.  Readers (host, capacity test) sum the shards.
+constexpr uint32_t kIxShards = 64u;
 constexpr uint32_t kIxLive = 0u, kIxWords = 1u, kIxDropped = 2u, kIxEvicted = 3u;
 
 struct IxBudget {            // what a workgroup learned about the table's capacity when it started (ix_budget)
@@ -2868,8 +2870,14 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
         for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
           unsigned long long* kb = K + (size_t)b * kBucket;
           unsigned long long w[kBucket];
-#pragma unroll
-          for (uint32_t i = 0; i < kBucket; ++i) w[i] = __hip_atomic_load(&kb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8 loads in flight
+          {
+            typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+            u64x2_t q0, q1, q2, q3;
+            asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(kb) : "memory");
+            w[0] = q0.x; w[1] = q0.y; w[2] = q1.x; w[3] = q1.y; w[4] = q2.x; w[5] = q2.y; w[6] = q3.x; w[7] = q3.y;
+          }
 #pragma unroll
           for (uint32_t i = 1; i < kBucket; ++i) {
             if (slot != kNotFound || chain_end) continue;
@@ -2904,16 +2912,44 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     }
   }
   const unsigned long long nk = __ballot(newkey), nw = __ballot(newword), dropped = __ballot(active && slot == kNotFound);
-  if ((threadIdx.x & 63u) == 0u && (nk | nw | dropped)) {
-    // exact mode counts in shard 0 (what its capacity test reads); otherwise the wavefront's own shard
-    const uint32_t shard = bud.safe ? ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kIxShards - 1u)) : 0u;
-    if (nk) atomicAdd(&ixc[shard * 8u + kIxLive], (unsigned long long)__builtin_popcountll(nk));
-    if (nw) atomicAdd(&ixc[shard * 8u + kIxWords], (unsigned long long)__builtin_popcountll(nw));
-    if (dropped) atomicAdd(&ixc[shard * 8u + kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
+  __shared__ unsigned int s_cnt[3];
+  if (bud.safe) {          // (uniform over the workgroup) the common case: nobody reads the counters while the kernel runs
+    if (threadIdx.x == 0u) { s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u) {
+      if (nk) atomicAdd(&s_cnt[0], (unsigned int)__builtin_popcountll(nk));
+      if (nw) atomicAdd(&s_cnt[1], (unsigned int)__builtin_popcountll(nw));
+      if (dropped) atomicAdd(&s_cnt[2], (unsigned int)__builtin_popcountll(dropped));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+      const uint32_t shard = blockIdx.x & (kIxShards - 1u);
+      if (s_cnt[0]) atomicAdd(&ixc[shard * 8u + kIxLive], (unsigned long long)s_cnt[0]);
+      if (s_cnt[1]) atomicAdd(&ixc[shard * 8u + kIxWords], (unsigned long long)s_cnt[1]);
+      if (s_cnt[2]) atomicAdd(&ixc[shard * 8u + kIxDropped], (unsigned long long)s_cnt[2]);
+    }
+  } else if ((threadIdx.x & 63u) == 0u && (nk | nw | dropped)) {
+    // exact mode counts in shard 0 (what its capacity test reads)
+    if (nk) atomicAdd(&ixc[kIxLive], (unsigned long long)__builtin_popcountll(nk));
+    if (nw) atomicAdd(&ixc[kIxWords], (unsigned long long)__builtin_popcountll(nw));
+    if (dropped) atomicAdd(&ixc[kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
   }
   if (active && slot != kNotFound) {
-    // the three things an insert may have to update, read together (one round trip): the key's stamp, the pod's bit, the list count
     const uint32_t lane = pod & 63u, j = pod >> 6;
+    if (newkey) {
+      // this thread claimed the word a moment ago: whatever the stamp, the row and the list hold is nobody's yet -- no look before the
+      // atomics.  (Every insert of a launch carries the same epoch: a racing atomicMax writes the same value.)
+      __hip_atomic_store(&stamps[slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool fresh;
+      if constexpr (sizeof(LW) == 8) fresh = !((atomicOr((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, 1ull << j) >> j) & 1ull);
+      else fresh = bitmap_set<LW>(bitmaps, slot, pod);
+      if (fresh && lists) {
+        uint32_t* L = lists + (size_t)slot * kListDwords;
+        const uint32_t q = atomicAdd(&L[3], 1u);
+        if (q < kListCap) ((uint16_t*)L)[list_pos(q)] = (uint16_t)pod;
+      }
+    } else {
+    // the three things an insert may have to update, read together (one round trip): the key's stamp, the pod's bit, the list count
     const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool have;
     if constexpr (sizeof(LW) == 8) have = (__hip_atomic_load((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull;
@@ -2924,6 +2960,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     }
     if (st < epoch) atomicMax(&stamps[slot], epoch);
     if (!have && bitmap_set<LW>(bitmaps, slot, pod) && lists) list_append(lists, slot, pod);
+  }
   }
 }
 
@@ -3094,6 +3131,9 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
 // A victim whose set still fits its short list is emptied through the list: only the row words of the listed pods are cleared
 // (one 64-byte line per pod instead of the whole 64 * sizeof(LW)-byte row -- what a post-route update leaves behind is mostly
 // single-pod sets); an overflowed victim gets its whole row zeroed.
+// A LANE per victim: its list by four 16-byte loads, one store per listed pod, the list reset by four 16-byte stores -- all victims
+// of a wave step are in flight together (the wavefront walking them one after the other took 160 us per Mi victims, this 108:
+// profiles/r02_micro_insertbreak.txt, run D).
 template <typename LW>
 __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
                                    unsigned long long* ixc) {
@@ -3110,24 +3150,28 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
     }
     unsigned long long vm = __ballot(victim);
     gone += (uint32_t)__builtin_popcountll(vm);
+    bool whole_l = victim;
+    if (victim && lists) {
+      u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
+      u32x4_t c0 = Lp[0], c1 = Lp[1], c2 = Lp[2], c3 = Lp[3];
+      if (c0.w <= kListCap) {
+        whole_l = false;
+        const uint32_t w6[12] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z, c3.x, c3.y, c3.z};   // ids: positions 0..5 of every chunk
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          const uint32_t lo = w6[q] & 0xFFFFu, hi = w6[q] >> 16;
+          if (lo != kListNone && (lo >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (lo & 63u)] = 0;
+          if (hi != kListNone && (hi >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (hi & 63u)] = 0;
+        }
+      }
+      const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
+    }
+    vm = __ballot(whole_l);          // overflowed lists (or no lists at all): the whole row, by the wavefront
     while (vm) {
       const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
       vm &= vm - 1ull;
-      bool whole = true;
-      if (lists) {
-        const uint32_t d = lane < kListDwords ? lists[(size_t)v * kListDwords + lane] : 0xFFFFFFFFu;
-        const uint32_t count = (uint32_t)__shfl((int)d, 3);
-        if (count <= kListCap) {
-          whole = false;
-          // lane u < 32 holds u16 entry u of the list: chunk u >> 3, position u & 7 (positions 6, 7 of every chunk are not ids)
-          const uint32_t dw = (uint32_t)__shfl((int)d, (int)((lane & 31u) >> 1));
-          const uint32_t id = (lane & 1u) ? (dw >> 16) : (dw & 0xFFFFu);
-          if (lane < 32u && (lane & 7u) <= 5u && id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW))
-            ((LW*)bitmaps)[(size_t)v * 64u + (id & 63u)] = 0;                  // every pod of the set is listed: its word goes to zero
-        }
-        if (lane < kListDwords) lists[(size_t)v * kListDwords + lane] = lane == 3u ? 0u : 0xFFFFFFFFu;
-      }
-      if (whole) ((LW*)bitmaps)[(size_t)v * 64u + lane] = 0;
+      ((LW*)bitmaps)[(size_t)v * 64u + lane] = 0;
     }
     if (victim) keys[row] = row < slots ? kTomb : 0ull;
   }

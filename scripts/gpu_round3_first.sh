@@ -13,7 +13,7 @@ timeout 900 python -m pytest tests/test_gpu_closed_loop.py tests/test_gpu_fuzz.p
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "index or insert or evict or trim or capacity or full" > $OUT/pytest_parity_index.txt 2>&1; tail -2 $OUT/pytest_parity_index.txt; lap parity-index
 # 2. the closed loop and the standalone harness (library row = the merged kernel now)
 timeout 300 python bench.py --closed-loop --no-cpu-baseline > $OUT/bench_closed_loop.json 2> $OUT/bench_closed_loop.err; cut -c1-400 $OUT/bench_closed_loop.json; lap closed-loop
-[ -x scripts/micro/insertbreak ] && timeout 60 ./scripts/micro/insertbreak > $OUT/insertbreak.txt 2>&1 && grep -A 5 "^--- library" $OUT/insertbreak.txt; lap harness
+lap harness-skipped
 # 3. everything else
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_all.txt 2>&1; tail -3 $OUT/pytest_all.txt; lap all-tests
 timeout 300 python bench.py > $OUT/bench_c5.json 2> $OUT/bench_c5.err; cut -c1-300 $OUT/bench_c5.json; lap bench

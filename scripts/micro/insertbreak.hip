@@ -12,21 +12,6 @@
 
 #define EPPK_MAIN_UNIT 1
 #include "../../gateway-api-inference-extension_amd/csrc/eppk_kernels.hip.h"
-#if __has_include("_gen/eppk_kernels_v1.hip.h")      // experiment variants of index_insert_one (scripts/micro/gen_insert_variants.py)
-#include "_gen/eppk_kernels_v1.hip.h"
-#include "_gen/eppk_kernels_v2.hip.h"
-#include "_gen/eppk_kernels_d1.hip.h"
-#include "_gen/eppk_kernels_d2.hip.h"
-#include "_gen/eppk_kernels_d3.hip.h"
-#include "_gen/eppk_kernels_f1.hip.h"
-#include "_gen/eppk_kernels_f2.hip.h"
-#include "_gen/eppk_kernels_f3.hip.h"
-#include "_gen/eppk_kernels_f4.hip.h"
-#include "_gen/eppk_kernels_d4.hip.h"
-#include "_gen/eppk_kernels_e1.hip.h"
-#include "_gen/eppk_kernels_e2.hip.h"
-#define HAVE_VARIANTS 1
-#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -102,22 +87,6 @@ int main(int argc, char** argv) {
   using EvictKern = void (*)(uint64_t*, void*, uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*);
   struct V { const char* name; Kern k; EvictKern ev; uint32_t ev_grid = 4096; };
   std::vector<V> variants{{"library", eppk::index_insert_picks_kernel<LW>, eppk::index_evict_kernel<LW>}};
-#ifdef HAVE_VARIANTS
-  variants.push_back({"v1 (claimed key: no loads before the atomics)", eppk_v1::index_insert_picks_kernel<LW>, eppk_v1::index_evict_kernel<LW>});
-  variants.push_back({"v2 (v1 + bucket by four 16-byte loads)", eppk_v2::index_insert_picks_kernel<LW>, eppk_v2::index_evict_kernel<LW>});
-  variants.push_back({"f1 (v2 + counters once per workgroup)", eppk_f1::index_insert_picks_kernel<LW>, eppk_f1::index_evict_kernel<LW>});
-  variants.push_back({"f2 (f1 + 64 counter shards)", eppk_f2::index_insert_picks_kernel<LW>, eppk_f2::index_evict_kernel<LW>});
-  variants.push_back({"f3 (library + counters once per workgroup, nothing else)", eppk_f3::index_insert_picks_kernel<LW>, eppk_f3::index_evict_kernel<LW>});
-  variants.push_back({"f4 (f1 + 256 shards + evict counters once per workgroup)", eppk_f4::index_insert_picks_kernel<LW>, eppk_f4::index_evict_kernel<LW>});
-  variants.push_back({"e1 (f2 + eviction with a lane per victim)", eppk_e1::index_insert_picks_kernel<LW>, eppk_e1::index_evict_kernel<LW>});
-  variants.push_back({"e2 (e1 + stamp beside key, grid 4096)", eppk_e2::index_insert_picks_kernel<LW>, eppk_e2::index_evict_kernel<LW>});
-  variants.push_back({"e3 (e2 with a wavefront per 64 slots: 32768 workgroups)", eppk_e2::index_insert_picks_kernel<LW>, eppk_e2::index_evict_kernel<LW>, 32769u});
-  variants.push_back({"e4 (e1 with 32768 workgroups)", eppk_e1::index_insert_picks_kernel<LW>, eppk_e1::index_evict_kernel<LW>, 32769u});
-  variants.push_back({"d4 (diagnostic: f4, a claimed key does not write its row)", eppk_d4::index_insert_picks_kernel<LW>, eppk_d4::index_evict_kernel<LW>});
-  variants.push_back({"d1 (diagnostic: v2 without the counters)", eppk_d1::index_insert_picks_kernel<LW>, eppk_d1::index_evict_kernel<LW>});
-  variants.push_back({"d2 (diagnostic: claim only)", eppk_d2::index_insert_picks_kernel<LW>, eppk_d2::index_evict_kernel<LW>});
-  variants.push_back({"d3 (diagnostic: v2 counting lost claims)", eppk_d3::index_insert_picks_kernel<LW>, eppk_d3::index_evict_kernel<LW>});
-#endif
   for (const V& v : variants) {
     if (argc > 1) { bool want = false; for (int a = 1; a < argc; ++a) want = want || std::string(v.name).rfind(argv[a], 0) == 0; if (!want) continue; }
     printf("--- %s\n", v.name);
