@@ -117,6 +117,7 @@ struct eppk_ctx {
 
   // measurement
   bool prof = false;
+  uint32_t prof_every = 1, prof_tick = 0;   // eppk_profile_enable(on = N > 1): only every Nth pick launch carries events and probe counts
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
   uint64_t fixed_bytes = 0;  // per-launch request/pod/pick bytes accumulated while profiling
@@ -148,6 +149,7 @@ struct eppk_ctx {
   uint8_t rep_masked[4096] = {0};              // ... and whether it was a masked batch
   uint64_t rep_unread = 0;                     // first launch whose report has not been consumed
   uint32_t quad_backoff = 0, quad_backoff_len = 0;
+  uint32_t wl_hint = 0xFFFFFFFFu;   // decaying maximum of the recent launches' deferred counts (0xFFFFFFFF: no report seen yet): sizes the work-list pass
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
   const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
   const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
@@ -175,6 +177,10 @@ void quad_consume_reports(eppk_ctx* c) {
     const uint32_t v = c->h_reports[slot];
     if (v == kReportPending) break;
     c->quad_deferred_seen += v;
+    {                                      // what the next work-list passes should expect: the largest recent count, decaying by 1/8 per report
+      const uint32_t dec = c->wl_hint == 0xFFFFFFFFu ? 0u : c->wl_hint - (c->wl_hint + 7u) / 8u;
+      c->wl_hint = v > dec ? v : dec;
+    }
     const uint32_t n = c->rep_n[slot];
     if (v > (c->rep_masked[slot] ? n / 8u : n / 4u)) {
       if (c->quad_backoff == 0) {
@@ -292,7 +298,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
   if (grid < 1) grid = 1;
 
-  unsigned long long* stats = c->prof ? c->stats + (size_t)(c->stat_bank++ % kStatBanks) * 2u * kStatSlots : nullptr;
+  const bool prof_now = c->prof && (c->prof_tick++ % c->prof_every) == 0u;     // (sampled profiling: eppk_profile_enable)
+  unsigned long long* stats = prof_now ? c->stats + (size_t)(c->stat_bank++ % kStatBanks) * 2u * kStatSlots : nullptr;
   // pick_quad_kernel first (four requests per wavefront: the common shape of a request), then the fast kernel's work-list
   // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
@@ -340,7 +347,9 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       if (dset->d) HIPCHK(c, hipFree(dset->d));
       dset->d = nullptr; dset->words = 0;
       HIPCHK(c, hipMalloc((void**)&dset->d, words * 4u));
-      HIPCHK(c, hipMemset(dset->d, 0, 64));          // the two total counters
+      HIPCHK(c, hipMemsetAsync(dset->d, 0, 64, st));  // the two total counters -- on the LAUNCH stream: a null-stream memset is not ordered
+                                                       // ahead of kernels on a non-blocking stream (the first launch of a stream could read a
+                                                       // garbage total: found when the work-list pass got faster, tests/test_gpu_quad.py)
       dset->words = words; dset->uses = 0;
     }
     rep_slot = (uint32_t)(c->quad_launches % kReportRing);
@@ -350,7 +359,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     ++c->quad_launches;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->prof) {
+  if (prof_now) {
     if (c->ev_used + 2 > c->ev.size()) {
       hipEvent_t a, b;
       HIPCHK(c, hipEventCreate(&a));
@@ -400,6 +409,17 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       grid = (uint32_t)c->num_cu * (uint32_t)c->wl_per_cu;
       if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
       if (grid * wpb > quad_segs) grid = (quad_segs + wpb - 1) / wpb;      // one wavefront per segment at most
+      // The pass is grid-stride over the segments, so ANY grid is correct; its size only has to fit what the quad kernel deferred.  A
+      // full grid of 1024-thread workgroups (~100 KB of LDS each) that all find an empty list took 8.5 us per launch
+      // (profiles/r02_kernel_stats.csv) -- dispatch cost, next to the other stream's quad kernel.  So: 16 workgroups (256 wavefronts:
+      // up to a few thousand deferred requests at a handful per wavefront) unless the recent launches' reports ask for more.  The host
+      // cannot wait for THIS launch's count, and a driver that enqueues a whole run ahead sees no report at all: the default has to be
+      // the cheap one.  A workload that defers a large part of its batches pauses the quad route altogether (quad_consume_reports).
+      {
+        uint32_t want = 16u;
+        if (c->wl_hint != 0xFFFFFFFFu && (2u * c->wl_hint + wpb - 1u) / wpb > want) want = (2u * c->wl_hint + wpb - 1u) / wpb;
+        if (grid > want) grid = want;
+      }
       if (grid < 1) grid = 1;
     }
     void* args[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &chf, &d_pick, &d_score, &stats, &topk, &wk};
@@ -411,7 +431,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   }
   c->last_done = e1;
   c->last_stream = st;
-  if (c->prof) {
+  if (prof_now) {
     c->fixed_bytes += (uint64_t)c->n_pods * sizeof(eppk_pod_row) + (uint64_t)n_reqs * ((uint64_t)c->stride + 4u);
     c->launches++;
   }
@@ -1541,6 +1561,8 @@ int eppk_profile_enable(eppk_ctx* c, int on) {
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemset(c->stats + 4, 0, 2 * (size_t)kStatSlots * kStatBanks * sizeof(unsigned long long)));
   c->prof = on != 0;
+  c->prof_every = on > 1 ? (uint32_t)on : 1u;
+  c->prof_tick = 0;
   c->ev_used = 0;
   c->fixed_bytes = 0;
   c->launches = 0;

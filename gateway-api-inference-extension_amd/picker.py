@@ -479,8 +479,9 @@ class BatchedPicker:
         return int(a.value), int(b.value)
 
     # -- measurement ------------------------------------------------------------------------
-    def profile(self, on: bool) -> None:
-        self._check(self._lib.eppk_profile_enable(self._ctx, 1 if on else 0), "profile_enable")
+    def profile(self, on) -> None:
+        """False / 0: off; True / 1: every pick launch carries events and probe counts; N > 1: every Nth launch (sampled)."""
+        self._check(self._lib.eppk_profile_enable(self._ctx, int(on)), "profile_enable")
 
     def profile_drain(self, cap: int = 65536) -> np.ndarray:
         ms = np.zeros(cap, dtype=np.float32)

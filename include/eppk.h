@@ -387,8 +387,9 @@ int eppk_chain_is_fused(const eppk_ctx* ctx);
 int eppk_quad_stats(eppk_ctx* ctx, uint64_t* launches, uint64_t* deferred);
 
 /* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,
- * every pick launch is bracketed by HIP events recorded on the launch stream and accumulates its
- * index-probe counts on device (one atomic per wavefront). */
+ * every pick launch (on == 1) -- or every on-th one (on > 1: sampled, what a throughput measurement uses so that the
+ * instrumentation is not part of what it times) -- is bracketed by HIP events recorded on the launch stream and accumulates its
+ * index-probe counts on device (one atomic per wavefront); eppk_profile_drain / eppk_profile_bytes report the sampled launches. */
 int eppk_profile_enable(eppk_ctx* ctx, int on);
 /* Synchronise and copy out up to cap kernel durations (ms) recorded since the last drain. */
 int eppk_profile_drain(eppk_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out);
