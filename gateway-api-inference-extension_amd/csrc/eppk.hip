@@ -95,7 +95,10 @@ struct eppk_ctx {
   uint32_t slots = 0, shift = 0, limit = 0;
   size_t rows_bytes = 0, index_bytes = 0;   // rows | keys in one allocation
   uint32_t* stamps = nullptr;               // [slots + 2] index epoch of the last insert of every key (ageing)
-  uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists beside the dense rows (EPPK_LISTS=0: not maintained)
+  uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists: where a set with at most kListCap members lives (always maintained)
+  bool list_routes = true;                  // EPPK_LISTS=0: the pick kernels' list routes are off (every request takes the dense route)
+  uint32_t* sortwl = nullptr;               // work list of index_lists_sort_kernel: cursors[2] | lost | arrived | slots[sortwl_cap]
+  uint32_t sortwl_cap = 0, sort_uses = 0;
   uint32_t index_epoch = 1;
   unsigned long long* stats = nullptr;  // device [4 + kStatBanks*2*kStatSlots]: scratch, live keys, non-empty words, dropped inserts, then
                                         // banks of per-wave {hits, lookups}: consecutive launches use different banks, so pick
@@ -235,7 +238,8 @@ KIndex make_kindex(const eppk_ctx* c) {
   k.table_bytes = k.small ? (uint32_t)c->index_bytes : 0u;
   k.keys_off = k.small ? (uint32_t)c->rows_bytes : 0u;
   // the pick reads the lists through one raw buffer descriptor: only while the list table is below 4 GiB (slots < 2^26)
-  k.lists = (c->lists && ((size_t)c->slots + 4u) * 64u < (1ull << 32)) ? c->lists : nullptr;
+  k.lists = (c->lists && c->list_routes && ((size_t)c->slots + 4u) * 64u < (1ull << 32)) ? c->lists : nullptr;
+  k.lists_all = c->lists;
   return k;
 }
 
@@ -274,7 +278,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   size_t lds;
   if (fast) {
     pwn = (c->pterm && c->has_p) ? (c->cfg.max_blocks + 1u) * c->pterm_ld : 0u;
-    lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (c->gen ? (size_t)sn.J * 64u * 16u : 0u);   // base | lw[4] | pterm | post0 | post1
+    lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (c->gen ? (size_t)sn.J * 64u * 16u : 0u) +   // base | lw[4] | pterm | post0 | post1
+          (size_t)wpb * 64u * (size_t)c->lw_bytes;                                                         // | 64 lane words per wavefront (set_from_list)
     if (c->has_p && c->npl == 6 && topk == 1 && ix.lists) {                                                // | per-wave pod histogram (SPARSE)
       const size_t hist = (size_t)wpb * sn.J * 64u;
       if (lds + hist <= c->max_lds) lds += hist;
@@ -282,7 +287,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     }
     // (ordered fallbacks use the uniform-lists route only: no histogram)
   } else {
-    lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u;
+    lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u + (size_t)wpb * 64u * (size_t)c->lw_bytes;   // ... | 64 lane words per wavefront (set_from_list)
   }
   // occupancy-sized persistent grid (cached per kernel/LDS size: these are host calls on the launch path)
   if (fn != c->occ_fn || lds != c->occ_lds) {
@@ -492,6 +497,34 @@ int by_lane_word(const eppk_ctx* c, F&& f) {
     case 4: return f((uint32_t)0);
     default: return f((uint64_t)0);
   }
+}
+
+// The work list of index_lists_sort_kernel (eppk_kernels.hip.h: SortWl): room for one entry per pair of the insert launch that is
+// about to be issued (capped at 16 Mi entries: beyond that a launch that overflows it makes the sort pass walk the table), and the
+// cursor this launch appends through.  Index updates of one context are ordered with respect to each other (one stream, or
+// events: include/eppk.h), so one work list serves them all.
+int sortwl_begin(eppk_ctx* c, uint64_t n_pairs, eppk::SortWl* sw) {
+  const uint32_t want = (uint32_t)(n_pairs < (1ull << 24) ? n_pairs : (1ull << 24));
+  if (!c->sortwl || want > c->sortwl_cap) {
+    HIPCHK(c, hipDeviceSynchronize());                 // (rare: the first insert, or a larger launch than ever before)
+    if (c->sortwl) HIPCHK(c, hipFree(c->sortwl));
+    c->sortwl = nullptr; c->sortwl_cap = 0;
+    const uint32_t cap = want < 4096u ? 4096u : want;
+    HIPCHK(c, hipMalloc((void**)&c->sortwl, (4u + (size_t)cap) * 4u));
+    HIPCHK(c, hipMemset(c->sortwl, 0, 16));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->sortwl_cap = cap; c->sort_uses = 0;
+  }
+  sw->wl = c->sortwl; sw->cap = c->sortwl_cap; sw->which = c->sort_uses & 1u;
+  ++c->sort_uses;
+  return EPPK_OK;
+}
+// ... and the sort pass behind the insert launch, on its stream.  The host does not know how many lists the launch touched: a
+// grid of 64 workgroups walks whatever the cursor says (a closed-loop step of a 64k batch re-sorts a few thousand lists at most).
+int sortwl_finish(eppk_ctx* c, const eppk::SortWl& sw, hipStream_t st) {
+  hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, st, c->lists, c->slots, sw.wl, sw.cap, sw.which);
+  HIPCHK(c, hipGetLastError());
+  return EPPK_OK;
 }
 
 // Remove every pod of the lane-transposed set `holes` from every index row (one pass; rows that become empty are tombstoned).
@@ -740,7 +773,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc((void**)&c->stamps, ((size_t)c->slots + 2u) * 4u));
     CHK(hipMemset(c->stamps, 0, ((size_t)c->slots + 2u) * 4u));
     const char* le = getenv("EPPK_LISTS");
-    if (!(le && atoi(le) == 0)) {
+    c->list_routes = !(le && atoi(le) == 0);
+    {
       const size_t nd = ((size_t)c->slots + 4u) * eppk::kListDwords;
       CHK(hipMalloc((void**)&c->lists, nd * 4u));
       hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, nd);
@@ -759,7 +793,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl);
   (void)hipFree(c->d_at); (void)hipFree(c->d_av); (void)hipFree(c->d_sk); (void)hipFree(c->d_so);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
@@ -833,10 +867,8 @@ int eppk_index_clear(eppk_ctx* c) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stamps, 0, ((size_t)c->slots + 2u) * 4u, c->stream));
-  if (c->lists) {
-    hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
-    HIPCHK(c, hipGetLastError());
-  }
+  hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemsetAsync(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
@@ -859,14 +891,19 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   HIPCHK(c, hipMemcpyAsync(d_h, hashes, (size_t)n * 8u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_p, pods, (size_t)n * 4u, hipMemcpyHostToDevice, c->stream));
   const uint32_t threads = 256, grid = (n + threads - 1) / threads;
+  eppk::SortWl sw{};
+  rc = sortwl_begin(c, n, &sw);
+  if (rc) return rc;
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
                        c->limit, c->index_epoch, c->ixc, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
-                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
+                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  rc = sortwl_finish(c, sw, c->stream);
+  if (rc) return rc;
   rcs = ixc_sum(c, eppk::kIxDropped, &after);
   if (rcs) return rcs;
   if (after != before) return fail(c, EPPK_ERR_INDEX_FULL, "eppk_index_insert: table at load limit, inserts dropped");
@@ -883,15 +920,19 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   const uint32_t threads = 256;
   const uint64_t grid64 = (total + threads - 1) / threads;
   if (grid64 > 0x7FFFFFFFull) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert_picks_device: batch too large");
-  int rc = by_lane_word(c, [&](auto tag) {
+  eppk::SortWl sw{};
+  int rc = sortwl_begin(c, total, &sw);
+  if (rc) return rc;
+  rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->ixc, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
-                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr);
+                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
-  return rc;
+  if (rc) return rc;
+  return sortwl_finish(c, sw, st);
 }
 
 int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
@@ -940,21 +981,32 @@ int eppk_index_selfcheck(eppk_ctx* c, uint64_t* n_bad) {
   *n_bad = 0;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long), c->stream));   // stats[0]: scratch counter of maintenance launches
+  int rct = ensure_tmp(c, 256u * 8u);                                          // bad count | records | eight offenders in full (index_selfcheck_kernel)
+  if (rct) return rct;
+  unsigned long long* d_bad = (unsigned long long*)c->d_tmp;
+  HIPCHK(c, hipMemsetAsync(d_bad, 0, 256u * 8u, c->stream));
   const uint32_t rows = c->slots + 3u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_selfcheck_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
-                       (const uint32_t*)c->lists, c->slots, c->stats);
+                       (const uint32_t*)c->lists, c->slots, d_bad);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
-  unsigned long long bad = 0;
-  HIPCHK(c, hipMemcpyAsync(&bad, c->stats, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long h_bad[256];
+  HIPCHK(c, hipMemcpyAsync(h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *n_bad = (uint64_t)bad;
+  *n_bad = (uint64_t)h_bad[0];
+  if (h_bad[0] && getenv("EPPK_SELFCHECK_VERBOSE")) {
+    for (unsigned long long k = 0; k < h_bad[1] && k < 8ull; ++k) {
+      const unsigned long long* r = h_bad + 2 + 24 * k;
+      std::fprintf(stderr, "[eppk selfcheck] slot %llu why 0x%llx key %016llx row members %llu bad-entry lanes %llx list:", r[0], r[1], r[2], r[3], r[4]);
+      for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %08llx", r[5 + i]);
+      std::fprintf(stderr, "\n");
+    }
+  }
   return rc;
 }
 
@@ -1010,7 +1062,7 @@ int eppk_index_trim_pods(eppk_ctx* c, uint32_t cap, uint64_t* n_removed) {
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_pod_hist_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
-                       (const uint32_t*)c->stamps, c->slots, c->index_epoch, hist);
+                       (const uint32_t*)c->lists, (const uint32_t*)c->stamps, c->slots, c->index_epoch, hist);
     hipLaunchKernelGGL(index_pod_cut_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, c->cfg.max_pods, cap, cutage, over_t);
     hipLaunchKernelGGL((index_pod_trim_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps,
                        c->slots, c->index_epoch, (const uint32_t*)cutage, (const uint64_t*)over_t, c->ixc, removed);

@@ -103,6 +103,7 @@ struct KSnap {
 constexpr uint32_t kBlobStatusTail = 4u;
 constexpr uint32_t kStatusBadRow = 1u;      // eppk.h: EPPK_LAUNCH_BAD_REQUEST_ROW
 constexpr uint32_t kStatusBadPick = 2u;     // eppk.h: EPPK_LAUNCH_BAD_PICK
+constexpr uint32_t kStatusIndexStall = 4u;  // eppk.h: EPPK_LAUNCH_INDEX_STALL
 
 // Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (8 u64 words =
 // 64 bytes: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..7 = keys, filled front
@@ -120,13 +121,17 @@ struct KIndex {
   uint32_t small;          // rows + keys (ONE allocation, rows first) are < 4 GiB: both are read through one buffer descriptor
   uint32_t table_bytes;    // bytes of that allocation when small
   uint32_t keys_off;       // byte offset of keys inside it
-  const uint32_t* lists;   // [slots+4][16] short pod lists (kListCap ids of 16 bits + count), nullptr = not maintained
+  const uint32_t* lists;   // [slots+4][16] short pod lists (kListCap ids of 16 bits + count) for the pick kernels' LIST ROUTES: nullptr when
+                           // those are off (EPPK_LISTS=0) or the table is beyond a 32-bit buffer descriptor (4 GiB: slots >= 2^26)
+  const uint32_t* lists_all;   // the same table, always: a set with at most kListCap members lives ONLY in its list (its dense row is
+                               // all-zero; "lists first", index maintenance section), so every reader of pod sets starts here
 };
 
-// Short pod lists.  Beside its dense row (one bit per pod: 64 * sizeof(LW) bytes) every slot keeps the same pod set as a list
-// of 16-bit pod ids while it has at most kListCap members -- 64 bytes instead of 512 at P = 4096, and what a prefix block's
-// pod set looks like in practice (a block is cached on a handful of replicas).  The pick kernel reads the lists of a
-// request's hits with ONE 16-byte load per lane and falls back to the dense rows when a hit's list has overflowed.
+// Short pod lists.  A slot's pod set is a list of 16-bit pod ids (ascending) while it has at most kListCap members -- 64 bytes
+// instead of the 512 of a dense row at P = 4096, and what a prefix block's pod set looks like in practice (a block is cached on a
+// handful of replicas); only a larger set lives in the slot's dense row (one bit per pod).  The pick kernel reads the lists of a
+// request's hits with ONE 16-byte load per lane; a hit whose list has overflowed sends the request to the dense route, where
+// every hit's set becomes a lane word -- from its row when overflowed, expanded from its list otherwise (set_from_list).
 // Layout (u16 view, 32 entries): four 16-byte chunks; id number j lives in chunk j & 3 at position j >> 2, so that the ids
 // of a short list are spread over the four lanes that read the slot; entries 6..7 of chunk 0 (dword 3) are the 32-bit count;
 // unused entries are 0xFFFF.  count > kListCap: overflowed (ids unspecified), the dense row alone is authoritative.
@@ -247,12 +252,36 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The dword of a list line that lane l reads on the dense routes: lanes 0..23 the one that holds id l, the others the count.
+__device__ __forceinline__ uint32_t list_lane_dw(int lane) { return (uint32_t)lane < kListCap ? 4u * ((uint32_t)lane & 3u) + ((uint32_t)lane >> 3) : 3u; }
+// A listed set as a lane word: lane l < cnt ORs the bit of "its" id into the owning lane's word in LDS (lv = the dword it read,
+// list_lane_dw), then every lane picks its word up and leaves zero behind.  Six LDS operations per set whatever its size.
+template <typename LW>
+__device__ __forceinline__ LW set_from_list(uint32_t lv, uint32_t cnt, int lane, LW* scr) {
+  if (cnt == 0u) return (LW)0;                                   // (wave-uniform: the all-zero row behind a request's last hit)
+  if ((uint32_t)lane < cnt) {
+    const uint32_t id = (((uint32_t)lane >> 2) & 1u) ? (lv >> 16) : (lv & 0xFFFFu);
+    const uint32_t e = id & 63u, j = id >> 6;
+    if (j < 8u * (uint32_t)sizeof(LW)) {
+      if constexpr (sizeof(LW) == 8) atomicOr((unsigned long long*)scr + e, 1ull << j);
+      else if constexpr (sizeof(LW) == 4) atomicOr((unsigned int*)scr + e, 1u << j);
+      else atomicOr((unsigned int*)scr + (e >> 1), (1u << j) << (16u * (e & 1u)));
+    }
+  }
+  wave_lds_fence();
+  const LW w = scr[lane];
+  scr[lane] = (LW)0;
+  wave_lds_fence();
+  return w;
+}
 // The prefix walk of one request (SEMANTICS.md §3 PREFIX) into bit-sliced counters.
-// Returns the number of non-empty index rows added (= leading non-empty look-ups).
+// Returns the number of non-empty pod sets added (= leading non-empty look-ups).  scr: this wavefront's 64 lane words of LDS
+// (all-zero between uses): a set with at most kListCap members is expanded from its list, a larger one read from its dense row.
 template <typename LW, int NPL>
 __device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t* hs, uint32_t nb, int lane,
-                                                LW (&c)[NPL]) {
+                                                LW (&c)[NPL], LW* scr) {
   const LW* bm = (const LW*)ix.bitmaps;
+  const uint32_t ldw = list_lane_dw(lane);
   uint32_t hits = 0;
   bool stop = false;
   for (uint32_t b0 = 0; b0 < nb && !stop; b0 += 64) {
@@ -263,13 +292,25 @@ __device__ __forceinline__ uint32_t prefix_walk(const KIndex& ix, const uint64_t
     const unsigned long long found = __ballot(slot != kNotFound);
     const uint32_t chunk = (nb - b0) < 64u ? (nb - b0) : 64u;
     const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);  // leading found
-    for (uint32_t k0 = 0; k0 < m && !stop; k0 += 8) {      // 8 independent row loads in flight
+    for (uint32_t k0 = 0; k0 < m && !stop; k0 += 8) {      // 8 independent list-line loads in flight
+      uint32_t lv[8];
       LW w[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const uint32_t k = k0 + (uint32_t)u;
         const uint32_t s = __builtin_amdgcn_readlane(slot, (k < m) ? k : 0);
-        w[u] = (k < m) ? bm[(size_t)s * 64u + (uint32_t)lane] : (LW)0;
+        lv[u] = (k < m) ? ix.lists_all[(size_t)s * kListDwords + ldw] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t k = k0 + (uint32_t)u;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lv[u], (int)kListCap);
+        if (cnt > kListCap) {
+          const uint32_t s = __builtin_amdgcn_readlane(slot, (k < m) ? k : 0);
+          w[u] = bm[(size_t)s * 64u + (uint32_t)lane];
+        } else {
+          w[u] = set_from_list<LW>(lv[u], cnt, lane, scr);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -670,33 +711,40 @@ __device__ __forceinline__ LW buffer_load_lw(__amdgpu_buffer_rsrc_t rs, uint32_t
 // (Round 1 used a STRUCTURED buffer descriptor here, stride = one row, slot = buffer index.  Its index * stride product wraps at
 // 4 GiB on gfx950: rows beyond that offset read as garbage -- found in round 2 by the dense-rows-only run of the 8.6 GB
 // closed-loop test; the round-1 test stopped at exactly 4 GiB.)
-struct RowSrc {                  // how the fast kernel reaches the pod-set rows
+struct RowSrc {                  // how the fast kernel reaches the pod sets of a request's hits on its DENSE route
   __amdgpu_buffer_rsrc_t raw;    // small index: raw descriptor over rows + keys, rows addressed by SGPR byte offsets
   const uint8_t* base;           // BIG: the rows' base address
+  const uint32_t* lists;         // KIndex::lists_all: where a set with at most kListCap members lives
+  void* scr;                     // this wavefront's 64 lane words of LDS, all-zero between uses (set_from_list)
 };
+// The pod sets of hits k0 .. k0 + N - 1 (hit k of the request is in lane pair k of slot_eff) as lane words: every hit's list line
+// first (one dword per lane, N loads in flight), then per hit either the expansion of its list or -- overflowed -- its dense row.
 template <typename LW, int N, bool BIG>
 __device__ __forceinline__ void load_rows(const RowSrc& src, uint32_t slot_eff, uint32_t k0, int lane, LW (&w)[N]) {
   const uint32_t voff = (uint32_t)lane * (uint32_t)sizeof(LW);
-  if constexpr (BIG) {
+  const uint32_t ldw = list_lane_dw(lane);
+  uint32_t lv[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) {
-      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
-      const LW* rowp = (const LW*)(src.base + (size_t)s * (size_t)(64u * sizeof(LW)));     // wave-uniform 64-bit base
-      w[u] = rowp[lane];
-    }
-    (void)voff;
-    return;
+  for (int u = 0; u < N; ++u) {
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
+    lv[u] = src.lists[(size_t)s * kListDwords + ldw];
   }
-  const __amdgpu_buffer_rsrc_t rs = src.raw;
   const uint32_t roff = slot_eff * (uint32_t)(64u * sizeof(LW));
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
-#ifdef EPPK_DBG_SKIP_ROWS   // timing experiment only (wrong results): no row loads, one pseudo pod per row
-    w[u] = ((uint32_t)lane == ((soff >> 9) & 63u)) ? (LW)((LW)1 << (u & 7)) : (LW)0;
-#else
-    w[u] = buffer_load_lw<LW>(rs, voff, soff);
-#endif
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lv[u], (int)kListCap);
+    if (__builtin_expect(cnt > kListCap, 0)) {
+      if constexpr (BIG) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k0 + (uint32_t)u)));
+        const LW* rowp = (const LW*)(src.base + (size_t)s * (size_t)(64u * sizeof(LW)));     // wave-uniform 64-bit base
+        w[u] = rowp[lane];
+      } else {
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)roff, (int)(2u * (k0 + (uint32_t)u)));
+        w[u] = buffer_load_lw<LW>(src.raw, voff, soff);
+      }
+    } else {
+      w[u] = set_from_list<LW>(lv[u], cnt, lane, (LW*)src.scr);
+    }
   }
 }
 
@@ -761,7 +809,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   // SPARSE: requests whose hits all have a short pod list are counted from the lists (one 16-byte load per lane instead of
   // 64 * sizeof(LW) bytes per hit) in a per-wave byte histogram in LDS; everything else takes the dense rows as before.
   constexpr bool SPARSE = HAS_P && NPL == 6;      // (TOPK: the uniform-lists route only; anything else falls back to the dense rows)
-  uint32_t* s_hist_all = (uint32_t*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);   // [waves][J * 16] dwords: one byte per pod
+  LW* s_scr_all = (LW*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);                // [waves][64] lane words: set_from_list's scratch (dense route)
+  uint32_t* s_hist_all = (uint32_t*)(s_scr_all + (size_t)(blockDim.x >> 6) * 64u);    // [waves][J * 16] dwords: one byte per pod
   const bool use_lists = SPARSE && ix.lists != nullptr;
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
   if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct: that costs scratch)
@@ -771,6 +820,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
     for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
   if (use_lists)
     for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * sn.J * 16u; i += blockDim.x) s_hist_all[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * 64u; i += blockDim.x) s_scr_all[i] = (LW)0;
   __syncthreads();
 
   const int lane = (int)(threadIdx.x & 63u);
@@ -785,6 +835,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   RowSrc rs;
   rs.raw = __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, BIG ? 0 : (int)ix.table_bytes, 0x00020000);
   rs.base = (const uint8_t*)ix.bitmaps;
+  rs.lists = ix.lists_all;
+  rs.scr = (void*)(s_scr_all + (size_t)(threadIdx.x >> 6) * 64u);
   const __amdgpu_buffer_rsrc_t rk = BIG ? __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000) : rs.raw;
   const uint32_t keys_off = BIG ? 0u : ix.keys_off;
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
@@ -2067,6 +2119,22 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   }
 }
 
+// Does the pod set of `slot` (wave-uniform) contain this lane's pod p?  A listed set: its ids, broadcast one by one, against p;
+// an overflowed one: p's bit in the dense row.
+template <typename LW>
+__device__ __forceinline__ uint32_t set_has(const KIndex& ix, uint32_t slot, uint32_t p, int lane) {
+  const uint32_t lv = ix.lists_all[(size_t)slot * kListDwords + list_lane_dw(lane)];
+  const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)kListCap);
+  if (cnt > kListCap) return (uint32_t)((((const LW*)ix.bitmaps)[(size_t)slot * 64u + (p & 63u)] >> (p >> 6)) & 1);
+  uint32_t has = 0;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const uint32_t dwv = (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)j);
+    const uint32_t id = ((j >> 2) & 1u) ? (dwv >> 16) : (dwv & 0xFFFFu);
+    has |= (uint32_t)(id == p);
+  }
+  return has;
+}
+
 // ---- CANDIDATE-MAJOR pick kernel (MASKED batches with few candidates: what a subset filter leaves, request.go:104-133) -----
 // The fast kernel's masked routes cost O(pods) per request (the mask row is transposed, every pod's counter planes are built, and
 // a candidate set that misses the snapshot-wide QUEUE extremes -- almost every small one -- takes the exact dense evaluation:
@@ -2089,7 +2157,6 @@ __global__ __launch_bounds__(256, 6) void pick_cands_kernel(KSnap sn, KIndex ix,
   const __amdgpu_buffer_rsrc_t rk = ix.small ? __builtin_amdgcn_make_buffer_rsrc((void*)ix.bitmaps, 0, (int)ix.table_bytes, 0x00020000)
                                              : __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
   const uint32_t keys_off = ix.small ? ix.keys_off : 0u;
-  const LW* bm = (const LW*)ix.bitmaps;
   bool has_q = false;
   for (uint32_t i = 0; i < ch.n; ++i) has_q |= ch.kind[i] == 1u;
   const uint32_t ki = (uint32_t)lane >> 1;
@@ -2186,19 +2253,12 @@ __global__ __launch_bounds__(256, 6) void pick_cands_kernel(KSnap sn, KIndex ix,
         bool v = f.v;
 #pragma unroll
         for (int i = 0; i < (int)EPPK_MAX_TOPK; ++i) v = v && p != rep[i];
-        // matched[p]: one word of the dense row of every leading hit
+        // matched[p]: is this lane's candidate in the pod set of every leading hit? (a listed set: its ids against p, one by one; an
+        // overflowed one: one word of its dense row)
         uint32_t cnt = 0;
-        for (uint32_t k0 = 0; k0 < m0; k0 += 8u) {                     // 8 independent loads in flight (lane pairs beyond m0 hold the all-zero row)
-          LW wd[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const uint32_t k = k0 + (uint32_t)u;
-            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k < kKeysPerProbe ? k : 0u)));
-            wd[u] = bm[(size_t)sk * 64u + (p & 63u)];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (k0 + (uint32_t)u < m0) cnt += (uint32_t)((wd[u] >> (p >> 6)) & 1);
+        for (uint32_t k = 0; k < m0; ++k) {                            // (lane pairs beyond m0 hold the all-zero row)
+          const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)slot_eff, (int)(2u * (k < kKeysPerProbe ? k : 0u)));
+          cnt += set_has<LW>(ix, sk, p, lane);
         }
         if (__builtin_expect(m0 == kKeysPerProbe && nb > kKeysPerProbe, 0)) {       // hashes beyond the first 32 (every earlier key hit)
           bool stop = false;
@@ -2211,7 +2271,7 @@ __global__ __launch_bounds__(256, 6) void pick_cands_kernel(KSnap sn, KIndex ix,
             const uint32_t m = (~found == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~found);
             for (uint32_t k = 0; k < m; ++k) {
               const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)k);
-              cnt += (uint32_t)((bm[(size_t)sk * 64u + (p & 63u)] >> (p >> 6)) & 1);
+              cnt += set_has<LW>(ix, sk, p, lane);
             }
             if (m < chunk) stop = true;
           }
@@ -2267,8 +2327,10 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
   const uint32_t wib = threadIdx.x >> 6;
   const uint32_t wpb = blockDim.x >> 6;
   double* s_pw = (double*)(s_q + (size_t)sn.J * 64u) + (size_t)wib * pwn;
+  LW* s_scr = (LW*)((double*)(s_q + (size_t)sn.J * 64u) + (size_t)wpb * pwn) + (size_t)wib * 64u;   // set_from_list's scratch: 64 lane words per wavefront
 
   for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_kv[i] = sn.kv[i]; s_q[i] = sn.queue[i]; }
+  s_scr[lane] = (LW)0;
   __syncthreads();
 
   bool has_q = false, has_l = false, has_p = false;
@@ -2305,7 +2367,7 @@ __global__ __launch_bounds__(512) void pick_generic_kernel(KSnap sn, KIndex ix, 
         LW cc[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) cc[q] = 0;
-        const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, cc);
+        const uint32_t hits = prefix_walk<LW, NPL>(ix, (const uint64_t*)(row + 8), nb, lane, cc, s_scr);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) c[q] = cc[q];
         w_hits += hits;
@@ -2726,10 +2788,45 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 }
 
 // ---- prefix index maintenance (0602-…/README.md:101-108) -----------------------------------------
+//
+// LISTS FIRST (round 3).  A key's pod set lives in ONE of two places:
+//   * its short list (64 bytes: at most kListCap 16-bit pod ids, ascending, + the count) while it has at most kListCap members --
+//     the dense row of such a slot is ALL ZERO and nobody touches it;
+//   * its dense row (64 * sizeof(LW) bytes, one bit per pod) once a 25th pod arrived: count > kListCap ("overflowed"), the ids in
+//     the list are then unspecified.  A row that shrinks back to kListCap members returns to its list (and is zeroed).
+// Invariants (index_selfcheck_kernel checks them all): an absent key (empty word, tombstone, bucket header, the zero row) has an
+// empty list -- count 0, every id 0xFFFF -- and an all-zero row; a present key has a non-empty set; list ids are unique, below
+// 64 * bits(LW), strictly ascending after every entry point of the library; unused id positions and the three spare dwords are 0xFFFF.
+// Why: the post-route update of a 64k x 32-block batch makes ~1 Mi NEW keys, each a single-pod set.  With the row as the arbiter
+// ("did my atomicOr set the bit?") a new key touched four random 64-byte HBM lines (bucket, stamp, row word, list); random-line
+// atomics run at 20 G lines/s on this GPU (scripts/micro/linermw.hip), so the update could not go below ~205 us per Mi keys and the
+// closed loop sat at 143 M decisions/s.  Now the LIST is the arbiter: an id is appended by a 32-bit compare-and-swap on the dword
+// that holds the first free position, so two inserters of one (key, pod) pair cannot both land it, and the row is not touched at
+// all: three lines per new key (bucket CAS, list CAS, stamp store), and an eviction victim costs its list and its key.
 
-// Set pod's bit in the row of `slot`; true iff this call set it.  Re-inserting a cached block is the common case of the
-// post-pick update, so the word is read first and the atomic issued only when the bit is still clear (bits are only
-// cleared by remove_pod / evict, never concurrently).
+// Coherent 64-byte line -> 16 dwords (four 16-byte loads that bypass the non-coherent caches).
+__device__ __forceinline__ void load_line16(const uint32_t* p, uint32_t (&d)[16]) {
+  u32x4_t q0, q1, q2, q3;
+  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(p) : "memory");
+  d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
+  d[8] = q2.x; d[9] = q2.y; d[10] = q2.z; d[11] = q2.w; d[12] = q3.x; d[13] = q3.y; d[14] = q3.z; d[15] = q3.w;
+}
+__device__ __forceinline__ void store_line16(uint32_t* p, const uint32_t (&d)[16]) {
+  u32x4_t* P = (u32x4_t*)p;
+  const u32x4_t q0 = {d[0], d[1], d[2], d[3]}, q1 = {d[4], d[5], d[6], d[7]}, q2 = {d[8], d[9], d[10], d[11]}, q3 = {d[12], d[13], d[14], d[15]};
+  P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3;
+}
+// id number j of a list: dword and half of the 16-dword line (list_pos(j) = 8 * (j & 3) + (j >> 2) as a u16 index)
+__host__ __device__ __forceinline__ constexpr uint32_t list_dw(uint32_t j) { return 4u * (j & 3u) + (j >> 3); }
+__host__ __device__ __forceinline__ constexpr uint32_t list_hi(uint32_t j) { return (j >> 2) & 1u; }
+__device__ __forceinline__ uint32_t list_id(const uint32_t (&d)[16], uint32_t j) {      // (j: compile-time constant after unrolling)
+  return list_hi(j) ? (d[list_dw(j)] >> 16) : (d[list_dw(j)] & 0xFFFFu);
+}
+constexpr uint32_t kListBusy = 0x80000000u;   // in the count dword, only while index_lists_sort_kernel works on the list
+
+// Set pod's bit in the row of `slot` (an OVERFLOWED set); true iff this call set it.
 template <typename LW>
 __device__ __forceinline__ bool bitmap_set(void* bitmaps, uint32_t slot, uint32_t pod) {
   const uint32_t lane = pod & 63u, j = pod >> 6;
@@ -2750,43 +2847,123 @@ __device__ __forceinline__ bool bitmap_set(void* bitmaps, uint32_t slot, uint32_
   }
 }
 
-// Append a pod whose bit was just set to the slot's short list.  Positions are handed out by an atomic counter; once it has
-// passed kListCap the list is overflowed and stays so (the counter is not bumped any further) until the row is rebuilt
-// (remove_pod) or freed (evict / clear).
-__device__ __forceinline__ void list_append(uint32_t* lists, uint32_t slot, uint32_t pod) {
-  uint32_t* L = lists + (size_t)slot * kListDwords;
-  if (__hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kListCap) return;
-  const uint32_t j = atomicAdd(&L[3], 1u);
-  if (j < kListCap) ((uint16_t*)L)[list_pos(j)] = (uint16_t)pod;
+// Add `pod` to the short list L whose line was read into d (KNOWN_EMPTY: the caller just claimed the key -- the list is in its
+// reset state and was not read).  Returns 0 = already listed, 1 = appended at position `pos`, 2 = the list is full of other pods.
+// Protocol: ids only ever appear (nothing is removed while an insert kernel runs) and an id goes into the FIRST free position, by a
+// compare-and-swap on the dword that holds it (two ids per dword: the CAS changes one half and fails if either half moved).  A
+// thread lands its pod at position f only after it has seen every position below f hold some OTHER pod -- in its first read of
+// the line or in the value a failed CAS returned -- so no pod is ever listed twice, whatever the interleaving, and the filled
+// positions always form a prefix: the count is an atomicMax of (position + 1).
+template <bool KNOWN_EMPTY>
+__device__ __forceinline__ uint32_t list_add(uint32_t* L, const uint32_t (&d)[16], uint32_t pod, uint32_t& pos) {
+  uint32_t j = kListCap, exp = 0xFFFFFFFFu;
+  if constexpr (KNOWN_EMPTY) {
+    j = 0u;
+  } else {
+    bool found = false;
+#pragma unroll
+    for (int jj = (int)kListCap - 1; jj >= 0; --jj) {
+      const uint32_t id = list_id(d, (uint32_t)jj);
+      if (id == kListNone) { j = (uint32_t)jj; exp = d[list_dw((uint32_t)jj)]; }
+      found = found || id == pod;
+    }
+    if (found) return 0u;
+  }
+  while (j < kListCap) {
+    const uint32_t hi = list_hi(j);
+    const uint32_t mine = hi ? (exp >> 16) : (exp & 0xFFFFu);
+    if (mine == pod) return 0u;
+    if (mine != kListNone) {                               // somebody else's pod sits here by now: on to the next position
+      ++j;
+      if (j < kListCap) exp = __hip_atomic_load(&L[list_dw(j)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    const uint32_t des = hi ? ((exp & 0x0000FFFFu) | (pod << 16)) : ((exp & 0xFFFF0000u) | pod);
+    const uint32_t seen = atomicCAS(&L[list_dw(j)], exp, des);
+    if (seen == exp) {
+      pos = j;
+      atomicMax(&L[3], j + 1u);
+      return 1u;
+    }
+    exp = seen;                                            // (either half moved: look again)
+  }
+  return 2u;
 }
 
-// Rebuild the short list of a slot from its dense row (one wavefront; v = this lane's word of the row).
+// The 25th pod of a set: the set moves to its dense row.  The thread that raises the count past kListCap copies the 24 listed
+// pods into the row (every position is final by then: the line is read again, coherently); every thread that arrives on a full
+// list -- the mover included -- sets its own pod's bit.  Inserts that come later see count > kListCap and go to the row directly.
 template <typename LW>
-__device__ __forceinline__ void list_rebuild(uint32_t* lists, uint32_t slot, LW v, uint32_t lane) {
-  const uint32_t cnt = (uint32_t)__builtin_popcountll((unsigned long long)v);
-  uint32_t incl = cnt;
-  for (uint32_t d = 1; d < 64u; d <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)d);
-    if (lane >= d) incl += t;
-  }
-  const uint32_t total = (uint32_t)__shfl((int)incl, 63), excl = incl - cnt;
-  uint32_t mine = 0xFFFFFFFFu;                                  // lane q < 16 assembles dword q of the list
-  if (total <= kListCap) {
-    for (uint32_t j = 0; j < total; ++j) {
-      const int own = __builtin_ctzll(__ballot(excl <= j && j < incl));   // the lane whose word holds member j
-      uint32_t pod = 0;
-      if ((int)lane == own) {
-        LW t = v;
-        for (uint32_t n = j - excl; n; --n) t = (LW)(t & (LW)(t - 1));
-        pod = ctz_lw<LW>(t) * 64u + lane;
-      }
-      pod = (uint32_t)__shfl((int)pod, own);
-      const uint32_t u = list_pos(j);
-      if (lane == (u >> 1)) mine = (u & 1u) ? ((mine & 0x0000FFFFu) | (pod << 16)) : ((mine & 0xFFFF0000u) | pod);
+__device__ __forceinline__ void list_overflow(void* bitmaps, uint32_t* L, uint32_t slot, uint32_t pod) {
+  const uint32_t old = atomicMax(&L[3], kListCap + 1u);
+  if (old <= kListCap) {
+    uint32_t d[16];
+    load_line16(L, d);
+#pragma unroll
+    for (uint32_t jj = 0; jj < kListCap; ++jj) {
+      const uint32_t id = list_id(d, jj);
+      if ((id >> 6) < 8u * (uint32_t)sizeof(LW)) bitmap_set<LW>(bitmaps, slot, id);
     }
   }
-  if (lane == 3u) mine = total;                                 // the count (> kListCap: overflowed)
-  if (lane < kListDwords) lists[(size_t)slot * kListDwords + lane] = mine;
+  bitmap_set<LW>(bitmaps, slot, pod);
+}
+
+// 24 ids ascending (unused positions 0xFFFF sort to the end): a bitonic network over 32 registers, fully unrolled.
+__device__ __forceinline__ void sort_ids(uint32_t (&a)[32]) {
+#pragma unroll
+  for (uint32_t k = 2; k <= 32u; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+#pragma unroll
+      for (uint32_t i = 0; i < 32u; ++i) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0u;
+          const uint32_t lo = a[i] < a[l] ? a[i] : a[l], hi = a[i] < a[l] ? a[l] : a[i];
+          a[i] = up ? lo : hi;
+          a[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+// d (a list line) with its ids sorted ascending; the count dword and the spare dwords are left alone
+__device__ __forceinline__ void list_sort_line(uint32_t (&d)[16]) {
+  uint32_t a[32];
+#pragma unroll
+  for (uint32_t j = 0; j < 32u; ++j) a[j] = j < kListCap ? list_id(d, j) : kListNone;
+  sort_ids(a);
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; ++q)          // dword 4q + t holds ids j = q + 8t (low half) and q + 8t + 4 (high half), t = 0..2
+#pragma unroll
+    for (uint32_t t = 0; t < 3u; ++t) d[4u * q + t] = a[q + 8u * t] | (a[q + 8u * t + 4u] << 16);
+}
+__device__ __forceinline__ void list_reset_line(uint32_t (&d)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = i == 3 ? 0u : 0xFFFFFFFFu;
+}
+
+// Rebuild the short list of a slot from its dense row, ids ascending (one wavefront; v = this lane's word of the row).  Returns
+// the member count; when it exceeds kListCap only the count is written (the set stays in its row).
+template <typename LW>
+__device__ __forceinline__ uint32_t list_rebuild(uint32_t* lists, uint32_t slot, LW v, uint32_t lane) {
+  uint32_t total = (uint32_t)__builtin_popcountll((unsigned long long)v);
+  for (uint32_t d = 32; d; d >>= 1) total += (uint32_t)__shfl_xor((int)total, (int)d);
+  uint32_t* L = lists + (size_t)slot * kListDwords;
+  if (lane < kListDwords) L[lane] = lane == 3u ? total : 0xFFFFFFFFu;
+  if (total > kListCap || total == 0u) return total;
+  __threadfence();                                          // the 2-byte stores below land on top of the reset line
+  uint32_t base = 0;
+  for (uint32_t j = 0; j < 8u * (uint32_t)sizeof(LW); ++j) {          // pod = j * 64 + lane: ascending = bit index first, lane second
+    const unsigned long long b = __ballot((v >> j) & 1);
+    if (b == 0ull) continue;
+    if ((v >> j) & 1) {
+      const uint32_t p = base + (uint32_t)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+      ((uint16_t*)L)[list_pos(p)] = (uint16_t)(j * 64u + lane);
+    }
+    base += (uint32_t)__builtin_popcountll(b);
+  }
+  return total;
 }
 
 #ifdef EPPK_MAIN_UNIT
@@ -2814,7 +2991,7 @@ struct IxBudget {            // what a workgroup learned about the table's capac
 
 // One wavefront of the workgroup sums the shards; `n_items` = pairs of this launch (an upper bound on its new keys).
 __device__ __forceinline__ IxBudget ix_budget(const unsigned long long* ixc, uint32_t limit, uint32_t slots, unsigned long long n_items,
-                                              unsigned long long* s_tmp /* __shared__ [3] */) {
+                                              unsigned long long* s_tmp /* __shared__ [4] */) {
   if (threadIdx.x < 64u) {
     const uint32_t l = threadIdx.x;
     unsigned long long lv = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
@@ -2832,6 +3009,15 @@ __device__ __forceinline__ IxBudget ix_budget(const unsigned long long* ixc, uin
   return b;
 }
 
+// Work list of the lists that index_lists_sort_kernel has to bring back into ascending order after an insert launch:
+// wl[0] / wl[1] = two alternating cursors (a launch appends through one; its sort pass zeroes the other for the next launch),
+// wl[2] = "entries were lost" (the sort pass then walks the whole table), wl[4 ..] = slots.
+struct SortWl {
+  uint32_t* wl;
+  uint32_t cap;       // entries
+  uint32_t which;     // cursor of this launch (0 / 1)
+};
+
 // Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters are bumped once per wavefront
 // (ballot + popcount).  Capacity: at most `limit` (= slots/2) live keys and 3/4 of the words non-empty.  A launch whose pairs all
 // fit (IxBudget::safe, the common case) inserts without looking at the counters; otherwise every new key is checked against an
@@ -2844,11 +3030,11 @@ __device__ __forceinline__ IxBudget ix_budget(const unsigned long long* ixc, uin
 // runs (evictions are separate launches), so every inserter of one key converges on the same word: no duplicates.
 // Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
 // Memory round trips per pair: one for the whole home bucket (its 8 words are loaded together), one CAS when the key is new,
-// one for {stamp, pod-set word, list count} together, one for the updates.
+// one for {stamp, list line} together (skipped for a key this thread just claimed), one for the list CAS.
 template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
                                                  uint32_t limit, uint32_t epoch, unsigned long long* ixc, const IxBudget& bud, uint64_t h, uint32_t pod,
-                                                 bool active, const LW* act) {
+                                                 bool active, const LW* act, const SortWl& sw, uint32_t* status) {
   // a hole of the current snapshot has no cache to record: the pair is ignored (SEMANTICS.md §6b; act == null: no snapshot yet)
   if (active && act && !((act[pod & 63u] >> (pod >> 6)) & 1)) active = false;
   uint32_t slot = kNotFound;
@@ -2871,12 +3057,10 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
           unsigned long long* kb = K + (size_t)b * kBucket;
           unsigned long long w[kBucket];
           {
-            typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-            u64x2_t q0, q1, q2, q3;
-            asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(kb) : "memory");
-            w[0] = q0.x; w[1] = q0.y; w[2] = q1.x; w[3] = q1.y; w[4] = q2.x; w[5] = q2.y; w[6] = q3.x; w[7] = q3.y;
+            uint32_t q[16];
+            load_line16((const uint32_t*)kb, q);
+#pragma unroll
+            for (int i = 0; i < (int)kBucket; ++i) w[i] = ((unsigned long long)q[2 * i + 1] << 32) | q[2 * i];
           }
 #pragma unroll
           for (uint32_t i = 1; i < kBucket; ++i) {
@@ -2934,52 +3118,80 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     if (nw) atomicAdd(&ixc[kIxWords], (unsigned long long)__builtin_popcountll(nw));
     if (dropped) atomicAdd(&ixc[kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
   }
-  if (active && slot != kNotFound) {
-    const uint32_t lane = pod & 63u, j = pod >> 6;
-    if (newkey) {
-      // this thread claimed the word a moment ago: whatever the stamp, the row and the list hold is nobody's yet -- no look before the
-      // atomics.  (Every insert of a launch carries the same epoch: a racing atomicMax writes the same value.)
-      __hip_atomic_store(&stamps[slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool fresh;
-      if constexpr (sizeof(LW) == 8) fresh = !((atomicOr((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, 1ull << j) >> j) & 1ull);
-      else fresh = bitmap_set<LW>(bitmaps, slot, pod);
-      if (fresh && lists) {
-        uint32_t* L = lists + (size_t)slot * kListDwords;
-        const uint32_t q = atomicAdd(&L[3], 1u);
-        if (q < kListCap) ((uint16_t*)L)[list_pos(q)] = (uint16_t)pod;
-      }
-    } else {
-    // the three things an insert may have to update, read together (one round trip): the key's stamp, the pod's bit, the list count
-    const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool have;
-    if constexpr (sizeof(LW) == 8) have = (__hip_atomic_load((unsigned long long*)bitmaps + (size_t)slot * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1ull;
-    else if constexpr (sizeof(LW) == 4) have = (__hip_atomic_load((unsigned int*)bitmaps + (size_t)slot * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> j) & 1u;
-    else {
-      const size_t e = (size_t)slot * 64u + lane;
-      have = (__hip_atomic_load((unsigned int*)bitmaps + (e >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j + 16u * (uint32_t)(e & 1u))) & 1u;
-    }
-    if (st < epoch) atomicMax(&stamps[slot], epoch);
-    if (!have && bitmap_set<LW>(bitmaps, slot, pod) && lists) list_append(lists, slot, pod);
+  bool unsorted = false;               // this thread appended behind other ids: the list needs its order back
+  const bool have = active && slot != kNotFound;
+  // (1) A key this thread claimed a moment ago: its list is in the reset state and its stamp is nobody's yet -- the first id and
+  // the count go in with ONE plain 16-byte store, the stamp with another: no atomic, nothing read.  Random-line atomics cost ~50 us
+  // per Mi on this GPU whatever line they hit (a new key used to take three: bucket CAS, list CAS, count), stores ~37.
+  // This block comes BEFORE (2) for every lane of the wavefront: a lane of (2) may wait for exactly this store.
+  if (have && newkey) {
+    uint32_t* L = lists + (size_t)slot * kListDwords;
+    const u32x4_t first = {0xFFFF0000u | pod, 0xFFFFFFFFu, 0xFFFFFFFFu, 1u};
+#ifdef EPPK_DBG_CLAIM_DWORDS
+    __hip_atomic_store(&L[0], first.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&L[3], first.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    // (agent scope, like the atomics around it.  The s_nop is the wait state the ISA demands between a store of more than 8 bytes
+    // and a write of its data registers: the compiler cannot see into the asm, reused the first register at once for the stamp below,
+    // and the list got the epoch instead of the pod -- found by tests/test_gpu_group.py)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(L), "v"(first) : "memory");
+#endif
+    __hip_atomic_store(&stamps[slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every insert of a launch carries the same epoch)
   }
+  // (the stores above are acknowledged before any lane of this wavefront looks at a list: no cache maintenance -- a __threadfence
+  // here, buffer_wbl2 + buffer_inv per wavefront, made the kernel four times slower)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (2) A key that was there: stamp and list line together (one round trip), then the list protocol (list_add).
+  if (have && !newkey) {
+    uint32_t* L = lists + (size_t)slot * kListDwords;
+    const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t d[16];
+    load_line16(L, d);
+    // A present key with an EMPTY list exists only between a claimer's compare-and-swap on the key word and its store above (an
+    // invariant of the index: present = non-empty): wait for that store -- the claimer never waits for anybody, so it arrives.
+    // Bounded all the same: a lane that gives up drops its pair and raises a launch-status flag instead of hanging the GPU.
+    uint32_t spins = 0;
+    while (d[3] == 0u && spins < (1u << 20)) { load_line16(L, d); ++spins; }
+    if (st < epoch) atomicMax(&stamps[slot], epoch);
+    uint32_t res = 0u, pos = 0;
+    if (d[3] == 0u) atomicOr(status, kStatusIndexStall);
+    else if (d[3] > kListCap) bitmap_set<LW>(bitmaps, slot, pod);         // overflowed: the row is the set
+    else res = list_add<false>(L, d, pod, pos);
+    if (res == 2u) list_overflow<LW>(bitmaps, L, slot, pod);
+    unsorted = res == 1u && pos != 0u;
+  }
+  // the lists to re-sort, appended to the work list once per wavefront
+  const unsigned long long um = __ballot(unsorted);
+  if (um) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(um)) base = atomicAdd(&sw.wl[sw.which], (uint32_t)__builtin_popcountll(um));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(um));
+    if (unsorted) {
+      const uint32_t at = base + (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull));
+      if (at < sw.cap) sw.wl[4u + at] = slot;
+      else sw.wl[2] = 1u;
+    }
   }
 }
 
 template <typename LW>
 __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                     uint32_t epoch, unsigned long long* ixc, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
-                                    const LW* act) {
+                                    const LW* act, SortWl sw, uint32_t* status) {
   __shared__ unsigned long long s_tmp[4];
   const IxBudget bud = ix_budget(ixc, limit, slots, n, s_tmp);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act, sw, status);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
 template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* ixc, const uint8_t* reqs, uint32_t stride,
-                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act) {
+                                          uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act,
+                                          SortWl sw) {
   __shared__ unsigned long long s_tmp[4];
   const IxBudget bud = ix_budget(ixc, limit, slots, (unsigned long long)n_reqs * max_blocks, s_tmp);
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2998,37 +3210,117 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, h, (uint32_t)pick, active, act);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, h, (uint32_t)pick, active, act, sw, status);
 }
 
-// Clear pod's bit in every row; a row that becomes empty gets its key tombstoned so that the hot path never
-// meets a present key with an empty pod set.  A wavefront per row, looping (rows = slots + 2: the reserved rows too).
-// `rm` (nullable): instead of the single `pod`, clear every pod whose bit is set in the lane-transposed row rm[64] (the holes of a
-// snapshot: eppk_snapshot_publish scrubs them out of the index in one pass).
+#ifdef EPPK_MAIN_UNIT
+// Behind every insert launch (same stream): the lists that got an id appended behind others go back to ascending order, so that
+// equal SETS are equal LINES again -- pick_quad_kernel and the fast kernel's uniform route compare the lists of a request's hits
+// bit for bit (the blocks of a shared prefix are cached on the same pods; after a post-route update they must still look alike).
+// A lane per work-list entry.  A slot can be listed several times (several appends in one launch): the count dword is the lock
+// (compare-and-swap count -> count | kListBusy), a lane that finds it taken leaves the list to its owner; one that comes after the
+// owner has finished sorts a sorted list again, harmlessly.  Lost entries (work list full): the whole table is walked.
+__global__ void index_lists_sort_kernel(uint32_t* lists, uint32_t slots, uint32_t* wl, uint32_t cap, uint32_t which) {
+  const uint32_t n_listed = wl[which] < cap ? wl[which] : cap;
+  const bool lost = wl[2] != 0u;
+  const uint32_t total = lost ? slots + 2u : n_listed;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = lost ? i : wl[4u + i];
+    uint32_t* L = lists + (size_t)slot * kListDwords;
+    const uint32_t cnt = __hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt < 2u || cnt > kListCap) continue;              // nothing to order / overflowed / another lane is on it
+    if (atomicCAS(&L[3], cnt, cnt | kListBusy) != cnt) continue;
+    uint32_t d[16];
+    load_line16(L, d);
+    list_sort_line(d);
+    d[3] = cnt | kListBusy;
+    store_line16(L, d);
+    __threadfence();
+    __hip_atomic_store(&L[3], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // the next launch's cursor (nobody reads it before that launch), and the lost flag once every thread of this grid has read it:
+  // the flag is only ever set by an insert launch, so clearing it from the LAST workgroup to arrive is safe
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    if (blockIdx.x == 0u) wl[which ^ 1u] = 0u;
+    __threadfence();
+    s_last = atomicAdd(&wl[3], 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0u) { wl[2] = 0u; wl[3] = 0u; }
+}
+#endif
+
+// Remove pods from every set; a set that becomes empty gets its key tombstoned so that the hot path never meets a present key
+// with an empty pod set.  `rm` (nullable): instead of the single `pod`, every pod whose bit is set in the lane-transposed row
+// rm[64] (the holes of a snapshot: eppk_snapshot_publish scrubs them out of the index in one pass).
+// A wavefront scans 64 slots per step (lane = slot: keys stream in coalesced); a listed set is edited by its lane (removed ids
+// become 0xFFFF, the sorting network closes the gaps and keeps the order); overflowed sets are then taken by the whole wavefront,
+// one after the other: bits cleared, and a row that is back at kListCap members or fewer returns to its list.
 template <typename LW>
 __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* ixc,
                                         const LW* rm) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t total = slots + 2u;
+  const LW my_rm = rm ? rm[lane] : (lane == (pod & 63u) ? (LW)((LW)1 << (pod >> 6)) : (LW)0);
+  auto removed = [&](uint32_t id) -> bool {
+    if (id == kListNone) return false;
+    if (!rm) return id == pod;
+    return (id >> 6) < 8u * (uint32_t)sizeof(LW) && ((rm[id & 63u] >> (id >> 6)) & 1);
+  };
   uint32_t gone = 0;
-  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
-    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;   // bucket header words are not keys (their rows are unused)
-    const uint64_t k = keys[row];
-    if (k == 0ull || (row < slots && k == kTomb)) continue;
-    LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
-    LW v = *w;
-    bool changed = false;
-    if (rm || lane == (pod & 63u)) {
-      const LW nv = (LW)(v & (LW)~(rm ? rm[lane] : (LW)((LW)1 << (pod >> 6))));
-      changed = nv != v;
-      if (changed) *w = nv;
-      v = nv;
+  for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
+    const uint32_t row = base + lane;
+    bool present = false;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {     // (bucket header words are not keys)
+      const uint64_t k = keys[row];
+      present = k != 0ull && !(row < slots && k == kTomb);
     }
-    if (lists && __any(changed)) list_rebuild<LW>(lists, row, v, lane);   // (also brings an overflowed list back when it fits again)
-    if (__ballot(v != 0) == 0ull) {
-      if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;     // reserved rows: clear presence
-      ++gone;
+    bool over = false, emptied = false;
+    if (present) {
+      uint32_t* L = lists + (size_t)row * kListDwords;
+      uint32_t d[16];
+      load_line16(L, d);
+      if (d[3] > kListCap) over = true;
+      else {
+        uint32_t nrm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kListCap; ++j) {
+          if (removed(list_id(d, j))) {
+            d[list_dw(j)] |= list_hi(j) ? 0xFFFF0000u : 0x0000FFFFu;
+            ++nrm;
+          }
+        }
+        if (nrm) {
+          list_sort_line(d);
+          d[3] -= nrm;
+          store_line16(L, d);
+          emptied = d[3] == 0u;
+        }
+      }
     }
+    unsigned long long om = __ballot(over);
+    while (om) {
+      const uint32_t v_row = base + (uint32_t)__builtin_ctzll(om);
+      om &= om - 1ull;
+      LW* w = (LW*)bitmaps + (size_t)v_row * 64u + lane;
+      LW v = *w;
+      const LW nv = (LW)(v & (LW)~my_rm);
+      if (!__any(nv != v)) continue;
+      uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)nv);
+      for (uint32_t dd = 32; dd; dd >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)dd);
+      if (members <= kListCap) {                       // back to the list (or gone): the row returns to all-zero
+        list_rebuild<LW>(lists, v_row, nv, lane);
+        *w = 0;
+        if (members == 0u && v_row == row) emptied = true;
+      } else if (nv != v) {
+        *w = nv;
+      }
+    }
+    if (emptied) keys[row] = row < slots ? kTomb : 0ull;     // reserved rows: clear presence
+    gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   if (lane == 0 && gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
 }
@@ -3037,27 +3329,52 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
 // A pod may be listed under at most `cap` hashes; what exceeds that goes oldest first, at epoch granularity: with
 // age(h) = min(63, epoch - stamp(h)) and cutage(p) = the smallest b >= 1 with #{h containing p : age(h) <= b} > cap, pod p is removed
 // from every hash of age >= cutage(p) (entries stamped in the current epoch always stay).  Three passes:
-//   (1) index_pod_hist_kernel   wave per row: hist[p][age] += 1 for every pod p of the row's set
+//   (1) index_pod_hist_kernel   hist[p][age] += 1 for every pod p of every set (a lane per listed set, the wavefront per overflowed row)
 //   (2) index_pod_cut_kernel    thread per pod: cutage[p] (kNoCut = within capacity), then the lane-transposed set `over` of the pods to trim
-//   (3) index_pod_trim_kernel   wave per row: clears the bits of the pods with cutage <= age(row), rebuilds the list, tombstones empty rows
+//   (3) index_pod_trim_kernel   removes the pods with cutage <= age(set) (same shape as index_remove_pod_kernel), tombstones empty sets
 constexpr uint32_t kTrimBins = 64u;
 constexpr uint32_t kNoCut = 0xFFFFFFFFu;
 
 template <typename LW>
-__global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* stamps, uint32_t slots, uint32_t epoch, uint32_t* hist) {
+__global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t epoch,
+                                      uint32_t* hist) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
-    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
-    const uint64_t k = keys[row];
-    if (k == 0ull || (row < slots && k == kTomb)) continue;
-    const uint32_t st = stamps[row];
-    const uint32_t age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
-    LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
-    while (v != 0) {
-      const uint32_t j = ctz_lw<LW>(v);
-      v = (LW)(v & (LW)(v - 1));
-      atomicAdd(&hist[(size_t)(j * 64u + lane) * kTrimBins + age], 1u);
+  const uint32_t total = slots + 2u;
+  for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
+    const uint32_t row = base + lane;
+    bool present = false;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {
+      const uint64_t k = keys[row];
+      present = k != 0ull && !(row < slots && k == kTomb);
+    }
+    bool over = false;
+    uint32_t age = 0;
+    if (present) {
+      const uint32_t st = stamps[row];
+      age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+      uint32_t d[16];
+      load_line16(lists + (size_t)row * kListDwords, d);
+      if (d[3] > kListCap) over = true;
+      else {
+#pragma unroll
+        for (uint32_t j = 0; j < kListCap; ++j) {
+          const uint32_t id = list_id(d, j);
+          if (id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW)) atomicAdd(&hist[(size_t)id * kTrimBins + age], 1u);
+        }
+      }
+    }
+    unsigned long long om = __ballot(over);
+    while (om) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(om);
+      om &= om - 1ull;
+      const uint32_t v_row = base + src, v_age = (uint32_t)__shfl((int)age, (int)src);
+      LW v = ((const LW*)bitmaps)[(size_t)v_row * 64u + lane];
+      while (v != 0) {
+        const uint32_t j = ctz_lw<LW>(v);
+        v = (LW)(v & (LW)(v - 1));
+        atomicAdd(&hist[(size_t)(j * 64u + lane) * kTrimBins + v_age], 1u);
+      }
     }
   }
 }
@@ -3091,32 +3408,72 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
                                       const uint32_t* cutage, const uint64_t* over_t, unsigned long long* ixc, unsigned long long* removed) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const LW over = (LW)over_t[lane];
+  const uint32_t total = slots + 2u;
+  const LW over_pods = (LW)over_t[lane];
   uint32_t gone = 0, pairs = 0;
-  for (uint32_t row = wave; row < slots + 2u; row += nwaves) {
-    if (row < slots && (row & (kBucket - 1u)) == 0u) continue;
-    const uint64_t k = keys[row];
-    if (k == 0ull || (row < slots && k == kTomb)) continue;
-    LW* w = (LW*)bitmaps + (size_t)row * 64u + lane;
-    LW v = *w;
-    LW cand = (LW)(v & over);
-    if (!__any(cand != 0)) continue;
-    const uint32_t st = stamps[row];
-    const uint32_t age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
-    LW rm = 0;
-    while (cand != 0) {
-      const uint32_t j = ctz_lw<LW>(cand);
-      cand = (LW)(cand & (LW)(cand - 1));
-      if (cutage[j * 64u + lane] <= age) rm |= (LW)((LW)1 << j);
+  for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
+    const uint32_t row = base + lane;
+    bool present = false;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {
+      const uint64_t k = keys[row];
+      present = k != 0ull && !(row < slots && k == kTomb);
     }
-    const bool changed = rm != 0;
-    if (changed) { v = (LW)(v & (LW)~rm); *w = v; pairs += (uint32_t)__builtin_popcountll((unsigned long long)rm); }
-    if (!__any(changed)) continue;
-    if (lists) list_rebuild<LW>(lists, row, v, lane);
-    if (__ballot(v != 0) == 0ull) {
-      if (lane == 0) keys[row] = row < slots ? kTomb : 0ull;
-      ++gone;
+    bool over = false, emptied = false;
+    uint32_t age = 0;
+    if (present) {
+      const uint32_t st = stamps[row];
+      age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+      uint32_t* L = lists + (size_t)row * kListDwords;
+      uint32_t d[16];
+      load_line16(L, d);
+      if (d[3] > kListCap) over = true;
+      else {
+        uint32_t nrm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kListCap; ++j) {
+          const uint32_t id = list_id(d, j);
+          if (id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW) && cutage[id] <= age) {
+            d[list_dw(j)] |= list_hi(j) ? 0xFFFF0000u : 0x0000FFFFu;
+            ++nrm;
+          }
+        }
+        if (nrm) {
+          list_sort_line(d);
+          d[3] -= nrm;
+          store_line16(L, d);
+          emptied = d[3] == 0u;
+          pairs += nrm;
+        }
+      }
     }
+    unsigned long long om = __ballot(over);
+    while (om) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(om);
+      om &= om - 1ull;
+      const uint32_t v_row = base + src, v_age = (uint32_t)__shfl((int)age, (int)src);
+      LW* w = (LW*)bitmaps + (size_t)v_row * 64u + lane;
+      const LW v = *w;
+      LW cand = (LW)(v & over_pods), rmw = 0;
+      while (cand != 0) {
+        const uint32_t j = ctz_lw<LW>(cand);
+        cand = (LW)(cand & (LW)(cand - 1));
+        if (cutage[j * 64u + lane] <= v_age) rmw |= (LW)((LW)1 << j);
+      }
+      if (!__any(rmw != 0)) continue;
+      const LW nv = (LW)(v & (LW)~rmw);
+      uint32_t nrm = (uint32_t)__builtin_popcountll((unsigned long long)rmw), members = (uint32_t)__builtin_popcountll((unsigned long long)nv);
+      for (uint32_t dd = 32; dd; dd >>= 1) { nrm += (uint32_t)__shfl_xor((int)nrm, (int)dd); members += (uint32_t)__shfl_xor((int)members, (int)dd); }
+      if (lane == src) pairs += nrm;
+      if (members <= kListCap) {
+        list_rebuild<LW>(lists, v_row, nv, lane);
+        *w = 0;
+        if (members == 0u && lane == src) emptied = true;
+      } else if (rmw != 0) {
+        *w = nv;
+      }
+    }
+    if (emptied) keys[row] = row < slots ? kTomb : 0ull;
+    gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   for (int off = 32; off >= 1; off >>= 1) pairs += (uint32_t)__shfl_xor((int)pairs, off);
   if (lane == 0) {
@@ -3127,13 +3484,9 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
 
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
 // drop every key last stamped before min_epoch -- pod set emptied, key tombstoned (reusable by later inserts).
-// A wavefront scans 64 slots per step (lane = slot: keys and stamps stream in coalesced), then empties its victims one by one.
-// A victim whose set still fits its short list is emptied through the list: only the row words of the listed pods are cleared
-// (one 64-byte line per pod instead of the whole 64 * sizeof(LW)-byte row -- what a post-route update leaves behind is mostly
-// single-pod sets); an overflowed victim gets its whole row zeroed.
-// A LANE per victim: its list by four 16-byte loads, one store per listed pod, the list reset by four 16-byte stores -- all victims
-// of a wave step are in flight together (the wavefront walking them one after the other took 160 us per Mi victims, this 108:
-// profiles/r02_micro_insertbreak.txt, run D).
+// A wavefront scans 64 slots per step (lane = slot: keys and stamps stream in coalesced).  A LANE per victim: its list line is
+// read (is the set in its row?) and reset by four 16-byte stores, the key word becomes a tombstone -- two lines per victim, the
+// dense row is not touched (it is all-zero for a listed set).  Overflowed victims get their row zeroed by the whole wavefront.
 template <typename LW>
 __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
                                    unsigned long long* ixc) {
@@ -3148,32 +3501,21 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
       const uint64_t k = keys[row];
       victim = k != 0ull && !(row < slots && k == kTomb) && stamps[row] < min_epoch;
     }
-    unsigned long long vm = __ballot(victim);
-    gone += (uint32_t)__builtin_popcountll(vm);
-    bool whole_l = victim;
-    if (victim && lists) {
+    gone += (uint32_t)__builtin_popcountll(__ballot(victim));
+    bool whole = false;
+    if (victim) {
       u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
-      u32x4_t c0 = Lp[0], c1 = Lp[1], c2 = Lp[2], c3 = Lp[3];
-      if (c0.w <= kListCap) {
-        whole_l = false;
-        const uint32_t w6[12] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z, c3.x, c3.y, c3.z};   // ids: positions 0..5 of every chunk
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-          const uint32_t lo = w6[q] & 0xFFFFu, hi = w6[q] >> 16;
-          if (lo != kListNone && (lo >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (lo & 63u)] = 0;
-          if (hi != kListNone && (hi >> 6) < 8u * (uint32_t)sizeof(LW)) ((LW*)bitmaps)[(size_t)row * 64u + (hi & 63u)] = 0;
-        }
-      }
+      whole = Lp[0].w > kListCap;
       const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
+      keys[row] = row < slots ? kTomb : 0ull;
     }
-    vm = __ballot(whole_l);          // overflowed lists (or no lists at all): the whole row, by the wavefront
+    unsigned long long vm = __ballot(whole);          // overflowed sets: the whole row, by the wavefront
     while (vm) {
       const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
       vm &= vm - 1ull;
       ((LW*)bitmaps)[(size_t)v * 64u + lane] = 0;
     }
-    if (victim) keys[row] = row < slots ? kTomb : 0ull;
   }
   if (lane == 0 && gone) {
     const uint32_t shard = (wave & (kIxShards - 1u)) * 8u;
@@ -3182,10 +3524,8 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
   }
 }
 
-// Diagnostic (eppk_index_selfcheck): counts the rows that break an invariant of the index -- a present key with an empty pod
-// set, an absent key (or a bucket header / the zero row) with a non-empty one, a short list that is not exactly the pod set
-// of its dense row (count, members, no duplicates, unused entries 0xFFFF), an overflowed list on an absent key.
-// A wavefront per row.
+// Diagnostic (eppk_index_selfcheck): counts the slots that break an invariant of the index (the list at the head of this section).
+// A wavefront per slot: its row word per lane, its list dwords in lanes 0..15.
 template <typename LW>
 __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, uint32_t slots, unsigned long long* bad) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -3198,30 +3538,37 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     const LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
     uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)v);
     for (uint32_t d = 32; d; d >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)d);
-    bool wrong = present ? members == 0u : members != 0u;
-    if (lists) {
-      const uint32_t* L = lists + (size_t)row * kListDwords;
-      const uint32_t count = L[3];
+    const uint32_t* L = lists + (size_t)row * kListDwords;
+    const uint32_t count = L[3];
+    // lane j < 24 looks at id j and its predecessor
+    const uint32_t j = lane < kListCap ? lane : 0u;
+    const uint32_t id = ((const uint16_t*)L)[list_pos(j)], prev = j ? ((const uint16_t*)L)[list_pos(j - 1u)] : 0u;
+    bool ok = true;
+    if (lane < kListCap) {
       if (count <= kListCap) {
-        if (count != members) wrong = true;
-        // lane u < 32 owns u16 entry u: chunk u >> 3, position u & 7 -> id number (u & 7) * 4 + (u >> 3)
-        const uint32_t u = lane & 31u;
-        const uint32_t e = ((const uint16_t*)L)[u];
-        const bool is_count = u == 6u || u == 7u;
-        const bool used = !is_count && (u & 7u) <= 5u && (u & 7u) * 4u + (u >> 3) < count;
-        bool ok = is_count || (used ? e != kListNone : e == kListNone);
-        for (uint32_t t = 0; t < 32u; ++t) {                 // every listed id: a member of the row, listed once
-          const uint32_t et = (uint32_t)__shfl((int)e, (int)t);
-          const bool ut = __shfl((int)used, (int)t) != 0;
-          if (ut && et != kListNone) {
-            if (lane == (et & 63u) && ((et >> 6) >= 8u * sizeof(LW) || !((v >> (et >> 6)) & 1))) ok = false;
-            if (lane < 32u && lane != t && used && e == et) ok = false;
-          }
-        }
-        if (__any(!ok)) wrong = true;
-      } else if (!present) wrong = true;
+        if (lane < count) ok = id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW) && (lane == 0u || prev < id);   // valid, strictly ascending
+        else ok = id == kListNone;
+      }
+    } else if (lane < kListCap + 3u) {
+      ok = L[7u + 4u * (lane - kListCap)] == 0xFFFFFFFFu;                  // the spare dwords 7, 11, 15
     }
-    if (wrong) ++nbad;
+    const unsigned long long notok = __ballot(!ok);
+    uint32_t why = notok ? 1u : 0u;                                        // bit 0: a list entry (ballot in the record), then per state
+    if (!present) why |= (count != 0u ? 2u : 0u) | (members != 0u ? 4u : 0u);            // absent: empty list, all-zero row
+    else if (count <= kListCap) why |= (count == 0u ? 8u : 0u) | (members != 0u ? 16u : 0u);   // listed: non-empty, all-zero row
+    else why |= members <= kListCap ? 32u : 0u;                            // overflowed: more than kListCap members in the row
+    if (why) {
+      ++nbad;
+      // the first eight offenders in full, for eppk_index_selfcheck's EPPK_SELFCHECK_VERBOSE: bad[2 + 24 k ..] = row, why, key, members, ballot, list[16]
+      unsigned long long at = 0;
+      if (lane == 0) at = atomicAdd(&bad[1], 1ull);
+      at = (unsigned long long)__shfl((long long)at, 0);
+      if (at < 8ull) {
+        unsigned long long* rec = bad + 2u + 24u * at;
+        if (lane == 0) { rec[0] = row; rec[1] = why; rec[2] = k; rec[3] = members; rec[4] = notok; }
+        if (lane < kListDwords) rec[5u + lane] = L[lane];
+      }
+    }
   }
   if (lane == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);
 }

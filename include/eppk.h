@@ -221,6 +221,9 @@ int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
  * in flight -- synchronise those streams first (eppk_index_insert_picks_device is ordered by the stream it is given). */
 #define EPPK_LAUNCH_BAD_REQUEST_ROW 1u   /* a request row on a *_device entry point was out of range: it got EPPK_NO_PICK */
 #define EPPK_LAUNCH_BAD_PICK        2u   /* eppk_index_insert_picks_device met a pick >= max_pods: ignored */
+#define EPPK_LAUNCH_INDEX_STALL     4u   /* an index insert gave up waiting for the first pod of a key that another thread of the same
+                                          * launch had just claimed (never observed; the wait is bounded so that a broken index cannot
+                                          * hang the device): that (hash, pod) pair was dropped */
 /* Synchronise the device and return (and clear) the sticky launch-status flags accumulated by every *_device launch of this
  * context since the last call.  0 = every row was in range. */
 int eppk_launch_status(eppk_ctx* ctx, uint32_t* flags);

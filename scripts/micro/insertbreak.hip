@@ -1,6 +1,6 @@
 // Measurement tool (not product code): where index_insert_picks_kernel's time goes.  The library's own kernel (eppk_kernels.hip.h,
 // included as is) on an 8 Mi-slot index with the shapes of a C5 closed-loop step, split into its two populations:
-//   new      65536 requests x 16 blocks nobody has seen      (1 Mi new keys: bucket CAS + stamp + row word + list)
+//   new      65536 requests x 16 blocks nobody has seen      (1 Mi new keys: bucket CAS + list CAS + stamp store; the dense row is not touched)
 //   known    65536 requests x 16 blocks of 256 hot prefixes, the (hash, pod) pair already present   (1 Mi look-ups on 4096 keys)
 //   known+   the same with the index epoch advanced (the first touch of a key refreshes its stamp)
 //   step     65536 requests x (16 known + 16 new): what the closed loop runs
@@ -25,9 +25,9 @@ __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const 
     const uint64_t k = keys[s];
     if (k == 0ull || k == eppk::kTomb) continue;
     unsigned long long pc = 0, ids = 0;
-    for (uint32_t i = 0; i < 64; ++i) pc += __popcll(rows[(size_t)s * 64u + i]);
     const uint32_t* L = lists + (size_t)s * eppk::kListDwords;
     const uint32_t cnt = L[3];
+    if (cnt > eppk::kListCap) { for (uint32_t i = 0; i < 64; ++i) pc += __popcll(rows[(size_t)s * 64u + i]); } else pc = cnt;   // (a listed set's row is all-zero)
     for (uint32_t q = 0; q < (cnt < eppk::kListCap ? cnt : eppk::kListCap); ++q) { const unsigned long long id = ((const uint16_t*)L)[eppk::list_pos(q)]; ids += (id + 1) * (id + 1); }
     unsigned long long z = k + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
     acc += z * (1ull + pc + 7ull * stamps[s] + 13ull * cnt + 31ull * ids);
@@ -68,7 +68,10 @@ int main(int argc, char** argv) {
   uint8_t* d_rows; int32_t* d_picks;
   CK(hipMalloc((void**)&d_rows, (size_t)R * stride)); CK(hipMalloc((void**)&d_picks, R * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*);
+  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*, eppk::SortWl);
+  uint32_t* d_wl; const uint32_t wl_cap = R * B; CK(hipMalloc((void**)&d_wl, (4u + (size_t)wl_cap) * 4u)); CK(hipMemset(d_wl, 0, 16));
+  uint32_t sort_uses = 0;
+  hipEvent_t e2; CK(hipEventCreate(&e2));
   Kern kern = eppk::index_insert_picks_kernel<LW>;
   auto run = [&](const char* what, int kind, uint64_t gen, uint32_t epoch, bool print) -> int {
     std::vector<uint8_t> rows; std::vector<int32_t> picks;
@@ -76,11 +79,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_rows, rows.data(), rows.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_picks, picks.data(), R * 4, hipMemcpyHostToDevice));
     const uint64_t total = (uint64_t)R * B;
     CK(hipEventRecord(e0));
+    const eppk::SortWl sw{d_wl, wl_cap, sort_uses & 1u};
+    ++sort_uses;
     hipLaunchKernelGGL(kern, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
-                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr);
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    if (print) printf("%-8s epoch %u: %8.1f us\n", what, epoch, ms * 1e3);
+                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw);
+    CK(hipEventRecord(e1));
+    hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
+    CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+    float ms, ms2; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
+    if (print) printf("%-8s epoch %u: %8.1f us  (+ sort pass %5.1f us)\n", what, epoch, ms * 1e3, ms2 * 1e3);
     return 0;
   };
   unsigned long long* d_dig; CK(hipMalloc((void**)&d_dig, 8));
