@@ -2804,12 +2804,23 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 // that holds the first free position, so two inserters of one (key, pod) pair cannot both land it, and the row is not touched at
 // all: three lines per new key (bucket CAS, list CAS, stamp store), and an eviction victim costs its list and its key.
 
-// Coherent 64-byte line -> 16 dwords (four 16-byte loads that bypass the non-coherent caches).
+// A 64-byte line -> 16 dwords by four 16-byte loads.  COHERENT: the loads bypass the non-coherent caches (the vector L1 of the CU,
+// and the L2 of this XCD for lines another XCD may have changed during this kernel) -- what every RETRY of the insert protocol uses;
+// the first look at a bucket or a list may be an ordinary cached load (half the cost: profiles/r03_d_micro_insert_variants.txt), because
+// a stale line only ever shows an EARLIER state of this launch (words and ids appear, nothing disappears while an insert kernel runs)
+// and every decision taken on it is confirmed by a compare-and-swap, which returns the truth.
+template <bool COHERENT = true>
 __device__ __forceinline__ void load_line16(const uint32_t* p, uint32_t (&d)[16]) {
   u32x4_t q0, q1, q2, q3;
-  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
-               "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(p) : "memory");
+  if constexpr (COHERENT) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(p) : "memory");
+  } else {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(p) : "memory");
+  }
   d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
   d[8] = q2.x; d[9] = q2.y; d[10] = q2.z; d[11] = q2.w; d[12] = q3.x; d[13] = q3.y; d[14] = q3.z; d[15] = q3.w;
 }
@@ -3047,7 +3058,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     } else {
       const uint32_t bmask = slots / kBucket - 1u;
       unsigned long long* K = (unsigned long long*)keys;
-      bool stop = false;
+      bool stop = false, again = false;     // again: a compare-and-swap lost its word to another key -> search again, coherently
       while (slot == kNotFound && !stop) {
         uint32_t b = home_bucket(h, shift);
         uint32_t free_slot = kNotFound;
@@ -3058,7 +3069,8 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
           unsigned long long w[kBucket];
           {
             uint32_t q[16];
-            load_line16((const uint32_t*)kb, q);
+            if (again) load_line16<true>((const uint32_t*)kb, q);
+            else load_line16<false>((const uint32_t*)kb, q);
 #pragma unroll
             for (int i = 0; i < (int)kBucket; ++i) w[i] = ((unsigned long long)q[2 * i + 1] << 32) | q[2 * i];
           }
@@ -3091,7 +3103,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
         const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
         if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
         else if (seen == (unsigned long long)h) slot = free_slot;
-        // else: somebody else took the word for another key -> search again
+        else again = true;                                        // somebody else took the word for another key -> search again
       }
     }
   }
@@ -3127,16 +3139,15 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   if (have && newkey) {
     uint32_t* L = lists + (size_t)slot * kListDwords;
     const u32x4_t first = {0xFFFF0000u | pod, 0xFFFFFFFFu, 0xFFFFFFFFu, 1u};
-#ifdef EPPK_DBG_CLAIM_DWORDS
-    __hip_atomic_store(&L[0], first.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&L[3], first.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     // (agent scope, like the atomics around it.  The s_nop is the wait state the ISA demands between a store of more than 8 bytes
     // and a write of its data registers: the compiler cannot see into the asm, reused the first register at once for the stamp below,
     // and the list got the epoch instead of the pod -- found by tests/test_gpu_group.py)
+#ifndef EPPK_DBG_NO_LISTSTORE
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(L), "v"(first) : "memory");
 #endif
+#ifndef EPPK_DBG_NO_STAMP
     __hip_atomic_store(&stamps[slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every insert of a launch carries the same epoch)
+#endif
   }
   // (the stores above are acknowledged before any lane of this wavefront looks at a list: no cache maintenance -- a __threadfence
   // here, buffer_wbl2 + buffer_inv per wavefront, made the kernel four times slower)
@@ -3146,7 +3157,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     uint32_t* L = lists + (size_t)slot * kListDwords;
     const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t d[16];
-    load_line16(L, d);
+    load_line16<false>(L, d);
     // A present key with an EMPTY list exists only between a claimer's compare-and-swap on the key word and its store above (an
     // invariant of the index: present = non-empty): wait for that store -- the claimer never waits for anybody, so it arrives.
     // Bounded all the same: a lane that gives up drops its pair and raises a launch-status flag instead of hanging the GPU.
@@ -3282,7 +3293,7 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
     if (present) {
       uint32_t* L = lists + (size_t)row * kListDwords;
       uint32_t d[16];
-      load_line16(L, d);
+      load_line16<false>(L, d);                         // (a launch of its own: nothing else writes the index meanwhile)
       if (d[3] > kListCap) over = true;
       else {
         uint32_t nrm = 0;
@@ -3354,7 +3365,7 @@ __global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps,
       const uint32_t st = stamps[row];
       age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
       uint32_t d[16];
-      load_line16(lists + (size_t)row * kListDwords, d);
+      load_line16<false>(lists + (size_t)row * kListDwords, d);
       if (d[3] > kListCap) over = true;
       else {
 #pragma unroll
@@ -3425,7 +3436,7 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
       age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
       uint32_t* L = lists + (size_t)row * kListDwords;
       uint32_t d[16];
-      load_line16(L, d);
+      load_line16<false>(L, d);                         // (a launch of its own: nothing else writes the index meanwhile)
       if (d[3] > kListCap) over = true;
       else {
         uint32_t nrm = 0;
