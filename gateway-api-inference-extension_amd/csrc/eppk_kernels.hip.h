@@ -2904,10 +2904,13 @@ __device__ __forceinline__ uint32_t list_add(uint32_t* L, const uint32_t (&d)[16
 // The 25th pod of a set: the set moves to its dense row.  The thread that raises the count past kListCap copies the 24 listed
 // pods into the row (every position is final by then: the line is read again, coherently); every thread that arrives on a full
 // list -- the mover included -- sets its own pod's bit.  Inserts that come later see count > kListCap and go to the row directly.
+// Bits 1..7 of a bucket's header word say which of its slots are overflowed (bit 0: the chain continues): the eviction scan, which
+// streams the key words anyway, then knows without reading a victim's list line whether a dense row has to be zeroed.
 template <typename LW>
-__device__ __forceinline__ void list_overflow(void* bitmaps, uint32_t* L, uint32_t slot, uint32_t pod) {
+__device__ __forceinline__ void list_overflow(uint64_t* keys, uint32_t slots, void* bitmaps, uint32_t* L, uint32_t slot, uint32_t pod) {
   const uint32_t old = atomicMax(&L[3], kListCap + 1u);
   if (old <= kListCap) {
+    if (slot < slots) atomicOr((unsigned long long*)&keys[slot & ~(kBucket - 1u)], 1ull << (slot & (kBucket - 1u)));   // bucket header: "slot overflowed"
     uint32_t d[16];
     load_line16(L, d);
 #pragma unroll
@@ -3168,7 +3171,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     if (d[3] == 0u) atomicOr(status, kStatusIndexStall);
     else if (d[3] > kListCap) bitmap_set<LW>(bitmaps, slot, pod);         // overflowed: the row is the set
     else res = list_add<false>(L, d, pod, pos);
-    if (res == 2u) list_overflow<LW>(bitmaps, L, slot, pod);
+    if (res == 2u) list_overflow<LW>(keys, slots, bitmaps, L, slot, pod);
     unsorted = res == 1u && pos != 0u;
   }
   // the lists to re-sort, appended to the work list once per wavefront
@@ -3325,6 +3328,7 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
       if (members <= kListCap) {                       // back to the list (or gone): the row returns to all-zero
         list_rebuild<LW>(lists, v_row, nv, lane);
         *w = 0;
+        if (lane == 0 && v_row < slots) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
         if (members == 0u && v_row == row) emptied = true;
       } else if (nv != v) {
         *w = nv;
@@ -3478,6 +3482,7 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
       if (members <= kListCap) {
         list_rebuild<LW>(lists, v_row, nv, lane);
         *w = 0;
+        if (lane == 0 && v_row < slots) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
         if (members == 0u && lane == src) emptied = true;
       } else if (rmw != 0) {
         *w = nv;
@@ -3495,9 +3500,10 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
 
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
 // drop every key last stamped before min_epoch -- pod set emptied, key tombstoned (reusable by later inserts).
-// A wavefront scans 64 slots per step (lane = slot: keys and stamps stream in coalesced).  A LANE per victim: its list line is
-// read (is the set in its row?) and reset by four 16-byte stores, the key word becomes a tombstone -- two lines per victim, the
-// dense row is not touched (it is all-zero for a listed set).  Overflowed victims get their row zeroed by the whole wavefront.
+// A wavefront scans 64 slots per step (lane = slot: keys -- bucket headers included -- and stamps stream in coalesced).  A LANE per
+// victim: its list line is reset by four 16-byte stores WITHOUT being read (whether the set had moved to its dense row is a bit of
+// the bucket header the scan holds already), the key word becomes a tombstone: one written line per victim beside the scan.
+// Overflowed victims get their row zeroed by the whole wavefront and their header bit cleared.
 template <typename LW>
 __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
                                    unsigned long long* ixc) {
@@ -3507,19 +3513,19 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
   uint32_t gone = 0;
   for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
     const uint32_t row = base + lane;
-    bool victim = false;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {     // (bucket header words are not keys)
-      const uint64_t k = keys[row];
-      victim = k != 0ull && !(row < slots && k == kTomb) && stamps[row] < min_epoch;
-    }
+    const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
+    const uint64_t k = row < total ? keys[row] : 0ull;
+    const uint32_t hdr = (uint32_t)__shfl((int)(uint32_t)k, (int)(lane & ~(kBucket - 1u)));   // this slot's bucket header (rows < slots)
+    const bool victim = row < total && !header && k != 0ull && !(row < slots && k == kTomb) && stamps[row] < min_epoch;
     gone += (uint32_t)__builtin_popcountll(__ballot(victim));
     bool whole = false;
     if (victim) {
       u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
-      whole = Lp[0].w > kListCap;
+      whole = row < slots ? ((hdr >> (row & (kBucket - 1u))) & 1u) != 0u : Lp[0].w > kListCap;   // (the two reserved rows have no header)
       const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
       keys[row] = row < slots ? kTomb : 0ull;
+      if (whole && row < slots) atomicAnd((unsigned long long*)&keys[row & ~(kBucket - 1u)], ~(1ull << (row & (kBucket - 1u))));
     }
     unsigned long long vm = __ballot(whole);          // overflowed sets: the whole row, by the wavefront
     while (vm) {
@@ -3568,6 +3574,8 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     if (!present) why |= (count != 0u ? 2u : 0u) | (members != 0u ? 4u : 0u);            // absent: empty list, all-zero row
     else if (count <= kListCap) why |= (count == 0u ? 8u : 0u) | (members != 0u ? 16u : 0u);   // listed: non-empty, all-zero row
     else why |= members <= kListCap ? 32u : 0u;                            // overflowed: more than kListCap members in the row
+    if (!header && row < slots)                                            // the bucket header's "overflowed" bit of this slot
+      why |= (((keys[row & ~(kBucket - 1u)] >> (row & (kBucket - 1u))) & 1ull) != 0ull) != (count > kListCap) ? 64u : 0u;
     if (why) {
       ++nbad;
       // the first eight offenders in full, for eppk_index_selfcheck's EPPK_SELFCHECK_VERBOSE: bad[2 + 24 k ..] = row, why, key, members, ballot, list[16]
