@@ -440,13 +440,13 @@ def main() -> None:
                  index_slots=(args.cl_slots if args.closed_loop else None), closed_loop=args.closed_loop)
     modes = ["single"] if not use_dist else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
     results = {}
-    cl_info = None
+    cl_info = cl_state = None
     for mode in modes:
         run.setup(mode, args.gather_every)
         age = None
         if args.closed_loop:
             cl_info = closed_loop_verify(run, wl, args)
-            state = {"epoch": cl_info["epoch"]}
+            state = cl_state = {"epoch": cl_info["epoch"]}
 
             def age(i, state=state):      # stream-ordered: behind the inserts of this step, ahead of the next pick
                 if (i + 1) % args.age_every == 0:
@@ -566,6 +566,7 @@ def main() -> None:
         out["config"]["p99_step_ms"] = roof["kernel_p99_ms"]
         if cl_info:
             out["closed_loop"] = cl_info
+            out["roofline_closed_loop"] = closed_loop_roofline(run, wl, args, cl_state, res["ms_per_step"])
         if args.host_path and world == 1 and not args.closed_loop:
             # host-observed pick latency: request rows in host memory -> pinned staging -> H2D -> kernel -> D2H (PCIe-inclusive;
             # never `value`)
@@ -592,6 +593,36 @@ def main() -> None:
                 out["host_path"]["staged"] = {"p50_ms": float(np.percentile(lat2, 50)), "p99_ms": float(np.percentile(lat2, 99)),
                                               "decisions_per_s_p50": R / (float(np.percentile(lat2, 50)) * 1e-3),
                                               "what": "eppk_pick_batch_staged: rows already in the pinned staging buffer: validate, H2D, kernel, D2H"}
+            if hasattr(run.pk, "stage_begin"):
+                # PIPELINED: two staging sets -- the rows of batch k + 1 cross PCIe while batch k is scored (eppk_pick_stage_*).  Same
+                # convention as `staged`: the rows are in the pinned buffers already (two different batches, one per set; building them
+                # is the caller's per-request work, timed separately below as one numpy copy per batch).  Throughput = batches over the
+                # wall time of the whole loop; latency = begin -> end of a batch while the other set's upload shares the link.
+                sb = [run.pk.stage_buffers(0)[0], run.pk.stage_buffers(1)[0]]
+                np.copyto(sb[0][:R], batches[0])
+                t0 = time.perf_counter()
+                np.copyto(sb[1][:R], batches[1 % len(batches)])
+                fill_ms = (time.perf_counter() - t0) * 1e3
+                nb_p = max(args.host_path, 8) + 2
+                lat3, t_begin = [], [0.0, 0.0]
+                t_begin[0] = time.perf_counter(); run.pk.stage_begin(0, R)
+                t_loop = None
+                for i in range(1, nb_p + 1):
+                    cur, prev = i & 1, (i - 1) & 1
+                    if i == 2:
+                        t_loop = time.perf_counter()
+                    if i < nb_p:
+                        t_begin[cur] = time.perf_counter()
+                        run.pk.stage_begin(cur, R)
+                    p_picks, _ = run.pk.stage_end(prev)
+                    lat3.append(time.perf_counter() - t_begin[prev])
+                t_all = time.perf_counter() - t_loop
+                lat3 = np.asarray(lat3[2:]) * 1e3
+                out["host_path"]["pipelined"] = {"batches": int(lat3.size), "decisions_per_s": R * (nb_p - 1) / t_all, "ms_per_batch": 1e3 * t_all / (nb_p - 1),
+                                                 "p50_ms": float(np.percentile(lat3, 50)), "p99_ms": float(np.percentile(lat3, 99)),
+                                                 "pcie_floor_ms": R * run.stride / 55e9 * 1e3, "caller_fill_ms_numpy_one_thread": fill_ms,
+                                                 "what": "eppk_pick_stage_begin / _end over two staging sets, rows already in the pinned sets: validate + upload of one batch under "
+                                                         "the kernel and download of the other; latency = begin -> end of a batch; the floor is the 17 MB of rows at ~55 GB/s of PCIe"}
         if world == 1 and not args.no_cpu_baseline and not args.closed_loop:
             orc = graft.load_oracle()
             cb, opicks, oscores = cpu_baseline(wl, orc, batches[last_batch], batches)
@@ -661,6 +692,72 @@ def closed_loop_verify(run, wl, args):
             "index_size": size_gpu, "index_size_oracle": size_orc, "index_dropped": run.pk.index_dropped(),
             "age_every": args.age_every, "keep_epochs": args.keep_epochs, "index_slots": args.cl_slots, "epoch": epoch,
             "verify_seconds": time.perf_counter() - t0}
+
+
+# measured ceilings of random 64-byte-line traffic on this GPU (scripts/micro/linermw.hip -> profiles/r02_micro_linermw.txt): what a
+# post-route index update is made of -- reads 46 G lines/s, plain stores 28 G, atomics 20 G (whatever line they hit)
+RANDOM_LINE_READS, RANDOM_LINE_STORES, RANDOM_LINE_ATOMICS = 46e9, 28e9, 20e9
+
+
+def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
+    """What a closed-loop step is made of, measured behind the timed region (same loop, every kernel group bracketed by events on
+    its stream and synchronised): pick, index update (insert + re-sort of the touched lists), ageing (amortised per step); the
+    HBM lines the index layout moves per step, their rate against the 8 TB/s peak and -- what actually bounds random 64-byte
+    lines -- against the measured random-line ceilings."""
+    torch = run.torch
+    st_t = run.computes[0]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_pick, t_ins, t_evict, new_keys, victims = [], [], [], [], []
+    run.pk.profile(False)
+    for i in range(steps):
+        slot = run.ring.next_slot()
+        b = run.batch_of(run.step_no)
+        st = run.streams[slot % len(run.streams)]
+        size0 = run.pk.index_size()                                   # (synchronises: the step below runs alone)
+        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        e0.record(st_t)
+        run.pk.pick_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
+        e1.record(st_t)
+        run.pk.index_insert_picks_device(run.p_batches[b] + run.lo * run.stride, run.p_picks[slot], run.n_mine, st)
+        e2.record(st_t)
+        run.ring.after_batch()
+        run.step_no += 1
+        torch.cuda.synchronize()
+        size1 = run.pk.index_size()
+        t_pick.append(e0.elapsed_time(e1)); t_ins.append(e1.elapsed_time(e2)); new_keys.append(size1 - size0)
+        if (i + 1) % args.age_every == 0:
+            state["epoch"] = run.pk.index_advance_epoch()
+            if state["epoch"] > args.keep_epochs:
+                e2.record(st_t)
+                run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, st)
+                e3.record(st_t)
+                torch.cuda.synchronize()
+                t_evict.append(e2.elapsed_time(e3)); victims.append(size1 - run.pk.index_size())
+    pick_ms, ins_ms = float(np.mean(t_pick)), float(np.mean(t_ins))
+    evict_ms = float(np.mean(t_evict)) / args.age_every if t_evict else 0.0
+    n_new = float(np.mean(new_keys)); n_vic = (float(np.mean(victims)) / args.age_every) if victims else 0.0
+    pairs = float(run.n_mine * wl.B)
+    # HBM lines per step under the "lists first" layout (64-byte lines; an atomic or a partial store reads and writes its line):
+    #   new key     bucket read + bucket CAS (read + write) + list line (write) + stamp line (read + write: a 4-byte store)
+    #   known pair  bucket + list line read (the 4 096 hot keys of this workload stay in L2: not counted)
+    #   victim      list line written whole (not read), key word written into the line the scan just read
+    #   scan        key words + stamps of every slot, once per ageing pass
+    scan_bytes = (args.cl_slots * 12.0) / args.age_every
+    bytes_step = n_new * 64.0 * 6.0 + n_vic * 64.0 * 2.0 + scan_bytes + run.n_mine * (run.stride + 12.0)
+    floor_ins = n_new * (1.0 / RANDOM_LINE_READS + 1.0 / RANDOM_LINE_ATOMICS + 2.0 / RANDOM_LINE_STORES)
+    floor_evict = n_vic / RANDOM_LINE_STORES + scan_bytes / (HBM_PEAK_GBS * 1e9)
+    step_s = ms_per_step * 1e-3
+    return {"bound": "hbm-random-lines", "achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "bytes_per_step": bytes_step, "ms_per_step_timed": ms_per_step,
+            "step_parts_ms": {"pick": pick_ms, "index_update": ins_ms, "ageing_per_step": evict_ms, "sum": pick_ms + ins_ms + evict_ms,
+                              "note": f"each part alone on the GPU, events around it, {steps} steps behind the timed region"},
+            "per_step": {"pairs": pairs, "new_keys": n_new, "victims": n_vic, "lines_per_new_key": 3, "lines_per_victim": 1},
+            "random_line_floor_ms": {"index_update": floor_ins * 1e3, "ageing_per_step": floor_evict * 1e3,
+                                     "definition": "new keys x (1 random line read / 46 G/s + 1 atomic / 20 G/s + 2 stores / 28 G/s); victims x 1 store + the streaming scan at 8 TB/s "
+                                                   "(measured ceilings: profiles/r02_micro_linermw.txt)"},
+            "frac_of_random_line_floor": {"index_update": floor_ins * 1e3 / ins_ms if ins_ms else None,
+                                          "ageing": floor_evict * 1e3 / evict_ms if evict_ms else None},
+            "kernels": "pick_quad_kernel + work-list pass | index_insert_picks_kernel + index_lists_sort_kernel | index_evict_kernel"}
 
 
 def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):

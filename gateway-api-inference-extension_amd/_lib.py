@@ -30,7 +30,7 @@ SYMBOLS = [
     "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
     "eppk_group_index_remove_pod", "eppk_group_index_advance_epoch", "eppk_group_index_evict_older", "eppk_group_pick_batch",
     "eppk_group_device_picks",
-    "eppk_host_staging", "eppk_pick_batch_staged", "eppk_chain_is_fused", "eppk_quad_stats", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
+    "eppk_host_staging", "eppk_pick_batch_staged", "eppk_pick_stage_buffers", "eppk_pick_stage_begin", "eppk_pick_stage_end", "eppk_chain_is_fused", "eppk_quad_stats", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
 
@@ -145,6 +145,9 @@ def load_library() -> C.CDLL:
     lib.eppk_quad_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.eppk_host_staging.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.eppk_pick_batch_staged.argtypes = [vp, u32, C.c_int, vp, vp]
+    lib.eppk_pick_stage_buffers.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]
+    lib.eppk_pick_stage_begin.argtypes = [vp, u32, u32, C.c_int, u32]
+    lib.eppk_pick_stage_end.argtypes = [vp, u32, vp, vp]
     lib.eppk_profile_enable.argtypes = [vp, C.c_int]
     lib.eppk_profile_drain.argtypes = [vp, vp, u32, C.POINTER(u32)]
     lib.eppk_profile_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]

@@ -115,6 +115,15 @@ struct eppk_ctx {
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
   void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
   void* d_tmp = nullptr; size_t d_tmp_bytes = 0;  // index insert staging
+  // the pipelined host path (eppk_pick_stage_*): per set its own pinned + device buffers, stream and events
+  struct StageSet {
+    hipStream_t st = nullptr; hipEvent_t picked = nullptr;
+    void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
+    void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
+    uint32_t n = 0; bool busy = false, had_mask = false;
+  };
+  StageSet stage[2];
+  hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update: the next pick waits for it
   void* d_tk_reqs = nullptr; uint64_t* d_tk_mask = nullptr; int32_t* d_tk_pick = nullptr; double* d_tk_score = nullptr;  // eppk_pick_topk
   eppk_pod_row* h_rows = nullptr; eppk_pod_row* d_rows = nullptr;  // raw pod rows of a publish (pinned staging + device copy)
 
@@ -800,6 +809,16 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->d_tk_reqs); (void)hipFree(c->d_tk_mask); (void)hipFree(c->d_tk_pick); (void)hipFree(c->d_tk_score);
   (void)hipFree(c->d_reqs); (void)hipFree(c->d_mask); (void)hipFree(c->d_pick); (void)hipFree(c->d_score); (void)hipFree(c->d_tmp);
   for (uint32_t b = 0; b < 8; ++b) (void)hipFree(c->dsets[b].d);
+  for (auto& s : c->stage) {
+    if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
+    if (s.picked) (void)hipEventDestroy(s.picked);
+    (void)hipFree(s.d_reqs); (void)hipFree(s.d_mask); (void)hipFree(s.d_pick); (void)hipFree(s.d_score);
+    if (s.h_reqs) (void)hipHostFree(s.h_reqs);
+    if (s.h_mask) (void)hipHostFree(s.h_mask);
+    if (s.h_pick) (void)hipHostFree(s.h_pick);
+    if (s.h_score) (void)hipHostFree(s.h_score);
+  }
+  if (c->learned) (void)hipEventDestroy(c->learned);
   if (c->h_reports) (void)hipHostFree((void*)c->h_reports);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
@@ -848,6 +867,9 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->epoch = epoch;
   c->have_snapshot = true;
+  c->have_addrs = false;     // the slot -> address table belongs to the snapshot it was set for: a publish may have re-mapped slots at the
+                             // same pod count, and a filter resolved against the old table could admit a pod outside the subset
+                             // (request.go:128-131 wants it strictly respected) -- eppk_snapshot_set_addresses again, or EPPK_ERR_NO_SNAPSHOT
   return EPPK_OK;
 }
 
@@ -1186,7 +1208,10 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
         const uint32_t nr = up_n - r0 < rows_per_chunk ? up_n - r0 : rows_per_chunk;
         const size_t off = (size_t)r0 * c->stride, len = (size_t)nr * c->stride;
         const uint8_t* from = src + off;
-        if (!pinned) { std::memcpy((uint8_t*)c->h_reqs + off, from, len); from = (const uint8_t*)c->h_reqs + off; }
+        if (!pinned) {
+          if (from != (const uint8_t*)c->h_reqs + off) std::memcpy((uint8_t*)c->h_reqs + off, from, len);   // (a caller may hand the staging buffer itself)
+          from = (const uint8_t*)c->h_reqs + off;
+        }
         if (validate_as) { rc = validate_rows(c, validate_as, from, nr, up_lo + r0); if (rc) return rc; }
         HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_reqs + off, from, len, hipMemcpyHostToDevice, c->stream));
       }
@@ -1257,6 +1282,95 @@ int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* 
   int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged");
   if (rc) return rc;
   return pick_host_end(c, n_reqs, use_mask != 0, out_pick, out_score);
+}
+
+// ---- the pipelined host path (include/eppk.h: eppk_pick_stage_*) ---------------------------------------------------------------
+
+namespace {
+int stage_ensure(eppk_ctx* c, uint32_t set, bool need_mask) {
+  eppk_ctx::StageSet& s = c->stage[set];
+  const size_t mb = c->cfg.max_batch;
+  if (!s.st) {
+    HIPCHK(c, hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&s.picked, hipEventDisableTiming));
+    HIPCHK(c, hipMalloc(&s.d_reqs, mb * c->stride));
+    HIPCHK(c, hipMalloc((void**)&s.d_pick, mb * 4u));
+    HIPCHK(c, hipMalloc((void**)&s.d_score, mb * 8u));
+    HIPCHK(c, hipHostMalloc(&s.h_reqs, mb * c->stride, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&s.h_pick, mb * 4u, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&s.h_score, mb * 8u, hipHostMallocDefault));
+  }
+  if (need_mask && !s.d_mask) {
+    HIPCHK(c, hipMalloc((void**)&s.d_mask, mb * c->jmax * 8u));
+    HIPCHK(c, hipHostMalloc((void**)&s.h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
+  }
+  if (!c->learned) HIPCHK(c, hipEventCreateWithFlags(&c->learned, hipEventDisableTiming));
+  return EPPK_OK;
+}
+}  // namespace
+
+int eppk_pick_stage_buffers(eppk_ctx* c, uint32_t set, void** reqs, uint64_t** cand_mask) {
+  if (!c || set >= EPPK_STAGE_SETS) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_buffers: no such set");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  int rc = stage_ensure(c, set, cand_mask != nullptr);
+  if (rc) return rc;
+  if (reqs) *reqs = c->stage[set].h_reqs;
+  if (cand_mask) *cand_mask = c->stage[set].h_mask;
+  return EPPK_OK;
+}
+
+int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_mask, uint32_t flags) {
+  if (!c || set >= EPPK_STAGE_SETS) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: no such set");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_stage_begin: no snapshot published");
+  if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_stage_begin: n_reqs > max_batch");
+  eppk_ctx::StageSet& s = c->stage[set];
+  if (!s.st || (use_mask && !s.h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: eppk_pick_stage_buffers was not called for these buffers");
+  if (s.busy) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: the set is in flight (end it first)");
+  if ((flags & EPPK_PICK_LEARN) && !c->slots) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: EPPK_PICK_LEARN without a prefix index");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true;
+  if (n_reqs == 0) return EPPK_OK;
+  const size_t J = (c->n_pods + 63u) / 64u;
+  // upload in chunks of whole rows, each validated while the previous one is on the link (as eppk_pick_batch_staged does)
+  const uint32_t rows_per_chunk = (uint32_t)(((size_t)2 << 20) / c->stride) ? (uint32_t)(((size_t)2 << 20) / c->stride) : 1u;
+  for (uint32_t r0 = 0; r0 < n_reqs; r0 += rows_per_chunk) {
+    const uint32_t nr = n_reqs - r0 < rows_per_chunk ? n_reqs - r0 : rows_per_chunk;
+    const size_t off = (size_t)r0 * c->stride;
+    int rc = validate_rows(c, "eppk_pick_stage_begin", (const uint8_t*)s.h_reqs + off, nr, r0);
+    if (rc) { s.busy = false; return rc; }
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)s.d_reqs + off, (const uint8_t*)s.h_reqs + off, (size_t)nr * c->stride, hipMemcpyHostToDevice, s.st));
+  }
+  if (use_mask && J) HIPCHK(c, hipMemcpyAsync(s.d_mask, s.h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, s.st));
+  // the pick sees the index every earlier LEARN left behind (the upload above did not have to wait for it)
+  if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
+  int rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.d_pick, s.d_score, s.st, 1u, false, 0ull, 0u);
+  if (rc) { s.busy = false; return rc; }
+  HIPCHK(c, hipMemcpyAsync(s.h_pick, s.d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, s.st));
+  HIPCHK(c, hipMemcpyAsync(s.h_score, s.d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, s.st));
+  HIPCHK(c, hipEventRecord(s.picked, s.st));
+  if (flags & EPPK_PICK_LEARN) {
+    rc = eppk_index_insert_picks_device(c, s.d_reqs, s.d_pick, n_reqs, (void*)s.st);
+    if (rc) return rc;                          // (the picks stand: end() still delivers them)
+    HIPCHK(c, hipEventRecord(c->learned, s.st));
+    c->learn_pending = true;
+  }
+  return EPPK_OK;
+}
+
+int eppk_pick_stage_end(eppk_ctx* c, uint32_t set, int32_t* out_pick, double* out_score) {
+  if (!c || set >= EPPK_STAGE_SETS) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_end: no such set");
+  eppk_ctx::StageSet& s = c->stage[set];
+  if (!s.busy) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_end: the set is not in flight");
+  if (!out_pick && s.n) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_end: null argument");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  s.busy = false;
+  if (s.n == 0) return EPPK_OK;
+  HIPCHK(c, hipEventSynchronize(s.picked));
+  const size_t J = (c->n_pods + 63u) / 64u;
+  std::memcpy(out_pick, s.h_pick, (size_t)s.n * 4u);
+  if (out_score) std::memcpy(out_score, s.h_score, (size_t)s.n * 8u);
+  if (s.had_mask && !J) for (uint32_t r = 0; r < s.n; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+  return EPPK_OK;
 }
 
 // ---- candidate-major pick (masked batches with few candidates) --------------------------------------------

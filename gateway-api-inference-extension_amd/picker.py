@@ -334,6 +334,32 @@ class BatchedPicker:
         self._check(self._lib.eppk_pick_batch_staged(self._ctx, R, 1 if use_mask else 0, picks.ctypes.data, scores.ctypes.data), "pick_batch_staged")
         return picks, scores
 
+    # -- the pipelined host path (include/eppk.h eppk_pick_stage_*): two staging sets, upload of one batch under the kernel of the other
+    def stage_buffers(self, which: int, with_mask: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Pinned request rows [max_batch, row_words] u64 (and the flat mask buffer) of staging set `which` (0 / 1)."""
+        rp, mp = C.c_void_p(0), C.c_void_p(0)
+        self._check(self._lib.eppk_pick_stage_buffers(self._ctx, which, C.byref(rp), C.byref(mp) if with_mask else None), "pick_stage_buffers")
+        reqs = np.frombuffer((C.c_uint64 * (self.max_batch * self.row_words)).from_address(rp.value), dtype=np.uint64).reshape(self.max_batch, self.row_words)
+        mask = None
+        if with_mask:
+            jmax = (self.max_pods + 63) // 64
+            mask = np.frombuffer((C.c_uint64 * (self.max_batch * jmax)).from_address(mp.value), dtype=np.uint64)
+        return reqs, mask
+
+    def stage_begin(self, which: int, R: int, use_mask: bool = False, learn: bool = False) -> None:
+        """Enqueue upload + pick (+ the post-route index update on the device when `learn`) + download of set `which`; returns at once."""
+        self._check(self._lib.eppk_pick_stage_begin(self._ctx, which, R, 1 if use_mask else 0, 1 if learn else 0), "pick_stage_begin")
+        self._stage_n = getattr(self, "_stage_n", {})
+        self._stage_n[which] = R
+
+    def stage_end(self, which: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Wait for the picks of set `which` and return (picks, scores)."""
+        R = getattr(self, "_stage_n", {}).get(which, 0)
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        self._check(self._lib.eppk_pick_stage_end(self._ctx, which, picks.ctypes.data, scores.ctypes.data), "pick_stage_end")
+        return picks, scores
+
     # -- subset filter resolved on the device (include/eppk.h "the subset filter for a whole batch") ------------------
     def set_addresses(self, endpoints: Sequence[Optional[Endpoint]]) -> None:
         """Address / port of every slot of the CURRENT snapshot (None = a hole)."""

@@ -204,6 +204,27 @@ int eppk_host_staging(eppk_ctx* ctx, void** reqs, uint64_t** cand_mask);
  * results, no host copy. */
 int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t* out_pick, double* out_score);
 
+/* The PIPELINED host path: EPPK_STAGE_SETS staging sets, each with its own pinned rows / masks / results, device buffers and
+ * stream, so that the rows of batch k + 1 cross PCIe while batch k is being scored (pkg/lwepp/handlers/request.go:141-163 is a
+ * per-request caller: what it can hand over is host memory, and a 64k x 32-block batch is 17 MB -- 0.3 ms of PCIe against 20 us of
+ * kernel; one synchronous batch at a time leaves the device idle for nine tenths of the time).  The caller alternates:
+ *     fill set A; begin(A);  fill set B; begin(B);  end(A) -> results of A;  fill A; begin(A);  end(B); ...
+ * eppk_pick_stage_buffers: the set's pinned request rows (max_batch rows) and mask rows (only when asked for), valid until
+ *     eppk_destroy, not to be written between the set's begin and end.
+ * eppk_pick_stage_begin: validates the rows (as eppk_pick_batch does), enqueues upload + pick + download on the set's stream and
+ *     returns.  flags & EPPK_PICK_LEARN chains the post-route index update (eppk_index_insert_picks_device: index[hash[r][i]] U=
+ *     {pick[r]}, 0602-…/README.md:101-108) behind the pick ON THE DEVICE -- rows and picks are there already; the picks are on their
+ *     way back to the host before the update starts.  A later begin (either set) scores against the index every earlier LEARN left
+ *     behind: its pick waits for that update on the device, its upload does not.
+ * eppk_pick_stage_end: waits for the set's picks and copies them out (the index update of a LEARN batch may still be running).
+ * Errors: EPPK_ERR_ARG for a set that is busy (begin twice) or idle (end without begin).  Snapshot publishes and the other index
+ * entry points must not be issued while a set is between begin and end. */
+#define EPPK_STAGE_SETS 2u
+#define EPPK_PICK_LEARN 1u
+int eppk_pick_stage_buffers(eppk_ctx* ctx, uint32_t set, void** reqs, uint64_t** cand_mask);
+int eppk_pick_stage_begin(eppk_ctx* ctx, uint32_t set, uint32_t n_reqs, int use_mask, uint32_t flags);
+int eppk_pick_stage_end(eppk_ctx* ctx, uint32_t set, int32_t* out_pick, double* out_score);
+
 /* Same, with every buffer already resident in this device's HBM; asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the context's own NON-BLOCKING stream, which is not ordered against the
  * legacy default stream — callers that mix this with other GPU work pass their own stream).  No n_reqs limit. */
@@ -347,7 +368,9 @@ int eppk_subset_mask(const char* const* addrs, const char* const* ports, uint32_
  *                                that is present but empty: zero entries, zero candidates, fail closed) -> out_keys[cap][2].
  *                                Returns the number of entries the filter has (write at most cap; retry when it exceeds cap).
  *   eppk_snapshot_set_addresses  Endpoint.Address / Endpoint.Port (datastore.go:43-44) of the slots of the CURRENT snapshot
- *                                (n_pods must match it; NULL address = a hole).  Call after every publish that changes them.
+ *                                (n_pods must match it; NULL address = a hole).  Call after EVERY eppk_snapshot_publish: a publish
+ *                                invalidates the table (it may have re-mapped slots; the device filter then answers
+ *                                EPPK_ERR_NO_SNAPSHOT instead of resolving against stale addresses).
  *   eppk_subset_masks[_device]   entries of n_reqs requests in CSR form (keys[off[r] .. off[r+1])) -> mask rows
  *                                [n_reqs][ceil(n_pods/64)] u64, the layout of eppk_pick_batch*'s cand_mask.
  *   eppk_pick_batch_subset       eppk_pick_batch with the masks built on the device from entry lists (host buffers in, picks out).

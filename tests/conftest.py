@@ -34,6 +34,30 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# ---- library modes --------------------------------------------------------------------------------------------------------
+# libeppk reads three switches when a context is created: EPPK_QUAD_MIN (smallest batch that takes pick_quad_kernel; 4 = every
+# eligible batch), EPPK_QUAD=0 (never: every request through pick_fast_kernel), EPPK_LISTS=0 (the pick kernels' list routes off:
+# every request takes the dense route, which expands listed sets through LDS).  The parity-critical GPU modules run once per mode,
+# so that ONE `pytest -m gpu` run -- the driver's -- exercises every route against the oracle, not only the default one.
+# (tests/test_gpu_quad.py sets its own switches; the full-size closed-loop / config tests run in the default mode only.)
+LIBRARY_MODES = {"default": {}, "quadmin4": {"EPPK_QUAD_MIN": "4"}, "quad0": {"EPPK_QUAD": "0"}, "lists0": {"EPPK_LISTS": "0"}}
+MODE_MODULES = {"test_gpu_parity", "test_gpu_fuzz", "test_gpu_holes", "test_gpu_pickers", "test_gpu_subset", "test_gpu_staging",
+                "test_gpu_device_rows"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in MODE_MODULES and "eppk_mode" in metafunc.fixturenames:
+        metafunc.parametrize("eppk_mode", list(LIBRARY_MODES), indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def eppk_mode(request, monkeypatch):
+    mode = getattr(request, "param", "default")
+    for k, v in LIBRARY_MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    return mode
+
+
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as g

@@ -40,11 +40,15 @@ class _Stream:
 
 
 class _Event:
-    def __init__(self):
+    def __init__(self, enable_timing=False):
         self.recorded = False
 
     def record(self, stream=None):
         self.recorded = True
+
+    def elapsed_time(self, other):
+        assert self.recorded and other.recorded
+        return 0.05
 
 
 def _fake_picker_class(pkg, orc, log):
@@ -182,7 +186,11 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     if closed:
         assert d["closed_loop"]["picks_equal_oracle"] and d["closed_loop"]["scores_bitwise_equal_oracle"]
         assert d["closed_loop"]["generations_verified"] == 3 and d["config"]["closed_loop"] is True
-        assert sum(1 for e in log if e[0] == "learn") == n_picks == 3 + d["steps"] + d["warmup"]    # every pick is followed by its index update
+        rc = d["roofline_closed_loop"]
+        assert rc["bound"] == "hbm-random-lines" and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-12
+        assert set(rc["step_parts_ms"]) >= {"pick", "index_update", "ageing_per_step"} and rc["per_step"]["new_keys"] >= 0
+        # every pick is followed by its index update (3 verified generations + the timed loop + the 24 instrumented steps of the roofline object)
+        assert sum(1 for e in log if e[0] == "learn") == n_picks == 3 + d["steps"] + d["warmup"] + 24
         return
     for key in ("value", "unit", "cores", "kind", "sample", "algorithm", "single_thread_value", "per_request_loop_value"):
         assert key in d["cpu_baseline"], key

@@ -301,3 +301,35 @@ def test_ordered_fallbacks(pkg, orc, R, P, k):
     assert np.array_equal(got_p, want_p), f"{np.count_nonzero(got_p != want_p)} entries differ"
     assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64))
     assert ql == 1 and qd < R
+
+
+def test_unordered_and_learned_lists_stay_on_the_quad_route(pkg, orc):
+    """The library keeps every list in ascending order itself (index_lists_sort_kernel behind every insert launch), so equal pod SETS
+    are equal list LINES whatever order the pairs arrived in: ONE insert call with the pairs shuffled, then two generations of a closed
+    loop whose chain pushes the picks AWAY from the cached pods (negative prefix weight: every learn appends new pods to all 16 blocks
+    of a group, in device order) -- the quad kernel still scores every request itself, bit-exact against the oracle."""
+    rng = np.random.default_rng(99)
+    wl = pkg.workload.make_workload(5, R=256, P=4096, n_groups=32)
+    wl.chain = [(1, 2), (2, 2), (3, 1), (4, -3)]
+    batches = [wl.reqs] + [pkg.workload.make_requests(wl, 500 + i) for i in range(2)]
+    perm = rng.permutation(wl.index_hashes.shape[0])
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    with quad_env(True):
+        with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=wl.R, index_slots=1 << 17) as pk:
+            pk.publish(wl.pods)
+            pk.index_insert(wl.index_hashes[perm], wl.index_pods[perm])
+            grew = 0
+            for g, reqs in enumerate(batches):
+                picks, scores = pk.pick(reqs)
+                op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B)
+                assert_same(picks, scores, op, osc)
+                hs = hashes_of(wl, reqs)
+                before = oix.size()
+                pk.index_insert(hs.reshape(-1), np.repeat(picks.astype(np.uint32), wl.B))
+                oix.insert_picks(reqs, wl.B, op)
+                grew += oix.size() - before
+                assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0, g
+            ql, qd = pk.quad_stats()
+            assert ql == len(batches) and qd == 0, f"{qd} requests left the quad route"
+            assert grew > 0 and pk.launch_status() == 0

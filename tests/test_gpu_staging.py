@@ -30,3 +30,53 @@ def test_staged_pick_equals_pick(pkg, orc, R, P, masked):
         st_reqs[0, 0] = np.uint64(1000) << np.uint64(32)
         with pytest.raises(Exception):
             pk.pick_staged(R, use_mask=masked)
+
+
+@pytest.mark.parametrize("R,learn,masked", [(3000, False, False), (3000, True, False), (1500, True, True), (20000, True, False)])
+def test_pipelined_stage_sets_against_the_oracle(pkg, orc, R, learn, masked):
+    """eppk_pick_stage_begin / _end: two staging sets in flight, batch k + 1 uploaded while batch k is scored.  Eight batches, picks and
+    scores of every one bit-exact against the oracle running the same sequence -- with EPPK_PICK_LEARN the post-route index update is
+    chained on the device behind each pick and batch k + 1 must already see what batch k taught the index (the oracle inserts between
+    batches), although its rows were uploaded before that update finished."""
+    wl = pkg.workload.make_workload(5, R=R, P=4096, n_groups=16, masked=masked)
+    batches = [wl.reqs] + [pkg.workload.make_requests(wl, 31 + i) for i in range(3)]
+    J = (wl.P + 63) // 64
+    with pkg.BatchedPicker(wl.chain, max_pods=4096, max_blocks=wl.B, max_batch=R, index_slots=1 << 23) as pk:     # (4 batches x 16 new blocks x R keys stay below the load limit)
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        oix = orc.OracleIndex()
+        oix.insert(wl.index_hashes, wl.index_pods)
+        bufs = [pk.stage_buffers(0, with_mask=masked), pk.stage_buffers(1, with_mask=masked)]
+
+        def fill(s, b):
+            bufs[s][0][:R] = batches[b % len(batches)]
+            if masked:
+                bufs[s][1][:R * J].reshape(R, J)[:] = wl.mask
+
+        def check(s, b):
+            picks, scores = pk.stage_end(s)
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[b % len(batches)], wl.B, wl.mask if masked else None)
+            assert np.array_equal(picks, op), f"batch {b}: {int((picks != op).sum())} picks differ"
+            assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), f"batch {b}"
+            if learn:
+                oix.insert_picks(batches[b % len(batches)], wl.B, op)
+
+        n_batches = 8
+        fill(0, 0)
+        pk.stage_begin(0, R, use_mask=masked, learn=learn)
+        for b in range(1, n_batches):
+            s = b & 1
+            fill(s, b)
+            pk.stage_begin(s, R, use_mask=masked, learn=learn)      # batch b is on its way before batch b - 1 has been collected
+            check(s ^ 1, b - 1)
+        check((n_batches - 1) & 1, n_batches - 1)
+        assert pk.launch_status() == 0 and pk.index_selfcheck() == 0 and pk.index_dropped() == 0
+        if learn:
+            assert pk.index_size() == oix.size()
+        # protocol errors: end without begin, begin twice
+        with pytest.raises(pkg.EppkError):
+            pk.stage_end(0)
+        pk.stage_begin(0, R, use_mask=masked)
+        with pytest.raises(pkg.EppkError):
+            pk.stage_begin(0, R, use_mask=masked)
+        pk.stage_end(0)
