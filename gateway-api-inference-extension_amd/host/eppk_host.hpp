@@ -108,6 +108,13 @@ class Backend {
   // to the device).  nullptr = not offered.
   virtual void* StagingRows() { return nullptr; }
   virtual int PickStaged(uint32_t, int32_t*, double*) { return EPPK_ERR_ARG; }
+  // Optional: the PIPELINED form of the same (eppk_pick_stage_*): two such buffers (set 0 / 1), each with its own stream -- the
+  // rows of one batch are uploaded while the other batch is scored.  Begin returns at once; with `learn` the post-route index update
+  // (IndexInsert of every (block hash, pick) pair) is chained behind the pick ON THE DEVICE and the next Begin of either set scores
+  // against it.  End waits for the set's picks.  nullptr from StageRows = not offered.
+  virtual void* StageRows(uint32_t /*set*/) { return nullptr; }
+  virtual int StageBegin(uint32_t /*set*/, uint32_t /*n*/, bool /*learn*/) { return EPPK_ERR_ARG; }
+  virtual int StageEnd(uint32_t /*set*/, int32_t*, double*) { return EPPK_ERR_ARG; }
   // k ordered candidates per request (pick + fallbacks), picks/scores hold n*k entries (eppk_pick_topk)
   virtual int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) = 0;
   // prefix index: pods[i] has cached the block with hash hashes[i] ("hash(chunk i): append server", 0602-…/README.md:101-108)
@@ -137,6 +144,13 @@ class LibEppkBackend : public Backend {  // include/eppk.h
     return staging_;
   }
   int PickStaged(uint32_t n, int32_t* picks, double* scores) override { return eppk_pick_batch_staged(ctx_, n, 0, picks, scores); }
+  void* StageRows(uint32_t set) override {
+    if (set >= EPPK_STAGE_SETS) return nullptr;
+    if (!stage_[set] && eppk_pick_stage_buffers(ctx_, set, &stage_[set], nullptr) != EPPK_OK) stage_[set] = nullptr;
+    return stage_[set];
+  }
+  int StageBegin(uint32_t set, uint32_t n, bool learn) override { return eppk_pick_stage_begin(ctx_, set, n, 0, learn ? EPPK_PICK_LEARN : 0u); }
+  int StageEnd(uint32_t set, int32_t* picks, double* scores) override { return eppk_pick_stage_end(ctx_, set, picks, scores); }
   int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
     return eppk_pick_topk(ctx_, reqs, n, mask, k, picks, scores);
   }
@@ -151,6 +165,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   explicit LibEppkBackend(eppk_ctx* c) : ctx_(c) {}
   eppk_ctx* ctx_;
   void* staging_ = nullptr;       // the context's pinned request-row buffer (eppk_host_staging), fetched on first use
+  void* stage_[EPPK_STAGE_SETS] = {nullptr, nullptr};   // the two pipelined sets (eppk_pick_stage_buffers)
 };
 
 // ---- GpuPicker: EndpointPicker over batched picks -------------------------------------------------------
@@ -194,7 +209,13 @@ class GpuPicker : public EndpointPicker {
     if (endpoints.size() != rows.size()) return {Code::Internal, "endpoints/rows size mismatch"};
     auto snap = std::make_shared<Snapshot>();
     snap->adapters = adapters;
-    std::lock_guard<std::mutex> bg(be_mu_);  // serialised with the dispatcher's PickBatch (contexts are single-caller)
+    // serialised with the dispatcher (contexts are single-caller), and never while a pipelined batch is between Begin and End
+    // (include/eppk.h: no publish then): the dispatcher sees publish_waiting_, collects what is in flight and lets us through
+    std::unique_lock<std::mutex> bg(be_mu_);
+    ++publish_waiting_;
+    be_cv_.wait(bg, [&] { return inflight_ == 0; });
+    --publish_waiting_;
+    struct Wake { std::condition_variable& cv; ~Wake() { cv.notify_all(); } } wake{be_cv_};   // (the dispatcher may be waiting for us)
     if (!opt_.stable_slots) {
       snap->endpoints = endpoints;
       snap->n_active = (uint32_t)endpoints.size();
@@ -211,9 +232,14 @@ class GpuPicker : public EndpointPicker {
         const size_t newcomers = endpoints.size() - staying, leavers = slot_of_.size() - staying;
         if (newcomers > leavers + free_slots_.size() + (size_t)(opt_.max_pods - n_slots_)) return {Code::Internal, "more endpoints than max_pods"};
       }
+      // A slot that stays empty is published as a hole and the library scrubs it out of the prefix index.  A slot that is handed
+      // to a newcomer in THIS publish, or trimmed off the end of the table, never appears as a hole: it is scrubbed here, or the
+      // next endpoint on it would inherit the departed endpoint's learned prefixes (false prefix affinity).
+      std::vector<uint32_t> vacated;
       for (auto it = slot_of_.begin(); it != slot_of_.end();) {
         if (now.count(it->first)) { ++it; continue; }
-        free_slots_.push_back(it->second);   // (the index forgets the slot when the snapshot with the hole is published)
+        free_slots_.push_back(it->second);
+        vacated.push_back(it->second);
         it = slot_of_.erase(it);
       }
       std::sort(free_slots_.begin(), free_slots_.end(), std::greater<uint32_t>());   // back() = lowest free slot
@@ -230,6 +256,10 @@ class GpuPicker : public EndpointPicker {
       while (n_slots_ > 0 && std::find(free_slots_.begin(), free_slots_.end(), n_slots_ - 1) != free_slots_.end()) {   // trailing holes: shrink
         free_slots_.erase(std::find(free_slots_.begin(), free_slots_.end(), n_slots_ - 1));
         --n_slots_;
+      }
+      for (uint32_t v : vacated) {     // reused at once, or beyond the new end of the table: not a hole of this snapshot -> scrub now
+        const bool stays_hole = v < n_slots_ && std::find(free_slots_.begin(), free_slots_.end(), v) != free_slots_.end();
+        if (!stays_hole && be_->IndexRemovePod(v) != EPPK_OK) return {Code::Internal, be_->LastError()};
       }
       // 3. rows by slot; a hole is an all-zero row flagged EPPK_POD_INACTIVE
       std::vector<eppk_pod_row> by_slot(n_slots_);
@@ -288,7 +318,16 @@ class GpuPicker : public EndpointPicker {
       fail_open_count_.fetch_add(1, std::memory_order_relaxed);
       return rr_.Pick(req, endpoints, out);
     }
-    if (slot.pick < 0) return {Code::Unavailable, "no endpoints available"};
+    if (slot.pick < 0) {
+      // The request HAS candidates (an empty list failed closed at the top) but the snapshot scores none of them -- every scrape
+      // failed, a wrong metrics port, endpoints the snapshot has not seen yet: the GPU picker fails OPEN, like on a backend error --
+      // it must never be what takes serving down.  A pick of -1 with scoreable candidates cannot happen.
+      if (slot.found == 0) {
+        fail_open_count_.fetch_add(1, std::memory_order_relaxed);
+        return rr_.Pick(req, endpoints, out);
+      }
+      return {Code::Unavailable, "no endpoints available"};
+    }
     out->endpoint = slot.endpoint;
     out->fallbacks = std::move(slot.fallbacks);
     return {};
@@ -364,6 +403,56 @@ class GpuPicker : public EndpointPicker {
     }
   }
 
+  // One batch of the pipelined path between StageBegin and StageEnd.
+  struct InFlight {
+    std::vector<Slot*> batch;
+    std::shared_ptr<Snapshot> snap;      // the endpoint table the device scored against
+    uint32_t set = 0;
+    bool active = false;
+  };
+
+  // picks -> "ip:port" (+ fallbacks) of every request of a batch; Slot fields other than `done` are read by the owner only after `done`
+  static void Resolve(const std::vector<Slot*>& batch, const Snapshot& snap, const int32_t* picks, uint32_t k) {
+    for (size_t i = 0; i < batch.size(); ++i) {
+      batch[i]->pick = picks[i * k];
+      batch[i]->fallbacks.clear();
+      for (uint32_t f = 0; f < k; ++f) {
+        const int32_t p = picks[i * k + f];
+        if (p < 0) break;
+        const Endpoint& e = snap.endpoints[(size_t)p];
+        if (f == 0) batch[i]->endpoint = JoinHostPort(e.address, e.port);
+        else batch[i]->fallbacks.push_back(JoinHostPort(e.address, e.port));
+      }
+    }
+  }
+
+  void Finish(std::vector<Slot*>& batch, bool failed) {          // wake the requests of a batch (takes mu_)
+    std::lock_guard<std::mutex> g(mu_);
+    for (Slot* s : batch) { s->fail_open = failed; s->done = true; s->cv.notify_one(); }   // under mu_: the Slot outlives the call
+    batches_.fetch_add(1);
+    if (batch.size() > largest_batch_.load()) largest_batch_.store(batch.size());
+  }
+
+  // collect a pipelined batch: wait for its picks, resolve, wake its requests
+  void Collect(InFlight& f, std::vector<int32_t>& picks, std::vector<double>& scores) {
+    bool failed;
+    {
+      std::lock_guard<std::mutex> bg(be_mu_);
+      picks.resize(f.batch.size());
+      scores.resize(f.batch.size());
+      failed = be_->StageEnd(f.set, picks.data(), scores.data()) != EPPK_OK;
+      if (!failed) Resolve(f.batch, *f.snap, picks.data(), 1u);
+      --inflight_;
+    }
+    be_cv_.notify_all();                 // (a publisher may be waiting for the pipeline to drain)
+    Finish(f.batch, failed);
+    f.active = false;
+    f.snap.reset();
+  }
+
+  // The dispatcher.  Two batches can be in the backend at once when it offers the pipelined staging sets (and the batch needs
+  // neither candidate masks nor fallback lists): the rows of batch k + 1 are built and uploaded while batch k is scored, batch k is
+  // collected afterwards -- the device is busy while requests keep arriving, instead of idling through PCIe and row construction.
   void Loop() {
     std::vector<Slot*> batch;
     std::vector<uint8_t> rows;
@@ -372,35 +461,56 @@ class GpuPicker : public EndpointPicker {
     std::vector<double> scores;
     std::vector<uint64_t> learn_h;
     std::vector<uint32_t> learn_p;
+    InFlight fly;
+    uint32_t next_set = 0;
     auto next_tick = std::chrono::steady_clock::now() + opt_.index_epoch_interval;
     std::unique_lock<std::mutex> g(mu_);
     for (;;) {
-      cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
-      if (stop_ && queue_.empty()) return;
-      if (queue_.size() < opt_.max_batch && !stop_)  // give concurrent callers a moment to join the batch
-        cv_.wait_for(g, opt_.window, [&] { return stop_ || queue_.size() >= opt_.max_batch; });
+      cv_.wait(g, [&] { return stop_ || !queue_.empty() || fly.active; });
+      if (queue_.empty()) {
+        if (fly.active) { g.unlock(); Collect(fly, picks, scores); g.lock(); continue; }   // nothing to overlap it with: collect
+        if (stop_) return;
+        continue;
+      }
+      if (!fly.active && queue_.size() < opt_.max_batch && !stop_)  // give concurrent callers a moment to join the batch (while a batch is
+        cv_.wait_for(g, opt_.window, [&] { return stop_ || queue_.size() >= opt_.max_batch; });   // in flight they have been joining already)
       const size_t n = queue_.size() < opt_.max_batch ? queue_.size() : opt_.max_batch;
       batch.assign(queue_.begin(), queue_.begin() + (long)n);
       queue_.erase(queue_.begin(), queue_.begin() + (long)n);
       g.unlock();  // row building and the kernel run without the queue lock
-      bool failed = false;
+      bool failed = false, begun = false;
       {
         // be_mu_ serialises the context (include/eppk.h: one caller per context) and pins the snapshot:
         // the endpoint table read here is the one the device scores against.
-        std::lock_guard<std::mutex> bg(be_mu_);
+        std::unique_lock<std::mutex> bg(be_mu_);
+        while (publish_waiting_ > 0) {          // a publish wants the context: let the pipeline drain first, then let it through
+          if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }
+          else be_cv_.wait(bg, [&] { return publish_waiting_ == 0; });
+        }
         std::shared_ptr<Snapshot> snap;
         { std::lock_guard<std::mutex> sg(mu_); snap = snap_; }
         failed = !snap;
         if (!failed) {
           const uint32_t P = (uint32_t)snap->endpoints.size(), W = (P + 63u) / 64u;
-          // rows are built in the backend's pinned staging buffer when it offers one: a batch without candidate masks then goes to
-          // the device without another host copy (eppk_pick_batch_staged)
-          uint8_t* rowp = (uint8_t*)be_->StagingRows();
+          const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
+          // masks first: they decide which entry point the batch takes, and with it the buffer its rows are built in
+          bool any_mask = false;
+          mask.assign(n * (size_t)(W ? W : 1), 0);
+          for (size_t i = 0; i < n; ++i) {
+            Slot& sl = *batch[i];
+            if (sl.mask_snap != snap) BuildMask(*snap, *sl.cands, &sl.mask, &sl.found);     // a publish came between Pick() and this batch
+            std::memcpy(mask.data() + i * (size_t)(W ? W : 1), sl.mask.data(), (size_t)(W ? W : 1) * 8u);
+            if (sl.found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
+          }
+          // rows are built in the backend's pinned buffers when it offers them: the pipelined set, else the single staging buffer
+          // (a batch without candidate masks then goes to the device without another host copy)
+          const bool plain = k == 1 && !any_mask;
+          uint8_t* rowp = plain ? (uint8_t*)be_->StageRows(next_set) : nullptr;
+          const bool pipelined = rowp != nullptr;
+          if (!pipelined) rowp = (uint8_t*)be_->StagingRows();
           const bool staged = rowp != nullptr;
           if (staged) std::memset(rowp, 0, n * stride_);
           else { rows.assign(n * stride_, 0); rowp = rows.data(); }
-          bool any_mask = false;
-          mask.assign(n * (size_t)(W ? W : 1), 0);
           for (size_t i = 0; i < n; ++i) {
             Slot& sl = *batch[i];
             eppk_req_hdr hdr;
@@ -409,50 +519,53 @@ class GpuPicker : public EndpointPicker {
             hdr.n_blocks = sl.n_blocks;
             std::memcpy(rowp + i * stride_, &hdr, sizeof hdr);
             std::memcpy(rowp + i * stride_ + 8, sl.hashes.data(), (size_t)sl.n_blocks * 8u);
-            if (sl.mask_snap != snap) BuildMask(*snap, *sl.cands, &sl.mask, &sl.found);     // a publish came between Pick() and this batch
-            std::memcpy(mask.data() + i * (size_t)(W ? W : 1), sl.mask.data(), (size_t)(W ? W : 1) * 8u);
-            const uint32_t found = sl.found;
-            if (found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
           }
-          const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
-          picks.resize(n * k);
-          scores.resize(n * k);
-          int rc;
-          if (staged && k == 1 && !any_mask) {
-            rc = be_->PickStaged((uint32_t)n, picks.data(), scores.data());
+          if (pipelined) {
+            // batch k + 1 goes to the device; batch k (the other set) is collected below, after be_mu_ is released
+            if (be_->StageBegin(next_set, (uint32_t)n, opt_.learn_prefixes) == EPPK_OK) {
+              begun = true;
+              ++inflight_;
+            } else {
+              failed = true;
+            }
           } else {
-            if (staged) { rows.assign(rowp, rowp + n * stride_); rowp = rows.data(); }     // (the other entry points copy FROM caller memory INTO that buffer)
-            rc = k == 1 ? be_->PickBatch(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data())
-                        : be_->PickTopK(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, k, picks.data(), scores.data());
-          }
-          failed = rc != EPPK_OK;
-          if (!failed)
-            for (size_t i = 0; i < n; ++i) {
-              batch[i]->pick = picks[i * k];  // Slot fields other than `done` are read by the owner only after `done`
-              batch[i]->fallbacks.clear();
-              for (uint32_t f = 0; f < k; ++f) {
-                const int32_t p = picks[i * k + f];
-                if (p < 0) break;
-                const Endpoint& e = snap->endpoints[(size_t)p];
-                if (f == 0) batch[i]->endpoint = JoinHostPort(e.address, e.port);
-                else batch[i]->fallbacks.push_back(JoinHostPort(e.address, e.port));
+            if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }      // keep the batches in order on the context
+            picks.resize(n * k);
+            scores.resize(n * k);
+            int rc;
+            if (staged && plain) {
+              rc = be_->PickStaged((uint32_t)n, picks.data(), scores.data());
+            } else {
+              if (staged) { rows.assign(rowp, rowp + n * stride_); rowp = rows.data(); }     // (the other entry points copy FROM caller memory INTO that buffer)
+              rc = k == 1 ? be_->PickBatch(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, picks.data(), scores.data())
+                          : be_->PickTopK(rowp, (uint32_t)n, any_mask ? mask.data() : nullptr, k, picks.data(), scores.data());
+            }
+            failed = rc != EPPK_OK;
+            if (!failed) Resolve(batch, *snap, picks.data(), k);
+            if (!failed && opt_.learn_prefixes) {  // index[hash[r][i]] gains pick[r], for every block of every routed request
+              learn_h.clear();
+              learn_p.clear();
+              for (size_t i = 0; i < n; ++i) {
+                const int32_t p = picks[i * k];
+                if (p < 0) continue;
+                eppk_req_hdr hdr;
+                std::memcpy(&hdr, rowp + i * stride_, sizeof hdr);
+                const uint64_t* h = (const uint64_t*)(rowp + i * stride_ + 8);
+                for (uint32_t b = 0; b < hdr.n_blocks; ++b) { learn_h.push_back(h[b]); learn_p.push_back((uint32_t)p); }
               }
+              if (!learn_h.empty() && be_->IndexInsert(learn_h.data(), learn_p.data(), (uint32_t)learn_h.size()) != EPPK_OK)
+                learn_drops_.fetch_add(1, std::memory_order_relaxed);  // (e.g. EPPK_ERR_INDEX_FULL: the picks themselves stand)
             }
-          if (!failed && opt_.learn_prefixes) {  // index[hash[r][i]] gains pick[r], for every block of every routed request
-            learn_h.clear();
-            learn_p.clear();
-            for (size_t i = 0; i < n; ++i) {
-              const int32_t p = picks[i * k];
-              if (p < 0) continue;
-              eppk_req_hdr hdr;
-              std::memcpy(&hdr, rowp + i * stride_, sizeof hdr);
-              const uint64_t* h = (const uint64_t*)(rowp + i * stride_ + 8);
-              for (uint32_t b = 0; b < hdr.n_blocks; ++b) { learn_h.push_back(h[b]); learn_p.push_back((uint32_t)p); }
-            }
-            if (!learn_h.empty() && be_->IndexInsert(learn_h.data(), learn_p.data(), (uint32_t)learn_h.size()) != EPPK_OK)
-              learn_drops_.fetch_add(1, std::memory_order_relaxed);  // (e.g. EPPK_ERR_INDEX_FULL: the picks themselves stand)
           }
+          if (begun) {                          // hand the batch over to the pipeline; the previous one is collected now
+            InFlight prev = std::move(fly);
+            fly.batch = batch; fly.snap = snap; fly.set = next_set; fly.active = true;
+            next_set ^= 1u;
+            if (prev.active) { bg.unlock(); Collect(prev, picks, scores); bg.lock(); }
+          }
+          // ageing between two batches (the index entry points must not run while a set is in flight: collect first)
           if (opt_.index_epoch_interval.count() > 0 && std::chrono::steady_clock::now() >= next_tick) {
+            if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }
             next_tick = std::chrono::steady_clock::now() + opt_.index_epoch_interval;
             uint32_t epoch = 0, gone = 0;
             if (be_->IndexAdvanceEpoch(&epoch) == EPPK_OK && epoch > opt_.index_keep_epochs &&
@@ -461,10 +574,8 @@ class GpuPicker : public EndpointPicker {
           }
         }
       }
+      if (!begun) Finish(batch, failed);
       g.lock();
-      for (Slot* s : batch) { s->fail_open = failed; s->done = true; s->cv.notify_one(); }   // under mu_: the Slot outlives the call
-      batches_.fetch_add(1);
-      if (n > largest_batch_.load()) largest_batch_.store(n);
     }
   }
 
@@ -474,6 +585,9 @@ class GpuPicker : public EndpointPicker {
   RoundRobinPicker rr_;
   std::mutex mu_;     // queue + snap_ pointer
   std::mutex be_mu_;  // backend context + snapshot consistency; always taken BEFORE mu_
+  std::condition_variable be_cv_;   // with be_mu_: the pipeline drained (inflight_ == 0) / the publisher is through (publish_waiting_ == 0)
+  uint32_t inflight_ = 0;           // pipelined batches between StageBegin and StageEnd (be_mu_)
+  uint32_t publish_waiting_ = 0;    // PublishSnapshot calls waiting for the pipeline to drain (be_mu_)
   std::condition_variable cv_;
   std::vector<Slot*> queue_;
   std::shared_ptr<Snapshot> snap_;

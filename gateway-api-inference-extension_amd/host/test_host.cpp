@@ -132,8 +132,11 @@ static int run_cpu() {
   Endpoint stranger;
   stranger.address = "192.168.0.1";
   stranger.port = "1";
-  std::vector<const Endpoint*> unknown{&stranger};  // candidates unknown to the snapshot: no scoreable endpoint
-  CHECK(gp.Pick({}, unknown, &pr).code == Code::Unavailable);
+  std::vector<const Endpoint*> unknown{&stranger};  // candidates unknown to the snapshot: no scoreable endpoint -> the picker fails OPEN
+  {                                                 // (round robin over the request's candidates; only an empty list fails closed)
+    const uint64_t fo = gp.fail_opens();
+    CHECK(gp.Pick({}, unknown, &pr).ok() && pr.endpoint == "192.168.0.1:1" && gp.fail_opens() == fo + 1);
+  }
 
   // concurrency: 16 threads x 200 picks are batched (fewer backend calls than picks), all correct
   const int before = fake->calls.load();
