@@ -47,3 +47,52 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert "func NewStreamingServer(datastore Datastore) *StreamingServer" in src and "NewStreamingServerWithPicker" in src
     # the reference's own tests keep compiling against the unchanged constructor
     assert "NewStreamingServer(ds)" in open(os.path.join(REF, "pkg/lwepp/handlers/request_test.go")).read()
+
+
+def _split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    out.append(cur)
+    return [a for a in out if a.strip()]
+
+
+def test_every_cgo_call_in_the_patch_matches_the_header():
+    """No Go toolchain here, so the compiler cannot check the cgo calls: every `C.eppk_*(...)` call in the patch must name a function
+    include/eppk.h declares, with the declared number of arguments; every `C.EPPK_*` constant must be a #define of the header."""
+    import re
+    text = "\n".join(ln[1:] for ln in open(PATCH).read().splitlines() if ln.startswith("+") and not ln.startswith("+++"))
+    hdr = open(os.path.join(ROOT, "include", "eppk.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(eppk_\w+)\s*\(([^;{]*?)\)\s*;", hdr_nc):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_args(args))
+    consts = set(re.findall(r"#define\s+(EPPK_\w+)", hdr)) | set(re.findall(r"\b(EPPK_\w+)\s*=", hdr_nc))
+    calls = 0
+    for m in re.finditer(r"\bC\.(eppk_\w+)\(", text):
+        name = m.group(1)
+        if name not in protos:      # a type conversion such as C.eppk_pod_row{} / (*C.eppk_req_hdr)(row) is not a call; anything else must be declared
+            assert re.search(r"\b%s\b" % name, hdr), f"{name} is not in include/eppk.h"
+            continue
+        depth, i, start = 1, m.end(), m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        inner = text[start:i - 1]
+        n = len(_split_args(inner)) if inner.strip() else 0
+        assert n == protos[name], f"C.{name} called with {n} arguments, the header declares {protos[name]}"
+        calls += 1
+    assert calls >= 15
+    for name in set(re.findall(r"\bC\.(EPPK_\w+)", text)):
+        assert name in consts, f"C.{name} is not defined in include/eppk.h"
+    # PickResult.Fallbacks is filled (server.go:74), several devices go through the group API, and the index learns on the device
+    assert "Fallbacks: r.fallbacks" in text and "C.eppk_pick_topk(" in text and "C.eppk_group_pick_batch(" in text and "C.EPPK_PICK_LEARN" in text
