@@ -95,11 +95,16 @@ int main(int argc, char** argv) {
   CHECK(prod.failed_scrapes() == 3);
   // the pick goes to the shorter queue (pod-2, the chunked server), whatever the candidates' order
   CHECK(picker.Pick({}, cands, &pr).ok() && pr.endpoint == std::string("127.0.0.1:") + argv[2]);
-  // a candidate list without it: the other one; only endpoints outside the snapshot: nothing scoreable -> Unavailable
+  // a candidate list without it: the other one; only endpoints the snapshot cannot score (their scrapes failed): the picker fails
+  // OPEN -- round robin over the request's candidates -- instead of taking the request down
   std::vector<const Endpoint*> only1{&first_pool[0], &first_pool[2]};
   CHECK(picker.Pick({}, only1, &pr).ok() && pr.endpoint == std::string("127.0.0.1:") + argv[1]);
   std::vector<const Endpoint*> none{&first_pool[2], &first_pool[3]};
-  CHECK(picker.Pick({}, none, &pr).code == Code::Unavailable);
+  {
+    const uint64_t fo = picker.fail_opens();
+    CHECK(picker.Pick({}, none, &pr).ok() && picker.fail_opens() == fo + 1);
+    CHECK(pr.endpoint == JoinHostPort(first_pool[2].address, first_pool[2].port) || pr.endpoint == JoinHostPort(first_pool[3].address, first_pool[3].port));
+  }
 
   // churn: pod-1 leaves the pool -> its slot becomes a hole (stable slots: pod-2 keeps candidate index 1)
   { std::lock_guard<std::mutex> g(pool_mu); pool.erase(pool.begin()); }
