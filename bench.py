@@ -165,6 +165,9 @@ class Runner:
         self.comm_handle = self.comm.cuda_stream
         self.closed_loop = closed_loop
         self.profile_every = max(1, int(getattr(args, "profile_every", 1)))
+        # N > 1: completion latency of a gather bucket -- a timing event on the compute stream right before the first launch that scores
+        # a bucket's batches, one on `comm` behind the collective that delivers their picks to every rank (timed region only)
+        self.lat_on, self.lat_start, self.lat_pairs = False, None, []
 
     # -- a timed region ---------------------------------------------------------------------------------------------------
     def setup(self, mode: str, gather_every: int):
@@ -220,6 +223,11 @@ class Runner:
         out = self.d_alls[self.ring.bucket_of(b0)][: self.world * n * self.per]
         self.dist.all_gather_into_tensor(out, self.d_picks_all[b0 * self.per:(b0 + n) * self.per])     # on `comm`, the current stream
         self.last_gather = (out, n)
+        if self.lat_on and self.lat_start is not None:
+            e_end = self.torch.cuda.Event(enable_timing=True)
+            e_end.record(self.comm)
+            self.lat_pairs.append((self.lat_start, e_end, n))
+            self.lat_start = None
         if self.grouped:
             k = self.ring.bucket_of(b0)
             if self.ev_bucket[k] is None:
@@ -242,6 +250,9 @@ class Runner:
         b = self.batch_of(self.step_no)
         st = self.streams[slot % len(self.streams)]
         if self.n_mine and not self.grouped:
+            if self.lat_on and self.use_dist and self.lat_start is None:      # first batch of a bucket
+                self.lat_start = self.torch.cuda.Event(enable_timing=True)
+                self.lat_start.record(self.computes[slot % len(self.computes)])
             self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
             if self.closed_loop:                              # post-route index update on the same stream: the next pick sees it
                 self.pk.index_insert_picks_device(self.p_batches[b] + self.lo * self.stride, self.p_picks[slot], self.n_mine, st)
@@ -266,6 +277,9 @@ class Runner:
         st = cs.cuda_stream
         if self.ev_bucket[k] is not None:
             cs.wait_event(self.ev_bucket[k])                 # the collective that read this bucket on its previous trip is done
+        if self.lat_on and self.lat_start is None:
+            self.lat_start = self.torch.cuda.Event(enable_timing=True)
+            self.lat_start.record(cs)
         self.pk.pick_device(self.p_shards + b0 * self.per * self.stride, n * self.per, None, self.p_picks[first], self.p_scores[first], st)
 
     def fence(self):
@@ -292,6 +306,7 @@ class Runner:
         # part of what the headline times.  The p99 samples (more_kernel_samples, outside the timed region) instrument every launch.
         self.pk.profile(self.profile_every)
         self.fence()
+        self.lat_on, self.lat_start, self.lat_pairs = self.use_dist, None, []
         t0 = time.perf_counter()
         for i in range(steps):
             self.step()
@@ -299,6 +314,9 @@ class Runner:
                 age(warmup + i)
         self.fence()
         elapsed = time.perf_counter() - t0
+        self.lat_on = False
+        self.bucket_latency_ms = np.asarray([a.elapsed_time(b) for a, b, _ in self.lat_pairs], dtype=np.float64)
+        self.bucket_batches = [n for _, _, n in self.lat_pairs]
         if self.use_dist:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -384,6 +402,9 @@ def main() -> None:
     ap.add_argument("--requests", type=int, default=None, help="override requests per batch")
     ap.add_argument("--batches", type=int, default=16, help="distinct request batches the timed region rotates through (16 x 17.3 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--scaling", choices=("strong", "weak", "both"), default="both", help="N>1: 'both' = strong scaling is the headline `value`, weak scaling is timed too and printed beside it")
+    ap.add_argument("--group", type=int, default=0, metavar="MEMBERS",
+                    help="ONE process, the C-ABI device group (eppk_group_*) instead of torch.distributed: MEMBERS contexts over the visible GPUs (round "
+                         "robin; all on device 0 of a one-GPU box), device-resident shards, one launch per member and gather bucket, peer all-gather")
     ap.add_argument("--closed-loop", action="store_true", help="pick -> insert_picks -> next different batch, ageing every --age-every steps (N=1; one stream)")
     ap.add_argument("--age-every", type=int, default=2, help="closed loop: tick the index epoch and evict every this many steps")
     ap.add_argument("--keep-epochs", type=int, default=2, help="closed loop: hashes not re-inserted during this many epochs are evicted")
@@ -422,6 +443,8 @@ def main() -> None:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.group:
+        return group_leg(graft.load_package(), torch, args)
     if args.closed_loop and use_dist:
         raise SystemExit("--closed-loop is a one-GPU mode (the group API applies the gathered update on every device: tests/test_gpu_group.py)")
 
@@ -455,6 +478,7 @@ def main() -> None:
                         run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, run.streams[0])
         elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
         results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per, launch_requests=run.launch_requests, grouped=run.grouped,
+                             bucket_latency_ms=run.bucket_latency_ms, bucket_batches=run.bucket_batches,
                              bucket=run.ring.gather_every,
                              value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
         if mode == modes[0]:
@@ -502,6 +526,14 @@ def main() -> None:
                            "note": "weak scaling timed in the same invocation: every rank scores one whole batch per step, picks all-gathered"}
         if use_dist:
             out["config"]["ranks_seen"] = int(dist.get_world_size())
+            bl = res["bucket_latency_ms"]
+            if bl.size:
+                # BASELINE's metric names p99 pick latency: at N > 1 a batch's picks exist on every rank when the collective of its
+                # gather bucket has finished -- with launch groups that is the whole bucket's launch + one all-gather later
+                out["completion_latency"] = {"p50_ms": float(np.percentile(bl, 50)), "p99_ms": float(np.percentile(bl, 99)), "max_ms": float(bl.max()),
+                                             "buckets": int(bl.size), "batches_per_bucket": int(max(res["bucket_batches"])),
+                                             "definition": "device time from the start of the (first) launch that scores a gather bucket's batches on this rank to the end of the "
+                                                           "all-gather that hands their picks to every rank (events on the compute and the collective stream, rank 0, timed region)"}
         k_timed = res["kern_ms"]
         k_all = np.concatenate([k_timed, extra_ms]) if extra_ms.size else k_timed
         # launch duration: the sampled launches of the timed region plus the every-launch samples taken behind it (same launch pattern)
@@ -657,6 +689,83 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def group_leg(pkg, torch, args):
+    """`--group M`: the strong-scaling step through the C ABI's device group -- what a Go host links -- in ONE process: M member
+    contexts (one per visible GPU, round robin), every member holding ITS rows of the 16 rotating batches; a step scores one batch,
+    a bucket of `--gather-every` steps is ONE eppk_group_pick_device call (one launch per member + the peer all-gather of the picks).
+    Prints one JSON line (not the driver's headline: `n_gpus` is the number of distinct devices used)."""
+    M = args.group
+    n_dev = max(1, torch.cuda.device_count())
+    devices = [i % n_dev for i in range(M)]
+    wl = pkg.workload.make_workload(args.config, R=args.requests, n_groups=args.groups, zipf_s=args.zipf, pods_per_group=args.pods_per_group)
+    batches = make_batches(pkg, wl, args, args.batches)
+    R, NB, G = wl.R, len(batches), max(1, args.gather_every)
+    assert NB % G == 0
+    per = (R + M - 1) // M
+    g = pkg.DeviceGroup(wl.chain, devices, max_pods=max(wl.P, 64), max_blocks=wl.B, max_batch=max(R, G * per), index_slots=wl.index_slots, gather=pkg.picker.GATHER_PEER)
+    g.publish(wl.pods)
+    g.index_insert(wl.index_hashes, wl.index_pods)
+    rows_w = 1 + wl.B
+    shards, n_rows = [], []
+    for i in range(M):
+        lo, hi = min(i * per, R), min((i + 1) * per, R)
+        with torch.cuda.device(devices[i]):
+            t = torch.from_numpy(np.concatenate([b[lo:hi] for b in batches]).view(np.int64)).cuda()      # [NB * n_i, rows_w]
+        shards.append(t)
+        n_rows.append(hi - lo)
+    tot = sum(n_rows) * G
+    d_picks = [[torch.empty(G * n_rows[i], dtype=torch.int32, device=f"cuda:{devices[i]}") for i in range(M)] for _ in range(2)]
+    d_all = [[torch.empty(tot, dtype=torch.int32, device=f"cuda:{devices[i]}") for i in range(M)] for _ in range(2)]
+
+    def bucket(k, slot):                       # batches k*G .. k*G + G - 1 of the ring
+        b0 = (k * G) % NB
+        g.pick_device([shards[i].data_ptr() + b0 * n_rows[i] * rows_w * 8 for i in range(M)], [G * n for n in n_rows],
+                      [t.data_ptr() for t in d_picks[slot]], None, [t.data_ptr() for t in d_all[slot]])
+
+    n_buckets_w, n_buckets = max(1, args.warmup // G), max(1, args.steps // G)
+    for k in range(n_buckets_w):
+        bucket(k, k & 1)
+    g.sync()
+    lat = []
+    t0 = time.perf_counter()
+    for k in range(n_buckets):
+        bucket(n_buckets_w + k, k & 1)
+    g.sync()
+    elapsed = time.perf_counter() - t0
+    for k in range(min(n_buckets, 50)):        # completion latency of a bucket, one at a time
+        t1 = time.perf_counter()
+        bucket(k, 0)
+        g.sync()
+        lat.append(time.perf_counter() - t1)
+    # parity: the gathered picks of the last bucket's first batch against the oracle (member 0's copy; every member holds the same)
+    orc = graft.load_oracle()
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    k_last = min(n_buckets, 50) - 1
+    b_first = (k_last * G) % NB
+    op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[b_first], wl.B, threads=os.cpu_count() or 1)
+    allp = d_all[0][0].cpu().numpy()
+    got, off = [], 0
+    for i in range(M):
+        got.append(allp[off:off + n_rows[i]])              # member i's rows of the bucket's FIRST batch come first in its shard
+        off += G * n_rows[i]
+    same = bool(np.array_equal(np.concatenate(got), op))
+    same_everywhere = all(bool(torch.equal(d_all[0][0].cpu(), d_all[0][i].cpu())) for i in range(M))
+    steps = n_buckets * G
+    lat = np.asarray(lat) * 1e3
+    out = {"metric": f"routing decisions/sec ({wl.name}), C-ABI device group", "value": R * steps / elapsed, "unit": "decisions/s", "n_gpus": len(set(devices)),
+           "steps": steps, "warmup": n_buckets_w * G, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": wl.name, "members": M, "devices": devices, "ranks_seen": int(g.ranks_seen), "requests_per_step": R, "requests_per_member": per,
+                      "batches_per_launch": G, "gather": "peer copies (hipMemcpyPeerAsync; device-to-device copies between members that share a GPU)",
+                      "entry_point": "eppk_group_pick_device + eppk_group_sync (device-resident shards, no host staging)"},
+           "completion_latency": {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "batches_per_bucket": G,
+                                  "definition": "host time of one bucket alone: eppk_group_pick_device -> eppk_group_sync"},
+           "parity": {"gathered_picks_equal_oracle": same, "every_member_holds_the_same_picks": same_everywhere}}
+    print(json.dumps(out), flush=True)
+    g.close()
 
 
 def closed_loop_verify(run, wl, args):

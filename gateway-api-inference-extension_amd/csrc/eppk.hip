@@ -2046,6 +2046,68 @@ int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, cons
   return EPPK_OK;
 }
 
+// Device-resident picks over a group (include/eppk.h): every member scores the rows that already sit in ITS memory, on its own
+// stream; nothing crosses the host.  With EPPK_GROUP_GATHER every member then receives every other member's picks (member-major).
+int eppk_group_pick_device(eppk_group* g, const void* const* d_reqs, const uint32_t* n_rows, int32_t* const* d_out_pick, double* const* d_out_score,
+                           int32_t* const* d_gathered, uint32_t flags) {
+  if (!g || !d_reqs || !n_rows || !d_out_pick) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: null argument");
+  const bool gather = (flags & EPPK_GROUP_GATHER) != 0;
+  if (flags & EPPK_GROUP_LEARN) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: EPPK_GROUP_LEARN needs the whole batch on every member: eppk_group_pick_batch");
+  if (gather && !d_gathered) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: EPPK_GROUP_GATHER without d_gathered");
+  if (gather && g->mode == EPPK_GATHER_HOST) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: a device-resident gather needs EPPK_GATHER_PEER or EPPK_GATHER_RCCL");
+  for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, "eppk_group_pick_device: no snapshot published");
+  const uint32_t G = (uint32_t)g->ctx.size();
+  std::vector<size_t> off(G + 1, 0);
+  GFOR(g, i) off[i + 1] = off[i] + n_rows[i];
+  GFOR(g, i) {
+    if (n_rows[i] == 0) continue;
+    if (!d_reqs[i] || !d_out_pick[i]) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: null shard pointer");
+    int rc = eppk_pick_batch_device(g->ctx[i], d_reqs[i], n_rows[i], nullptr, d_out_pick[i], d_out_score ? d_out_score[i] : nullptr, (void*)g->ctx[i]->stream);
+    if (rc) return gfail(g, rc, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(g->ctx[i]));
+  }
+  if (!gather) return EPPK_OK;
+  if (g->mode == EPPK_GATHER_PEER) {
+    GFOR(g, i) {
+      if (n_rows[i] == 0) continue;
+      eppk_ctx* m = g->ctx[i];
+      (void)hipSetDevice(g->dev[i]);
+      GFOR(g, p) {
+        if (!d_gathered[p]) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: null d_gathered entry");
+        const hipError_t e = g->dev[p] == g->dev[i]
+            ? hipMemcpyAsync(d_gathered[p] + off[i], d_out_pick[i], (size_t)n_rows[i] * 4u, hipMemcpyDeviceToDevice, m->stream)
+            : hipMemcpyPeerAsync(d_gathered[p] + off[i], g->dev[p], d_out_pick[i], g->dev[i], (size_t)n_rows[i] * 4u, m->stream);
+        if (e != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, std::string("eppk_group_pick_device: peer copy failed: ") + hipGetErrorString(e));
+      }
+      if (hipEventRecord(g->ev[i], m->stream) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_device: hipEventRecord failed");
+    }
+    GFOR(g, p) {                                     // member p's stream continues once every shard has landed in ITS array
+      (void)hipSetDevice(g->dev[p]);
+      GFOR(g, i) if (i != p && n_rows[i]) (void)hipStreamWaitEvent(g->ctx[p]->stream, g->ev[i], 0);
+    }
+  } else {                                           // RCCL: equal shards, one all-gather
+    GFOR(g, i) if (n_rows[i] != n_rows[0] || !d_gathered[i]) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: EPPK_GATHER_RCCL needs equal shards on every member");
+    int nrc = g->nccl_group_start();
+    GFOR(g, i) {
+      (void)hipSetDevice(g->dev[i]);
+      if (nrc == 0) nrc = g->nccl_all_gather(d_out_pick[i], d_gathered[i], n_rows[0], /*ncclInt32*/ 2, g->comms[i], g->ctx[i]->stream);
+    }
+    const int erc = g->nccl_group_end();
+    if (nrc != 0 || erc != 0) return gfail(g, EPPK_ERR_DEVICE, std::string("ncclAllGather: ") + (g->nccl_err ? g->nccl_err(nrc ? nrc : erc) : "error"));
+  }
+  return EPPK_OK;
+}
+
+int eppk_group_sync(eppk_group* g) {
+  if (!g) return EPPK_ERR_ARG;
+  GFOR(g, i) {
+    (void)hipSetDevice(g->dev[i]);
+    if (hipStreamSynchronize(g->ctx[i]->stream) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_sync: device " + std::to_string(g->dev[i]));
+  }
+  return EPPK_OK;
+}
+
+void* eppk_group_stream(eppk_group* g, uint32_t i) { return (g && i < g->ctx.size()) ? (void*)g->ctx[i]->stream : nullptr; }
+
 const int32_t* eppk_group_device_picks(eppk_group* g, uint32_t i) {
   return (g && i < g->ctx.size()) ? g->ctx[i]->d_pick : nullptr;
 }

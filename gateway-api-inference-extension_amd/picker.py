@@ -647,3 +647,19 @@ class DeviceGroup:
 
     def device_picks_ptr(self, i: int) -> int:
         return int(self._lib.eppk_group_device_picks(self._g, i) or 0)
+
+    def pick_device(self, d_reqs: Sequence[int], n_rows: Sequence[int], d_picks: Sequence[int], d_scores: Optional[Sequence[int]] = None,
+                    d_gathered: Optional[Sequence[int]] = None) -> None:
+        """eppk_group_pick_device: member i scores the n_rows[i] rows at device pointer d_reqs[i] (its own memory) into d_picks[i]
+        (/ d_scores[i]); with `d_gathered` every member also receives all picks, member-major.  Asynchronous: `sync()` waits."""
+        n = len(d_reqs)
+        arr = lambda xs: (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in xs])
+        self._check(self._lib.eppk_group_pick_device(self._g, arr(d_reqs), (C.c_uint32 * n)(*[int(x) for x in n_rows]), arr(d_picks),
+                                                     arr(d_scores) if d_scores is not None else None,
+                                                     arr(d_gathered) if d_gathered is not None else None, 2 if d_gathered is not None else 0), "group_pick_device")
+
+    def sync(self) -> None:
+        self._check(self._lib.eppk_group_sync(self._g), "group_sync")
+
+    def member_stream(self, i: int) -> int:
+        return int(self._lib.eppk_group_stream(self._g, i) or 0)

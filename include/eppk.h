@@ -324,6 +324,19 @@ int eppk_group_index_evict_older(eppk_group* g, uint32_t min_epoch, uint32_t* n_
 /* eppk_pick_batch over the group: same arguments and results (out_pick / out_score hold all n_reqs entries, in request order). */
 int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick,
                           double* out_score, uint32_t flags);
+/* The DEVICE-RESIDENT form: member i scores the n_rows[i] request rows at d_reqs[i] -- already in ITS device memory (what a
+ * producer that hashes prompts on the device leaves there, eppk_hash_prompts_device) -- into d_out_pick[i] / d_out_score[i] (its
+ * memory too; d_out_score nullable), enqueued on the member's own stream (eppk_group_stream) without touching the host: no staging,
+ * no synchronisation -- eppk_group_sync waits for every member.  A shard may hold the member's rows of SEVERAL batches back to back
+ * (one launch per member for a whole gather bucket: what makes strong scaling of 64k-request batches over 8 devices launch-bound
+ * otherwise).  flags: EPPK_GROUP_GATHER -> every member also receives every other member's picks, member-major, in
+ * d_gathered[i] (sum of n_rows entries; member j's picks at offset n_rows[0] + ... + n_rows[j-1]): peer copies over xGMI
+ * (EPPK_GATHER_PEER) or one ncclAllGather (EPPK_GATHER_RCCL: equal shards); each member's stream continues when its array is
+ * complete.  EPPK_GROUP_LEARN is refused here (it needs the whole batch on every member: eppk_group_pick_batch). */
+int   eppk_group_pick_device(eppk_group* g, const void* const* d_reqs, const uint32_t* n_rows, int32_t* const* d_out_pick,
+                             double* const* d_out_score, int32_t* const* d_gathered, uint32_t flags);
+int   eppk_group_sync(eppk_group* g);
+void* eppk_group_stream(eppk_group* g, uint32_t i);      /* member i's hipStream_t */
 /* Device pointer to member i's copy of the gathered picks of the last LEARN / GATHER batch (n_reqs entries, request order). */
 const int32_t* eppk_group_device_picks(eppk_group* g, uint32_t i);
 

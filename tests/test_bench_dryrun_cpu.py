@@ -258,6 +258,8 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     # headline = strong scaling: each 64-request batch is split 32 + 32, every rank ends up with all 64 picks (checked against the oracle)
     assert d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 32 and d["config"]["requests_per_step"] == 64
     assert "cpu_baseline" not in d and "split R/2 per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
+    cl = d["completion_latency"]                  # N > 1: when a batch's picks exist on every rank (per gather bucket)
+    assert cl["buckets"] >= 1 and cl["p50_ms"] <= cl["p99_ms"] <= cl["max_ms"] and cl["batches_per_bucket"] >= 1
     assert d["parity"]["gathered_picks_equal_oracle"] is True
     assert ("ONE launch" in d["config"]["sharding"]) == grouped and d["config"]["requests_per_launch"] == (4 * 32 if grouped else 32)
     assert abs(d["value"] - 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]

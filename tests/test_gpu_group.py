@@ -134,3 +134,47 @@ def test_rccl_gather_on_two_gpus(pkg, orc):
             _same(picks, scores, op, osc)
             oix.insert_picks(wl.reqs, wl.B, op)
             assert g.member_index_size(0) == g.member_index_size(1) == oix.size()
+
+
+@pytest.mark.parametrize("members,bucket", [(2, 1), (4, 4), (3, 2)])
+def test_device_resident_shards_with_launch_groups(pkg, orc, members, bucket):
+    """eppk_group_pick_device: every member scores ITS rows of `bucket` batches with one launch (rows already in its memory), the
+    picks are all-gathered member-major by peer copies; member i's gathered array holds, for every member j, exactly the picks the
+    oracle gives for j's rows -- nothing goes through the host between the upload of the rows and the final copy-out."""
+    import torch
+    wl = pkg.workload.make_workload(3, R=960, P=900)
+    batches = [wl.reqs] + [pkg.workload.make_requests(wl, 70 + i) for i in range(bucket - 1)]
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    want = [_oracle(orc, wl, b, oix=oix)[:2] for b in batches]
+    per = (wl.R + members - 1) // members
+    with pkg.DeviceGroup(wl.chain, [0] * members, max_pods=1024, max_blocks=wl.B, max_batch=bucket * per, index_slots=1 << 16) as g:
+        g.publish(wl.pods)
+        g.index_insert(wl.index_hashes, wl.index_pods)
+        shards, n_rows = [], []
+        for i in range(members):
+            lo, hi = min(i * per, wl.R), min((i + 1) * per, wl.R)
+            rows = np.concatenate([b[lo:hi] for b in batches])           # member i's rows of every batch of the bucket, back to back
+            shards.append(torch.from_numpy(rows.view(np.int64)).cuda())
+            n_rows.append(rows.shape[0])
+        total = sum(n_rows)
+        d_picks = [torch.full((n,), -9, dtype=torch.int32, device="cuda") for n in n_rows]
+        d_scores = [torch.empty(n, dtype=torch.float64, device="cuda") for n in n_rows]
+        d_all = [torch.full((total,), -9, dtype=torch.int32, device="cuda") for _ in range(members)]
+        torch.cuda.synchronize()
+        for _ in range(2):                                               # twice: the second call reuses every buffer
+            g.pick_device([t.data_ptr() for t in shards], n_rows, [t.data_ptr() for t in d_picks], [t.data_ptr() for t in d_scores],
+                          [t.data_ptr() for t in d_all])
+            g.sync()
+        off = 0
+        for i in range(members):
+            lo, hi = min(i * per, wl.R), min((i + 1) * per, wl.R)
+            exp_p = np.concatenate([w[0][lo:hi] for w in want])
+            exp_s = np.concatenate([w[1][lo:hi] for w in want])
+            assert np.array_equal(d_picks[i].cpu().numpy(), exp_p)
+            assert np.array_equal(d_scores[i].cpu().numpy().view(np.uint64), exp_s.view(np.uint64))
+            for m in range(members):
+                assert np.array_equal(d_all[m].cpu().numpy()[off:off + n_rows[i]], exp_p), (m, i)
+            off += n_rows[i]
+        with pytest.raises(pkg.picker.EppkError):                        # LEARN needs the whole batch on every member
+            g._check(g._lib.eppk_group_pick_device(g._g, None, None, None, None, None, 1), "x")
