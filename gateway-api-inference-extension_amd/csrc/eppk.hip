@@ -99,6 +99,7 @@ struct eppk_ctx {
   bool list_routes = true;                  // EPPK_LISTS=0: the pick kernels' list routes are off (every request takes the dense route)
   uint32_t* sortwl = nullptr;               // work list of index_lists_sort_kernel: cursors[2] | lost | arrived | slots[sortwl_cap]
   uint32_t sortwl_cap = 0, sort_uses = 0;
+  eppk::IxLaunch* d_ixl = nullptr;          // the capacity verdict of the insert launch in flight (index_budget_kernel)
   uint32_t index_epoch = 1;
   unsigned long long* stats = nullptr;  // device [4 + kStatBanks*2*kStatSlots]: scratch, live keys, non-empty words, dropped inserts, then
                                         // banks of per-wave {hits, lookups}: consecutive launches use different banks, so pick
@@ -765,6 +766,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   CHK(hipMemset(c->stats, 0, (4 + 2 * (size_t)kStatSlots * kStatBanks) * sizeof(unsigned long long)));
   CHK(hipMalloc((void**)&c->ixc, eppk::kIxShards * 8u * sizeof(unsigned long long)));
   CHK(hipMemset(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long)));
+  CHK(hipMalloc((void**)&c->d_ixl, sizeof(eppk::IxLaunch)));
   CHK(hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t)));
   CHK(hipMemset(c->d_status, 0, 2 * sizeof(uint32_t)));
   if (cfg->index_slots) {
@@ -802,7 +804,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
   (void)hipFree(c->d_at); (void)hipFree(c->d_av); (void)hipFree(c->d_sk); (void)hipFree(c->d_so);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
@@ -916,11 +918,12 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   eppk::SortWl sw{};
   rc = sortwl_begin(c, n, &sw);
   if (rc) return rc;
+  hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, c->stream, c->ixc, c->limit, c->slots, (unsigned long long)n, c->d_ixl);
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
                        c->limit, c->index_epoch, c->ixc, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
-                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status);
+                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status, (const eppk::IxLaunch*)c->d_ixl);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -945,11 +948,12 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
   eppk::SortWl sw{};
   int rc = sortwl_begin(c, total, &sw);
   if (rc) return rc;
+  hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, st, c->ixc, c->limit, c->slots, (unsigned long long)total, c->d_ixl);
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->ixc, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
-                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw);
+                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, (const eppk::IxLaunch*)c->d_ixl);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());

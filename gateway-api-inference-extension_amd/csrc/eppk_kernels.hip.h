@@ -2996,32 +2996,61 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 // ix_budget reads those lines meanwhile: scripts/micro/insertbreak.hip, profiles/r02_micro_insertbreak.txt).  Now the insert and
 // evict kernels bump them once per WORKGROUP (LDS first) and there are 64 shards.  Readers (host, capacity test) sum the shards.
 constexpr uint32_t kIxShards = 64u;
-constexpr uint32_t kIxLive = 0u, kIxWords = 1u, kIxDropped = 2u, kIxEvicted = 3u;
+constexpr uint32_t kIxLive = 0u, kIxWords = 1u, kIxDropped = 2u, kIxEvicted = 3u, kIxReserved = 4u;
 
-struct IxBudget {            // what a workgroup learned about the table's capacity when it started (ix_budget)
-  bool safe;                 // every pair of this launch fits below both limits even if each brings a new key: no per-key checks
-  unsigned long long others_live, others_words;   // exact mode: sum of the shards other than shard 0 (exact-mode adds go to shard 0)
+// The capacity test of an insert launch.  index_budget_kernel (one wavefront, right in front of the insert launch on its stream) sums
+// the shards ONCE and leaves the verdict in IxLaunch; every workgroup of the insert launch reads that one read-only line instead of
+// gathering the 64 shard lines itself while other workgroups hammer them with their end-of-workgroup atomics (8 192 workgroups x 64
+// lines were HALF of the kernel: profiles/r03_h_micro_insert_prologue.txt).  Capacity: at most `limit` (= slots / 2) live keys and
+// 3/4 of the words non-empty; `left` = what the launch may still add under both.  Two regimes:
+//   safe      every pair of this LAUNCH fits even if each brings a new key: nobody looks at a counter again;
+//   per key   the launch as a whole might not fit: `left` is dealt out over the 64 shards' kIxReserved words (share(s) = left / 64,
+//             the remainder one each to the first shards: the shares add up to `left` exactly) and a thread BOOKS its key -- one
+//             atomic on a shard that still has room, starting with its workgroup's -- before it claims a word for it (and gives the
+//             booking back when the key turns out to be there already).  The launch admits exactly `left` new keys, the rest is
+//             dropped and counted: EPPK_ERR_INDEX_FULL stays exact for a caller that fills a table to the brim.  One sharded atomic
+//             per NEW key -- the per-key path used to READ all the counters per key, 4.1 ms instead of 0.56 ms per Mi new keys for
+//             every launch into a table more than half-way to its limit (profiles/r02_micro_insertbreak.txt).
+//             (Booking in bulk per workgroup -- the keys its first look found missing -- was tried: pairs of one key sit in many
+//             lanes, the bookings over-state the need several times over and crowd out real keys near the limit.)
+struct IxLaunch {                 // written by index_budget_kernel, read-only while the insert kernel runs
+  long long left;                 // min(limit - live, 3/4 slots - words) when the launch started
+  uint32_t safe, pad;
 };
-
-// One wavefront of the workgroup sums the shards; `n_items` = pairs of this launch (an upper bound on its new keys).
-__device__ __forceinline__ IxBudget ix_budget(const unsigned long long* ixc, uint32_t limit, uint32_t slots, unsigned long long n_items,
-                                              unsigned long long* s_tmp /* __shared__ [4] */) {
-  if (threadIdx.x < 64u) {
-    const uint32_t l = threadIdx.x;
-    unsigned long long lv = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    unsigned long long wd = l < kIxShards ? __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    const unsigned long long lv0 = __shfl((long long)lv, 0), wd0 = __shfl((long long)wd, 0);
-    for (int off = 32; off >= 1; off >>= 1) { lv += __shfl_xor((long long)lv, off); wd += __shfl_xor((long long)wd, off); }
-    if (l == 0u) { s_tmp[0] = lv; s_tmp[1] = wd; s_tmp[2] = lv0; s_tmp[3] = wd0; }
-  }
-  __syncthreads();
-  IxBudget b;
-  const unsigned long long live = s_tmp[0], words = s_tmp[1];   // (live may transiently read "negative": removals land in other shards)
-  b.safe = (long long)live >= 0 && live + n_items < (unsigned long long)limit && words + n_items < (unsigned long long)(slots / 4u * 3u);
-  b.others_live = live - s_tmp[2];
-  b.others_words = words - s_tmp[3];
-  return b;
+__device__ __forceinline__ long long ix_share(const IxLaunch* il, uint32_t shard) {
+  return il->left <= 0 ? 0ll : il->left / (long long)kIxShards + ((long long)shard < il->left % (long long)kIxShards ? 1ll : 0ll);
 }
+// One key, in per-key mode: book it on the first shard (from `start` on) that has room.  kIxShards as result: no room anywhere.
+__device__ __forceinline__ uint32_t ix_book_one(unsigned long long* ixc, const IxLaunch* il, uint32_t start) {
+  for (uint32_t t = 0; t < kIxShards; ++t) {
+    const uint32_t sh = (start + t) & (kIxShards - 1u);
+    const long long share = ix_share(il, sh);
+    if (share <= 0) continue;
+    if ((long long)__hip_atomic_load(&ixc[sh * 8u + kIxReserved], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= share) continue;
+    const long long before = (long long)atomicAdd(&ixc[sh * 8u + kIxReserved], 1ull);
+    if (before + 1 <= share) return sh;
+    atomicAdd(&ixc[sh * 8u + kIxReserved], (unsigned long long)(0ll - 1ll));
+  }
+  return kIxShards;
+}
+
+#ifdef EPPK_MAIN_UNIT
+__global__ void index_budget_kernel(unsigned long long* ixc, uint32_t limit, uint32_t slots, unsigned long long n_items, IxLaunch* out) {
+  const uint32_t l = threadIdx.x;          // one wavefront, lane = shard
+  unsigned long long lv = __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long wd = __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ixc[l * 8u + kIxReserved] = 0ull;
+  for (int off = 32; off >= 1; off >>= 1) { lv += __shfl_xor((long long)lv, off); wd += __shfl_xor((long long)wd, off); }
+  if (l == 0u) {
+    const long long live = (long long)lv, words = (long long)wd;     // (sums over the shards: a single shard may read "negative", removals land anywhere)
+    long long left = (long long)limit - live;
+    const long long left_w = (long long)(slots / 4u * 3u) - words;
+    if (left_w < left) left = left_w;
+    out->left = left;
+    out->safe = (live >= 0 && (unsigned long long)live + n_items < (unsigned long long)limit && (unsigned long long)words + n_items < (unsigned long long)(slots / 4u * 3u)) ? 1u : 0u;
+  }
+}
+#endif
 
 // Work list of the lists that index_lists_sort_kernel has to bring back into ascending order after an insert launch:
 // wl[0] / wl[1] = two alternating cursors (a launch appends through one; its sort pass zeroes the other for the next launch),
@@ -3034,9 +3063,8 @@ struct SortWl {
 
 // Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters are bumped once per wavefront
 // (ballot + popcount).  Capacity: at most `limit` (= slots/2) live keys and 3/4 of the words non-empty.  A launch whose pairs all
-// fit (IxBudget::safe, the common case) inserts without looking at the counters; otherwise every new key is checked against an
-// exact count (shard 0 + the other shards as they were when the workgroup started) that lags by the keys of in-flight wavefronts
-// only: a table is only ever full at 7/8 slots, so the slack is harmless.
+// fit (IxLaunch::safe, the common case) inserts without looking at the counters; otherwise every new key is booked before it is
+// claimed (IxLaunch, above): the launch admits exactly what was left when it started.
 //
 // A key goes into the first FREE word (empty, or a tombstone left by an eviction) of its bucket chain -- home bucket, then
 // the following buckets for as long as the overflow flags say the chain continues -- but only after the whole chain has
@@ -3047,72 +3075,118 @@ struct SortWl {
 // one for {stamp, list line} together (skipped for a key this thread just claimed), one for the list CAS.
 template <typename LW>
 __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
-                                                 uint32_t limit, uint32_t epoch, unsigned long long* ixc, const IxBudget& bud, uint64_t h, uint32_t pod,
-                                                 bool active, const LW* act, const SortWl& sw, uint32_t* status) {
+                                                 uint32_t limit, uint32_t epoch, unsigned long long* ixc, const IxLaunch* il, unsigned long long* s_tmp,
+                                                 uint64_t h, uint32_t pod, bool active, const LW* act, const SortWl& sw, uint32_t* status) {
   // a hole of the current snapshot has no cache to record: the pair is ignored (SEMANTICS.md §6b; act == null: no snapshot yet)
   if (active && act && !((act[pod & 63u] >> (pod >> 6)) & 1)) active = false;
   uint32_t slot = kNotFound;
-  bool newkey = false, newword = false;
+  bool newkey = false, newword = false, stop = false;
+  const bool reserved_hash = h == 0 || h == kTomb;
+  const uint32_t bmask = slots / kBucket - 1u;
+  unsigned long long* K = (unsigned long long*)keys;
+  uint32_t free_slot = kNotFound;
+  unsigned long long free_val = 0ull;
+  // One walk of the key's bucket chain: `slot` when the key is there, else the first free word (`free_slot`, holding `free_val`).
+  auto search = [&](bool coherent) {
+    uint32_t bkt = home_bucket(h, shift);
+    free_slot = kNotFound;
+    free_val = 0ull;
+    bool chain_end = false;
+    for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
+      unsigned long long* kb = K + (size_t)bkt * kBucket;
+      unsigned long long w[kBucket];
+      {
+        uint32_t q[16];
+        if (coherent) load_line16<true>((const uint32_t*)kb, q);
+        else load_line16<false>((const uint32_t*)kb, q);
+#pragma unroll
+        for (int i = 0; i < (int)kBucket; ++i) w[i] = ((unsigned long long)q[2 * i + 1] << 32) | q[2 * i];
+      }
+#pragma unroll
+      for (uint32_t i = 1; i < kBucket; ++i) {
+        if (slot != kNotFound || chain_end) continue;
+        const unsigned long long k = w[i];
+        if (k == (unsigned long long)h) { slot = bkt * kBucket + i; continue; }
+        if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = bkt * kBucket + i; free_val = k; }
+        if (k == 0ull) chain_end = true;                      // buckets fill front to back: nothing lives behind an empty word
+      }
+      if (slot != kNotFound || chain_end) break;
+      if (w[0] & 1ull) { bkt = (bkt + 1) & bmask; continue; }   // chain continues
+      if (free_slot != kNotFound) break;                      // chain ends here and a tombstone is free
+      atomicOr(&kb[0], 1ull);                                 // full bucket, no free word anywhere: extend the chain
+      bkt = (bkt + 1) & bmask;
+    }
+    if (slot == kNotFound && free_slot == kNotFound) stop = true;   // walked the whole table
+  };
+  // (1) the first look (ordinary cached loads: load_line16)
+  if (active && !reserved_hash) search(false);
+  // (2) the capacity regime (IxLaunch above): safe launch-wide, or every new key booked before it is claimed
+  const bool safe = il->safe != 0u;        // (uniform over the launch)
+  const uint32_t my_shard = blockIdx.x & (kIxShards - 1u);
+  // (3) claim
+  uint32_t booked_on = kIxShards;          // per-key regime: the shard this lane's key is booked on
   if (active) {
-    if (h == 0 || h == kTomb) {
+    if (reserved_hash) {
       slot = h == 0 ? slots : slots + 1u;
-      const unsigned long long was = atomicExch((unsigned long long*)&keys[slot], 1ull);
-      newkey = was == 0ull;
-    } else {
-      const uint32_t bmask = slots / kBucket - 1u;
-      unsigned long long* K = (unsigned long long*)keys;
-      bool stop = false, again = false;     // again: a compare-and-swap lost its word to another key -> search again, coherently
-      while (slot == kNotFound && !stop) {
-        uint32_t b = home_bucket(h, shift);
-        uint32_t free_slot = kNotFound;
-        unsigned long long free_val = 0ull;
-        bool chain_end = false;
-        for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
-          unsigned long long* kb = K + (size_t)b * kBucket;
-          unsigned long long w[kBucket];
-          {
-            uint32_t q[16];
-            if (again) load_line16<true>((const uint32_t*)kb, q);
-            else load_line16<false>((const uint32_t*)kb, q);
-#pragma unroll
-            for (int i = 0; i < (int)kBucket; ++i) w[i] = ((unsigned long long)q[2 * i + 1] << 32) | q[2 * i];
-          }
-#pragma unroll
-          for (uint32_t i = 1; i < kBucket; ++i) {
-            if (slot != kNotFound || chain_end) continue;
-            const unsigned long long k = w[i];
-            if (k == (unsigned long long)h) { slot = b * kBucket + i; continue; }
-            if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = b * kBucket + i; free_val = k; }
-            if (k == 0ull) chain_end = true;                      // buckets fill front to back: nothing lives behind an empty word
-          }
-          if (slot != kNotFound || chain_end) break;
-          if (w[0] & 1ull) { b = (b + 1) & bmask; continue; }     // chain continues
-          if (free_slot != kNotFound) break;                      // chain ends here and a tombstone is free
-          atomicOr(&kb[0], 1ull);                                 // full bucket, no free word anywhere: extend the chain
-          b = (b + 1) & bmask;
-        }
-        if (slot != kNotFound) break;
-        if (free_slot == kNotFound) { stop = true; break; }       // walked the whole table
-        if (!bud.safe) {
-          // exact mode (table near a limit): recycling is per bucket chain, so tombstones of other chains keep their words until a
-          // key of that chain arrives -- hence the separate limit on non-empty words
-          const unsigned long long live = bud.others_live + __hip_atomic_load(&ixc[kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((long long)live >= (long long)limit) { stop = true; break; }
-          if (free_val == 0ull) {
-            const unsigned long long words = bud.others_words + __hip_atomic_load(&ixc[kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (words >= (unsigned long long)(slots / 4u * 3u)) { stop = true; break; }
-          }
-        }
-        const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
-        if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
-        else if (seen == (unsigned long long)h) slot = free_slot;
-        else again = true;                                        // somebody else took the word for another key -> search again
+      bool go = true;
+      if (!safe && __hip_atomic_load((unsigned long long*)&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+        booked_on = ix_book_one(ixc, il, my_shard);
+        go = booked_on != kIxShards;
+      }
+      if (go) {
+        const unsigned long long was = atomicExch((unsigned long long*)&keys[slot], 1ull);
+        newkey = was == 0ull;
+      } else {
+        slot = kNotFound;                                       // no room: dropped
       }
     }
   }
+  // The pairs of one new key often sit in neighbouring threads (a block cached on many pods: hundreds of pairs of one hash in a row).
+  // In the per-key regime only ONE lane per key and wavefront books and claims; the others look again afterwards and find the key.
+  bool follower = false;
+  if (!safe) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool needy = active && !reserved_hash && slot == kNotFound && !stop;
+    unsigned long long todo = __ballot(needy);
+    while (todo) {
+      const int first = __builtin_ctzll(todo);
+      const uint64_t hf = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h >> 32), first) << 32) | (uint32_t)__shfl((int)(uint32_t)h, first);
+      const unsigned long long same = __ballot(needy && h == hf);
+      if (needy && h == hf && (int)lane != first) follower = true;
+      todo &= ~same;
+    }
+  }
+  auto claim = [&]() {
+    while (slot == kNotFound && !stop) {
+      if (!safe && booked_on == kIxShards) {                  // the key needs a booking before it may claim a word
+        // No room may be a passing state: threads of other wavefronts with pairs of the same new key book as well, one claims, the
+        // others give their bookings back -- so look for the key again (coherently) and try a few more times before the pair is dropped.
+        for (uint32_t tries = 0; tries < 64u && booked_on == kIxShards && slot == kNotFound && !stop; ++tries) {
+          booked_on = ix_book_one(ixc, il, my_shard);
+          if (booked_on == kIxShards) { __builtin_amdgcn_s_sleep(16); search(true); }
+        }
+        if (slot != kNotFound || stop) break;
+        if (booked_on == kIxShards) { stop = true; break; }   // the launch has admitted all it may: dropped
+      }
+      const unsigned long long seen = atomicCAS(&K[free_slot], free_val, (unsigned long long)h);
+      if (seen == free_val) { slot = free_slot; newkey = true; newword = free_val == 0ull; }
+      else if (seen == (unsigned long long)h) slot = free_slot;
+      else search(true);                                    // somebody else took the word for another key -> search again, coherently
+    }
+  };
+  if (active && !reserved_hash) {
+    if (!follower) claim();
+  }
+  if (follower) {                                           // (after the leaders of this wavefront: the key is there now, as a rule)
+    search(true);
+    claim();
+  }
+  if (active) {
+    if (booked_on != kIxShards && !newkey) atomicAdd(&ixc[booked_on * 8u + kIxReserved], (unsigned long long)(0ll - 1ll));   // the key was there after all
+  }
   const unsigned long long nk = __ballot(newkey), nw = __ballot(newword), dropped = __ballot(active && slot == kNotFound);
   __shared__ unsigned int s_cnt[3];
-  if (bud.safe) {          // (uniform over the workgroup) the common case: nobody reads the counters while the kernel runs
+  if (safe) {              // (uniform over the launch) the common case: nobody reads the counters while the kernel runs
     if (threadIdx.x == 0u) { s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; }
     __syncthreads();
     if ((threadIdx.x & 63u) == 0u) {
@@ -3128,10 +3202,11 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
       if (s_cnt[2]) atomicAdd(&ixc[shard * 8u + kIxDropped], (unsigned long long)s_cnt[2]);
     }
   } else if ((threadIdx.x & 63u) == 0u && (nk | nw | dropped)) {
-    // exact mode counts in shard 0 (what its capacity test reads)
-    if (nk) atomicAdd(&ixc[kIxLive], (unsigned long long)__builtin_popcountll(nk));
-    if (nw) atomicAdd(&ixc[kIxWords], (unsigned long long)__builtin_popcountll(nw));
-    if (dropped) atomicAdd(&ixc[kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
+    // per-key regime: the counts once per wavefront (the bookings stay: each claimed key is one)
+    const uint32_t shard = blockIdx.x & (kIxShards - 1u);
+    if (nk) atomicAdd(&ixc[shard * 8u + kIxLive], (unsigned long long)__builtin_popcountll(nk));
+    if (nw) atomicAdd(&ixc[shard * 8u + kIxWords], (unsigned long long)__builtin_popcountll(nw));
+    if (dropped) atomicAdd(&ixc[shard * 8u + kIxDropped], (unsigned long long)__builtin_popcountll(dropped));
   }
   bool unsorted = false;               // this thread appended behind other ids: the list needs its order back
   const bool have = active && slot != kNotFound;
@@ -3192,12 +3267,11 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
 template <typename LW>
 __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                     uint32_t epoch, unsigned long long* ixc, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
-                                    const LW* act, SortWl sw, uint32_t* status) {
+                                    const LW* act, SortWl sw, uint32_t* status, const IxLaunch* il) {
   __shared__ unsigned long long s_tmp[4];
-  const IxBudget bud = ix_budget(ixc, limit, slots, n, s_tmp);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act, sw, status);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, il, s_tmp, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act, sw, status);
 }
 
 // thread (r, i): append picks[r] to hash i of request r
@@ -3205,9 +3279,8 @@ template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* ixc, const uint8_t* reqs, uint32_t stride,
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act,
-                                          SortWl sw) {
+                                          SortWl sw, const IxLaunch* il) {
   __shared__ unsigned long long s_tmp[4];
-  const IxBudget bud = ix_budget(ixc, limit, slots, (unsigned long long)n_reqs * max_blocks, s_tmp);
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
   bool active = r < n_reqs;
@@ -3224,7 +3297,7 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
   }
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, bud, h, (uint32_t)pick, active, act, sw, status);
+  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, il, s_tmp, h, (uint32_t)pick, active, act, sw, status);
 }
 
 #ifdef EPPK_MAIN_UNIT

@@ -68,7 +68,8 @@ int main(int argc, char** argv) {
   uint8_t* d_rows; int32_t* d_picks;
   CK(hipMalloc((void**)&d_rows, (size_t)R * stride)); CK(hipMalloc((void**)&d_picks, R * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*, eppk::SortWl);
+  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*, eppk::SortWl, const eppk::IxLaunch*);
+  eppk::IxLaunch* d_ixl; CK(hipMalloc((void**)&d_ixl, sizeof(eppk::IxLaunch)));
   uint32_t* d_wl; const uint32_t wl_cap = R * B; CK(hipMalloc((void**)&d_wl, (4u + (size_t)wl_cap) * 4u)); CK(hipMemset(d_wl, 0, 16));
   uint32_t sort_uses = 0;
   hipEvent_t e2; CK(hipEventCreate(&e2));
@@ -81,8 +82,9 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     const eppk::SortWl sw{d_wl, wl_cap, sort_uses & 1u};
     ++sort_uses;
+    hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, 0, ixc, limit, slots, (unsigned long long)total, d_ixl);
     hipLaunchKernelGGL(kern, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
-                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw);
+                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl);
     CK(hipEventRecord(e1));
     hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));

@@ -70,3 +70,36 @@ def test_other_baseline_configs_at_full_size(pkg, orc, config):
         picks, scores = pk.pick(wl.reqs)
         op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, threads=cores)
         _same(picks, scores, op, osc, wl.name)
+
+
+def test_a_table_past_half_of_its_limit_keeps_the_fast_insert_path(pkg):
+    """The capacity test of the index update is per LAUNCH when every pair of the launch fits as a new key; otherwise every new key is
+    BOOKED (one sharded atomic) before it is claimed, and the launch admits exactly what was left -- a post-route update into a table
+    more than half-way to its limit used to cost 7 x the time of the same update into a roomy one (every new key read all the counters).
+    The same three updates go into a table they fill to 3/4 of its limit and into one eight times as large: same index sizes, nothing
+    dropped, and the last update -- the one that no longer fits launch-wide -- within 1.5 x of the roomy table's."""
+    import torch
+    R = 32768
+    wl = pkg.workload.make_workload(5, R=R)
+    batches = [wl.reqs] + [pkg.workload.make_requests(wl, 900 + i) for i in range(2)]
+    times, sizes = {}, {}
+    for name, slots in (("tight", 1 << 22), ("roomy", 1 << 25)):
+        with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=slots) as pk:
+            pk.publish(wl.pods)
+            pk.index_insert(wl.index_hashes, wl.index_pods)
+            d_batches = [torch.from_numpy(b.view(np.int64)).cuda() for b in batches]
+            d_pick = torch.zeros(R, dtype=torch.int32, device="cuda")           # every request "routed" to pod 0
+            st = torch.cuda.Stream()
+            ts = []
+            for rep in range(3):                                                # (the third batch is what is timed; repeat it as known pairs for a steadier figure)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                pk.index_insert_picks_device(d_batches[rep].data_ptr(), d_pick.data_ptr(), R, st.cuda_stream)
+                e1.record(st)
+                st.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            times[name], sizes[name] = ts, pk.index_size()
+            assert pk.index_dropped() == 0 and pk.launch_status() == 0 and pk.index_selfcheck() == 0
+    # tight: limit 2 Mi keys; 4096 + 3 x 512 Ki = 1.5 Mi keys at the end, and the third launch's 1 Mi pairs no longer fit launch-wide
+    assert sizes["tight"] == sizes["roomy"] == 4096 + 3 * R * 16
+    assert times["tight"][2] <= 1.5 * times["roomy"][2] + 0.05, times
