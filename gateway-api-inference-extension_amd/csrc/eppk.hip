@@ -147,8 +147,9 @@ struct eppk_ctx {
   // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>
   // (eppk_kernels.hip.h: KWork)
   bool quad_on = true;            // EPPK_QUAD=0 switches it off (every request through pick_fast_kernel)
-  uint32_t quad_min = 24576;      // smallest batch that takes the route (EPPK_QUAD_MIN overrides): below ~20k requests the second launch
-                                  // costs more than the leaner kernel saves (8k x 1024: 16.7 vs 10.5 us per step, measured)
+  uint32_t quad_min = 4096;       // smallest batch that takes the route (EPPK_QUAD_MIN overrides).  With a second launch behind every batch
+                                  // the route only paid off from ~24k requests on; in its one-launch form it wins from 4k on (C5 rows, us
+                                  // per step, fast kernel vs quad: 4k 6.8 / 5.9, 8k 8.4 / 6.7, 16k 12.2 / 9.1: profiles/r03_j_quad_min.txt)
   uint32_t quad_threads = 512;    // EPPK_QUAD_THREADS overrides (tuning knob; <= the kernel's launch bound)
   // One work-list buffer per STREAM that has launched picks (launches of one stream are ordered, so a buffer is never written
   // while an earlier launch still reads it; launches of different streams never share one).  More than kDeferSets distinct streams:
@@ -163,6 +164,9 @@ struct eppk_ctx {
   uint64_t rep_unread = 0;                     // first launch whose report has not been consumed
   uint32_t quad_backoff = 0, quad_backoff_len = 0;
   uint32_t wl_hint = 0xFFFFFFFFu;   // decaying maximum of the recent launches' deferred counts (0xFFFFFFFF: no report seen yet): sizes the work-list pass
+  bool quad_tail_on = true;         // EPPK_QUAD_TAIL=0: always the two-launch form (pick_quad_kernel + work-list pass)
+  uint64_t quad_tail_launches = 0;  // launches that took the one-launch form (pick_quad_kernel<TAIL>)
+  bool quad_tail_warm = false;      // the one-launch form has been launched once (empty): its first real launch pays neither module load nor scratch set-up
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
   const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
   const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
@@ -333,14 +337,27 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const void* quad_fn = nullptr;
   uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0, rep_slot = 0;
   size_t quad_lds = 0;
+  // ONE launch (pick_quad_kernel<TAIL>: its last workgroup scores the deferred requests itself) while the recent launches deferred
+  // next to nothing -- a single workgroup is no match for a work list of hundreds of requests -- else the two-launch form.  Unmasked
+  // picks only.  Until the first report is in, the two-launch form (whose work-list pass copes with anything).
+  bool tail = false;
   if (quad) {
     const bool tkq = topk > 1;
-    quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked, tkq)
-                                                                                                          : eppk::pick_quad_u64(c->has_l, c->p_first, masked, tkq);
     const uint32_t qwpb = c->quad_threads / 64u;
+    tail = c->quad_tail_on && !masked && !tkq && c->wl_hint != 0xFFFFFFFFu && c->wl_hint <= 4u * qwpb;
+    if (tail)
+      quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first)
+                                                                                                   : eppk::pick_quad_tail_u64(c->has_l, c->p_first);
+    else
+      quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked, tkq)
+                                                                                                            : eppk::pick_quad_u64(c->has_l, c->p_first, masked, tkq);
     // LDS: base[] | lw[4] | pterm | one "listed" bit per pod for each of the 4 rows of each wavefront
     //      (masked: + the snapshot's three natural-layout sets + the candidate words of each row)
     quad_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 4u * sn.J * 8u + (masked ? 192u * 8u + (size_t)qwpb * 4u * sn.J * 8u : 0u);
+    if (tail) {     // ... or the fast kernel's layout for a workgroup of this size, whichever is larger: base | lw | pterm | scratch | histogram
+      const size_t fast_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 64u * (size_t)c->lw_bytes + (size_t)qwpb * sn.J * 64u;
+      if (fast_lds > quad_lds) quad_lds = fast_lds;
+    }
     if (quad_fn != c->quad_occ_fn || quad_lds != c->quad_occ_lds) {
       HIPCHK(c, hipFuncSetAttribute(quad_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds));
       int per_cu = 0;
@@ -356,13 +373,13 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     if (quad_grid < 1) quad_grid = 1;
     quad_segs = quad_grid * qwpb;
     defer_cap = 4u * ((nblk + quad_segs - 1) / quad_segs);
-    const size_t words = 16u + (size_t)quad_segs + (size_t)quad_segs * defer_cap;
+    const size_t words = 32u + (size_t)quad_segs + (size_t)quad_segs * defer_cap;     // header: total[2] | done counters[17] (TAIL) | cnt | list
     if (words > dset->words) {             // grow this stream's buffer (rare: its first launch, or a larger batch than ever before)
       HIPCHK(c, hipStreamSynchronize(st));
       if (dset->d) HIPCHK(c, hipFree(dset->d));
       dset->d = nullptr; dset->words = 0;
       HIPCHK(c, hipMalloc((void**)&dset->d, words * 4u));
-      HIPCHK(c, hipMemsetAsync(dset->d, 0, 64, st));  // the two total counters -- on the LAUNCH stream: a null-stream memset is not ordered
+      HIPCHK(c, hipMemsetAsync(dset->d, 0, 128, st)); // the two total counters and the done counters -- on the LAUNCH stream: a null-stream memset is not ordered
                                                        // ahead of kernels on a non-blocking stream (the first launch of a stream could read a
                                                        // garbage total: found when the work-list pass got faster, tests/test_gpu_quad.py)
       dset->words = words; dset->uses = 0;
@@ -399,10 +416,42 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       uint32_t* d_total = dset->d + (dset->uses & 1u);
       uint32_t* d_total_next = dset->d + ((dset->uses + 1u) & 1u);
       ++dset->uses;
-      uint32_t* d_cnt = dset->d + 16;
-      uint32_t* d_list = dset->d + 16 + quad_segs;
+      uint32_t* d_cnt = dset->d + 32;
+      uint32_t* d_list = dset->d + 32 + quad_segs;
+      uint32_t* d_done = dset->d + 2;       // TAIL: workgroups that have reported in (back to zero when the launch ends)
+      if (!tail && c->quad_tail_on && !masked && topk == 1 && !c->quad_tail_warm) {
+        // The library will switch to the one-launch form as soon as a report says the batches defer next to nothing.  That kernel's
+        // first launch costs about a millisecond (code object, scratch set-up, occupancy query): pay it now, with an EMPTY launch
+        // behind which the real one queues, instead of in the middle of the caller's steady state (a 20-step measurement saw 70 us
+        // per step instead of 17).
+        c->quad_tail_warm = true;
+        const void* tfn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first)
+                                                                                                            : eppk::pick_quad_tail_u64(c->has_l, c->p_first);
+        const uint32_t qwpb = c->quad_threads / 64u;
+        size_t tl_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 64u * (size_t)c->lw_bytes + (size_t)qwpb * sn.J * 64u;
+        if (tl_lds < quad_lds) tl_lds = quad_lds;
+        HIPCHK(c, hipFuncSetAttribute(tfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds));
+        uint32_t zero_reqs = 0u;
+        uint32_t* w_total = dset->d + 20; uint32_t* w_next = dset->d + 21;     // (spare header words: the warm-up must not touch the real counters)
+        uint32_t* w_rep = (uint32_t*)&c->h_reports[kReportRing];
+        void* wargs[] = {&sn, &ix, &tl, &reqs8, &stride, &zero_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &w_total, &w_next,
+                         &topk, &d_done, &w_rep};
+        HIPCHK(c, hipExtLaunchKernel(tfn, dim3(1), dim3(c->quad_threads), wargs, tl_lds, st, nullptr, nullptr, 0));
+      }
+      uint32_t* h_rep = (uint32_t*)&c->h_reports[rep_slot];
       void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next,
-                       &topk};
+                       &topk, &d_done, &h_rep};
+      if (tail) {                           // one launch: the kernel's last workgroup is the work-list pass
+        HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, e1, 0));
+        ++c->quad_tail_launches;
+        c->last_done = e1;
+        c->last_stream = st;
+        if (prof_now) {
+          c->fixed_bytes += (uint64_t)c->n_pods * sizeof(eppk_pod_row) + (uint64_t)n_reqs * ((uint64_t)c->stride + 4u);
+          c->launches++;
+        }
+        return EPPK_OK;
+      }
       HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, nullptr, 0));
       e0 = nullptr;                         // (the pair is timed from the quad kernel's start to the work-list kernel's end)
       wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = (uint32_t*)&c->h_reports[rep_slot]; wk.cap = defer_cap; wk.n_segs = quad_segs;
@@ -667,12 +716,13 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
+  if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
   if (const char* qt = getenv("EPPK_QUAD_THREADS")) {
     const int v = atoi(qt);
     if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;
   }
-  CHK(hipHostMalloc((void**)&c->h_reports, kReportRing * sizeof(uint32_t), hipHostMallocDefault));
-  for (uint32_t i = 0; i < kReportRing; ++i) c->h_reports[i] = 0u;
+  CHK(hipHostMalloc((void**)&c->h_reports, (kReportRing + 1u) * sizeof(uint32_t), hipHostMallocDefault));   // (+ 1: the word the warm-up launch reports to)
+  for (uint32_t i = 0; i <= kReportRing; ++i) c->h_reports[i] = 0u;
   c->lw_bytes = cfg->max_pods <= 1024 ? 2 : cfg->max_pods <= 2048 ? 4 : 8;
   c->npl = cfg->max_blocks <= 63 ? 6 : 9;
   c->pwn = (cfg->max_blocks + 2u) & ~1u;

@@ -781,23 +781,30 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 // Issue order inside an iteration is rows(r) -> keys(r+1) -> row(r+2): vmcnt retires loads in order, so everything the
 // current request waits for is queued AHEAD of the loads that serve later requests.
 // WL (work-list) instantiations: the same kernel over the requests pick_quad_kernel deferred (KWork) instead of 0 .. n_reqs - 1.
+// The kernel's body as a function of a VIRTUAL grid position: pick_fast_kernel calls it with its own block index and grid size;
+// pick_quad_kernel<..., TAIL> calls the work-list form from the LAST of its workgroups to finish, as a grid of one (`tail`), over
+// what the whole launch deferred -- no second launch behind the common batch that defers nothing.  smem: the dynamic LDS of the
+// calling kernel (the layout below); stat_base: first probe-statistics slot of this grid's wavefronts.
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false>
-__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
-                                                        uint32_t stride, uint32_t n_reqs, uint32_t pwn,
-                                                        const uint64_t* __restrict__ cand_mask, KChain ch,
-                                                        int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                        unsigned long long* __restrict__ stats, uint32_t topk, KWork wk) {
+__device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint32_t vgrid, const uint32_t stat_base, const bool tail, unsigned char* smem,
+                                               const KSnap& sn, const KIndex& ix, const KTail& tl, const uint8_t* __restrict__ reqs,
+                                               uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                               const uint64_t* __restrict__ cand_mask, const KChain& ch,
+                                               int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                               unsigned long long* __restrict__ stats, uint32_t topk, const KWork& wk) {
+  // (the work list is read with agent-scope loads: in the tail form its writers are other workgroups of the SAME launch, possibly
+  // on another XCD, whose stores went through to memory -- pick_quad_kernel -- but not into this XCD's L2)
+  auto wl_word = [](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   if constexpr (WL) {
-    const uint32_t total = *wk.total;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *wk.report = total;
+    const uint32_t total = wl_word(wk.total);
+    if (!tail && vblock == 0 && threadIdx.x == 0) *wk.report = total;
     if (total == 0u) return;                               // nothing was deferred: done before any staging
     // a workgroup none of whose wavefronts owns a segment with work leaves as well
     uint32_t mine = 0;
-    const uint32_t nw_ = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); seg < wk.n_segs; seg += nw_) mine |= wk.cnt[seg];
+    const uint32_t nw_ = vgrid * (blockDim.x >> 6);
+    for (uint32_t seg = vblock * (blockDim.x >> 6) + (threadIdx.x >> 6); seg < wk.n_segs; seg += nw_) mine |= wl_word(&wk.cnt[seg]);
     if (!__syncthreads_or((int)mine)) return;
   }
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;      // [4] LoRA tier terms (an LDS look-up keeps the evaluation loop branch-free)
   double* s_pterm = s_lw + 4;
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t wpb = blockDim.x >> 6;
   // wave-uniform ids in SGPRs: every per-request address below is scalar arithmetic
-  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vblock * wpb + (threadIdx.x >> 6)));
+  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vgrid * wpb));
   // Buffer descriptors (gfx9 word 3: 32-bit data format).  Small index (< 4 GiB): ONE raw descriptor over rows + keys (one
   // allocation, rows first), rows addressed by SGPR byte offsets.  BIG: the rows through wave-uniform 64-bit
   // bases (RowSrc) and a raw descriptor over the keys.  Plus the snapshot tables and the request rows: every hot-loop load is
@@ -1523,10 +1530,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
   if constexpr (WL) {
     // the segments the quad kernel's wavefronts left behind: seg = gwave, gwave + nwaves, ...; the same pipeline inside a segment
     for (uint32_t seg = gwave; seg < wk.n_segs; seg += nwaves) {
-      const uint32_t len = wk.cnt[seg];
+      const uint32_t len = wl_word(&wk.cnt[seg]);
       if (len == 0u) continue;
       const uint32_t* sl = wk.list + (size_t)seg * wk.cap;
-      auto req_at = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)sl[j < len ? j : len - 1u]); };   // (past the end: the last row again, never used)
+      auto req_at = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)wl_word(&sl[j < len ? j : len - 1u])); };   // (past the end: the last row again, never used)
       uint32_t r0 = req_at(0u), r1 = req_at(1u);
       issue_row(r0, r0, qa);
       issue_row(r1, r1, qb);
@@ -1559,11 +1566,24 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 #endif
   // probe statistics: one private slot per wavefront (plain read-modify-write; same-address atomics
   // from ~10^4 waves serialise at ~12 ns each and would add >100 us of tail to the launch)
-  if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && gwave < kStatSlots) {
-    stats[4 + 2 * gwave] += w_hits;
-    stats[5 + 2 * gwave] += w_lookups;
+  if (HAS_P && stats && lane == 0 && (w_hits | w_lookups) && stat_base + gwave < kStatSlots) {
+    stats[4 + 2 * (stat_base + gwave)] += w_hits;
+    stats[5 + 2 * (stat_base + gwave)] += w_lookups;
   }
 }
+
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false>
+__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fast_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+                                                        uint32_t stride, uint32_t n_reqs, uint32_t pwn,
+                                                        const uint64_t* __restrict__ cand_mask, KChain ch,
+                                                        int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                                        unsigned long long* __restrict__ stats, uint32_t topk, KWork wk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  pick_fast_body<LW, NPL, HAS_L, HAS_P, P_FIRST, MASKED, BIG, GEN, TOPK, WL>(blockIdx.x, gridDim.x, 0u, false, smem, sn, ix, tl, reqs, stride, n_reqs, pwn, cand_mask, ch,
+                                                                              out_pick, out_score, stats, topk, wk);
+}
+
+
 
 // ---- QUAD pick kernel: FOUR requests per wavefront, every gather laid out for the vector memory pipe ------------------------
 // pick_fast_kernel spends a whole wavefront on one request (~180 vector + ~145 scalar instructions per decision).  The common
@@ -1621,13 +1641,21 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 // lanes -- the listed pods' totals (ids 4q + j and 16 + 4q + j) and the 16 table entries that are not listed -- so round i of the
 // merge is one more row argmax over each lane's best remaining candidate; the winner leaves the pool.  A round that finds the table's
 // pool empty although the table goes on beyond its 16th entry cannot know the next value: deferred.
-template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false>
+// TAIL: no second launch.  Every workgroup reports in on a counter when it is done; the LAST one to arrive reads what the whole launch
+// deferred and -- in the common case, nothing -- writes the report and leaves; otherwise it runs the work-list form of
+// pick_fast_kernel's body itself, as a grid of one (pick_fast_body: the LDS of this workgroup is re-staged in that kernel's layout).
+// A second launch behind every batch cost 4-10 us of a 14 us pick although it had nothing to do: its workgroups cannot start before
+// this kernel's persistent wavefronts leave (all 512 VGPRs per SIMD are theirs), and the host pays for two launches per batch.  The
+// library takes this form while the recent launches deferred next to nothing, and the two-launch form otherwise (a single
+// workgroup is no match for a work list of hundreds of requests).
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false>
 __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                                  uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                                  int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                                  unsigned long long* __restrict__ stats,
                                                                  uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk) {
+                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk,
+                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -2070,7 +2098,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
           acc_look += (m + 1u < nb) ? m + 1u : nb;
         }
       } else {
-        my_list[n_def + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull))] = r;
+        __hip_atomic_store(&my_list[n_def + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull))], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (through to memory: TAIL)
       }
     }
     n_def += (uint32_t)__builtin_popcountll(dm);
@@ -2092,23 +2120,25 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     for (uint32_t i = threadIdx.x; i < 192u; i += blockDim.x) s_nat[i] = sn.nat[i];
   __syncthreads();
   if (idle) {
-    if (lane == 0) defer_cnt[gwave] = 0u;
-    return;
+    if (lane == 0) __hip_atomic_store(&defer_cnt[gwave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (!TAIL) return;
   }
+  if (!idle) {
 #if EPPK_QUAD_PIPE_KEYS
-  issue_keys(qa, pb);
+    issue_keys(qa, pb);
 #endif
-  for (uint32_t blk = gwave; blk < nblk; blk += 2u * nwaves) {
-    process(blk, qa, qb, pb);
-    if (blk + nwaves >= nblk) break;
-    process(blk + nwaves, qb, qa, pb);
-  }
+    for (uint32_t blk = gwave; blk < nblk; blk += 2u * nwaves) {
+      process(blk, qa, qb, pb);
+      if (blk + nwaves >= nblk) break;
+      process(blk + nwaves, qb, qa, pb);
+    }
 #if EPPK_QUAD_PREFETCH > 0
-  asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
+    asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
 #endif
-  if (lane == 0) {
-    defer_cnt[gwave] = n_def;
-    if (n_def) atomicAdd(defer_total, n_def);
+    if (lane == 0) {
+      __hip_atomic_store(&defer_cnt[gwave], n_def, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n_def) atomicAdd(defer_total, n_def);
+    }
   }
   if (stats && gwave < kStatSlots) {
     const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 0) + (uint32_t)__builtin_amdgcn_readlane((int)acc_hits, 16) +
@@ -2116,6 +2146,43 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 0) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 16) +
                         (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 48);
     if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
+  }
+  if constexpr (TAIL) {
+    // this wavefront's part of the work list has reached memory (agent-scope stores, acknowledged) before the workgroup reports in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // "Who is last?" in two levels -- the persistent workgroups all finish within a microsecond of each other, and 512 atomics on ONE
+    // word queue up for 6 us: 16 group counters (done_ctr[1 + (block & 15)]), the workgroup that completes its group bumps the top
+    // counter (done_ctr[0]), the one that completes that is the last of the launch.
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+      const uint32_t grp = blockIdx.x & 15u, n_grp = gridDim.x < 16u ? gridDim.x : 16u;
+      const uint32_t in_grp = (gridDim.x - grp + 15u) / 16u;                            // workgroups with this group number
+      uint32_t last = 0u;
+      if (atomicAdd(&done_ctr[1u + grp], 1u) == in_grp - 1u) {
+        __hip_atomic_store(&done_ctr[1u + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for this buffer set's next launch)
+        if (atomicAdd(&done_ctr[0], 1u) == n_grp - 1u) {
+          __hip_atomic_store(&done_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = 1u;
+        }
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const uint32_t total = __hip_atomic_load(defer_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef EPPK_DBG_TAIL_NO_REPORT      // (timing experiment: what the write to host memory costs the kernel's end)
+    if (threadIdx.x == 0u && total != 0u) *report = total;
+#else
+    if (threadIdx.x == 0u) *report = total;                                            // (pinned host word: the library's feedback)
+#endif
+    if (total == 0u) return;
+    __syncthreads();                           // (every wavefront is done with the LDS of the quad layout)
+    KWork wk;
+    wk.cnt = defer_cnt; wk.list = defer_list; wk.total = defer_total; wk.report = report; wk.cap = defer_cap; wk.n_segs = gridDim.x * wpb;
+    const KChain no_chain{};                   // (MASKED tails would need the chain for their exact evaluation: not instantiated)
+    pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true>(
+        0u, 1u, gridDim.x * wpb, true, smem, sn, ix, tl, reqs, stride, n_reqs, pwn, cand_mask, no_chain, out_pick, out_score, stats, topk, wk);
   }
 }
 

@@ -419,10 +419,11 @@ int eppk_chain_is_fused(const eppk_ctx* ctx);
 /* Diagnostic.  Unmasked single-pick batches of a fused chain with a PREFIX scorer (max_blocks <= 63) go through the
  * four-requests-per-wavefront kernel first (csrc/eppk_kernels.hip.h: pick_quad_kernel); a request outside its common shape
  * (differing or overflowed pod lists, more than 32 cached blocks, reserved hashes, an out-of-range row ...) is DEFERRED to the general
- * kernel, launched right behind it on the same stream -- same picks and scores either way.  Synchronises the device and returns
- * how many pick launches took that route and how many requests they deferred.  (Environment: EPPK_QUAD=0 switches the route off;
- * EPPK_QUAD_MIN = smallest batch that takes it, default 24576 requests -- below that the second launch costs more than the leaner
- * kernel saves.  A workload that keeps deferring a large part of its batches pauses it by itself.) */
+ * kernel -- by the LAST workgroup of the same launch while the recent batches deferred next to nothing (the one-launch form), by a
+ * second launch right behind it on the same stream otherwise -- same picks and scores either way.  Synchronises the device and
+ * returns how many pick launches took that route and how many requests they deferred.  (Environment: EPPK_QUAD=0 switches the route
+ * off; EPPK_QUAD_MIN = smallest batch that takes it, default 4096 requests; EPPK_QUAD_TAIL=0 keeps the two-launch form.  A workload
+ * that keeps deferring a large part of its batches pauses the route by itself.) */
 int eppk_quad_stats(eppk_ctx* ctx, uint64_t* launches, uint64_t* deferred);
 
 /* Enabling resets the event ring, the launch counter and the probe statistics.  While enabled,

@@ -26,7 +26,7 @@ class quad_env:
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in ("EPPK_QUAD", "EPPK_QUAD_MIN")}
         os.environ["EPPK_QUAD"] = "1" if self.on else "0"
-        os.environ["EPPK_QUAD_MIN"] = "4"                    # (by default only batches of 24576 requests and more take the route)
+        os.environ["EPPK_QUAD_MIN"] = "4"                    # (by default only batches of 4096 requests and more take the route)
 
     def __exit__(self, *a):
         for k, v in self.old.items():
