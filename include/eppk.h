@@ -150,7 +150,11 @@ int eppk_index_clear(eppk_ctx* ctx);
 /* "hash(chunk i): append s" for n (hash, pod) pairs. */
 int eppk_index_insert(eppk_ctx* ctx, const uint64_t* hashes, const uint32_t* pods, uint32_t n);
 /* Post-pick update on device: for every request r with picks[r] >= 0 append picks[r] to each of
- * its n_blocks hashes.  d_reqs / d_picks are DEVICE pointers (see eppk_pick_batch_device). */
+ * its n_blocks hashes.  d_reqs / d_picks are DEVICE pointers (see eppk_pick_batch_device).  Three launches on `stream`: the
+ * capacity verdict of the update, the update, and a pass that puts the pod lists it touched back into ascending order (equal pod
+ * sets are then equal 64-byte lines again, which the pick kernels' fast routes test bit for bit).  Index updates of one context --
+ * this call, eppk_index_evict_older_device, the synchronous entry points -- must be ORDERED with respect to each other (one
+ * stream, or events between streams): they share the update's work list and capacity counters. */
 int eppk_index_insert_picks_device(eppk_ctx* ctx, const void* d_reqs, const int32_t* d_picks,
                                    uint32_t n_reqs, void* stream);
 /* Drop pod from every entry (endpoint deleted / cache flushed). */
@@ -161,8 +165,11 @@ int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
  * eppk_index_insert reports them as EPPK_ERR_INDEX_FULL; the asynchronous eppk_index_insert_picks_device cannot, so a shim
  * polls this counter (and grows or ages the index). */
 int eppk_index_dropped(eppk_ctx* ctx, uint64_t* n_dropped);
-/* Diagnostic: number of index rows that violate an internal invariant (present hash with an empty pod set, pod set left
- * behind a removed hash, short pod list out of step with its dense row).  0 on a healthy index; synchronous full scan. */
+/* Diagnostic: number of index slots that violate an internal invariant: a present hash with an empty pod set, a pod set left behind
+ * a removed hash, a pod list that is not strictly ascending / holds an id twice / has entries behind its count, a set of at most
+ * 24 pods that is not in its list (or whose dense row is not all-zero), a dense row with fewer than 25 pods, a bucket header whose
+ * "moved to its dense row" bit disagrees with the list.  0 on a healthy index; synchronous full scan.  EPPK_SELFCHECK_VERBOSE in
+ * the environment prints the first eight offenders to stderr. */
 int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
 /* Ageing -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)", 0602-…/README.md:82.
  * Every insert (eppk_index_insert, eppk_index_insert_picks_device) stamps its hashes with the context's index epoch
