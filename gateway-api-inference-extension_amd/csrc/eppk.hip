@@ -322,7 +322,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   // pick_quad_kernel first (four requests per wavefront: the common shape of a request), then the fast kernel's work-list
   // instantiation over what it deferred.  Skipped for a while when a recent launch deferred a large part of its batch (a workload
   // of differing or overflowed lists: the quad pass is wasted on it); the pause doubles while that keeps happening.
-  bool quad = fast && c->quad_on && (topk == 1 || !masked) /* ordered fallbacks: unmasked batches only */ && c->has_p && c->npl == 6 && !c->gen &&
+  bool quad = fast && c->quad_on && c->has_p && c->npl == 6 && !c->gen &&
               c->pterm && ix.lists && ix.slots != 0u && c->cfg.max_blocks >= 1 && n_reqs >= c->quad_min;
   if (quad) quad_consume_reports(c);
   if (quad && c->quad_backoff) { --c->quad_backoff; quad = false; }
@@ -457,7 +457,10 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       wk.cnt = d_cnt; wk.list = d_list; wk.total = d_total; wk.report = (uint32_t*)&c->h_reports[rep_slot]; wk.cap = defer_cap; wk.n_segs = quad_segs;
       // the work-list instantiation of the same fast kernel (same LDS, same geometry)
       const bool big = c->slots != 0 && c->index_bytes >= (1ull << 32);
-      if (topk > 1)
+      if (topk > 1 && masked)
+        fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_topk_masked_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_fast_wl_topk_masked_u32(c->has_l, c->p_first)
+                                                                                                            : eppk::pick_fast_wl_topk_masked_u64(c->has_l, c->p_first);
+      else if (topk > 1)
         fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_topk_u16(c->has_l, c->p_first, big) : c->lw_bytes == 4 ? eppk::pick_fast_wl_topk_u32(c->has_l, c->p_first, big)
                                                                                                           : eppk::pick_fast_wl_topk_u64(c->has_l, c->p_first, big);
       else

@@ -1912,8 +1912,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     const uint32_t top_p = k + arow;
 #else
     const u32x4_t te = __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)(arow * 256u + k * 16u), (int)SnapOff<LW>::top16, 0);   // entry k: {T, pod}
-    const double top_t = __hiloint2double((int)te.y, (int)te.x);
-    const uint32_t top_p = te.z;
+    double top_t = __hiloint2double((int)te.y, (int)te.x);            // (TOPK: a row whose pool runs dry loads the table's next 16 entries into these)
+    uint32_t top_p = te.z;
 #endif
     u32x4_t mk0 = (u32x4_t)(0u), mk1 = (u32x4_t)(0u);
     if (MASKED) {     // words 4k .. 4k+3 of the request's candidate row (a read past the last row returns zeros: buffer range)
@@ -2025,15 +2025,36 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     bool tok = tpv && !((bits[tq >> 5] >> (tq & 31u)) & 1u);         // entry k exists and is not listed
     if (MASKED) tok = tok && ((s_cn[tq >> 6] >> (tq & 63u)) & 1ull);  // ... and is a candidate of this request
     wave_lds_fence();
-    if (lsA) bits[pA >> 5] = 0u;
-    if (anyB && lsB) bits[pB >> 5] = 0u;
-    const uint32_t tvr = row16(__ballot(tpv));
+    if (!TOPK) {                                                      // (TOPK keeps the bitmap until its rounds are over: refills look entries up)
+      if (lsA) bits[pA >> 5] = 0u;
+      if (anyB && lsB) bits[pB >> 5] = 0u;
+    }
+    uint32_t tvr = row16(__ballot(tpv));
     if constexpr (TOPK) {
       // ---- ordered fallbacks: topk rounds of a row argmax over every lane's best remaining candidate
       bool vA = lsA, vB = lsB, vT = tok;
       const uint32_t tk = topk;
+      uint32_t tbase = 0u;                                            // first table entry of the window this row's lanes hold
       for (uint32_t round = 0; round < tk; ++round) {
-        badm |= __ballot(row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand);   // the table's pool is empty but the table goes on: entry 17.. is unknown
+        // The table's pool is empty but the table goes on (with candidate masks half of a window's entries are no candidates, and every
+        // round may take one): the row loads the NEXT 16 entries (of 64) and looks them up in the listed bitmap and the candidate row --
+        // a request used to be deferred to the dense route for that, 20-odd us each.  Beyond entry 64: deferred after all.
+        for (int refill = 0; refill < 3; ++refill) {
+          const bool dry = row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand && tbase < 48u;   // (the table holds 64 entries)
+          if (!__any(dry)) break;
+          if (dry) {
+            tbase += 16u;
+            top_t = __longlong_as_double((long long)buffer_load_u64(rsn, (tbase + k) * 8u, SnapOff<LW>::topv + arow * 512u));
+            top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)((tbase + k) * 4u), (int)(SnapOff<LW>::topi + arow * 256u), 0);
+            const bool ex = top_p != kNoPod;
+            const uint32_t tq2 = ex ? top_p : 0u;
+            vT = ex && !((bits[tq2 >> 5] >> (tq2 & 31u)) & 1u);
+            if (MASKED) vT = vT && ((s_cn[tq2 >> 6] >> (tq2 & 63u)) & 1ull);
+          }
+          const uint32_t tv2 = row16(__ballot(top_p != kNoPod));
+          if (dry) tvr = tv2;                                         // (a full window: the table may go on)
+        }
+        badm |= __ballot(row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
         double lb = vA ? tA : -__builtin_inf();
         uint32_t lp = vA ? pA : kNoPod;
         if (vB && (tB_keep > lb || (tB_keep == lb && pB < lp))) { lb = tB_keep; lp = pB; }
@@ -2057,6 +2078,9 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
         if (vB && pB == wi) vB = false;
         if (vT && top_p == wi) vT = false;
       }
+      wave_lds_fence();
+      if (lsA) bits[pA >> 5] = 0u;
+      if (anyB && lsB) bits[pB >> 5] = 0u;
     }
     double wmax = best;
     uint32_t widx = kNoPod;

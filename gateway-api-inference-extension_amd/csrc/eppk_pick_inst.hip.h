@@ -20,7 +20,7 @@ const void* pick_kernel_u64_6(const PickVariant& v);
 const void* pick_kernel_u64_9(const PickVariant& v);
 // pick_quad_kernel (four requests per wavefront; prefix scorer present, <= 63 blocks, no interpreted tail) and the work-list
 // instantiation of the fast kernel that scores what it defers; defined in eppk_pick_quad.hip / eppk_pick_wl.hip
-const void* pick_quad_u16(bool has_l, bool p_first, bool masked, bool topk);     // (masked && topk: no instantiation, nullptr)
+const void* pick_quad_u16(bool has_l, bool p_first, bool masked, bool topk);
 const void* pick_quad_u32(bool has_l, bool p_first, bool masked, bool topk);
 const void* pick_quad_u64(bool has_l, bool p_first, bool masked, bool topk);
 const void* pick_quad_tail_u16(bool has_l, bool p_first);                         // unmasked picks, no second launch (eppk_pick_quad_tail.hip)
@@ -29,6 +29,9 @@ const void* pick_quad_tail_u64(bool has_l, bool p_first);
 const void* pick_fast_wl_topk_u16(bool has_l, bool p_first, bool big);          // work-list instantiations with ordered fallbacks (eppk_pick_wl_topk.hip)
 const void* pick_fast_wl_topk_u32(bool has_l, bool p_first, bool big);
 const void* pick_fast_wl_topk_u64(bool has_l, bool p_first, bool big);
+const void* pick_fast_wl_topk_masked_u16(bool has_l, bool p_first);               // ... with candidate masks as well (eppk_pick_wl_topk_masked.hip)
+const void* pick_fast_wl_topk_masked_u32(bool has_l, bool p_first);
+const void* pick_fast_wl_topk_masked_u64(bool has_l, bool p_first);
 const void* pick_fast_wl_u16(bool has_l, bool p_first, bool big, bool masked);
 const void* pick_fast_wl_u32(bool has_l, bool p_first, bool big, bool masked);
 const void* pick_fast_wl_u64(bool has_l, bool p_first, bool big, bool masked);

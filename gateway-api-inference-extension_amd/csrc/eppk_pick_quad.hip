@@ -11,7 +11,7 @@ static const void* quad_ptr(bool has_l, bool p_first) {
 }
 template <typename LW>
 static const void* quad_ptr(bool has_l, bool p_first, bool masked, bool topk) {
-  if (masked) return topk ? nullptr : quad_ptr<LW, true, false>(has_l, p_first);
+  if (masked) return topk ? quad_ptr<LW, true, true>(has_l, p_first) : quad_ptr<LW, true, false>(has_l, p_first);
   return topk ? quad_ptr<LW, false, true>(has_l, p_first) : quad_ptr<LW, false, false>(has_l, p_first);
 }
 const void* pick_quad_u16(bool has_l, bool p_first, bool masked, bool topk) { return quad_ptr<uint16_t>(has_l, p_first, masked, topk); }

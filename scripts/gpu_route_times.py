@@ -51,6 +51,12 @@ def main():
             avg, p99 = timed(pk, lambda: pk._check(pk._lib.eppk_pick_topk_device(pk._ctx, d_reqs.data_ptr(), R, None, k, d_pick.data_ptr(), d_score.data_ptr(),
                                                                                   st.cuda_stream), "topk"), n=30)
             out[f"topk_{k}"] = {"kernel_avg_us": avg * 1e3, "kernel_p99_us": p99 * 1e3}
+        d_mask50 = torch.from_numpy(wl.mask.view(np.int64)).to(dev)
+        for k in (2, 4, 8):                       # ordered fallbacks WITH candidate masks (50 % subsets): pick_quad_kernel<MASKED, TOPK>
+            avg, p99 = timed(pk, lambda: pk._check(pk._lib.eppk_pick_topk_device(pk._ctx, d_reqs.data_ptr(), R, d_mask50.data_ptr(), k, d_pick.data_ptr(),
+                                                                                  d_score.data_ptr(), st.cuda_stream), "topk"), n=30)
+            ql1, qd1 = pk.quad_stats()
+            out[f"mask_50pct_topk_{k}"] = {"kernel_avg_us": avg * 1e3, "kernel_p99_us": p99 * 1e3, "quad_launches_so_far": ql1, "quad_deferred_so_far": qd1}
         pods = wl.pods.copy()
         pods["flags"] = (rng.random(wl.P) < 0.1).astype(np.uint32)
         pk.publish(pods)

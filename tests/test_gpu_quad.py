@@ -333,3 +333,46 @@ def test_unordered_and_learned_lists_stay_on_the_quad_route(pkg, orc):
             ql, qd = pk.quad_stats()
             assert ql == len(batches) and qd == 0, f"{qd} requests left the quad route"
             assert grew > 0 and pk.launch_status() == 0
+
+
+@pytest.mark.parametrize("R,P,k,density", [(1024, 4096, 4, 0.5), (600, 4096, 8, 0.25), (300, 1000, 3, 0.5), (256, 64, 8, 0.5), (640, 2048, 2, 0.5),
+                                           (2048, 4096, 8, 0.12), (512, 96, 8, 0.25), (777, 48, 6, 0.25), (1500, 130, 8, 0.06)])
+def test_ordered_fallbacks_with_candidate_masks(pkg, orc, R, P, k, density):
+    """eppk_pick_topk with a candidate mask per request on the quad route (protocol: ordered fallbacks within the subset hint,
+    docs/proposals/004-endpoint-picker-protocol/README.md:73, request.go:104-133): the merge of listed pods and table entries runs over
+    the request's candidates only; rows without any candidate, rows with fewer than k candidates (padded with EPPK_NO_PICK), rows whose
+    candidates miss the snapshot-wide QUEUE extremes (deferred to the masked work-list pass)."""
+    wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=12, masked=True)
+    rng = np.random.default_rng(R * k + P)
+    W = (P + 63) // 64
+    mask = wl.mask.copy()
+    d = 0.5
+    while d > density * 1.01:                                # every AND with a random word halves the density
+        mask &= rng.integers(0, 2**63, (R, W), dtype=np.uint64) | (rng.integers(0, 2, (R, W), dtype=np.uint64) << np.uint64(63))
+        d *= 0.5
+    mask[3] = 0                                              # no candidate at all
+    for r in range(11, R, 53):                               # two or three candidates: fewer than k
+        keep = rng.choice(P, size=min(P, 2 + (r & 1)), replace=False)
+        mask[r] = 0
+        for p in keep:
+            mask[r, p // 64] |= np.uint64(1) << np.uint64(p % 64)
+    if P % 64:
+        mask[:, -1] &= np.uint64((1 << (P % 64)) - 1)
+    sets = group_sets(wl)
+    calls = pairs_by_pod(sets)
+    oix = orc.OracleIndex()
+    for h, p in calls:
+        oix.insert(h, p)
+    want_p, want_s = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, k, mask)
+    for on in (True, False):
+        with quad_env(on):
+            with pkg.BatchedPicker(wl.chain, max_pods=max(P, 64), max_blocks=wl.B, max_batch=R, index_slots=max(wl.index_slots, 1024)) as pk:
+                pk.publish(wl.pods)
+                for h, p in calls:
+                    pk.index_insert(h, p)
+                got_p, got_s = pk.pick_topk(wl.reqs, k, mask)
+                ql, qd = pk.quad_stats()
+        assert np.array_equal(got_p, want_p), f"quad {on}: {np.count_nonzero(got_p != want_p)} entries differ"
+        assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64))
+        assert (got_p[3] == -1).all()
+        assert (ql, qd < R) == ((1, True) if on else (0, True))
