@@ -8,10 +8,15 @@ kernel -> picks in HBM (+ for N>1 an RCCL all-gather of the per-rank picks).  Wo
 What is timed (and what is not):
   * the timed region ROTATES through `--batches` (default 16) DISTINCT request batches -- 16 x 17.3 MB = 277 MB, more than the
     256 MB Infinity Cache -- so request rows stream from HBM every step (a single resident batch would be served by the cache);
-  * N=1: the whole batch on one GPU.  N>1, `--scaling strong` (default; BASELINE.json configs[4] "request-sharded 8xMI355X with
-    RCCL all-gather of picks"): every step's 64k-request batch is split R/N per rank, the picks are all-gathered so that every
-    rank holds all of them; the same invocation then also times `weak` scaling (every rank scores a whole 64k batch of its own,
-    picks all-gathered) and prints it beside (`"weak": {...}`).  `--scaling weak` makes that the headline instead;
+  * N=1: the whole batch on one GPU.  N>1 (BASELINE.json configs[4] "request-sharded 8xMI355X with RCCL all-gather of picks"):
+    the headline is WEAK scaling -- every rank scores a whole 64k batch per step (the shard size the metric is quoted on; N x 64k
+    requests per step), the picks of all ranks are all-gathered in buckets of 16 batches so that every rank holds all of them;
+    the same invocation then also times STRONG scaling (each step's ONE 64k batch split R/N per rank, a rank's shards of a
+    bucket scored by one launch) and prints it beside (`"strong": {...}`).  `--scaling strong` makes that the headline instead.
+    (Until round 3 strong was the headline: a strong-scaled step is 2 us of kernel per rank at 8 GPUs, so the driver's 20-step
+    timed region -- 0.4 ms on one GPU -- would time one collective's latency and a fence: profiles/r03_y_short_runs.txt.)
+  * the closing fence reads the clock when this rank's device is idle (every step's picks gathered), BEFORE the barrier; the
+    region's time is the MAX of that over the ranks;
   * `--closed-loop`: pick -> eppk_index_insert_picks_device (the post-route index update, SEMANTICS.md §6) -> next, DIFFERENT
     batch, with ageing every `--age-every` steps; its first generations are checked against the oracle at full size.
   * batches are independent, so two of them are in flight (`--inflight 2`: consecutive launches alternate between two streams);
@@ -45,6 +50,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+DBG = os.environ.get("EPPK_BENCH_DBG", "")      # measurement switches of the N > 1 path (nolat / nocast / nogather): timing experiments only
+HOSTTIME = os.environ.get("EPPK_BENCH_HOSTTIME", "0") == "1"   # stderr: where the host's time of a timed region goes (N > 1 path)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMD16; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
@@ -168,6 +175,8 @@ class Runner:
         # N > 1: completion latency of a gather bucket -- a timing event on the compute stream right before the first launch that scores
         # a bucket's batches, one on `comm` behind the collective that delivers their picks to every rank (timed region only)
         self.lat_on, self.lat_start, self.lat_pairs = False, None, []
+        self.host_t = {}
+        self.ev_pool, self.ev_pool_used = [], 0
 
     # -- a timed region ---------------------------------------------------------------------------------------------------
     def setup(self, mode: str, gather_every: int):
@@ -180,8 +189,17 @@ class Runner:
         # (strong scaling with launch groups: four buckets, so that launches run ahead of the collectives that free their buckets)
         want_groups = (mode == "strong" and self.use_dist and not self.closed_loop and gather_every > 1 and self.NB % gather_every == 0
                        and self.n_mine > 0 and not getattr(self.args, "no_launch_groups", False))
-        self.ring = self.pkg.distributed.GatherRing(nbuf=(4 * gather_every if want_groups else 16) if mode == "strong" else 8, gather_every=gather_every)
+        # Four gather buckets in the ring: a launch waits only for the collective that last read ITS bucket (ev_bucket), so launches run
+        # up to three buckets ahead of the collectives.  (The ring used to be one trip of 8 / 16 slots that every compute stream
+        # re-entered only behind the LAST collective of the previous trip: a pipeline bubble per trip -- 35 us per step instead of 21 in a
+        # 20-step run of the weak mode on one GPU, gpurun_out/r3y.)
+        self.ring = self.pkg.distributed.GatherRing(nbuf=4 * gather_every if self.use_dist else 8, gather_every=gather_every)
         NBUF, G = self.ring.nbuf, self.ring.gather_every
+        # weak scaling gathers WHOLE batches (world x G x R picks per bucket: 32 MiB of int32 at 8 GPUs and G = 16).  `--pack16` sends pod
+        # indices below 2^15 as int16 (EPPK_NO_PICK = -1 stays -1), which halves what the collective moves over xGMI -- OFF by default:
+        # the cast is one more small kernel on the collective stream, and on one GPU every such kernel between the persistent pick
+        # kernels opened a 25-50 us hole in their timeline (gpurun_out/r3z4_gaps.txt: 20-step region 437 us with the cast, 389 without)
+        self.pack16 = self.use_dist and mode == "weak" and self.wl.P <= 32767 and bool(getattr(self.args, "pack16", False))
         self.d_picks_all = torch.full((NBUF * self.per,), -1, dtype=torch.int32, device=self.dev)
         self.d_picks = [self.d_picks_all[i * self.per:(i + 1) * self.per] for i in range(NBUF)]
         self.d_scores_all = torch.empty(NBUF * self.per, dtype=torch.float64, device=self.dev)
@@ -210,8 +228,10 @@ class Runner:
         self.launch_requests = (G * self.per) if self.grouped else self.n_mine
         self.p_picks = [t.data_ptr() for t in self.d_picks]
         self.p_scores = [t.data_ptr() for t in self.d_scores]
-        self.d_alls = [torch.empty(W * G * self.per, dtype=torch.int32, device=self.dev) for _ in range(NBUF // G)] if self.use_dist else None
-        self.ev_gather = torch.cuda.Event()
+        pdt = torch.int16 if self.pack16 else torch.int32
+        self.d_alls = [torch.empty(W * G * self.per, dtype=pdt, device=self.dev) for _ in range(NBUF // G)] if self.use_dist else None
+        self.d_p16 = [torch.empty(G * self.per, dtype=torch.int16, device=self.dev) for _ in range(NBUF // G)] if self.pack16 else None
+        self.gather_views = {}
         self.last_gather = None
         self.step_no = 0
         self.last_batch = 0
@@ -219,22 +239,48 @@ class Runner:
     def _gather(self, due):
         if due is None:
             return
+        if HOSTTIME:
+            t_h = time.perf_counter()
+            self._gather_body(due)
+            self.host_t["gather"] = self.host_t.get("gather", 0.0) + time.perf_counter() - t_h
+            self.host_t["gathers"] = self.host_t.get("gathers", 0) + 1
+            return
+        self._gather_body(due)
+
+    def _gather_body(self, due):
         b0, n, closes_trip = due
-        out = self.d_alls[self.ring.bucket_of(b0)][: self.world * n * self.per]
-        self.dist.all_gather_into_tensor(out, self.d_picks_all[b0 * self.per:(b0 + n) * self.per])     # on `comm`, the current stream
+        k = self.ring.bucket_of(b0)
+        views = self.gather_views.get((b0, n))           # (slicing and re-viewing five tensors costs the host ~15 us per collective)
+        if views is None:
+            out = self.d_alls[k][: self.world * n * self.per]
+            src = self.d_picks_all[b0 * self.per:(b0 + n) * self.per]
+            p16 = self.d_p16[k][: n * self.per] if self.pack16 else None
+            views = self.gather_views[(b0, n)] = (out, src, p16, out.view(self.torch.uint8) if self.pack16 else None,
+                                                  p16.view(self.torch.uint8) if self.pack16 else None)
+        out, src, p16, out8, p16_8 = views
+        if self.pack16:                                  # (on `comm`, the current stream, behind the kernels' completion events)
+            p16.copy_(src)
+            if DBG != "nogather":
+                self.dist.all_gather_into_tensor(out8, p16_8)   # (as bytes: gloo has no int16)
+        elif DBG != "nogather":
+            self.dist.all_gather_into_tensor(out, src)  # on `comm`, the current stream
         self.last_gather = (out, n)
         if self.lat_on and self.lat_start is not None:
-            e_end = self.torch.cuda.Event(enable_timing=True)
+            e_end = self._timing_event()
             e_end.record(self.comm)
             self.lat_pairs.append((self.lat_start, e_end, n))
             self.lat_start = None
-        if self.grouped:
-            k = self.ring.bucket_of(b0)
-            if self.ev_bucket[k] is None:
-                self.ev_bucket[k] = self.torch.cuda.Event()
-            self.ev_bucket[k].record(self.comm)
-        elif closes_trip:
-            self.ev_gather.record(self.comm)
+        if self.ev_bucket[k] is None:
+            self.ev_bucket[k] = self.torch.cuda.Event()
+        self.ev_bucket[k].record(self.comm)              # bucket k's slots may be overwritten behind this
+
+    def _timing_event(self):
+        """Timing events for the bucket latencies come from a pool created outside the timed region (creating one costs the host ~5 us)."""
+        if self.ev_pool_used == len(self.ev_pool):
+            self.ev_pool.append(self.torch.cuda.Event(enable_timing=True))
+        e = self.ev_pool[self.ev_pool_used]
+        self.ev_pool_used += 1
+        return e
 
     def batch_of(self, step: int) -> int:
         # weak scaling: ranks walk the same ring of batches at different offsets, so that no two ranks score the same batch at
@@ -261,15 +307,17 @@ class Runner:
                 self.pk.stream_wait_pick(self.comm_handle)   # comm waits for the kernel's own completion event
             self._gather(due)
             return
-        if self.use_dist and not self.grouped and ring.begins_trip():
-            for c in self.computes:
-                c.wait_event(self.ev_gather)                 # every all-gather of the previous trip is done: the ring is free again
         slot = ring.next_slot()
+        if self.use_dist and slot % ring.gather_every == 0:
+            ev = self.ev_bucket[slot // ring.gather_every]
+            if ev is not None:
+                for c in self.computes:
+                    c.wait_event(ev)                         # the collective that read this bucket on its previous trip is done
         b = self.batch_of(self.step_no)
         st = self.streams[slot % len(self.streams)]
         if self.n_mine and not self.grouped:
             if self.lat_on and self.use_dist and self.lat_start is None:      # first batch of a bucket
-                self.lat_start = self.torch.cuda.Event(enable_timing=True)
+                self.lat_start = self._timing_event()
                 self.lat_start.record(self.computes[slot % len(self.computes)])
             self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
             if self.closed_loop:                              # post-route index update on the same stream: the next pick sees it
@@ -278,8 +326,11 @@ class Runner:
         if self.grouped and due is not None:
             self._launch_group(due, b)
         if self.use_dist:
-            if self.n_mine and (not self.grouped or due is not None):
-                self.pk.stream_wait_pick(self.comm_handle)   # comm waits for the kernel's own completion event
+            # comm waits for the completion event of the LAST launch on every compute stream before a bucket's collective: the last
+            # `inflight` launches of the bucket (consecutive launches alternate between the streams; each stream runs its own in order).
+            # (A wait per launch was 2 HIP calls = ~4 us of host time per step on a path whose host side is what bounds a short run.)
+            if self.n_mine and (due is not None or (slot % ring.gather_every) >= ring.gather_every - len(self.streams)):
+                self.pk.stream_wait_pick(self.comm_handle)
             self._gather(due)
         self.last_batch, self.last_slot = b, slot
         self.step_no += 1
@@ -296,21 +347,30 @@ class Runner:
         if self.ev_bucket[k] is not None:
             cs.wait_event(self.ev_bucket[k])                 # the collective that read this bucket on its previous trip is done
         if self.lat_on and self.lat_start is None:
-            self.lat_start = self.torch.cuda.Event(enable_timing=True)
+            self.lat_start = self._timing_event()
             self.lat_start.record(cs)
         self.pk.pick_device(self.p_shards + b0 * self.per * self.stride, n * self.per, None, self.p_picks[first], self.p_scores[first], st)
 
-    def fence(self):
+    def fence(self, t0=None):
+        """Flush + device synchronize (+ barrier).  With `t0` (the closing fence of a timed region) returns this rank's elapsed time, read
+        when ITS device is idle -- every step's picks gathered -- and BEFORE the barrier: the region's time is the MAX over ranks of
+        these (timed()), so the barrier's own cost (a device all-reduce plus a host round trip, tens of microseconds against a
+        20-step region of 0.4 ms) is not charged to the steps; it still separates the region from whatever follows."""
         due = self.ring.flush()
         if self.grouped and due is not None:
             self._launch_group(due, self.last_batch)
             self.pk.stream_wait_pick(self.comm_handle)
         if self.use_dist:
+            if due is not None and not self.grouped:
+                for c in self.computes:
+                    self.comm.wait_stream(c)                 # (a partly filled bucket: its last launches may sit on either compute stream)
             self._gather(due)                                # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
         self.torch.cuda.synchronize()
+        elapsed = None if t0 is None else time.perf_counter() - t0
         if self.use_dist:
             self.dist.barrier()
             self.torch.cuda.synchronize()
+        return elapsed
 
     def timed(self, steps: int, warmup: int, age=None):
         """`warmup` untimed steps, then exactly `steps` timed ones between fences; returns (elapsed max over ranks, kernel ms list,
@@ -324,14 +384,23 @@ class Runner:
         # part of what the headline times.  The p99 samples (more_kernel_samples, outside the timed region) instrument every launch.
         self.pk.profile(self.profile_every)
         self.fence()
-        self.lat_on, self.lat_start, self.lat_pairs = self.use_dist, None, []
+        self.lat_on, self.lat_start, self.lat_pairs = self.use_dist and DBG != "nolat", None, []
+        if self.use_dist:
+            while len(self.ev_pool) < 64:
+                self.ev_pool.append(self.torch.cuda.Event(enable_timing=True))
+        self.ev_pool_used = 0
+        self.host_t = {}
         t0 = time.perf_counter()
         for i in range(steps):
             self.step()
             if age:
                 age(warmup + i)
-        self.fence()
-        elapsed = time.perf_counter() - t0
+        if HOSTTIME:
+            self.host_t["issue_all_steps"] = time.perf_counter() - t0
+        elapsed = self.fence(t0)
+        if HOSTTIME:
+            log(f"[bench] host time, mode {self.mode}: " + ", ".join(f"{k} {v * 1e6:.1f} us" if isinstance(v, float) else f"{k} {v}" for k, v in self.host_t.items())
+                + f", region {elapsed * 1e6:.1f} us")
         self.lat_on = False
         self.bucket_latency_ms = np.asarray([a.elapsed_time(b) for a, b, _ in self.lat_pairs], dtype=np.float64)
         self.bucket_batches = [n for _, _, n in self.lat_pairs]
@@ -369,11 +438,14 @@ class Runner:
         allp = out.cpu().numpy().reshape(self.world, n, self.per)
         mine = self.d_picks[self.last_slot].cpu().numpy()
         assert np.array_equal(allp[self.rank, n - 1], mine), "all-gather returned a different shard"
-        return allp[:, n - 1, :].reshape(-1)[: self.R] if self.mode == "strong" else allp[self.rank, n - 1]
+        # strong: the whole batch in request order; weak: [world, R] -- row r = the picks of the batch rank r scored in the last step
+        return allp[:, n - 1, :].reshape(-1)[: self.R] if self.mode == "strong" else allp[:, n - 1, :].astype(np.int32)
 
     def close(self):
         self.pk.close()
 
+
+WEAK_BUCKET = 16               # weak scaling: batches per all-gather (16 x 64k picks per rank as int16 = 2 MiB per rank and collective)
 
 L2_GATHER_PEAK_GBS = 16900.0   # measured ceiling of 64-byte line gathers out of an L2-resident table, one quad per line (the quad kernel's
                                # access pattern): 0.515 lines / clock / CU (profiles/r02_g_micro_l2gather.txt)
@@ -419,7 +491,7 @@ def main() -> None:
     ap.add_argument("--config", type=int, default=5, help="BASELINE.json config number (1-based); 5 = headline")
     ap.add_argument("--requests", type=int, default=None, help="override requests per batch")
     ap.add_argument("--batches", type=int, default=16, help="distinct request batches the timed region rotates through (16 x 17.3 MB > the 256 MB Infinity Cache)")
-    ap.add_argument("--scaling", choices=("strong", "weak", "both"), default="both", help="N>1: 'both' = strong scaling is the headline `value`, weak scaling is timed too and printed beside it")
+    ap.add_argument("--scaling", choices=("strong", "weak", "both"), default="both", help="N>1: 'both' = weak scaling is the headline `value`, strong scaling is timed too and printed beside it")
     ap.add_argument("--group", type=int, default=0, metavar="MEMBERS",
                     help="ONE process, the C-ABI device group (eppk_group_*) instead of torch.distributed: MEMBERS contexts over the visible GPUs (round "
                          "robin; all on device 0 of a one-GPU box), device-resident shards, one launch per member and gather bucket, peer all-gather")
@@ -437,6 +509,7 @@ def main() -> None:
     ap.add_argument("--inflight", type=int, default=2, choices=(1, 2, 3, 4), help="batches in flight: consecutive (independent) batches alternate between this many compute streams")
     ap.add_argument("--no-launch-groups", action="store_true", help="N>1 strong scaling: one launch per batch shard instead of one per gather bucket")
     ap.add_argument("--gather-every", type=int, default=16, help="N>1: all-gather the picks of this many batches with one RCCL call (1 = one collective per batch)")
+    ap.add_argument("--pack16", action="store_true", help="N>1 weak scaling: all-gather the picks as int16 (one cast kernel per bucket; see Runner.setup)")
     ap.add_argument("--profile-every", type=int, default=8, help="inside the timed region only every Nth pick launch carries HIP events and probe counters (1 = all)")
     ap.add_argument("--p99-samples", type=int, default=1000, help="kernel durations collected for the p99 (beyond the timed region if it has fewer launches)")
     ap.add_argument("--host-path", type=int, default=1000, help="also time N batches through the host-buffer entry point (H2D + kernel + D2H): the pick latency a host caller observes; 0 = skip")
@@ -479,11 +552,16 @@ def main() -> None:
 
     run = Runner(pkg, torch, dist, wl, batches, args, rank, world, local_rank,
                  index_slots=(args.cl_slots if args.closed_loop else None), closed_loop=args.closed_loop)
-    modes = ["single"] if not use_dist else (["strong", "weak"] if args.scaling == "both" else [args.scaling])
+    # N > 1: WEAK scaling is the headline (every rank scores a whole 64k batch per step -- the shard the metric is quoted on -- and the
+    # picks of all ranks are all-gathered); strong scaling (the step's ONE 64k batch split R/N) is timed in the same invocation and
+    # printed beside it.  Why: a strong-scaled step is 2 us of kernel per rank at 8 GPUs, so a short timed region (the driver's
+    # --steps 20: 0.4 ms on one GPU, 50 us at ideal 8-GPU strong scaling) measures one collective's latency and one fence, not the
+    # path (one-GPU dry run of both at --steps 20 in profiles/r03_y_short_runs.txt).
+    modes = ["single"] if not use_dist else (["weak", "strong"] if args.scaling == "both" else [args.scaling])
     results = {}
     cl_info = cl_state = None
     for mode in modes:
-        run.setup(mode, args.gather_every)
+        run.setup(mode, args.gather_every if mode != "weak" else min(args.gather_every, WEAK_BUCKET))
         age = None
         if args.closed_loop:
             cl_info = closed_loop_verify(run, wl, args)
@@ -497,13 +575,14 @@ def main() -> None:
         elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
         results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per, launch_requests=run.launch_requests, grouped=run.grouped,
                              bucket_latency_ms=run.bucket_latency_ms, bucket_batches=run.bucket_batches,
-                             bucket=run.ring.gather_every,
+                             bucket=run.ring.gather_every, pack16=run.pack16,
                              value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
         if mode == modes[0]:
             extra_ms = run.more_kernel_samples(len(kern_ms), args.p99_samples) if not args.closed_loop else np.zeros(0)
             picks, scores = run.last_outputs()
             last_batch, lo, n_mine = run.last_batch, run.lo, run.n_mine
             gathered = run.check_gather()
+            last_step = run.step_no - 1
         else:
             run.check_gather()
     run.pk.profile(False)
@@ -517,7 +596,8 @@ def main() -> None:
         sharding = {"single": "single GPU",
                     "strong": (f"each 64k batch split R/{world} per rank, RCCL all-gather of picks (buckets of {G} batches) overlapped with the following kernels" +
                                (f"; a rank scores its {G} shards of a bucket with ONE launch ({G} x {run.per} contiguous rows)" if res.get("grouped") else "")),
-                    "weak": f"one whole batch per rank per step, RCCL all-gather of picks (buckets of {G} batches)"}[main_mode]
+                    "weak": (f"one whole batch per rank per step ({world} x {R} requests per step), RCCL all-gather of all ranks' picks (buckets of {G} batches" +
+                             (", int16 payload" if res.get("pack16") else "") + ") overlapped with the following kernels")}[main_mode]
         out = {
             "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if headline else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf}{', closed loop' if args.closed_loop else ''})",
             "value": res["value"],
@@ -542,6 +622,16 @@ def main() -> None:
             w = results["weak"]
             out["weak"] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "requests_per_gpu": R,
                            "note": "weak scaling timed in the same invocation: every rank scores one whole batch per step, picks all-gathered"}
+        if "strong" in results and main_mode != "strong":
+            st = results["strong"]
+            out["strong"] = {"value": st["value"], "ms_per_step": st["ms_per_step"], "requests_per_gpu": st["per"], "requests_per_step": R,
+                             "requests_per_launch": int(st["launch_requests"]), "batches_per_bucket": int(st["bucket"]),
+                             "note": "strong scaling timed in the same invocation: each step's ONE batch split R/N per rank, picks all-gathered per bucket" +
+                                     ("; a rank scores its shards of a whole bucket with ONE launch" if st.get("grouped") else "")}
+            sbl = st["bucket_latency_ms"]
+            if sbl.size:
+                out["strong"]["completion_latency_p50_ms"] = float(np.percentile(sbl, 50))
+                out["strong"]["completion_latency_p99_ms"] = float(np.percentile(sbl, 99))
         if use_dist:
             out["config"]["ranks_seen"] = int(dist.get_world_size())
             bl = res["bucket_latency_ms"]
@@ -680,12 +770,19 @@ def main() -> None:
             out["parity"] = {"picks_equal_oracle": bool(np.array_equal(picks, opicks[lo:lo + n_mine])),
                              "scores_bitwise_equal_oracle": bool(np.array_equal(scores.view(np.uint64), oscores[lo:lo + n_mine].view(np.uint64))),
                              "batch": int(last_batch)}
-        elif use_dist and gathered is not None and main_mode == "strong" and not args.no_cpu_baseline and R <= 4096:
+        elif use_dist and gathered is not None and not args.no_cpu_baseline and R <= 4096:
             orc = graft.load_oracle()
             oix = orc.OracleIndex()
             oix.insert(wl.index_hashes, wl.index_pods)
-            op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[last_batch], wl.B)
-            out["parity"] = {"gathered_picks_equal_oracle": bool(np.array_equal(gathered, op))}
+            if main_mode == "strong":
+                op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[last_batch], wl.B)
+                out["parity"] = {"gathered_picks_equal_oracle": bool(np.array_equal(gathered, op))}
+            else:       # weak: rank r scored batch (step + r) % NB in the last step; rank 0 holds everybody's picks
+                ok = True
+                for r in range(world):
+                    op, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[(last_step + r) % len(batches)], wl.B)
+                    ok = ok and bool(np.array_equal(gathered[r][:R], op))
+                out["parity"] = {"gathered_picks_equal_oracle": ok, "ranks_checked": world}
     run.close()
 
     # roofline_cold: the same kernel on an index that does not fit the caches (rank 0, N=1, headline runs only)

@@ -35,6 +35,9 @@ class _Stream:
     def wait_event(self, ev):
         assert ev.recorded, "waiting for an event that was never recorded"
 
+    def wait_stream(self, other):
+        assert other is not self
+
     def synchronize(self):
         pass
 
@@ -197,18 +200,20 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     assert d["parity"]["picks_equal_oracle"] and d["parity"]["scores_bitwise_equal_oracle"]
     if "--force-dist" in argv:
         both = "--scaling" not in argv
-        assert d["scaling"] == ("strong" if both else "weak") and d["config"]["ranks_seen"] == 1
-        assert ("weak" in d) == both
+        assert d["scaling"] == "weak" and d["config"]["ranks_seen"] == 1          # N > 1: weak scaling is the headline, strong beside it
+        assert ("strong" in d) == both and "weak" not in d
         extra = max(0, 40 - d["steps"]) if "--p99-samples" in argv else 0
         steps = d["steps"] + d["warmup"]
         if both:
             # strong scaling scores the shards of a whole gather bucket (16 batches) with ONE launch; weak scaling one launch per batch
-            assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 16 * 96
+            assert "ONE launch" in d["strong"]["note"] and d["strong"]["requests_per_launch"] == 16 * 96 and d["config"]["requests_per_launch"] == 96
+            assert "int16" not in d["config"]["sharding"]                                   # (--pack16 is opt-in)
             assert n_picks >= (steps + 15) // 16 + steps + extra                              # (extra = launches beyond the timed region: samples)
         else:
             assert n_picks >= steps + extra
-        warm = 2 if both else 0                                                            # (grouped mode: one sizing launch per compute stream in setup)
-        assert sum(1 for e in log if e[0] == "wait") == n_picks - warm                   # one cross-stream dependency per launch
+        # cross-stream dependencies: the collective stream waits for the last launch on every compute stream of a bucket, not for every launch
+        n_waits = sum(1 for e in log if e[0] == "wait")
+        assert (steps + 15) // 16 <= n_waits <= n_picks
         if extra:
             assert d["roofline"]["kernel_samples"] >= 40
     else:
@@ -243,7 +248,7 @@ def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5"), requ
         f.write(out.getvalue())
 
 
-@pytest.mark.parametrize("extra,grouped", [(("--batches", "5"), False),                        # 5 batches do not tile into buckets: a launch per shard
+@pytest.mark.parametrize("extra,grouped", [(("--batches", "5", "--pack16"), False),            # 5 batches do not tile into buckets: a launch per shard
                                            (("--batches", "8", "--gather-every", "4"), True)])  # one launch per bucket of 4 shards
 def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     """World size 2 over gloo: both ranks run bench.py's N>1 path to the end, rank 0 alone prints the JSON line, with the
@@ -255,26 +260,29 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     assert not any(ln.lstrip().startswith("{") for ln in out1)
     d = json.loads(out0[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3
-    # headline = strong scaling: each 64-request batch is split 32 + 32, every rank ends up with all 64 picks (checked against the oracle)
-    assert d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 32 and d["config"]["requests_per_step"] == 64
-    assert "cpu_baseline" not in d and "split R/2 per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
+    # headline = weak scaling: a whole 64-request batch per rank and step, the aggregate counts BOTH ranks; every rank ends up with the
+    # picks of both (rank 0 checks each rank's part against the oracle on the batch that rank scored)
+    assert d["scaling"] == "weak" and d["config"]["requests_per_gpu"] == 64 and d["config"]["requests_per_step"] == 128
+    assert "cpu_baseline" not in d and "one whole batch per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
+    assert ("int16" in d["config"]["sharding"]) == ("--pack16" in extra) and d["config"]["requests_per_launch"] == 64
     cl = d["completion_latency"]                  # N > 1: when a batch's picks exist on every rank (per gather bucket)
     assert cl["buckets"] >= 1 and cl["p50_ms"] <= cl["p99_ms"] <= cl["max_ms"] and cl["batches_per_bucket"] >= 1
-    assert d["parity"]["gathered_picks_equal_oracle"] is True
-    assert ("ONE launch" in d["config"]["sharding"]) == grouped and d["config"]["requests_per_launch"] == (4 * 32 if grouped else 32)
-    assert abs(d["value"] - 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
-    # weak scaling timed beside it: a whole batch per rank and step, the aggregate counts BOTH ranks
-    w = d["weak"]
-    assert w["requests_per_gpu"] == 64 and abs(w["value"] - 2 * 64 * 10 / (w["ms_per_step"] * 1e-3 * 10)) < 1e-6 * w["value"]
+    assert d["parity"] == {"gathered_picks_equal_oracle": True, "ranks_checked": 2}
+    assert abs(d["value"] - 2 * 64 * 10 / (d["ms_per_step"] * 1e-3 * 10)) < 1e-6 * d["value"]
+    # strong scaling timed beside it: each 64-request batch is split 32 + 32
+    st = d["strong"]
+    assert st["requests_per_gpu"] == 32 and st["requests_per_step"] == 64 and abs(st["value"] - 64 * 10 / (st["ms_per_step"] * 1e-3 * 10)) < 1e-6 * st["value"]
+    assert ("ONE launch" in st["note"]) == grouped and st["requests_per_launch"] == (4 * 32 if grouped else 32)
+    assert st["completion_latency_p50_ms"] <= st["completion_latency_p99_ms"]
 
 
 def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
     """71 requests over 2 ranks: shards of 36 and 35 rows; the short shard is padded with filler rows inside the grouped launches and
     the gathered batch still equals the oracle's."""
     world = 2
-    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), ("--batches", "8", "--gather-every", "4"), 71), nprocs=world, join=True)
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), ("--batches", "8", "--gather-every", "4", "--scaling", "strong"), 71), nprocs=world, join=True)
     out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
     d = json.loads(out0[-1])
-    assert d["n_gpus"] == 2 and d["config"]["requests_per_gpu"] == 36 and d["config"]["requests_per_step"] == 71
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 36 and d["config"]["requests_per_step"] == 71
     assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 4 * 36
     assert d["parity"]["gathered_picks_equal_oracle"] is True
