@@ -115,12 +115,14 @@ struct eppk_ctx {
   // staging for the host-buffer entry point
   void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
   void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
+  void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;   // the pinned buffers as the device addresses them
   void* d_tmp = nullptr; size_t d_tmp_bytes = 0;  // index insert staging
   // the pipelined host path (eppk_pick_stage_*): per set its own pinned + device buffers, stream and events
   struct StageSet {
     hipStream_t st = nullptr; hipEvent_t picked = nullptr;
     void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
     void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
+    void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;
     uint32_t n = 0; bool busy = false, had_mask = false;
   };
   StageSet stage[2];
@@ -151,6 +153,14 @@ struct eppk_ctx {
                                   // the route only paid off from ~24k requests on; in its one-launch form it wins from 4k on (C5 rows, us
                                   // per step, fast kernel vs quad: 4k 6.8 / 5.9, 8k 8.4 / 6.7, 16k 12.2 / 9.1: profiles/r03_j_quad_min.txt)
   uint32_t quad_threads = 512;    // EPPK_QUAD_THREADS overrides (tuning knob; <= the kernel's launch bound)
+  // Host-buffer picks of at most this many requests run ZERO-COPY: the kernel reads the request rows (and the mask) straight out of
+  // the pinned staging buffer and writes picks and scores straight into the pinned result buffers -- one launch instead of
+  // upload + launch + two downloads.  A small batch is all latency -- host-observed p50 of eppk_pick_batch_staged, rows freshly written
+  // by the caller (C5 snapshot, profiles/r03_z_small_batch_latency.txt): 16 requests 25.8 -> 21.1 us, 128: 33.2 -> 21.7, 2048: 44.9 ->
+  // 32.8, 8192: 137 -> 116; from ~12k requests on the copy engine's 55 GB/s beats the shader's reads over PCIe (16k: 190 vs 202 us,
+  // 64k: 516 vs 690).  EPPK_ZERO_COPY_MAX overrides, 0 = off.
+  uint32_t zero_copy_max = 8192;
+  bool zc_last = false;           // the batch in flight between pick_host_begin and pick_host_end took that path
   // One work-list buffer per STREAM that has launched picks (launches of one stream are ordered, so a buffer is never written
   // while an earlier launch still reads it; launches of different streams never share one).  More than kDeferSets distinct streams:
   // the later ones stay on pick_fast_kernel.
@@ -720,6 +730,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
+  if (const char* zc = getenv("EPPK_ZERO_COPY_MAX")) c->zero_copy_max = atoi(zc) > 0 ? (uint32_t)atoi(zc) : 0u;
   if (const char* qt = getenv("EPPK_QUAD_THREADS")) {
     const int v = atoi(qt);
     if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;
@@ -1233,10 +1244,15 @@ int ensure_host_staging(eppk_ctx* c, bool need_mask) {
     HIPCHK(c, hipHostMalloc(&c->h_reqs, mb * c->stride, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&c->h_pick, mb * 4u, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&c->h_score, mb * 8u, hipHostMallocDefault));
+    // (what the device calls the same memory: the zero-copy path of small batches hands these to the kernel)
+    HIPCHK(c, hipHostGetDevicePointer(&c->h_reqs_dev, c->h_reqs, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_pick_dev, c->h_pick, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_score_dev, c->h_score, 0));
   }
   if (need_mask && !c->d_mask) {
     HIPCHK(c, hipMalloc((void**)&c->d_mask, mb * c->jmax * 8u));
     HIPCHK(c, hipHostMalloc((void**)&c->h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_mask_dev, c->h_mask, 0));
   }
   return EPPK_OK;
 }
@@ -1246,11 +1262,24 @@ int ensure_host_staging(eppk_ctx* c, bool need_mask) {
 // mask_on_device: c->d_mask already holds the shard's mask rows (built by subset_masks_kernel on the context stream)
 // validate_as != nullptr: the rows are validated on the way (chunk by chunk, while the previous chunk is on the PCIe link), under that name
 int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full_n, uint32_t lo, uint32_t n, bool upload_all,
-                    const uint64_t* cand_mask_shard, bool mask_on_device = false, const char* validate_as = nullptr) {
+                    const uint64_t* cand_mask_shard, bool mask_on_device = false, const char* validate_as = nullptr, bool allow_zero_copy = false) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   const size_t J = (c->n_pods + 63u) / 64u;
   int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
   if (rc) return rc;
+  c->zc_last = false;
+  if (allow_zero_copy && n != 0 && n <= c->zero_copy_max && !upload_all && lo == 0 && full_n == n && !mask_on_device) {
+    // ZERO-COPY (a small batch of one context): rows (and mask) into the pinned staging buffers unless they are there already, then
+    // ONE launch that reads them over PCIe and writes the results into the pinned result buffers; pick_host_end waits for the stream.
+    if (base != (const uint8_t*)c->h_reqs) std::memcpy(c->h_reqs, base, (size_t)n * c->stride);
+    if (validate_as) { rc = validate_rows(c, validate_as, c->h_reqs, n, 0u); if (rc) return rc; }
+    const bool use_mask = cand_mask_shard != nullptr && J != 0;
+    if (use_mask && cand_mask_shard != c->h_mask) std::memcpy(c->h_mask, cand_mask_shard, (size_t)n * J * 8u);
+    rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n, use_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, 1u, false, 0ull, 0u);
+    if (rc) return rc;
+    c->zc_last = true;
+    return EPPK_OK;
+  }
   const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;
   const uint8_t* src = base + (size_t)up_lo * c->stride;
   if (up_n) {
@@ -1315,7 +1344,7 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
   // (rows are validated on the host, chunk by chunk on their way to the device: never hand the kernel an out-of-range adapter / block count)
-  int rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask, false, "eppk_pick_batch");
+  int rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask, false, "eppk_pick_batch", true);
   if (rc) return rc;
   return pick_host_end(c, n_reqs, cand_mask != nullptr, out_pick, out_score);
 }
@@ -1336,7 +1365,7 @@ int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* 
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_staged: n_reqs > max_batch");
   if (!c->h_reqs || (use_mask && !c->h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: eppk_host_staging was not called for these buffers");
   if (n_reqs == 0) return EPPK_OK;
-  int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged");
+  int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged", true);
   if (rc) return rc;
   return pick_host_end(c, n_reqs, use_mask != 0, out_pick, out_score);
 }
@@ -1356,10 +1385,14 @@ int stage_ensure(eppk_ctx* c, uint32_t set, bool need_mask) {
     HIPCHK(c, hipHostMalloc(&s.h_reqs, mb * c->stride, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&s.h_pick, mb * 4u, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&s.h_score, mb * 8u, hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer(&s.h_reqs_dev, s.h_reqs, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_pick_dev, s.h_pick, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_score_dev, s.h_score, 0));
   }
   if (need_mask && !s.d_mask) {
     HIPCHK(c, hipMalloc((void**)&s.d_mask, mb * c->jmax * 8u));
     HIPCHK(c, hipHostMalloc((void**)&s.h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_mask_dev, s.h_mask, 0));
   }
   if (!c->learned) HIPCHK(c, hipEventCreateWithFlags(&c->learned, hipEventDisableTiming));
   return EPPK_OK;
@@ -1388,6 +1421,17 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true;
   if (n_reqs == 0) return EPPK_OK;
   const size_t J = (c->n_pods + 63u) / 64u;
+  if (n_reqs <= c->zero_copy_max && !(flags & EPPK_PICK_LEARN)) {
+    // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
+    // (Not with LEARN: the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned.)
+    int rc = validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
+    if (rc) { s.busy = false; return rc; }
+    if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
+    rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
+    if (rc) { s.busy = false; return rc; }
+    HIPCHK(c, hipEventRecord(s.picked, s.st));
+    return EPPK_OK;
+  }
   // upload in chunks of whole rows, each validated while the previous one is on the link (as eppk_pick_batch_staged does)
   const uint32_t rows_per_chunk = (uint32_t)(((size_t)2 << 20) / c->stride) ? (uint32_t)(((size_t)2 << 20) / c->stride) : 1u;
   for (uint32_t r0 = 0; r0 < n_reqs; r0 += rows_per_chunk) {

@@ -80,3 +80,47 @@ def test_pipelined_stage_sets_against_the_oracle(pkg, orc, R, learn, masked):
         with pytest.raises(pkg.EppkError):
             pk.stage_begin(0, R, use_mask=masked)
         pk.stage_end(0)
+
+
+@pytest.mark.parametrize("zc_max", ["0", None, "1000000"])
+@pytest.mark.parametrize("R,masked", [(1, False), (37, True), (2048, False), (8192, True), (8193, False)])
+def test_zero_copy_small_batches(pkg, orc, monkeypatch, zc_max, R, masked):
+    """Host-buffer picks of at most EPPK_ZERO_COPY_MAX requests run zero-copy (the kernel reads the pinned staging rows and writes the
+    pinned result buffers: one launch, no upload / download): every entry point that takes the path -- eppk_pick_batch on pageable rows,
+    eppk_pick_batch_staged, eppk_pick_stage_begin / _end -- against the oracle, with the path off, at its default and forced for every size."""
+    if zc_max is None:
+        monkeypatch.delenv("EPPK_ZERO_COPY_MAX", raising=False)           # the library's default (8192)
+    else:
+        monkeypatch.setenv("EPPK_ZERO_COPY_MAX", zc_max)
+    wl = pkg.workload.make_workload(5, R=R, P=4096, n_groups=16, masked=masked)
+    J = (wl.P + 63) // 64
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    op, os_, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, wl.mask)
+    with pkg.BatchedPicker(wl.chain, max_pods=4096, max_blocks=wl.B, max_batch=R + 3, index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        for rep in range(2):                                           # (twice: the buffers are reused)
+            p, s = pk.pick(wl.reqs, wl.mask)
+            assert np.array_equal(p, op) and np.array_equal(s.view(np.uint64), os_.view(np.uint64)), "eppk_pick_batch"
+            st_reqs, st_mask = pk.staging(with_mask=masked)
+            st_reqs[:R] = wl.reqs
+            if masked:
+                st_mask[:R * J].reshape(R, J)[:] = wl.mask
+            p, s = pk.pick_staged(R, use_mask=masked)
+            assert np.array_equal(p, op) and np.array_equal(s.view(np.uint64), os_.view(np.uint64)), "eppk_pick_batch_staged"
+            for which in (0, 1):
+                b_reqs, b_mask = pk.stage_buffers(which, with_mask=masked)
+                b_reqs[:R] = wl.reqs
+                if masked:
+                    b_mask[:R * J].reshape(R, J)[:] = wl.mask
+                pk.stage_begin(which, R, use_mask=masked)
+            for which in (0, 1):
+                p, s = pk.stage_end(which)
+                assert np.array_equal(p, op) and np.array_equal(s.view(np.uint64), os_.view(np.uint64)), f"stage set {which}"
+        # a row out of range is refused on this path too, and nothing is launched
+        st_reqs, _ = pk.staging(with_mask=masked)
+        st_reqs[R - 1, 0] = np.uint64(1000) << np.uint64(32)
+        with pytest.raises(Exception):
+            pk.pick_staged(R, use_mask=masked)
+        assert pk.launch_status() == 0
