@@ -733,6 +733,25 @@ def main() -> None:
                 out["host_path"]["staged"] = {"p50_ms": float(np.percentile(lat2, 50)), "p99_ms": float(np.percentile(lat2, 99)),
                                               "decisions_per_s_p50": R / (float(np.percentile(lat2, 50)) * 1e-3),
                                               "what": "eppk_pick_batch_staged: rows already in the pinned staging buffer: validate, H2D, kernel, D2H"}
+            if hasattr(run.pk, "staging"):
+                # BASELINE's metric names the p99 pick latency: what a dispatcher that drains a few dozen to a few thousand pending requests
+                # per call observes -- one batch of n requests through eppk_pick_batch_staged, fresh rows written into the pinned buffer
+                # before every call (not timed).  Up to 8192 requests the library runs these zero-copy (one launch, no upload / download).
+                by_n = {}
+                for n in (16, 128, 2048, 8192):
+                    if n > R:
+                        continue
+                    l4 = []
+                    for i in range(min(args.host_path, 200) + 10):
+                        off = (i * n) % max(1, R - n + 1)
+                        np.copyto(st_reqs[:n], batches[i % len(batches)][off:off + n])
+                        t0 = time.perf_counter()
+                        run.pk.pick_staged(n)
+                        l4.append(time.perf_counter() - t0)
+                    l4 = np.asarray(l4[10:] or l4) * 1e6
+                    by_n[str(n)] = {"p50_us": float(np.percentile(l4, 50)), "p99_us": float(np.percentile(l4, 99))}
+                out["host_path"]["latency_by_batch"] = {"requests": by_n, "what": "eppk_pick_batch_staged, one batch at a time, host-observed (call -> picks and scores in "
+                                                        "caller memory); zero-copy up to EPPK_ZERO_COPY_MAX (default 8192) requests"}
             if hasattr(run.pk, "stage_begin"):
                 # PIPELINED: two staging sets -- the rows of batch k + 1 cross PCIe while batch k is scored (eppk_pick_stage_*).  Same
                 # convention as `staged`: the rows are in the pinned buffers already (two different batches, one per set; building them
