@@ -120,6 +120,7 @@ struct eppk_ctx {
   // the pipelined host path (eppk_pick_stage_*): per set its own pinned + device buffers, stream and events
   struct StageSet {
     hipStream_t st = nullptr; hipEvent_t picked = nullptr;
+    hipStream_t st_copy = nullptr; hipEvent_t copied = nullptr; bool copy_pending = false;   // zero-copy pick + LEARN: the rows' device copy rides beside the pick
     void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
     void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
     void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;
@@ -878,6 +879,8 @@ void eppk_destroy(eppk_ctx* c) {
   for (auto& s : c->stage) {
     if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     if (s.picked) (void)hipEventDestroy(s.picked);
+    if (s.st_copy) { (void)hipStreamSynchronize(s.st_copy); (void)hipStreamDestroy(s.st_copy); }
+    if (s.copied) (void)hipEventDestroy(s.copied);
     (void)hipFree(s.d_reqs); (void)hipFree(s.d_mask); (void)hipFree(s.d_pick); (void)hipFree(s.d_score);
     if (s.h_reqs) (void)hipHostFree(s.h_reqs);
     if (s.h_mask) (void)hipHostFree(s.h_mask);
@@ -1421,15 +1424,35 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true;
   if (n_reqs == 0) return EPPK_OK;
   const size_t J = (c->n_pods + 63u) / 64u;
-  if (n_reqs <= c->zero_copy_max && !(flags & EPPK_PICK_LEARN)) {
+  if (n_reqs <= c->zero_copy_max) {
     // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
-    // (Not with LEARN: the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned.)
+    // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
+    // reads a DEVICE copy of the rows, uploaded on a stream of its own beside the pick (_end waits for that upload too), and the picks
+    // out of the pinned result buffer (which only this set's next pick writes, and that one is ordered behind the update).
     int rc = validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
     if (rc) { s.busy = false; return rc; }
+    const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
+    if (learn) {
+      if (!s.st_copy) {
+        HIPCHK(c, hipStreamCreateWithFlags(&s.st_copy, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+      }
+      if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st_copy, c->learned, 0));     // (an earlier update may still read s.d_reqs)
+      HIPCHK(c, hipMemcpyAsync(s.d_reqs, s.h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, s.st_copy));
+      HIPCHK(c, hipEventRecord(s.copied, s.st_copy));
+      s.copy_pending = true;
+    }
     if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
     rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
     if (rc) { s.busy = false; return rc; }
     HIPCHK(c, hipEventRecord(s.picked, s.st));
+    if (learn) {
+      HIPCHK(c, hipStreamWaitEvent(s.st, s.copied, 0));
+      rc = eppk_index_insert_picks_device(c, s.d_reqs, s.h_pick_dev, n_reqs, (void*)s.st);
+      if (rc) return rc;                        // (the picks stand: end() still delivers them)
+      HIPCHK(c, hipEventRecord(c->learned, s.st));
+      c->learn_pending = true;
+    }
     return EPPK_OK;
   }
   // upload in chunks of whole rows, each validated while the previous one is on the link (as eppk_pick_batch_staged does)
@@ -1467,6 +1490,7 @@ int eppk_pick_stage_end(eppk_ctx* c, uint32_t set, int32_t* out_pick, double* ou
   s.busy = false;
   if (s.n == 0) return EPPK_OK;
   HIPCHK(c, hipEventSynchronize(s.picked));
+  if (s.copy_pending) { HIPCHK(c, hipEventSynchronize(s.copied)); s.copy_pending = false; }   // (the caller may refill the rows now)
   const size_t J = (c->n_pods + 63u) / 64u;
   std::memcpy(out_pick, s.h_pick, (size_t)s.n * 4u);
   if (out_score) std::memcpy(out_score, s.h_score, (size_t)s.n * 8u);

@@ -2,4 +2,4 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out/r3zc
 mkdir -p $OUT
-for intr in 1 0 1 0; do echo "== HSA_ENABLE_INTERRUPT=$intr"; HSA_ENABLE_INTERRUPT=$intr timeout 120 python scripts/gpu_small_batch_latency.py 2>&1 | grep "n=" | head -6; done | tee $OUT/latency_interrupt.txt
+timeout 900 python -m pytest tests/test_gpu_staging.py tests/test_gpupicker_cpp.py tests/test_host_cpp.py tests/test_scheduler_cpp.py -m gpu -q -x 2>&1 | tail -5 | tee $OUT/pytest_sel2.txt

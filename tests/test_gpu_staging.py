@@ -32,12 +32,17 @@ def test_staged_pick_equals_pick(pkg, orc, R, P, masked):
             pk.pick_staged(R, use_mask=masked)
 
 
+@pytest.mark.parametrize("zc_max", [None, "0", "1000000"])      # zero-copy picks of small batches: the library's default limit / never / every size
 @pytest.mark.parametrize("R,learn,masked", [(3000, False, False), (3000, True, False), (1500, True, True), (20000, True, False)])
-def test_pipelined_stage_sets_against_the_oracle(pkg, orc, R, learn, masked):
+def test_pipelined_stage_sets_against_the_oracle(pkg, orc, monkeypatch, eppk_mode, R, learn, masked, zc_max):
     """eppk_pick_stage_begin / _end: two staging sets in flight, batch k + 1 uploaded while batch k is scored.  Eight batches, picks and
     scores of every one bit-exact against the oracle running the same sequence -- with EPPK_PICK_LEARN the post-route index update is
     chained on the device behind each pick and batch k + 1 must already see what batch k taught the index (the oracle inserts between
     batches), although its rows were uploaded before that update finished."""
+    if zc_max is not None:
+        if eppk_mode != "default":
+            pytest.skip("the zero-copy switch is varied in the default library mode only (GPU time)")
+        monkeypatch.setenv("EPPK_ZERO_COPY_MAX", zc_max)
     wl = pkg.workload.make_workload(5, R=R, P=4096, n_groups=16, masked=masked)
     batches = [wl.reqs] + [pkg.workload.make_requests(wl, 31 + i) for i in range(3)]
     J = (wl.P + 63) // 64
@@ -84,13 +89,15 @@ def test_pipelined_stage_sets_against_the_oracle(pkg, orc, R, learn, masked):
 
 @pytest.mark.parametrize("zc_max", ["0", None, "1000000"])
 @pytest.mark.parametrize("R,masked", [(1, False), (37, True), (2048, False), (8192, True), (8193, False)])
-def test_zero_copy_small_batches(pkg, orc, monkeypatch, zc_max, R, masked):
+def test_zero_copy_small_batches(pkg, orc, monkeypatch, eppk_mode, zc_max, R, masked):
     """Host-buffer picks of at most EPPK_ZERO_COPY_MAX requests run zero-copy (the kernel reads the pinned staging rows and writes the
     pinned result buffers: one launch, no upload / download): every entry point that takes the path -- eppk_pick_batch on pageable rows,
     eppk_pick_batch_staged, eppk_pick_stage_begin / _end -- against the oracle, with the path off, at its default and forced for every size."""
     if zc_max is None:
         monkeypatch.delenv("EPPK_ZERO_COPY_MAX", raising=False)           # the library's default (8192)
     else:
+        if eppk_mode != "default":
+            pytest.skip("the zero-copy switch is varied in the default library mode only (GPU time)")
         monkeypatch.setenv("EPPK_ZERO_COPY_MAX", zc_max)
     wl = pkg.workload.make_workload(5, R=R, P=4096, n_groups=16, masked=masked)
     J = (wl.P + 63) // 64
