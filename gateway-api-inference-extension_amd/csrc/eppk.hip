@@ -121,6 +121,8 @@ struct eppk_ctx {
   struct StageSet {
     hipStream_t st = nullptr; hipEvent_t picked = nullptr;
     hipStream_t st_copy = nullptr; hipEvent_t copied = nullptr; bool copy_pending = false;   // zero-copy pick + LEARN: the rows' device copy rides beside the pick
+    uint32_t* h_bad = nullptr; uint32_t* h_bad_dev = nullptr; hipStream_t st_check = nullptr; hipEvent_t checked = nullptr;   // device-side row check (eppk_ctx::RowCheck)
+    bool check_pending = false, check_side = false;
     void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
     void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
     void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;
@@ -162,6 +164,17 @@ struct eppk_ctx {
   // 64k: 516 vs 690).  EPPK_ZERO_COPY_MAX overrides, 0 = off.
   uint32_t zero_copy_max = 8192;
   bool zc_last = false;           // the batch in flight between pick_host_begin and pick_host_end took that path
+  // Request rows that arrive in PINNED memory are range-checked ON THE DEVICE (rows_check_kernel: a thread per row header, the lowest
+  // bad row into a pinned word by atomicMin) instead of by a host loop in front of the launch: that loop touches one cache line per row
+  // -- 300-500 us for a 64k-request batch, more than the rows' PCIe time, and 65 of the 117 us of an 8192-request zero-copy batch.
+  // The kernels give a row out of range EPPK_NO_PICK and the index update skips it, exactly as on the *_device entry points; the call
+  // still fails with EPPK_ERR_ARG naming the row (from _end), and delivers nothing.  Batches of at most host_check_max rows keep the
+  // host loop (cheaper than a second launch and its event: 2048 requests 33 us with the loop, 41-45 with the kernel; 8192: 117 vs 107;
+  // 64k staged: 478 vs 402 us, profiles/r03_z_small_batch_latency.txt).  EPPK_HOST_CHECK_MAX overrides.
+  struct RowCheck { uint32_t* h_bad = nullptr; uint32_t* h_bad_dev = nullptr; hipStream_t st = nullptr; hipEvent_t done = nullptr;
+                    bool pending = false, side = false; const char* who = nullptr; };
+  RowCheck check;
+  uint32_t host_check_max = 2048;
   // One work-list buffer per STREAM that has launched picks (launches of one stream are ordered, so a buffer is never written
   // while an earlier launch still reads it; launches of different streams never share one).  More than kDeferSets distinct streams:
   // the later ones stay on pick_fast_kernel.
@@ -732,6 +745,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
   if (const char* zc = getenv("EPPK_ZERO_COPY_MAX")) c->zero_copy_max = atoi(zc) > 0 ? (uint32_t)atoi(zc) : 0u;
+  if (const char* hc = getenv("EPPK_HOST_CHECK_MAX")) c->host_check_max = atoi(hc) > 0 ? (uint32_t)atoi(hc) : 0u;
   if (const char* qt = getenv("EPPK_QUAD_THREADS")) {
     const int v = atoi(qt);
     if (v >= 64 && v <= EPPK_QUAD_MAX_THREADS && v % 64 == 0) c->quad_threads = (uint32_t)v;
@@ -881,6 +895,9 @@ void eppk_destroy(eppk_ctx* c) {
     if (s.picked) (void)hipEventDestroy(s.picked);
     if (s.st_copy) { (void)hipStreamSynchronize(s.st_copy); (void)hipStreamDestroy(s.st_copy); }
     if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.st_check) { (void)hipStreamSynchronize(s.st_check); (void)hipStreamDestroy(s.st_check); }
+    if (s.checked) (void)hipEventDestroy(s.checked);
+    if (s.h_bad) (void)hipHostFree(s.h_bad);
     (void)hipFree(s.d_reqs); (void)hipFree(s.d_mask); (void)hipFree(s.d_pick); (void)hipFree(s.d_score);
     if (s.h_reqs) (void)hipHostFree(s.h_reqs);
     if (s.h_mask) (void)hipHostFree(s.h_mask);
@@ -888,6 +905,9 @@ void eppk_destroy(eppk_ctx* c) {
     if (s.h_score) (void)hipHostFree(s.h_score);
   }
   if (c->learned) (void)hipEventDestroy(c->learned);
+  if (c->check.st) { (void)hipStreamSynchronize(c->check.st); (void)hipStreamDestroy(c->check.st); }
+  if (c->check.done) (void)hipEventDestroy(c->check.done);
+  if (c->check.h_bad) (void)hipHostFree(c->check.h_bad);
   if (c->h_reports) (void)hipHostFree((void*)c->h_reports);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
   (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
@@ -1228,6 +1248,48 @@ int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
 // every device) and the shard starts at row `lo` of them.
 namespace {
 
+// Range check of request-row headers on the device: the lowest row out of range lands in *bad (pinned host word, 0xFFFFFFFF = none).
+__global__ void rows_check_kernel(const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n, uint32_t max_blocks, uint32_t* bad) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const eppk_req_hdr h = *(const eppk_req_hdr*)(reqs + (size_t)r * stride);
+  if (h.n_blocks > max_blocks || h.adapter < -1 || h.adapter >= (int32_t)EPPK_MAX_ADAPTERS)
+    __hip_atomic_fetch_min(bad, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int rows_check_launch(eppk_ctx* c, const void* rows_dev, uint32_t n, uint32_t* h_bad, uint32_t* h_bad_dev, hipStream_t st) {
+  *h_bad = 0xFFFFFFFFu;
+  hipLaunchKernelGGL(rows_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint8_t*)rows_dev, c->stride, n, c->cfg.max_blocks, h_bad_dev);
+  HIPCHK(c, hipGetLastError());
+  return EPPK_OK;
+}
+
+// A batch with a row out of range has been scored (that row: EPPK_NO_PICK) and the kernels have raised the sticky BAD_REQUEST_ROW flag
+// of the *_device entry points: take it back (the host-buffer call reports the row itself) and fail the call.
+int rows_check_fail(eppk_ctx* c, const char* who, uint32_t row) {
+  (void)hipDeviceSynchronize();
+  uint32_t* words[3] = {c->d_status, (uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail), (uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail)};
+  for (uint32_t* w : words) {
+    uint32_t v = 0;
+    if (hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && (v & EPPK_LAUNCH_BAD_REQUEST_ROW)) {
+      v &= ~EPPK_LAUNCH_BAD_REQUEST_ROW;
+      (void)hipMemcpy(w, &v, sizeof v, hipMemcpyHostToDevice);
+    }
+  }
+  return fail(c, EPPK_ERR_ARG, std::string(who ? who : "eppk_pick_batch") + ": request row " + std::to_string(row) + " out of range");
+}
+
+int row_check_ensure(eppk_ctx* c, uint32_t** h_bad, uint32_t** h_bad_dev, hipStream_t* st, hipEvent_t* ev) {
+  if (!*h_bad) {
+    HIPCHK(c, hipHostMalloc((void**)h_bad, 64, hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void**)h_bad_dev, *h_bad, 0));
+    **h_bad = 0xFFFFFFFFu;
+    HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  }
+  return EPPK_OK;
+}
+
 int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row = 0) {
   for (uint32_t r = 0; r < n_reqs; ++r) {
     eppk_req_hdr h;
@@ -1271,23 +1333,43 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
   int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
   if (rc) return rc;
   c->zc_last = false;
+  c->check.pending = false;
   if (allow_zero_copy && n != 0 && n <= c->zero_copy_max && !upload_all && lo == 0 && full_n == n && !mask_on_device) {
     // ZERO-COPY (a small batch of one context): rows (and mask) into the pinned staging buffers unless they are there already, then
     // ONE launch that reads them over PCIe and writes the results into the pinned result buffers; pick_host_end waits for the stream.
     if (base != (const uint8_t*)c->h_reqs) std::memcpy(c->h_reqs, base, (size_t)n * c->stride);
-    if (validate_as) { rc = validate_rows(c, validate_as, c->h_reqs, n, 0u); if (rc) return rc; }
+    const bool dev_check = validate_as && n > c->host_check_max;
+    if (validate_as && !dev_check) { rc = validate_rows(c, validate_as, c->h_reqs, n, 0u); if (rc) return rc; }
     const bool use_mask = cand_mask_shard != nullptr && J != 0;
     if (use_mask && cand_mask_shard != c->h_mask) std::memcpy(c->h_mask, cand_mask_shard, (size_t)n * J * 8u);
     rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n, use_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, 1u, false, 0ull, 0u);
     if (rc) return rc;
+    if (dev_check) {        // beside the pick, on a stream of its own (it reads the row headers over PCIe as the pick does the rows)
+      rc = row_check_ensure(c, &c->check.h_bad, &c->check.h_bad_dev, &c->check.st, &c->check.done);
+      if (rc) return rc;
+      rc = rows_check_launch(c, c->h_reqs_dev, n, c->check.h_bad, c->check.h_bad_dev, c->check.st);
+      if (rc) return rc;
+      HIPCHK(c, hipEventRecord(c->check.done, c->check.st));
+      c->check.pending = true; c->check.side = true; c->check.who = validate_as;
+    }
     c->zc_last = true;
     return EPPK_OK;
   }
   const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;
   const uint8_t* src = base + (size_t)up_lo * c->stride;
   if (up_n) {
-    if (pinned && !validate_as) {
+    if (pinned) {
+      // ONE DMA for all rows.  (In 2 MB chunks, each validated by the host before its own copy, the copy engine paid a hand-off between
+      // dependent copies nine times per 64k-request batch and the host loop itself took longer than the link: p50 0.52 ms against a
+      // PCIe time of 0.31.)
       HIPCHK(c, hipMemcpyAsync(c->d_reqs, src, (size_t)up_n * c->stride, hipMemcpyHostToDevice, c->stream));
+      if (validate_as) {    // on the device, behind the upload and in front of the pick (4 MB of headers out of HBM: microseconds)
+        rc = row_check_ensure(c, &c->check.h_bad, &c->check.h_bad_dev, &c->check.st, &c->check.done);
+        if (rc) return rc;
+        rc = rows_check_launch(c, c->d_reqs, up_n, c->check.h_bad, c->check.h_bad_dev, c->stream);
+        if (rc) return rc;
+        c->check.pending = true; c->check.side = false; c->check.who = validate_as;
+      }
     } else {
       // In chunks of whole rows: pageable caller memory goes through the pinned staging buffer, and the copy (and the validation) of
       // chunk i + 1 runs while chunk i is on its way over PCIe (one pass over 17 MB followed by one DMA of 17 MB was 1.2 ms per
@@ -1331,6 +1413,11 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
 int pick_host_end(eppk_ctx* c, uint32_t n, bool had_mask, int32_t* out_pick, double* out_score) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->check.pending) {
+    c->check.pending = false;
+    if (c->check.side) HIPCHK(c, hipEventSynchronize(c->check.done));
+    if (*c->check.h_bad != 0xFFFFFFFFu) return rows_check_fail(c, c->check.who, *c->check.h_bad);
+  }
   if (n == 0) return EPPK_OK;
   const size_t J = (c->n_pods + 63u) / 64u;
   std::memcpy(out_pick, c->h_pick, (size_t)n * 4u);
@@ -1421,7 +1508,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   if (s.busy) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: the set is in flight (end it first)");
   if ((flags & EPPK_PICK_LEARN) && !c->slots) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: EPPK_PICK_LEARN without a prefix index");
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true;
+  s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true; s.check_pending = false;
   if (n_reqs == 0) return EPPK_OK;
   const size_t J = (c->n_pods + 63u) / 64u;
   if (n_reqs <= c->zero_copy_max) {
@@ -1429,9 +1516,16 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
     // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
     // reads a DEVICE copy of the rows, uploaded on a stream of its own beside the pick (_end waits for that upload too), and the picks
     // out of the pinned result buffer (which only this set's next pick writes, and that one is ordered behind the update).
-    int rc = validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
+    const bool dev_check = n_reqs > c->host_check_max;
+    int rc = dev_check ? row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked) : validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
     if (rc) { s.busy = false; return rc; }
     const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
+    if (dev_check) {        // beside the pick, on a stream of its own (eppk_ctx::RowCheck)
+      rc = rows_check_launch(c, s.h_reqs_dev, n_reqs, s.h_bad, s.h_bad_dev, s.st_check);
+      if (rc) { s.busy = false; return rc; }
+      HIPCHK(c, hipEventRecord(s.checked, s.st_check));
+      s.check_pending = true; s.check_side = true;
+    }
     if (learn) {
       if (!s.st_copy) {
         HIPCHK(c, hipStreamCreateWithFlags(&s.st_copy, hipStreamNonBlocking));
@@ -1455,14 +1549,13 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
     }
     return EPPK_OK;
   }
-  // upload in chunks of whole rows, each validated while the previous one is on the link (as eppk_pick_batch_staged does)
-  const uint32_t rows_per_chunk = (uint32_t)(((size_t)2 << 20) / c->stride) ? (uint32_t)(((size_t)2 << 20) / c->stride) : 1u;
-  for (uint32_t r0 = 0; r0 < n_reqs; r0 += rows_per_chunk) {
-    const uint32_t nr = n_reqs - r0 < rows_per_chunk ? n_reqs - r0 : rows_per_chunk;
-    const size_t off = (size_t)r0 * c->stride;
-    int rc = validate_rows(c, "eppk_pick_stage_begin", (const uint8_t*)s.h_reqs + off, nr, r0);
+  // one upload, its row headers checked on the device (as eppk_pick_batch_staged does: eppk_ctx::RowCheck)
+  HIPCHK(c, hipMemcpyAsync(s.d_reqs, s.h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, s.st));
+  {
+    int rc = row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked);
+    if (!rc) rc = rows_check_launch(c, s.d_reqs, n_reqs, s.h_bad, s.h_bad_dev, s.st);      // behind the upload, in front of the pick
     if (rc) { s.busy = false; return rc; }
-    HIPCHK(c, hipMemcpyAsync((uint8_t*)s.d_reqs + off, (const uint8_t*)s.h_reqs + off, (size_t)nr * c->stride, hipMemcpyHostToDevice, s.st));
+    s.check_pending = true; s.check_side = false;
   }
   if (use_mask && J) HIPCHK(c, hipMemcpyAsync(s.d_mask, s.h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, s.st));
   // the pick sees the index every earlier LEARN left behind (the upload above did not have to wait for it)
@@ -1491,6 +1584,11 @@ int eppk_pick_stage_end(eppk_ctx* c, uint32_t set, int32_t* out_pick, double* ou
   if (s.n == 0) return EPPK_OK;
   HIPCHK(c, hipEventSynchronize(s.picked));
   if (s.copy_pending) { HIPCHK(c, hipEventSynchronize(s.copied)); s.copy_pending = false; }   // (the caller may refill the rows now)
+  if (s.check_pending) {
+    s.check_pending = false;
+    if (s.check_side) HIPCHK(c, hipEventSynchronize(s.checked));
+    if (*s.h_bad != 0xFFFFFFFFu) return rows_check_fail(c, "eppk_pick_stage_end", *s.h_bad);
+  }
   const size_t J = (c->n_pods + 63u) / 64u;
   std::memcpy(out_pick, s.h_pick, (size_t)s.n * 4u);
   if (out_score) std::memcpy(out_score, s.h_score, (size_t)s.n * 8u);

@@ -131,3 +131,49 @@ def test_zero_copy_small_batches(pkg, orc, monkeypatch, eppk_mode, zc_max, R, ma
         with pytest.raises(Exception):
             pk.pick_staged(R, use_mask=masked)
         assert pk.launch_status() == 0
+
+
+@pytest.mark.parametrize("R", [300, 3000, 20000])          # host loop (<= 2048 rows) / device check beside a zero-copy pick / device check behind the upload
+def test_rows_out_of_range_are_reported_by_every_host_path(pkg, orc, R):
+    """Request rows in pinned memory are range-checked on the device (a thread per row header) instead of by a host loop in front of the
+    launch: the call still fails and names the LOWEST bad row, delivers nothing, leaves no sticky launch-status flag behind and the
+    index in order -- and the next, clean batch is bit-exact against the oracle."""
+    wl = pkg.workload.make_workload(5, R=R, P=4096, n_groups=16)
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    op, os_, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+    bad = wl.reqs.copy()
+    lo, hi = R // 3, R - 1
+    bad[hi, 0] = np.uint64(1000) << np.uint64(32)                 # n_blocks = 1000
+    bad[lo, 0] = np.uint64(200)                                   # adapter 200
+    with pkg.BatchedPicker(wl.chain, max_pods=4096, max_blocks=wl.B, max_batch=R, index_slots=1 << 21) as pk:      # (room for what the LEARN batch teaches it)
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        st_reqs, _ = pk.staging()
+        st_reqs[:R] = bad
+        with pytest.raises(pkg.EppkError, match=f"row {lo} "):
+            pk.pick_staged(R)
+        with pytest.raises(pkg.EppkError, match=f"row {lo} "):
+            pk.pick(bad)
+        for learn in (False, True):
+            b_reqs, _ = pk.stage_buffers(0)
+            b_reqs[:R] = bad
+            try:
+                pk.stage_begin(0, R, learn=learn)
+                with pytest.raises(pkg.EppkError, match=f"row {lo} "):
+                    pk.stage_end(0)
+            except pkg.EppkError as e:                               # (the host loop of a small batch refuses it in _begin)
+                assert f"row {lo} " in str(e) and R <= 2048
+        assert pk.launch_status() == 0 and pk.index_selfcheck() == 0
+        # a LEARN batch with bad rows taught the index its other rows; without LEARN nothing changed: clean batches still match the oracle
+        st_reqs[:R] = wl.reqs
+        p, s = pk.pick_staged(R)
+        if R <= 2048:                                                # (refused in _begin: the index never saw the batch)
+            assert np.array_equal(p, op) and np.array_equal(s.view(np.uint64), os_.view(np.uint64))
+        else:
+            good = np.ones(R, dtype=bool); good[[lo, hi]] = False
+            picks_learned = op.copy(); picks_learned[~good] = -1
+            oix.insert_picks(bad, wl.B, picks_learned)               # what the device learned: every row but the two bad ones
+            op2, os2, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)
+            assert np.array_equal(p, op2) and np.array_equal(s.view(np.uint64), os2.view(np.uint64))
+            assert pk.index_size() == oix.size()
