@@ -1371,9 +1371,10 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
         c->check.pending = true; c->check.side = false; c->check.who = validate_as;
       }
     } else {
-      // In chunks of whole rows: pageable caller memory goes through the pinned staging buffer, and the copy (and the validation) of
-      // chunk i + 1 runs while chunk i is on its way over PCIe (one pass over 17 MB followed by one DMA of 17 MB was 1.2 ms per
-      // 64k-request batch).  A row out of range: nothing is launched (the chunks already uploaded are simply not used).
+      // In chunks of whole rows: pageable caller memory goes through the pinned staging buffer, and the copy of chunk i + 1 runs while
+      // chunk i is on its way over PCIe (one pass over 17 MB followed by one DMA of 17 MB was 1.2 ms per 64k-request batch).
+      // (Helper threads for that copy -- 1, 3 or 7, chunks handed out by an atomic cursor, a third of the batch per DMA -- changed
+      // nothing: 0.63-0.67 ms per 64k-request batch with or without them, gpurun_out/r3dma/copy_threads.txt; not kept.)
       const uint32_t rows_per_chunk = (uint32_t)(((size_t)2 << 20) / c->stride) ? (uint32_t)(((size_t)2 << 20) / c->stride) : 1u;
       for (uint32_t r0 = 0; r0 < up_n; r0 += rows_per_chunk) {
         const uint32_t nr = up_n - r0 < rows_per_chunk ? up_n - r0 : rows_per_chunk;
@@ -1383,8 +1384,14 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
           if (from != (const uint8_t*)c->h_reqs + off) std::memcpy((uint8_t*)c->h_reqs + off, from, len);   // (a caller may hand the staging buffer itself)
           from = (const uint8_t*)c->h_reqs + off;
         }
-        if (validate_as) { rc = validate_rows(c, validate_as, from, nr, up_lo + r0); if (rc) return rc; }
         HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_reqs + off, from, len, hipMemcpyHostToDevice, c->stream));
+      }
+      if (validate_as) {    // the row headers: on the device, behind the last chunk (the host loop was a third of this path's time)
+        rc = row_check_ensure(c, &c->check.h_bad, &c->check.h_bad_dev, &c->check.st, &c->check.done);
+        if (rc) return rc;
+        rc = rows_check_launch(c, c->d_reqs, up_n, c->check.h_bad, c->check.h_bad_dev, c->stream);
+        if (rc) return rc;
+        c->check.pending = true; c->check.side = false; c->check.who = validate_as;
       }
     }
   }
