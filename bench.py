@@ -736,7 +736,7 @@ def main() -> None:
             if hasattr(run.pk, "staging"):
                 # BASELINE's metric names the p99 pick latency: what a dispatcher that drains a few dozen to a few thousand pending requests
                 # per call observes -- one batch of n requests through eppk_pick_batch_staged, fresh rows written into the pinned buffer
-                # before every call (not timed).  Up to 8192 requests the library runs these zero-copy (one launch, no upload / download).
+                # before every call (not timed).  Up to 3072 requests the library runs these zero-copy (one launch, no upload / download); above, one upload and no download (the kernel writes the pinned results).
                 by_n = {}
                 for n in (16, 128, 2048, 8192):
                     if n > R:
@@ -751,7 +751,7 @@ def main() -> None:
                     l4 = np.asarray(l4[10:] or l4) * 1e6
                     by_n[str(n)] = {"p50_us": float(np.percentile(l4, 50)), "p99_us": float(np.percentile(l4, 99))}
                 out["host_path"]["latency_by_batch"] = {"requests": by_n, "what": "eppk_pick_batch_staged, one batch at a time, host-observed (call -> picks and scores in "
-                                                        "caller memory); zero-copy up to EPPK_ZERO_COPY_MAX (default 8192) requests"}
+                                                        "caller memory); zero-copy up to EPPK_ZERO_COPY_MAX (default 3072) requests"}
             if hasattr(run.pk, "stage_begin"):
                 # PIPELINED: two staging sets -- the rows of batch k + 1 cross PCIe while batch k is scored (eppk_pick_stage_*).  Same
                 # convention as `staged`: the rows are in the pinned buffers already (two different batches, one per set; building them

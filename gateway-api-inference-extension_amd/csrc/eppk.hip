@@ -160,16 +160,17 @@ struct eppk_ctx {
   // the pinned staging buffer and writes picks and scores straight into the pinned result buffers -- one launch instead of
   // upload + launch + two downloads.  A small batch is all latency -- host-observed p50 of eppk_pick_batch_staged, rows freshly written
   // by the caller (C5 snapshot, profiles/r03_z_small_batch_latency.txt): 16 requests 25.8 -> 21.1 us, 128: 33.2 -> 21.7, 2048: 44.9 ->
-  // 32.8, 8192: 137 -> 116; from ~12k requests on the copy engine's 55 GB/s beats the shader's reads over PCIe (16k: 190 vs 202 us,
-  // 64k: 516 vs 690).  EPPK_ZERO_COPY_MAX overrides, 0 = off.
-  uint32_t zero_copy_max = 8192;
+  // 33.  The shader reads host memory at ~28 GB/s, the copy engine at 55: once the copy path had lost its host validation loop, its
+  // chunking and its download copies, it won from ~3000 requests on (4096: 54.7 vs 62.6 us; 2048: 41.7 vs 33.1).
+  // EPPK_ZERO_COPY_MAX overrides, 0 = off.
+  uint32_t zero_copy_max = 3072;
   bool zc_last = false;           // the batch in flight between pick_host_begin and pick_host_end took that path
   // Request rows that arrive in PINNED memory are range-checked ON THE DEVICE (rows_check_kernel: a thread per row header, the lowest
   // bad row into a pinned word by atomicMin) instead of by a host loop in front of the launch: that loop touches one cache line per row
-  // -- 300-500 us for a 64k-request batch, more than the rows' PCIe time, and 65 of the 117 us of an 8192-request zero-copy batch.
+  // -- 300-500 us for a 64k-request batch, more than the rows' PCIe time, and a good part of a mid-sized zero-copy batch.
   // The kernels give a row out of range EPPK_NO_PICK and the index update skips it, exactly as on the *_device entry points; the call
   // still fails with EPPK_ERR_ARG naming the row (from _end), and delivers nothing.  Batches of at most host_check_max rows keep the
-  // host loop (cheaper than a second launch and its event: 2048 requests 33 us with the loop, 41-45 with the kernel; 8192: 117 vs 107;
+  // host loop (cheaper than a second launch and its event: 2048 requests 33 us with the loop, 41-45 with the kernel;
   // 64k staged: 478 vs 402 us, profiles/r03_z_small_batch_latency.txt).  EPPK_HOST_CHECK_MAX overrides.
   struct RowCheck { uint32_t* h_bad = nullptr; uint32_t* h_bad_dev = nullptr; hipStream_t st = nullptr; hipEvent_t done = nullptr;
                     bool pending = false, side = false; const char* who = nullptr; };
@@ -1409,11 +1410,17 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
     }
   }
   const uint8_t* d_shard = (const uint8_t*)c->d_reqs + (upload_all ? (size_t)lo * c->stride : 0u);
-  rc = run_pick(c, d_shard, n, ((cand_mask_shard || mask_on_device) && J) ? c->d_mask : nullptr, c->d_pick + (upload_all ? lo : 0u),
-                c->d_score + (upload_all ? lo : 0u), c->stream, 1u, false, 0ull, 0u);
+  // A single context's host entry points let the kernel write picks and scores straight into the pinned result buffers (posted PCIe
+  // writes: 12 bytes per request) -- no download copies, two enqueues and two engine hand-offs less per batch; a group member keeps
+  // its picks on the device (the gather reads them there).
+  const bool host_out = allow_zero_copy && !upload_all;
+  rc = run_pick(c, d_shard, n, ((cand_mask_shard || mask_on_device) && J) ? c->d_mask : nullptr, host_out ? c->h_pick_dev : c->d_pick + (upload_all ? lo : 0u),
+                host_out ? c->h_score_dev : c->d_score + (upload_all ? lo : 0u), c->stream, 1u, false, 0ull, 0u);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick + (upload_all ? lo : 0u), (size_t)n * 4u, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score + (upload_all ? lo : 0u), (size_t)n * 8u, hipMemcpyDeviceToHost, c->stream));
+  if (!host_out) {
+    HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick + (upload_all ? lo : 0u), (size_t)n * 4u, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score + (upload_all ? lo : 0u), (size_t)n * 8u, hipMemcpyDeviceToHost, c->stream));
+  }
   return EPPK_OK;
 }
 
@@ -1567,13 +1574,13 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   if (use_mask && J) HIPCHK(c, hipMemcpyAsync(s.d_mask, s.h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, s.st));
   // the pick sees the index every earlier LEARN left behind (the upload above did not have to wait for it)
   if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
-  int rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.d_pick, s.d_score, s.st, 1u, false, 0ull, 0u);
+  // (picks and scores: written by the kernel straight into the set's pinned result buffers -- no download copies; a LEARN update reads
+  // the picks from there, and only this set's next pick, ordered behind that update, writes them again)
+  int rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
   if (rc) { s.busy = false; return rc; }
-  HIPCHK(c, hipMemcpyAsync(s.h_pick, s.d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, s.st));
-  HIPCHK(c, hipMemcpyAsync(s.h_score, s.d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, s.st));
   HIPCHK(c, hipEventRecord(s.picked, s.st));
   if (flags & EPPK_PICK_LEARN) {
-    rc = eppk_index_insert_picks_device(c, s.d_reqs, s.d_pick, n_reqs, (void*)s.st);
+    rc = eppk_index_insert_picks_device(c, s.d_reqs, s.h_pick_dev, n_reqs, (void*)s.st);
     if (rc) return rc;                          // (the picks stand: end() still delivers them)
     HIPCHK(c, hipEventRecord(c->learned, s.st));
     c->learn_pending = true;

@@ -208,7 +208,7 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
  * C memory anyway).  Valid until eppk_destroy; not to be written while a eppk_pick_batch* call of this context is running. */
 int eppk_host_staging(eppk_ctx* ctx, void** reqs, uint64_t** cand_mask);
 /* eppk_pick_batch over the first n_reqs rows (and, with use_mask != 0, mask rows) of the staging buffers: same validation, same
- * results, no host copy.  Batches of at most EPPK_ZERO_COPY_MAX requests (environment, default 8192; 0 = never) are scored ZERO-COPY
+ * results, no host copy.  Batches of at most EPPK_ZERO_COPY_MAX requests (environment, default 3072; 0 = never) are scored ZERO-COPY
  * by all host-buffer entry points: the kernel reads the pinned rows and writes the pinned results itself -- one launch, no upload or
  * download (a small batch is all latency: 128 requests 33 -> 22 us host-observed). */
 int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t* out_pick, double* out_score);

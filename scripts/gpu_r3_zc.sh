@@ -2,4 +2,4 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out/r3zc
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_staging.py tests/test_gpupicker_cpp.py tests/test_host_cpp.py tests/test_scheduler_cpp.py -m gpu -q -x 2>&1 | tail -5 | tee $OUT/pytest_sel2.txt
+for zc in 1024 2048 4096 1024 2048 4096; do echo "== EPPK_ZERO_COPY_MAX=$zc"; EPPK_ZERO_COPY_MAX=$zc timeout 120 python scripts/gpu_small_batch_latency.py 2>&1 | grep "n=" | sed -n 4,7p; done | tee $OUT/latency_zc_threshold2.txt

@@ -88,13 +88,13 @@ def test_pipelined_stage_sets_against_the_oracle(pkg, orc, monkeypatch, eppk_mod
 
 
 @pytest.mark.parametrize("zc_max", ["0", None, "1000000"])
-@pytest.mark.parametrize("R,masked", [(1, False), (37, True), (2048, False), (8192, True), (8193, False)])
+@pytest.mark.parametrize("R,masked", [(1, False), (37, True), (2048, False), (3072, True), (3073, False), (8200, False)])
 def test_zero_copy_small_batches(pkg, orc, monkeypatch, eppk_mode, zc_max, R, masked):
     """Host-buffer picks of at most EPPK_ZERO_COPY_MAX requests run zero-copy (the kernel reads the pinned staging rows and writes the
     pinned result buffers: one launch, no upload / download): every entry point that takes the path -- eppk_pick_batch on pageable rows,
     eppk_pick_batch_staged, eppk_pick_stage_begin / _end -- against the oracle, with the path off, at its default and forced for every size."""
     if zc_max is None:
-        monkeypatch.delenv("EPPK_ZERO_COPY_MAX", raising=False)           # the library's default (8192)
+        monkeypatch.delenv("EPPK_ZERO_COPY_MAX", raising=False)           # the library's default (3072)
     else:
         if eppk_mode != "default":
             pytest.skip("the zero-copy switch is varied in the default library mode only (GPU time)")
