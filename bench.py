@@ -718,7 +718,7 @@ def main() -> None:
             lat = np.asarray(lat[2:] or lat) * 1e3
             out["host_path"] = {"batches": int(lat.size), "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                                 "decisions_per_s_p50": R / (float(np.percentile(lat, 50)) * 1e-3),
-                                "what": "eppk_pick_batch on pageable caller rows: chunked copy into pinned staging overlapped with the H2D DMA, kernel, D2H"}
+                                "what": "eppk_pick_batch on pageable caller rows: chunked copy into pinned staging overlapped with the H2D DMA, row check + pick kernel writing the pinned results"}
             if hasattr(run.pk, "staging"):
                 # the same with the rows BUILT in the library's pinned staging buffer (eppk_host_staging / eppk_pick_batch_staged): what a
                 # dispatcher that writes its request rows straight into that buffer sees; the fill is the caller's row construction, not timed
@@ -732,7 +732,7 @@ def main() -> None:
                 lat2 = np.asarray(lat2[2:] or lat2) * 1e3
                 out["host_path"]["staged"] = {"p50_ms": float(np.percentile(lat2, 50)), "p99_ms": float(np.percentile(lat2, 99)),
                                               "decisions_per_s_p50": R / (float(np.percentile(lat2, 50)) * 1e-3),
-                                              "what": "eppk_pick_batch_staged: rows already in the pinned staging buffer: validate, H2D, kernel, D2H"}
+                                              "what": "eppk_pick_batch_staged: rows already in the pinned staging buffer: one H2D, row check on the device, pick kernel writing the pinned results"}
             if hasattr(run.pk, "staging"):
                 # BASELINE's metric names the p99 pick latency: what a dispatcher that drains a few dozen to a few thousand pending requests
                 # per call observes -- one batch of n requests through eppk_pick_batch_staged, fresh rows written into the pinned buffer
