@@ -164,7 +164,6 @@ struct eppk_ctx {
   // chunking and its download copies, it won from ~3000 requests on (4096: 54.7 vs 62.6 us; 2048: 41.7 vs 33.1).
   // EPPK_ZERO_COPY_MAX overrides, 0 = off.
   uint32_t zero_copy_max = 3072;
-  bool zc_last = false;           // the batch in flight between pick_host_begin and pick_host_end took that path
   // Request rows that arrive in PINNED memory are range-checked ON THE DEVICE (rows_check_kernel: a thread per row header, the lowest
   // bad row into a pinned word by atomicMin) instead of by a host loop in front of the launch: that loop touches one cache line per row
   // -- 300-500 us for a 64k-request batch, more than the rows' PCIe time, and a good part of a mid-sized zero-copy batch.
@@ -1333,7 +1332,6 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
   const size_t J = (c->n_pods + 63u) / 64u;
   int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
   if (rc) return rc;
-  c->zc_last = false;
   c->check.pending = false;
   if (allow_zero_copy && n != 0 && n <= c->zero_copy_max && !upload_all && lo == 0 && full_n == n && !mask_on_device) {
     // ZERO-COPY (a small batch of one context): rows (and mask) into the pinned staging buffers unless they are there already, then
@@ -1353,7 +1351,6 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
       HIPCHK(c, hipEventRecord(c->check.done, c->check.st));
       c->check.pending = true; c->check.side = true; c->check.who = validate_as;
     }
-    c->zc_last = true;
     return EPPK_OK;
   }
   const uint32_t up_lo = upload_all ? 0u : lo, up_n = upload_all ? full_n : n;

@@ -198,7 +198,11 @@ int eppk_index_evict_older_device(eppk_ctx* ctx, uint32_t min_epoch, void* strea
  *   cand_mask nullable; else [n_reqs][ceil(n_pods/64)] u64, bit p%64 of word p/64 set = pod p is a
  *             candidate (the subset filter of request.go:104-133 as a bitmask)
  *   out_pick  [n_reqs] candidate index, or EPPK_NO_PICK when the request has no candidates
- *   out_score nullable; [n_reqs] weighted total of the picked endpoint (NaN-free; 0 for NO_PICK) */
+ *   out_score nullable; [n_reqs] weighted total of the picked endpoint (NaN-free; 0 for NO_PICK)
+ * A request row out of range (n_blocks > max_blocks, adapter outside [-1, EPPK_MAX_ADAPTERS)) fails the whole call with
+ * EPPK_ERR_ARG naming the lowest such row; nothing is written to out_pick / out_score.  (Round 3: the check runs on the device for
+ * batches of more than EPPK_HOST_CHECK_MAX = 2048 rows -- a host loop over 64k row headers took longer than their PCIe transfer -- so
+ * the batch HAS been scored when the error is returned; see the pipelined form below for what that means with EPPK_PICK_LEARN.) */
 int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask,
                     int32_t* out_pick, double* out_score);
 
@@ -207,7 +211,7 @@ int eppk_pick_batch(eppk_ctx* ctx, const void* reqs, uint32_t n_reqs, const uint
  * pageable caller memory (that copy, not PCIe, is most of a 64k-request batch's 1.2 ms; INTEGRATION.md: the cgo dispatcher fills
  * C memory anyway).  Valid until eppk_destroy; not to be written while a eppk_pick_batch* call of this context is running. */
 int eppk_host_staging(eppk_ctx* ctx, void** reqs, uint64_t** cand_mask);
-/* eppk_pick_batch over the first n_reqs rows (and, with use_mask != 0, mask rows) of the staging buffers: same validation, same
+/* eppk_pick_batch over the first n_reqs rows (and, with use_mask != 0, mask rows) of the staging buffers: same row check, same
  * results, no host copy.  Batches of at most EPPK_ZERO_COPY_MAX requests (environment, default 3072; 0 = never) are scored ZERO-COPY
  * by all host-buffer entry points: the kernel reads the pinned rows and writes the pinned results itself -- one launch, no upload or
  * download (a small batch is all latency: 128 requests 33 -> 22 us host-observed). */
@@ -220,8 +224,11 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
  *     fill set A; begin(A);  fill set B; begin(B);  end(A) -> results of A;  fill A; begin(A);  end(B); ...
  * eppk_pick_stage_buffers: the set's pinned request rows (max_batch rows) and mask rows (only when asked for), valid until
  *     eppk_destroy, not to be written between the set's begin and end.
- * eppk_pick_stage_begin: validates the rows (as eppk_pick_batch does), enqueues upload + pick + download on the set's stream and
- *     returns.  flags & EPPK_PICK_LEARN chains the post-route index update (eppk_index_insert_picks_device: index[hash[r][i]] U=
+ * eppk_pick_stage_begin: enqueues upload + row check + pick on the set's stream and returns (the kernel writes picks and scores into
+ *     the set's pinned result buffers; at most EPPK_ZERO_COPY_MAX requests: no upload either, the kernel reads the pinned rows).  Rows
+ *     out of range: at most EPPK_HOST_CHECK_MAX rows are checked here, on the host, and refused at once; larger batches are checked ON
+ *     THE DEVICE and eppk_pick_stage_end fails with EPPK_ERR_ARG naming the lowest bad row and delivers nothing -- such a row was scored
+ *     as EPPK_NO_PICK and a LEARN update has skipped it (the rest of the batch was learned).  flags & EPPK_PICK_LEARN chains the post-route index update (eppk_index_insert_picks_device: index[hash[r][i]] U=
  *     {pick[r]}, 0602-…/README.md:101-108) behind the pick ON THE DEVICE -- rows and picks are there already; the picks are on their
  *     way back to the host before the update starts.  A later begin (either set) scores against the index every earlier LEARN left
  *     behind: its pick waits for that update on the device, its upload does not.
@@ -240,8 +247,8 @@ int eppk_pick_stage_end(eppk_ctx* ctx, uint32_t set, int32_t* out_pick, double* 
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
-/* Trust contract of the *_device entry points.  The host-buffer entry points validate every request row before anything is
- * launched (EPPK_ERR_ARG names the row).  The *_device entry points cannot read the rows, so the KERNELS check them: a row whose
+/* Trust contract of the *_device entry points.  The host-buffer entry points check every request row and fail the call with
+ * EPPK_ERR_ARG naming the row (above).  The *_device entry points return before the rows are looked at, so the KERNELS check them: a row whose
  * n_blocks exceeds max_blocks or whose adapter lies outside [-1, EPPK_MAX_ADAPTERS) is not scored -- its pick (every entry of its
  * fallback list) is EPPK_NO_PICK, its score 0.0 -- and eppk_index_insert_picks_device ignores a pick >= max_pods (and the picks of
  * such rows); either event sets a sticky flag that eppk_launch_status reports.  Nothing is read or written out of bounds and no
