@@ -1831,8 +1831,23 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
     for (size_t i = 0; i < (size_t)n_reqs * k; ++i) { out_pick[i] = EPPK_NO_PICK; if (out_score) out_score[i] = 0.0; }
     return EPPK_OK;
   }
-  // device buffers are kept in the context (allocated on first use); transfers are plain pageable copies
   const size_t mb = c->cfg.max_batch;
+  if (n_reqs <= c->zero_copy_max && (size_t)n_reqs * k <= mb) {
+    // ZERO-COPY, as the single-pick entry points do it for small batches (a dispatcher that asks for fallback lists sends EVERY batch
+    // through here): rows (and mask) into the pinned staging buffers, one launch that reads them and writes the n x k lists into the
+    // pinned result buffers (max_batch entries each: n x k fits), no upload, no download.
+    int rc = ensure_host_staging(c, cand_mask != nullptr);
+    if (rc) return rc;
+    if (reqs != c->h_reqs) std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+    if (cand_mask && cand_mask != c->h_mask) std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
+    rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n_reqs, cand_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, k, false, 0ull, 0u);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * k * 4u);
+    if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * k * 8u);
+    return EPPK_OK;
+  }
+  // device buffers are kept in the context (allocated on first use); transfers are plain pageable copies
   if (!c->d_tk_reqs) {
     HIPCHK(c, hipMalloc(&c->d_tk_reqs, mb * c->stride));
     HIPCHK(c, hipMalloc((void**)&c->d_tk_pick, mb * EPPK_MAX_TOPK * 4u));
@@ -1880,16 +1895,17 @@ int eppk_pick_random_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const 
   }
   rc = ensure_host_staging(c, cand_mask != nullptr);
   if (rc) return rc;
-  std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
-  HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
-  if (cand_mask) {
-    std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
-    HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+  if (reqs != c->h_reqs) std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+  if (cand_mask && cand_mask != c->h_mask) std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
+  if (n_reqs <= c->zero_copy_max) {          // zero-copy (small batch): the kernels read the pinned rows and write the pinned results
+    rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n_reqs, cand_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, k, true, seed, 0u);
+    if (rc) return rc;
+  } else {                                   // one upload; the results still land in the pinned buffers (no download copies)
+    HIPCHK(c, hipMemcpyAsync(c->d_reqs, c->h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
+    if (cand_mask) HIPCHK(c, hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
+    rc = run_pick(c, (const uint8_t*)c->d_reqs, n_reqs, cand_mask ? c->d_mask : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, k, true, seed, 0u);
+    if (rc) return rc;
   }
-  rc = run_pick(c, (const uint8_t*)c->d_reqs, n_reqs, cand_mask ? c->d_mask : nullptr, c->d_pick, c->d_score, c->stream, k, true, seed, 0u);
-  if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->h_pick, c->d_pick, (size_t)n_reqs * 4u, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_score, c->d_score, (size_t)n_reqs * 8u, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
   if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);

@@ -125,6 +125,16 @@ def test_zero_copy_small_batches(pkg, orc, monkeypatch, eppk_mode, zc_max, R, ma
             for which in (0, 1):
                 p, s = pk.stage_end(which)
                 assert np.array_equal(p, op) and np.array_equal(s.view(np.uint64), os_.view(np.uint64)), f"stage set {which}"
+        # ordered fallbacks and the random-top-k picker go through the same staging (eppk_pick_topk / eppk_pick_random_topk)
+        rp, rs = pk.pick_random_topk(wl.reqs, 3, 7, wl.mask)
+        orp, ors = orc.pick_random_topk(wl.chain, wl.pods, oix, wl.reqs, wl.B, 3, 7, wl.mask)
+        assert np.array_equal(rp, orp) and np.array_equal(rs.view(np.uint64), ors.view(np.uint64)), "eppk_pick_random_topk"
+        tp, ts = pk.pick_topk(wl.reqs, 3, wl.mask)
+        assert np.array_equal(tp[:, 0], op) and np.array_equal(ts[:, 0].view(np.uint64), os_.view(np.uint64)), "eppk_pick_topk: head of the list"
+        assert all(rp[r] in tp[r] for r in range(R))
+        if R <= 64:                                                    # (the oracle's list builder is a Python loop)
+            otp, ots = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, 3, wl.mask)
+            assert np.array_equal(tp, otp) and np.array_equal(ts.view(np.uint64), ots.view(np.uint64)), "eppk_pick_topk"
         # a row out of range is refused on this path too, and nothing is launched
         st_reqs, _ = pk.staging(with_mask=masked)
         st_reqs[R - 1, 0] = np.uint64(1000) << np.uint64(32)
