@@ -56,6 +56,8 @@ def load() -> C.CDLL:
     lib.orc_score_row.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp]
     lib.orc_pick_batch_assumed.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, vp, vp]
     lib.orc_pick_random_topk.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, u64, vp, vp]
+    lib.orc_pick_topk.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, vp, u32, C.c_int, vp, vp]
+    lib.orc_pick_topk.restype = C.c_int
     lib.orc_index_insert_picks.argtypes = [vp, vp, u32, u32, vp]
     lib.orc_tables_new.argtypes = [vp, u32, vp, u32]
     lib.orc_tables_new.restype = vp
@@ -253,6 +255,28 @@ def pick_random_topk(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs
         mptr = mask.ctypes.data
     rc = lib.orc_pick_random_topk(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], index.h if index is not None else None,
                                   reqs.ctypes.data, max_blocks, R, mptr, k, seed & 0xFFFFFFFFFFFFFFFF, picks.ctypes.data, scores.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle rc={rc}")
+    return picks, scores
+
+
+def pick_topk_batch(chain, pods: np.ndarray, index: Optional[OracleIndex], reqs: np.ndarray, max_blocks: int, k: int,
+                    mask: Optional[np.ndarray] = None, threads: int = 1):
+    """Ordered fallbacks of a whole batch in C (orc_pick_topk: k selection passes per request, `threads` host threads): what checks
+    fallback lists at full batch sizes.  tests/test_oracle_golden.py holds it equal to `pick_topk` below (an independent formulation)."""
+    lib = load()
+    ch = _chain_array(chain)
+    pods = np.ascontiguousarray(pods)
+    reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+    R = reqs.shape[0]
+    picks = np.empty((R, k), dtype=np.int32)
+    scores = np.empty((R, k), dtype=np.float64)
+    mptr = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        mptr = mask.ctypes.data
+    rc = lib.orc_pick_topk(ch.ctypes.data, len(chain), pods.ctypes.data, pods.shape[0], index.h if index is not None else None,
+                           reqs.ctypes.data, max_blocks, R, mptr, k, threads, picks.ctypes.data, scores.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"oracle rc={rc}")
     return picks, scores

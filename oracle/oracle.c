@@ -771,6 +771,81 @@ int orc_pick_random_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers, 
   return rc;
 }
 
+/* Ordered fallbacks (SEMANTICS.md 2a; PickResult.Fallbacks, pkg/lwepp/handlers/server.go:72-77; "multiple comma-separated fallbacks",
+ * docs/proposals/004-endpoint-picker-protocol/README.md:73): the k best candidates of every request under (total descending, index
+ * ascending), padded with EPPK_NO_PICK / 0.0 -- the same k selection passes as orc_pick_random_topk, for whole batches and on several
+ * threads, so that the GPU's fallback lists can be checked at full batch sizes (binding.py keeps the independent formulation -- a
+ * lexsort over orc_score_row's totals -- and tests/test_oracle_golden.py holds the two equal). */
+static int topk_range(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods, uint32_t n_pods,
+                      const orc_index* ix, const uint8_t* reqs, uint32_t max_blocks, uint32_t r0, uint32_t r1,
+                      const uint64_t* cand_mask, uint32_t k, int32_t* out_pick, double* out_score) {
+  orc_scratch s;
+  if (scratch_init(&s, n_pods)) { scratch_free(&s); return -6; }
+  const size_t stride = sizeof(eppk_req_hdr) + 8u * (size_t)max_blocks;
+  const size_t mw = (n_pods + 63u) / 64u;
+  int rc = 0;
+  for (uint32_t r = r0; r < r1 && rc == 0; ++r) {
+    int32_t pick; double sc; uint32_t nc = 0;
+    rc = schedule_one(chain, n_scorers, pods, n_pods, ix, reqs + stride * r, max_blocks, cand_mask ? cand_mask + mw * r : NULL, &s,
+                      &pick, &sc, NULL, &nc);
+    if (rc) break;
+    uint32_t top[EPPK_MAX_TOPK]; uint32_t n = 0;
+    for (uint32_t i = 0; i < k && i < nc; ++i) {
+      int best = -1;
+      for (uint32_t c = 0; c < nc; ++c) {
+        int taken = 0;
+        for (uint32_t t = 0; t < n; ++t) taken |= top[t] == c;
+        if (taken) continue;
+        if (best < 0 || s.total[c] > s.total[best]) best = (int)c;   /* candidates ascend by index: strict > keeps the lowest */
+      }
+      top[n++] = (uint32_t)best;
+    }
+    for (uint32_t i = 0; i < k; ++i) {
+      out_pick[(size_t)r * k + i] = i < n ? (int32_t)s.cand[top[i]] : EPPK_NO_PICK;
+      if (out_score) out_score[(size_t)r * k + i] = i < n ? s.total[top[i]] : 0.0;
+    }
+  }
+  scratch_free(&s);
+  return rc;
+}
+
+typedef struct {
+  const eppk_weighted_scorer* chain; uint32_t n_scorers; const eppk_pod_row* pods; uint32_t n_pods; const orc_index* ix;
+  const uint8_t* reqs; uint32_t max_blocks, r0, r1, k; const uint64_t* mask; int32_t* pick; double* score; int rc;
+} topk_job;
+
+static void* topk_main(void* arg) {
+  topk_job* j = (topk_job*)arg;
+  j->rc = topk_range(j->chain, j->n_scorers, j->pods, j->n_pods, j->ix, j->reqs, j->max_blocks, j->r0, j->r1, j->mask, j->k, j->pick, j->score);
+  return NULL;
+}
+
+int orc_pick_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods, uint32_t n_pods,
+                  const orc_index* ix, const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
+                  uint32_t k, int threads, int32_t* out_pick, double* out_score) {
+  if (k < 1 || k > EPPK_MAX_TOPK || n_scorers > EPPK_MAX_SCORERS) return -1;
+  if ((!chain && n_scorers) || (!pods && n_pods) || (!reqs && n_reqs) || (!out_pick && n_reqs)) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if ((uint32_t)threads > n_reqs) threads = n_reqs ? (int)n_reqs : 1;
+  pthread_t tid[256];
+  topk_job job[256];
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    topk_job* j = &job[t];
+    j->chain = chain; j->n_scorers = n_scorers; j->pods = pods; j->n_pods = n_pods; j->ix = ix; j->reqs = (const uint8_t*)reqs;
+    j->max_blocks = max_blocks; j->k = k; j->mask = cand_mask; j->pick = out_pick; j->score = out_score; j->rc = 0;
+    j->r0 = (uint32_t)((uint64_t)n_reqs * (uint64_t)t / (uint64_t)threads);
+    j->r1 = (uint32_t)((uint64_t)n_reqs * (uint64_t)(t + 1) / (uint64_t)threads);
+    if (threads == 1 || pthread_create(&tid[t], NULL, topk_main, j)) { topk_main(j); tid[t] = 0; }
+  }
+  for (int t = 0; t < threads; ++t) {
+    if (tid[t]) pthread_join(tid[t], NULL);
+    if (job[t].rc) rc = job[t].rc;
+  }
+  return rc;
+}
+
 int orc_score_row(const eppk_weighted_scorer* chain, uint32_t n_scorers, const eppk_pod_row* pods,
                   uint32_t n_pods, const orc_index* ix, const void* req, const uint64_t* mask_row,
                   double* out_total) {

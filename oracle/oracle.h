@@ -79,6 +79,13 @@ int orc_pick_random_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers,
                          const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
                          uint32_t k, uint64_t seed, int32_t* out_pick, double* out_score);
 
+/* SEMANTICS.md 2a: ordered fallbacks -- the k (<= 8) best candidates of every request under (total descending, index ascending),
+ * [n_reqs][k] entries padded with EPPK_NO_PICK / 0.0; `threads` host threads over request ranges. */
+int orc_pick_topk(const eppk_weighted_scorer* chain, uint32_t n_scorers,
+                  const eppk_pod_row* pods, uint32_t n_pods, const orc_index* ix,
+                  const void* reqs, uint32_t max_blocks, uint32_t n_reqs, const uint64_t* cand_mask,
+                  uint32_t k, int threads, int32_t* out_pick, double* out_score);
+
 /* Full weighted totals of ONE request over all pods (non-candidates get NaN); debugging aid. */
 int orc_score_row(const eppk_weighted_scorer* chain, uint32_t n_scorers,
                   const eppk_pod_row* pods, uint32_t n_pods, const orc_index* ix,

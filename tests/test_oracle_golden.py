@@ -75,6 +75,35 @@ def test_sparse_cpu_algorithm_equals_the_per_request_loop(pkg, orc):
     assert (p1 == -1).all() and (s1 == 0.0).all()
 
 
+@pytest.mark.parametrize("cfg,masked", [(2, False), (3, False), (3, True), (5, True)])
+def test_batch_fallback_lists_equal_the_per_request_formulation(pkg, orc, cfg, masked):
+    """orc_pick_topk (C, threaded: what can check the GPU's fallback lists at full batch sizes) against binding.pick_topk (a lexsort
+    over orc_score_row's totals, one request at a time): lists and scores bitwise equal for k = 1 / 3 / 8, with candidate masks that
+    leave some requests fewer than k candidates or none, with holes in the snapshot; column 0 is the pick of orc_pick_batch."""
+    wl = pkg.workload.make_workload(cfg, R=300, P=777 if cfg != 5 else 4096, masked=masked)
+    mask = wl.mask
+    if masked:
+        mask = mask.copy()
+        mask[0, :] = 0                                        # no candidate
+        mask[1, :] = 0; mask[1, 0] = np.uint64(0b101)         # two candidates
+    pods = wl.pods.copy()
+    pods["flags"][5::7] = 1                                   # EPPK_POD_INACTIVE: holes
+    oix = orc.OracleIndex()
+    if wl.index_slots:
+        oix.insert(wl.index_hashes, wl.index_pods)
+        oix.scrub_inactive(pods)
+    p1, s1, _ = orc.pick_batch(wl.chain, pods, oix, wl.reqs, wl.B, mask)
+    for k in (1, 3, 8):
+        a_p, a_s = orc.pick_topk(wl.chain, pods, oix, wl.reqs, k, mask)
+        for threads in (1, 5):
+            b_p, b_s = orc.pick_topk_batch(wl.chain, pods, oix, wl.reqs, wl.B, k, mask, threads=threads)
+            assert np.array_equal(a_p, b_p), (k, threads, np.nonzero((a_p != b_p).any(axis=1))[0][:5])
+            assert np.array_equal(a_s.view(np.uint64), b_s.view(np.uint64)), (k, threads)
+        assert np.array_equal(b_p[:, 0], p1) and np.array_equal(b_s[:, 0].view(np.uint64), s1.view(np.uint64))
+        if masked:
+            assert (b_p[0] == -1).all() and (b_s[0] == 0.0).all() and (b_p[1, 2:] == -1).all()
+
+
 def test_oracle_mt_equals_sequential(gold, pkg, orc):
     c = load_case(gold, "full_masked")
     reqs, B = rows_of(pkg, c)
