@@ -50,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-DBG = os.environ.get("EPPK_BENCH_DBG", "")      # measurement switches of the N > 1 path (nolat / nocast / nogather): timing experiments only
+DBG = os.environ.get("EPPK_BENCH_DBG", "")      # measurement switches of the N > 1 path (nolat / nogather; with or without --pack16): timing experiments only (scripts/gpu_r3_z4.sh)
 HOSTTIME = os.environ.get("EPPK_BENCH_HOSTTIME", "0") == "1"   # stderr: where the host's time of a timed region goes (N > 1 path)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMD16; a wave64 VALU instruction occupies its SIMD for 4 cycles

@@ -1,12 +1,13 @@
 #!/bin/bash
 # kernel timeline of a 20-step weak-scaling region on one GPU (where do the 100 us beyond the single-GPU region go?)
+# (as run in round 3 the int16 cast was the default and the variant without it was called "nocast": gpurun_out/r3z4_gaps.txt)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r3z4
 rm -rf $OUT; mkdir -p $OUT
-for dbg in none nolat nocast nogather; do
+for dbg in none nolat nopack nogather; do   # (all but "nopack" with --pack16: the cast kernel is what the experiment is about)
 rm -rf $OUT/trace
-( cd /tmp; EPPK_BENCH_DBG=$dbg timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o weak -- python $GRAFT_REPO_ROOT/bench.py --force-dist --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-cold-ref --host-path 0 --p99-samples 0 > $OUT/weak.json 2> $OUT/weak.err )
+( cd /tmp; EPPK_BENCH_DBG=$dbg timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o weak -- python $GRAFT_REPO_ROOT/bench.py --force-dist --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-cold-ref --host-path 0 --p99-samples 0 $( [ $dbg = nopack ] || echo --pack16 ) > $OUT/weak.json 2> $OUT/weak.err )
 DBGN=$dbg python - <<'P'
 import csv, glob, os
 f = glob.glob(os.environ['OUT'] + '/trace/**/*kernel_trace.csv', recursive=True)[0]
