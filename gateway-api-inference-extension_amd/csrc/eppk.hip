@@ -129,7 +129,11 @@ struct eppk_ctx {
     uint32_t n = 0; bool busy = false, had_mask = false;
   };
   StageSet stage[2];
-  hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update: the next pick waits for it
+  hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update; every later pick, index update and
+                                                              // publish of this context -- on whatever stream -- is ordered behind it (learn_fence)
+  bool quiet_rows = false;        // a host-buffer launch is being enqueued: its kernels raise "row out of range" on a word of their own
+                                  // (the call reports the row itself), not on the sticky flag of the *_device entry points
+  uint32_t host_flags = 0;        // sticky launch-status flags raised by the host side (EPPK_LAUNCH_LEARN_FAILED)
   void* d_tk_reqs = nullptr; uint64_t* d_tk_mask = nullptr; int32_t* d_tk_pick = nullptr; double* d_tk_score = nullptr;  // eppk_pick_topk
   eppk_pod_row* h_rows = nullptr; eppk_pod_row* d_rows = nullptr;  // raw pod rows of a publish (pinned staging + device copy)
 
@@ -190,7 +194,6 @@ struct eppk_ctx {
   uint32_t wl_hint = 0xFFFFFFFFu;   // decaying maximum of the recent launches' deferred counts (0xFFFFFFFF: no report seen yet): sizes the work-list pass
   bool quad_tail_on = true;         // EPPK_QUAD_TAIL=0: always the two-launch form (pick_quad_kernel + work-list pass)
   uint64_t quad_tail_launches = 0;  // launches that took the one-launch form (pick_quad_kernel<TAIL>)
-  bool quad_tail_warm = false;      // the one-launch form has been launched once (empty): its first real launch pays neither module load nor scratch set-up
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
   const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
   const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
@@ -260,12 +263,14 @@ KSnap make_ksnap(const eppk_ctx* c) {
   k.base = s.base; k.post[0] = s.post[0]; k.post[1] = s.post[1]; k.queue = s.queue; k.kv = s.kv;
   k.thi_t = s.thi_t; k.tlo_t = s.tlo_t;
   k.topv = s.topv; k.topi = s.topi;
-  k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes;
+  // (host-buffer launches: the blob descriptor ends 8 bytes early, so that the fast kernel's "last dword" is a spare word of the blob's
+  // tail instead of the sticky status word -- see eppk_ctx::quiet_rows)
+  k.blob = s.blob; k.blob_bytes = (uint32_t)c->lay.bytes - (c->quiet_rows ? 8u : 0u);
   k.qmin_t = s.qmin_t; k.qmax_t = s.qmax_t; k.act_t = s.act_t; k.nat = s.nat; k.lead_queue = c->lead_queue ? 1u : 0u;
   k.pterm = c->pterm; k.pterm_ld = c->pterm_ld;
   k.n_pods = c->n_pods; k.J = (c->n_pods + 63u) / 64u;
   k.qrange = s.qrange;
-  k.status = c->d_status;
+  k.status = c->d_status + (c->quiet_rows ? 1 : 0);
   return k;
 }
 
@@ -301,6 +306,17 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk
 // topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries): extra selection rounds of the
 // fast kernel for fused chains, the TOPK generic kernel otherwise
 template <typename F> int by_lane_word(const eppk_ctx* c, F&& f);
+
+// The post-route update of an EPPK_PICK_LEARN batch (budget, insert and list-sort kernels) runs on its staging set's PRIVATE stream and
+// may still be running when eppk_pick_stage_end returns.  Whatever touches the index or reads it afterwards -- a pick, an insert, an
+// eviction, a removal, a trim, a clear, a publish (index scrub), the self check -- is ordered behind it here, on the stream it is
+// about to use: the update's kernels assume that nothing disappears while they run and share one sort work list and capacity verdict.
+int learn_fence(eppk_ctx* c, hipStream_t st) {
+  if (!c->learn_pending) return EPPK_OK;
+  if (hipEventQuery(c->learned) == hipSuccess) { c->learn_pending = false; return EPPK_OK; }
+  HIPCHK(c, hipStreamWaitEvent(st, c->learned, 0));
+  return EPPK_OK;
+}
 
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
                 double* d_score, hipStream_t st, uint32_t topk = 1) {
@@ -361,17 +377,16 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
   const void* quad_fn = nullptr;
   uint32_t quad_grid = 0, defer_cap = 0, quad_segs = 0, rep_slot = 0;
   size_t quad_lds = 0;
-  // ONE launch (pick_quad_kernel<TAIL>: its last workgroup scores the deferred requests itself) while the recent launches deferred
-  // next to nothing -- a single workgroup is no match for a work list of hundreds of requests -- else the two-launch form.  Unmasked
-  // picks only.  Until the first report is in, the two-launch form (whose work-list pass copes with anything).
+  // ONE launch (pick_quad_kernel<TAIL>: every workgroup scores what its own wavefronts deferred, right behind its loop) for picks,
+  // masked picks and ordered fallbacks alike; EPPK_QUAD_TAIL=0 keeps the two-launch form (pick_quad_kernel + a work-list pass).
   bool tail = false;
   if (quad) {
     const bool tkq = topk > 1;
     const uint32_t qwpb = c->quad_threads / 64u;
-    tail = c->quad_tail_on && !masked && !tkq && c->wl_hint != 0xFFFFFFFFu && c->wl_hint <= 4u * qwpb;
+    tail = c->quad_tail_on;
     if (tail)
-      quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first)
-                                                                                                   : eppk::pick_quad_tail_u64(c->has_l, c->p_first);
+      quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first, masked, tkq)
+                                                                                                               : eppk::pick_quad_tail_u64(c->has_l, c->p_first, masked, tkq);
     else
       quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_u32(c->has_l, c->p_first, masked, tkq)
                                                                                                             : eppk::pick_quad_u64(c->has_l, c->p_first, masked, tkq);
@@ -443,29 +458,10 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       uint32_t* d_cnt = dset->d + 32;
       uint32_t* d_list = dset->d + 32 + quad_segs;
       uint32_t* d_done = dset->d + 2;       // TAIL: workgroups that have reported in (back to zero when the launch ends)
-      if (!tail && c->quad_tail_on && !masked && topk == 1 && !c->quad_tail_warm) {
-        // The library will switch to the one-launch form as soon as a report says the batches defer next to nothing.  That kernel's
-        // first launch costs about a millisecond (code object, scratch set-up, occupancy query): pay it now, with an EMPTY launch
-        // behind which the real one queues, instead of in the middle of the caller's steady state (a 20-step measurement saw 70 us
-        // per step instead of 17).
-        c->quad_tail_warm = true;
-        const void* tfn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first)
-                                                                                                            : eppk::pick_quad_tail_u64(c->has_l, c->p_first);
-        const uint32_t qwpb = c->quad_threads / 64u;
-        size_t tl_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 64u * (size_t)c->lw_bytes + (size_t)qwpb * sn.J * 64u;
-        if (tl_lds < quad_lds) tl_lds = quad_lds;
-        HIPCHK(c, hipFuncSetAttribute(tfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds));
-        uint32_t zero_reqs = 0u;
-        uint32_t* w_total = dset->d + 20; uint32_t* w_next = dset->d + 21;     // (spare header words: the warm-up must not touch the real counters)
-        uint32_t* w_rep = (uint32_t*)&c->h_reports[kReportRing];
-        void* wargs[] = {&sn, &ix, &tl, &reqs8, &stride, &zero_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &w_total, &w_next,
-                         &topk, &d_done, &w_rep};
-        HIPCHK(c, hipExtLaunchKernel(tfn, dim3(1), dim3(c->quad_threads), wargs, tl_lds, st, nullptr, nullptr, 0));
-      }
       uint32_t* h_rep = (uint32_t*)&c->h_reports[rep_slot];
       void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next,
-                       &topk, &d_done, &h_rep};
-      if (tail) {                           // one launch: the kernel's last workgroup is the work-list pass
+                       &topk, &d_done, &h_rep, &chf};
+      if (tail) {                           // one launch: every workgroup is its own work-list pass
         HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, e1, 0));
         ++c->quad_tail_launches;
         c->last_done = e1;
@@ -537,6 +533,7 @@ int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st);
 //   random            picker "random-top-k" (§3b)      (n entries), r0 = batch index of the first request (the rule hashes it)
 int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick, double* d_score, hipStream_t st,
              uint32_t k, bool random, uint64_t seed, uint32_t r0) {
+  { const int rcf = learn_fence(c, st); if (rcf) return rcf; }     // (the index an earlier EPPK_PICK_LEARN batch leaves behind)
   const uint32_t E = c->assumed_epochs;
   const uint32_t per = E ? (n_reqs + E - 1u) / E : n_reqs;
   const size_t J = (c->n_pods + 63u) / 64u;
@@ -926,6 +923,7 @@ int eppk_snapshot_publish(eppk_ctx* c, const eppk_pod_row* rows, uint32_t n_pods
   if (!c || (!rows && n_pods)) return fail(c, EPPK_ERR_ARG, "eppk_snapshot_publish: null argument");
   if (n_pods > c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_snapshot_publish: n_pods > max_pods");
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }      // (the index scrub below; a LEARN update reads the active-pods row of the current snapshot)
 
   // holes (flags & EPPK_POD_INACTIVE) are never candidates; the QUEUE normalisers range over the ACTIVE pods (snap_qrange_kernel)
   uint64_t act[64] = {0};                      // lane-transposed active set (u64 words serve every lane-word width)
@@ -976,6 +974,7 @@ int eppk_index_clear(eppk_ctx* c) {
   if (!c) return EPPK_ERR_ARG;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->stamps, 0, ((size_t)c->slots + 2u) * 4u, c->stream));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
@@ -992,6 +991,7 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
     if (pods[i] >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_insert: pod >= max_pods");
   if (n == 0) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   int rc = ensure_tmp(c, (size_t)n * 12u);
   if (rc) return rc;
   uint64_t* d_h = (uint64_t*)c->d_tmp;
@@ -1010,7 +1010,7 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
                        c->limit, c->index_epoch, c->ixc, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
-                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status, (const eppk::IxLaunch*)c->d_ixl);
+                       c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status + (c->quiet_rows ? 1 : 0), (const eppk::IxLaunch*)c->d_ixl);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -1022,12 +1022,12 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   return rc;
 }
 
-int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, void* stream) {
-  if (!c || ((!d_reqs || !d_picks) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: null argument");
-  if (!c->slots) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: no index");
+namespace {
+// The post-route update "index[hash[r][i]] U= {pick[r]}" (0602-…/README.md:101-108) for a batch whose rows and picks are on the device:
+// capacity verdict, update, re-sort of the lists it touched -- three launches on `st`.
+int learn_picks(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, hipStream_t st) {
   if (n_reqs == 0 || c->cfg.max_blocks == 0) return EPPK_OK;
-  HIPCHK(c, hipSetDevice(c->cfg.device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  { const int rcf = learn_fence(c, st); if (rcf) return rcf; }
   const uint64_t total = (uint64_t)n_reqs * c->cfg.max_blocks;
   const uint32_t threads = 256;
   const uint64_t grid64 = (total + threads - 1) / threads;
@@ -1040,12 +1040,20 @@ int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->ixc, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
-                       c->cfg.max_pods, c->d_status, c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, (const eppk::IxLaunch*)c->d_ixl);
+                       c->cfg.max_pods, c->d_status + (c->quiet_rows ? 1 : 0), c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, (const eppk::IxLaunch*)c->d_ixl);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
   if (rc) return rc;
   return sortwl_finish(c, sw, st);
+}
+}  // namespace
+
+int eppk_index_insert_picks_device(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, void* stream) {
+  if (!c || ((!d_reqs || !d_picks) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: null argument");
+  if (!c->slots) return fail(c, EPPK_ERR_ARG, "eppk_index_insert_picks_device: no index");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  return learn_picks(c, d_reqs, d_picks, n_reqs, stream ? (hipStream_t)stream : c->stream);
 }
 
 int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
@@ -1053,6 +1061,7 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   if (pod >= c->cfg.max_pods) return fail(c, EPPK_ERR_LIMIT, "eppk_index_remove_pod: pod >= max_pods");
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
@@ -1094,6 +1103,7 @@ int eppk_index_selfcheck(eppk_ctx* c, uint64_t* n_bad) {
   *n_bad = 0;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   int rct = ensure_tmp(c, 256u * 8u);                                          // bad count | records | eight offenders in full (index_selfcheck_kernel)
   if (rct) return rct;
   unsigned long long* d_bad = (unsigned long long*)c->d_tmp;
@@ -1136,6 +1146,7 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   if (n_evicted) *n_evicted = 0;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   for (uint32_t sh = 0; sh < eppk::kIxShards; ++sh)     // "evicted by this launch" (sharded like the other index counters)
     HIPCHK(c, hipMemsetAsync(c->ixc + sh * 8u + eppk::kIxEvicted, 0, sizeof(unsigned long long), c->stream));
   const uint32_t rows = c->slots + 2u, threads = 256;
@@ -1160,6 +1171,7 @@ int eppk_index_trim_pods(eppk_ctx* c, uint32_t cap, uint64_t* n_removed) {
   if (n_removed) *n_removed = 0;
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   // scratch: hist[4096][64] u32 | cutage[4096] u32 | over_t[64] u64 | removed u64
   const size_t hist_b = 4096u * (size_t)eppk::kTrimBins * 4u, cut_b = 4096u * 4u, over_b = 64u * 8u;
   int rc = ensure_tmp(c, hist_b + cut_b + over_b + 8u);
@@ -1194,6 +1206,7 @@ int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream)
   if (!c->slots) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  { const int rcf = learn_fence(c, st); if (rcf) return rcf; }
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
@@ -1248,6 +1261,15 @@ int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
 // every device) and the shard starts at row `lo` of them.
 namespace {
 
+// While one of these lives, the kernels this context enqueues raise "request row out of range" on a word of their own instead of the
+// sticky flag of the *_device entry points: a host-buffer call reports the row itself (EPPK_ERR_ARG naming it), and a flag that an
+// earlier or concurrent *_device launch of the same context raised legitimately must survive that (eppk_launch_status).
+struct QuietRows {
+  eppk_ctx* c;
+  explicit QuietRows(eppk_ctx* c_) : c(c_) { c->quiet_rows = true; }
+  ~QuietRows() { c->quiet_rows = false; }
+};
+
 // Range check of request-row headers on the device: the lowest row out of range lands in *bad (pinned host word, 0xFFFFFFFF = none).
 __global__ void rows_check_kernel(const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n, uint32_t max_blocks, uint32_t* bad) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1264,18 +1286,9 @@ int rows_check_launch(eppk_ctx* c, const void* rows_dev, uint32_t n, uint32_t* h
   return EPPK_OK;
 }
 
-// A batch with a row out of range has been scored (that row: EPPK_NO_PICK) and the kernels have raised the sticky BAD_REQUEST_ROW flag
-// of the *_device entry points: take it back (the host-buffer call reports the row itself) and fail the call.
+// A batch with a row out of range has been scored (that row: EPPK_NO_PICK; its kernels ran under QuietRows, so the sticky flag of the
+// *_device entry points is untouched): fail the call, naming the row.
 int rows_check_fail(eppk_ctx* c, const char* who, uint32_t row) {
-  (void)hipDeviceSynchronize();
-  uint32_t* words[3] = {c->d_status, (uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail), (uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail)};
-  for (uint32_t* w : words) {
-    uint32_t v = 0;
-    if (hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && (v & EPPK_LAUNCH_BAD_REQUEST_ROW)) {
-      v &= ~EPPK_LAUNCH_BAD_REQUEST_ROW;
-      (void)hipMemcpy(w, &v, sizeof v, hipMemcpyHostToDevice);
-    }
-  }
   return fail(c, EPPK_ERR_ARG, std::string(who ? who : "eppk_pick_batch") + ": request row " + std::to_string(row) + " out of range");
 }
 
@@ -1333,6 +1346,8 @@ int pick_host_begin(eppk_ctx* c, const uint8_t* base, bool pinned, uint32_t full
   int rc = ensure_host_staging(c, cand_mask_shard != nullptr || mask_on_device);
   if (rc) return rc;
   c->check.pending = false;
+  // rows that the call validates itself (on the host, or by rows_check_kernel) report through the call, not through the sticky flag
+  struct MaybeQuiet { eppk_ctx* c; bool on; MaybeQuiet(eppk_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->quiet_rows = true; } ~MaybeQuiet() { if (on) c->quiet_rows = false; } } quiet(c, validate_as != nullptr);
   if (allow_zero_copy && n != 0 && n <= c->zero_copy_max && !upload_all && lo == 0 && full_n == n && !mask_on_device) {
     // ZERO-COPY (a small batch of one context): rows (and mask) into the pinned staging buffers unless they are there already, then
     // ONE launch that reads them over PCIe and writes the results into the pinned result buffers; pick_host_end waits for the stream.
@@ -1521,19 +1536,31 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   HIPCHK(c, hipSetDevice(c->cfg.device));
   s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true; s.check_pending = false;
   if (n_reqs == 0) return EPPK_OK;
+  // A begin that fails has NOT begun: whatever it had enqueued on the set's stream is waited for and the set is idle again (both
+  // shims treat a failed begin that way and never call end for it; a set left busy would fail every later begin).  One exception: the
+  // picks were launched and only the chained LEARN update could not be -- the call then succeeds, end() delivers the picks, and
+  // the missed update is reported through eppk_launch_status (EPPK_LAUNCH_LEARN_FAILED) and eppk_last_error.
+  struct Abort {
+    eppk_ctx::StageSet& s; bool armed = true;
+    ~Abort() { if (armed) { (void)hipStreamSynchronize(s.st); if (s.st_copy) (void)hipStreamSynchronize(s.st_copy); if (s.st_check) (void)hipStreamSynchronize(s.st_check);
+                            s.busy = false; s.copy_pending = false; s.check_pending = false; } }
+  } abort_guard{s};
+  QuietRows quiet(c);                        // rows out of range are reported by end(), naming the row (eppk_ctx::quiet_rows)
   const size_t J = (c->n_pods + 63u) / 64u;
-  if (n_reqs <= c->zero_copy_max) {
+  const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
+  const bool zero_copy = n_reqs <= c->zero_copy_max;
+  int rc;
+  if (zero_copy) {
     // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
     // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
     // reads a DEVICE copy of the rows, uploaded on a stream of its own beside the pick (_end waits for that upload too), and the picks
     // out of the pinned result buffer (which only this set's next pick writes, and that one is ordered behind the update).
     const bool dev_check = n_reqs > c->host_check_max;
-    int rc = dev_check ? row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked) : validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
-    if (rc) { s.busy = false; return rc; }
-    const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
+    rc = dev_check ? row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked) : validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
+    if (rc) return rc;
     if (dev_check) {        // beside the pick, on a stream of its own (eppk_ctx::RowCheck)
       rc = rows_check_launch(c, s.h_reqs_dev, n_reqs, s.h_bad, s.h_bad_dev, s.st_check);
-      if (rc) { s.busy = false; return rc; }
+      if (rc) return rc;
       HIPCHK(c, hipEventRecord(s.checked, s.st_check));
       s.check_pending = true; s.check_side = true;
     }
@@ -1542,45 +1569,37 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
         HIPCHK(c, hipStreamCreateWithFlags(&s.st_copy, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
       }
-      if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st_copy, c->learned, 0));     // (an earlier update may still read s.d_reqs)
+      rc = learn_fence(c, s.st_copy);          // (an earlier update may still read s.d_reqs)
+      if (rc) return rc;
       HIPCHK(c, hipMemcpyAsync(s.d_reqs, s.h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, s.st_copy));
       HIPCHK(c, hipEventRecord(s.copied, s.st_copy));
       s.copy_pending = true;
     }
-    if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
     rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
-    if (rc) { s.busy = false; return rc; }
+    if (rc) return rc;
     HIPCHK(c, hipEventRecord(s.picked, s.st));
-    if (learn) {
-      HIPCHK(c, hipStreamWaitEvent(s.st, s.copied, 0));
-      rc = eppk_index_insert_picks_device(c, s.d_reqs, s.h_pick_dev, n_reqs, (void*)s.st);
-      if (rc) return rc;                        // (the picks stand: end() still delivers them)
-      HIPCHK(c, hipEventRecord(c->learned, s.st));
-      c->learn_pending = true;
-    }
-    return EPPK_OK;
-  }
-  // one upload, its row headers checked on the device (as eppk_pick_batch_staged does: eppk_ctx::RowCheck)
-  HIPCHK(c, hipMemcpyAsync(s.d_reqs, s.h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, s.st));
-  {
-    int rc = row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked);
+    if (learn) HIPCHK(c, hipStreamWaitEvent(s.st, s.copied, 0));
+  } else {
+    // one upload, its row headers checked on the device (as eppk_pick_batch_staged does: eppk_ctx::RowCheck)
+    HIPCHK(c, hipMemcpyAsync(s.d_reqs, s.h_reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, s.st));
+    rc = row_check_ensure(c, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked);
     if (!rc) rc = rows_check_launch(c, s.d_reqs, n_reqs, s.h_bad, s.h_bad_dev, s.st);      // behind the upload, in front of the pick
-    if (rc) { s.busy = false; return rc; }
+    if (rc) return rc;
     s.check_pending = true; s.check_side = false;
+    if (use_mask && J) HIPCHK(c, hipMemcpyAsync(s.d_mask, s.h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, s.st));
+    // the pick sees the index every earlier LEARN left behind (run_pick: learn_fence; the upload above did not have to wait for it).
+    // Picks and scores: written by the kernel straight into the set's pinned result buffers -- no download copies; a LEARN update reads
+    // the picks from there, and only this set's next pick, ordered behind that update, writes them again.
+    rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(s.picked, s.st));
   }
-  if (use_mask && J) HIPCHK(c, hipMemcpyAsync(s.d_mask, s.h_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, s.st));
-  // the pick sees the index every earlier LEARN left behind (the upload above did not have to wait for it)
-  if (c->learn_pending) HIPCHK(c, hipStreamWaitEvent(s.st, c->learned, 0));
-  // (picks and scores: written by the kernel straight into the set's pinned result buffers -- no download copies; a LEARN update reads
-  // the picks from there, and only this set's next pick, ordered behind that update, writes them again)
-  int rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
-  if (rc) { s.busy = false; return rc; }
-  HIPCHK(c, hipEventRecord(s.picked, s.st));
-  if (flags & EPPK_PICK_LEARN) {
-    rc = eppk_index_insert_picks_device(c, s.d_reqs, s.h_pick_dev, n_reqs, (void*)s.st);
-    if (rc) return rc;                          // (the picks stand: end() still delivers them)
-    HIPCHK(c, hipEventRecord(c->learned, s.st));
-    c->learn_pending = true;
+  abort_guard.armed = false;                 // the picks are on their way: from here on the call succeeds and end() delivers them
+  if (learn) {
+    // the post-route update, chained on the device: rows and picks are there already (eppk_pick_learn_device's second half)
+    rc = learn_picks(c, s.d_reqs, s.h_pick_dev, n_reqs, s.st);
+    if (rc == EPPK_OK && hipEventRecord(c->learned, s.st) == hipSuccess) c->learn_pending = true;
+    else c->host_flags |= EPPK_LAUNCH_LEARN_FAILED;        // (eppk_last_error holds the reason; the picks stand)
   }
   return EPPK_OK;
 }
@@ -1654,6 +1673,7 @@ int eppk_pick_batch_candidates_device(eppk_ctx* c, const void* d_reqs, uint32_t 
   if (n_reqs == 0) return EPPK_OK;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  { const int rcf = learn_fence(c, st); if (rcf) return rcf; }
   if (c->assumed_epochs)                                           // assumed load works in epochs of the general path (SEMANTICS.md §2b)
     return k == 1 ? eppk_pick_batch_device(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream)
                   : eppk_pick_topk_device(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, stream);
@@ -1942,13 +1962,20 @@ int eppk_launch_status(eppk_ctx* c, uint32_t* flags) {
   if (!c || !flags) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipDeviceSynchronize());     // every launch of this context, on whatever stream the caller used
-  uint32_t f = 0;
-  uint32_t* words[3] = {c->d_status, (uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail), (uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail)};
-  for (uint32_t* w : words) {
+  uint32_t f = c->host_flags;
+  c->host_flags = 0;
+  // sticky words: d_status[0] and the last dword of either snapshot blob.  The words of the host-buffer launches (d_status[1], the
+  // dword 8 bytes earlier in the blobs: eppk_ctx::quiet_rows) only ever matter for what is NOT a row error -- those calls name the row
+  // themselves -- and are cleared along.
+  struct W { uint32_t* p; uint32_t keep; };
+  const W words[6] = {{c->d_status, ~0u}, {c->d_status + 1, ~EPPK_LAUNCH_BAD_REQUEST_ROW},
+                      {(uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail), ~0u}, {(uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail), ~0u},
+                      {(uint32_t*)(c->snap[0].blob + c->lay.bytes - kBlobStatusTail - 8u), 0u}, {(uint32_t*)(c->snap[1].blob + c->lay.bytes - kBlobStatusTail - 8u), 0u}};
+  for (const W& w : words) {
     uint32_t v = 0;
-    HIPCHK(c, hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost));
-    if (v) HIPCHK(c, hipMemset(w, 0, sizeof v));
-    f |= v;
+    HIPCHK(c, hipMemcpy(&v, w.p, sizeof v, hipMemcpyDeviceToHost));
+    if (v) HIPCHK(c, hipMemset(w.p, 0, sizeof v));
+    f |= v & w.keep;
   }
   *flags = f;
   return EPPK_OK;

@@ -782,9 +782,10 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 // current request waits for is queued AHEAD of the loads that serve later requests.
 // WL (work-list) instantiations: the same kernel over the requests pick_quad_kernel deferred (KWork) instead of 0 .. n_reqs - 1.
 // The kernel's body as a function of a VIRTUAL grid position: pick_fast_kernel calls it with its own block index and grid size;
-// pick_quad_kernel<..., TAIL> calls the work-list form from the LAST of its workgroups to finish, as a grid of one (`tail`), over
-// what the whole launch deferred -- no second launch behind the common batch that defers nothing.  smem: the dynamic LDS of the
-// calling kernel (the layout below); stat_base: first probe-statistics slot of this grid's wavefronts.
+// pick_quad_kernel<..., TAIL> calls the work-list form from EVERY workgroup when its own loop is over (`tail`), with the workgroup's
+// real position: wavefront w of workgroup b then owns exactly the segment it filled itself -- no second launch, no waiting for any
+// other workgroup, and a burst of deferred requests is spread over the whole grid.  smem: the dynamic LDS of the calling kernel
+// (the layout below); stat_base: first probe-statistics slot of this grid's wavefronts.
 template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false>
 __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint32_t vgrid, const uint32_t stat_base, const bool tail, unsigned char* smem,
                                                const KSnap& sn, const KIndex& ix, const KTail& tl, const uint8_t* __restrict__ reqs,
@@ -796,10 +797,13 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
   // on another XCD, whose stores went through to memory -- pick_quad_kernel -- but not into this XCD's L2)
   auto wl_word = [](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   if constexpr (WL) {
-    const uint32_t total = wl_word(wk.total);
-    if (!tail && vblock == 0 && threadIdx.x == 0) *wk.report = total;
-    if (total == 0u) return;                               // nothing was deferred: done before any staging
-    // a workgroup none of whose wavefronts owns a segment with work leaves as well
+    if (!tail) {                                             // (tail: the other workgroups of the launch may still be adding to the total)
+      const uint32_t total = wl_word(wk.total);
+      if (vblock == 0 && threadIdx.x == 0) *wk.report = total;
+      if (total == 0u) return;                               // nothing was deferred: done before any staging
+    }
+    // a workgroup none of whose wavefronts owns a segment with work leaves as well (tail: the barrier also says that every
+    // wavefront of the workgroup is done with the LDS of the quad layout)
     uint32_t mine = 0;
     const uint32_t nw_ = vgrid * (blockDim.x >> 6);
     for (uint32_t seg = vblock * (blockDim.x >> 6) + (threadIdx.x >> 6); seg < wk.n_segs; seg += nw_) mine |= wl_word(&wk.cnt[seg]);
@@ -1641,13 +1645,58 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 // lanes -- the listed pods' totals (ids 4q + j and 16 + 4q + j) and the 16 table entries that are not listed -- so round i of the
 // merge is one more row argmax over each lane's best remaining candidate; the winner leaves the pool.  A round that finds the table's
 // pool empty although the table goes on beyond its 16th entry cannot know the next value: deferred.
-// TAIL: no second launch.  Every workgroup reports in on a counter when it is done; the LAST one to arrive reads what the whole launch
-// deferred and -- in the common case, nothing -- writes the report and leaves; otherwise it runs the work-list form of
-// pick_fast_kernel's body itself, as a grid of one (pick_fast_body: the LDS of this workgroup is re-staged in that kernel's layout).
-// A second launch behind every batch cost 4-10 us of a 14 us pick although it had nothing to do: its workgroups cannot start before
-// this kernel's persistent wavefronts leave (all 512 VGPRs per SIMD are theirs), and the host pays for two launches per batch.  The
-// library takes this form while the recent launches deferred next to nothing, and the two-launch form otherwise (a single
-// workgroup is no match for a work list of hundreds of requests).
+// TAIL: no second launch.  A wavefront keeps the requests it defers in a segment of its own, so when a workgroup's loop is over the
+// work-list form of pick_fast_kernel's body runs right there, over the segments of that workgroup's own wavefronts (pick_fast_body:
+// the workgroup's LDS is re-staged in that kernel's layout -- only when it deferred anything, which a workgroup of the common batch
+// does not).  Nobody waits for another workgroup, and a burst of deferred requests is spread over the whole grid.  (Round 3 gave the
+// whole launch's work list to the LAST workgroup to arrive: one workgroup was no match for a list of hundreds, so the library kept a
+// two-launch form beside it and chose between them from the deferred counts of EARLIER launches -- a latency cliff for the first batch
+// of a burst.)  A second launch behind every batch cost 4-10 us of a 14 us pick although it had nothing to do: its workgroups cannot
+// start before this kernel's persistent wavefronts leave (all 512 VGPRs per SIMD are theirs), and the host pays for two launches per
+// batch.  The arrival counters survive for the report only (how much the launch deferred: the library's back-off feedback).
+// The work-list pass of the one-launch form as a function of its OWN (never inlined).  Inlined, pick_fast_body shared the kernel's
+// register allocation and the hot loop paid for it (round 3: 128 VGPRs, 24 bytes of scratch, 5 VGPR and 97 SGPR spills against
+// 112 / 0 / 0 / 8 without the tail) although one workgroup per launch runs it, and almost never.  The function takes NO arguments
+// beyond the LDS base: handed the kernel's argument structs -- by reference or by value -- the compiler copies them to the stack in
+// the kernel's prologue (every wavefront pays) and, by reference, re-reads them from there inside the hot loop.  It reads the
+// kernel's arguments itself, from the kernarg segment, through a struct that mirrors pick_quad_kernel's parameter list.
+struct QuadKernArgs {
+  KSnap sn; KIndex ix; KTail tl; const uint8_t* reqs; uint32_t stride, n_reqs, pwn; const uint64_t* cand_mask; int32_t* out_pick; double* out_score;
+  unsigned long long* stats; uint32_t* defer_cnt; uint32_t* defer_list; uint32_t defer_cap; uint32_t* defer_total; uint32_t* defer_total_next; uint32_t topk;
+  uint32_t* done_ctr; uint32_t* report;
+  KChain chain;    // (MASKED tails: the exact evaluation of a request whose candidates miss the snapshot-wide QUEUE extremes needs the chain)
+};
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED, bool TOPK>
+__device__ __attribute__((noinline)) void quad_tail_pass(unsigned char* smem) {
+  const QuadKernArgs* a = (const QuadKernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  // this wavefront's part of the work list (and its count) has reached memory: agent-scope stores, acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {   // (1) the requests THIS workgroup deferred: the work-list form of pick_fast_kernel's body over its own segments (it leaves at
+      //     once when they are empty -- the common case; otherwise it re-stages the workgroup's LDS in that kernel's layout)
+    KWork wk;
+    wk.cnt = a->defer_cnt; wk.list = a->defer_list; wk.total = a->defer_total; wk.report = a->report; wk.cap = a->defer_cap; wk.n_segs = gridDim.x * (blockDim.x >> 6);
+    pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true>(
+        blockIdx.x, gridDim.x, 0u, true, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, a->n_reqs, a->pwn, a->cand_mask, a->chain, a->out_pick, a->out_score, a->stats, a->topk, wk);
+  }
+  // (2) the report (the library's feedback: how much the launch deferred) by the LAST workgroup to arrive.  "Who is last?" in two levels
+  // -- the persistent workgroups all finish within a microsecond of each other, and 512 atomics on ONE word queue up for 6 us: 16
+  // group counters (done_ctr[1 + (block & 15)]), the workgroup that completes its group bumps the top counter (done_ctr[0]), the
+  // one that completes that is the last of the launch.
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t* done_ctr = a->done_ctr;
+    const uint32_t grp = blockIdx.x & 15u, n_grp = gridDim.x < 16u ? gridDim.x : 16u;
+    const uint32_t in_grp = (gridDim.x - grp + 15u) / 16u;                            // workgroups with this group number
+    if (atomicAdd(&done_ctr[1u + grp], 1u) == in_grp - 1u) {
+      __hip_atomic_store(&done_ctr[1u + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for this buffer set's next launch)
+      if (atomicAdd(&done_ctr[0], 1u) == n_grp - 1u) {
+        __hip_atomic_store(&done_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *a->report = __hip_atomic_load(a->defer_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (pinned host word)
+      }
+    }
+  }
+}
+
 template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false>
 __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                                  uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
@@ -1655,7 +1704,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
                                                                  unsigned long long* __restrict__ stats,
                                                                  uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
                                                                  uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk,
-                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report) {
+                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report, KChain tail_chain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -2172,41 +2221,9 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
   }
   if constexpr (TAIL) {
-    // this wavefront's part of the work list has reached memory (agent-scope stores, acknowledged) before the workgroup reports in
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // "Who is last?" in two levels -- the persistent workgroups all finish within a microsecond of each other, and 512 atomics on ONE
-    // word queue up for 6 us: 16 group counters (done_ctr[1 + (block & 15)]), the workgroup that completes its group bumps the top
-    // counter (done_ctr[0]), the one that completes that is the last of the launch.
-    __shared__ uint32_t s_last;
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-      const uint32_t grp = blockIdx.x & 15u, n_grp = gridDim.x < 16u ? gridDim.x : 16u;
-      const uint32_t in_grp = (gridDim.x - grp + 15u) / 16u;                            // workgroups with this group number
-      uint32_t last = 0u;
-      if (atomicAdd(&done_ctr[1u + grp], 1u) == in_grp - 1u) {
-        __hip_atomic_store(&done_ctr[1u + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for this buffer set's next launch)
-        if (atomicAdd(&done_ctr[0], 1u) == n_grp - 1u) {
-          __hip_atomic_store(&done_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = 1u;
-        }
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const uint32_t total = __hip_atomic_load(defer_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef EPPK_DBG_TAIL_NO_REPORT      // (timing experiment: what the write to host memory costs the kernel's end)
-    if (threadIdx.x == 0u && total != 0u) *report = total;
-#else
-    if (threadIdx.x == 0u) *report = total;                                            // (pinned host word: the library's feedback)
-#endif
-    if (total == 0u) return;
-    __syncthreads();                           // (every wavefront is done with the LDS of the quad layout)
-    KWork wk;
-    wk.cnt = defer_cnt; wk.list = defer_list; wk.total = defer_total; wk.report = report; wk.cap = defer_cap; wk.n_segs = gridDim.x * wpb;
-    const KChain no_chain{};                   // (MASKED tails would need the chain for their exact evaluation: not instantiated)
-    pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true>(
-        0u, 1u, gridDim.x * wpb, true, smem, sn, ix, tl, reqs, stride, n_reqs, pwn, cand_mask, no_chain, out_pick, out_score, stats, topk, wk);
+    // the end of the one-launch form -- the work-list pass over what THIS workgroup deferred (rarely anything), the arrival counters and
+    // the report -- lives in a function that is never inlined: the hot loop above is compiled as if it were not there
+    quad_tail_pass<LW, HAS_L, P_FIRST, MASKED, TOPK>(smem);
   }
 }
 

@@ -23,9 +23,14 @@ const void* pick_kernel_u64_9(const PickVariant& v);
 const void* pick_quad_u16(bool has_l, bool p_first, bool masked, bool topk);
 const void* pick_quad_u32(bool has_l, bool p_first, bool masked, bool topk);
 const void* pick_quad_u64(bool has_l, bool p_first, bool masked, bool topk);
-const void* pick_quad_tail_u16(bool has_l, bool p_first);                         // unmasked picks, no second launch (eppk_pick_quad_tail.hip)
-const void* pick_quad_tail_u32(bool has_l, bool p_first);
-const void* pick_quad_tail_u64(bool has_l, bool p_first);
+// the one-launch form (every workgroup scores what it deferred itself): one translation unit per (masked, topk) pair,
+// eppk_pick_quad_tail[_masked][_topk].hip; eppk_pick_quad_tail.hip also holds the dispatchers
+const void* pick_quad_tail_u16(bool has_l, bool p_first, bool masked, bool topk);
+const void* pick_quad_tail_u32(bool has_l, bool p_first, bool masked, bool topk);
+const void* pick_quad_tail_u64(bool has_l, bool p_first, bool masked, bool topk);
+const void* pick_quad_tail_masked(int lw_bytes, bool has_l, bool p_first);
+const void* pick_quad_tail_topk(int lw_bytes, bool has_l, bool p_first);
+const void* pick_quad_tail_topk_masked(int lw_bytes, bool has_l, bool p_first);
 const void* pick_fast_wl_topk_u16(bool has_l, bool p_first, bool big);          // work-list instantiations with ordered fallbacks (eppk_pick_wl_topk.hip)
 const void* pick_fast_wl_topk_u32(bool has_l, bool p_first, bool big);
 const void* pick_fast_wl_topk_u64(bool has_l, bool p_first, bool big);
@@ -68,3 +73,18 @@ const void* EPPK_PICK_INST_NAME(const PickVariant& v) {
 #endif
 
 }  // namespace eppk
+
+#ifdef EPPK_QUAD_TAIL_UNIT
+// (the body of a eppk_pick_quad_tail*.hip unit: EPPK_QUAD_TAIL_UNIT = its function's name, EPPK_QUAD_TAIL_MASKED / _TOPK = its pair)
+namespace eppk {
+template <typename LW>
+static const void* quad_tail_unit_ptr(bool has_l, bool p_first) {
+  constexpr bool M = EPPK_QUAD_TAIL_MASKED, T = EPPK_QUAD_TAIL_TOPK;
+  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true, M, T, true> : (const void*)pick_quad_kernel<LW, true, false, M, T, true>;
+  return (const void*)pick_quad_kernel<LW, false, false, M, T, true>;
+}
+const void* EPPK_QUAD_TAIL_UNIT(int lw_bytes, bool has_l, bool p_first) {
+  return lw_bytes == 2 ? quad_tail_unit_ptr<uint16_t>(has_l, p_first) : lw_bytes == 4 ? quad_tail_unit_ptr<uint32_t>(has_l, p_first) : quad_tail_unit_ptr<uint64_t>(has_l, p_first);
+}
+}  // namespace eppk
+#endif

@@ -490,18 +490,36 @@ class GpuPicker : public EndpointPicker {
         std::shared_ptr<Snapshot> snap;
         { std::lock_guard<std::mutex> sg(mu_); snap = snap_; }
         failed = !snap;
+        const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
+        uint32_t P = 0, W = 0;
+        bool any_mask = false;
         if (!failed) {
-          const uint32_t P = (uint32_t)snap->endpoints.size(), W = (P + 63u) / 64u;
-          const uint32_t k = 1u + (opt_.fallbacks < EPPK_MAX_TOPK ? opt_.fallbacks : EPPK_MAX_TOPK - 1u);
-          // masks first: they decide which entry point the batch takes, and with it the buffer its rows are built in
-          bool any_mask = false;
-          mask.assign(n * (size_t)(W ? W : 1), 0);
-          for (size_t i = 0; i < n; ++i) {
-            Slot& sl = *batch[i];
-            if (sl.mask_snap != snap) BuildMask(*snap, *sl.cands, &sl.mask, &sl.found);     // a publish came between Pick() and this batch
-            std::memcpy(mask.data() + i * (size_t)(W ? W : 1), sl.mask.data(), (size_t)(W ? W : 1) * 8u);
-            if (sl.found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
+          // masks first: they decide which entry point the batch takes, and with it the buffer its rows are built in.  A batch that
+          // cannot be pipelined (masks or fallbacks) has to collect the batch in flight first, and collecting RELEASES be_mu_: a
+          // publish that was waiting for the pipeline to drain may come through in that window.  The masks, the mask width and the
+          // endpoint table this batch resolves its picks against must all belong to the snapshot the device scores against, so the
+          // snapshot is read again behind the collect and the masks are rebuilt when it changed (`mask_snap` tells).
+          for (;;) {
+            P = (uint32_t)snap->endpoints.size(); W = (P + 63u) / 64u;
+            any_mask = false;
+            mask.assign(n * (size_t)(W ? W : 1), 0);
+            for (size_t i = 0; i < n; ++i) {
+              Slot& sl = *batch[i];
+              if (sl.mask_snap != snap) { BuildMask(*snap, *sl.cands, &sl.mask, &sl.found); sl.mask_snap = snap; }   // a publish came between Pick() and this batch
+              std::memcpy(mask.data() + i * (size_t)(W ? W : 1), sl.mask.data(), (size_t)(W ? W : 1) * 8u);
+              if (sl.found != snap->n_active) any_mask = true;   // (all ACTIVE endpoints are candidates: no mask; holes are the library's business)
+            }
+            if ((k == 1 && !any_mask && be_->StageRows(next_set) != nullptr) || !fly.active) break;    // pipelined, or nothing in flight
+            bg.unlock(); Collect(fly, picks, scores); bg.lock();                                      // keep the batches in order on the context
+            std::shared_ptr<Snapshot> now;
+            { std::lock_guard<std::mutex> sg(mu_); now = snap_; }
+            if (now == snap) break;
+            snap = now;                                                                                // published meanwhile: once more
+            if (!snap) break;
           }
+          failed = !snap;
+        }
+        if (!failed) {
           // rows are built in the backend's pinned buffers when it offers them: the pipelined set, else the single staging buffer
           // (a batch without candidate masks then goes to the device without another host copy)
           const bool plain = k == 1 && !any_mask;
@@ -529,7 +547,7 @@ class GpuPicker : public EndpointPicker {
               failed = true;
             }
           } else {
-            if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }      // keep the batches in order on the context
+            // (the batch in flight was collected above, before this batch's masks were final)
             picks.resize(n * k);
             scores.resize(n * k);
             int rc;

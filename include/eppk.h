@@ -261,6 +261,8 @@ int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
 #define EPPK_LAUNCH_INDEX_STALL     4u   /* an index insert gave up waiting for the first pod of a key that another thread of the same
                                           * launch had just claimed (never observed; the wait is bounded so that a broken index cannot
                                           * hang the device): that (hash, pod) pair was dropped */
+#define EPPK_LAUNCH_LEARN_FAILED    8u   /* eppk_pick_stage_begin(EPPK_PICK_LEARN) launched the picks but could not enqueue the post-route index
+                                          * update behind them (eppk_last_error says why): the picks were delivered, the index did not learn them */
 /* Synchronise the device and return (and clear) the sticky launch-status flags accumulated by every *_device launch of this
  * context since the last call.  0 = every row was in range. */
 int eppk_launch_status(eppk_ctx* ctx, uint32_t* flags);

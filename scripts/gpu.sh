@@ -1,0 +1,84 @@
+#!/bin/bash
+# ONE runner for everything that needs the GPU box:   gpurun --timeout N -- 'bash scripts/gpu.sh <tag> <stage> [<stage> ...]'
+# Every stage writes into gpurun_out/<tag>/ (merged back by gpurun) and prints a short digest.  Stages:
+#   smoke                 __graft_entry__.smoke()
+#   tests[:<pytest -k expression>]        the GPU suite (or a subset), -x -q
+#   quick                 tests/cpp/parity_quick (C5 open loop + 4 closed-loop generations vs the oracle, seconds)
+#   bench20 / bench200    the headline line at the driver's protocol (--steps 20 --warmup 5) / at the default; full line kept
+#   benchq20 / benchq200  the same without cold reference, host path and CPU baseline (A/B runs)
+#   closed                bench.py --closed-loop (oracle-verified generations + step parts)
+#   closedq               ... without verification (A/B runs)
+#   configs               bench lines of BASELINE configs 2-4
+#   routes                scripts/gpu_route_times.py (masked / top-k route times at 64k)
+#   small                 scripts/gpu_small_batch_latency.py
+#   doorbell claim evictloop insertbreak     scripts/micro/_bin/<name> (built in the build container)
+#   stats / stats_cl      rocprofv3 --kernel-trace --stats of the headline / the closed loop
+#   pmc / pmc_cold        the PMC passes behind profiles/pmc_*.json (then scripts/make_pmc_json.py in the build container)
+# Environment variables pass through (EPPK_QUAD_TAIL=0 bash scripts/gpu.sh ...).
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+TAG=$1; shift
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+T0=$(date +%s)
+lap() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
+digest() { python - "$1" <<'EOF'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("   (no JSON line:", e, ")"); sys.exit(0)
+r = d.get("roofline") or {}
+s = f"   value {d['value'] / 1e6:9.1f} M/s  {d['ms_per_step'] * 1e3:7.2f} us/step  kernel avg {1e3 * (r.get('kernel_avg_ms') or 0):6.2f} us  hbm_frac {r.get('hbm_frac') or r.get('frac') or 0:.3f}"
+p = d.get("parity") or {}
+if p: s += f"  parity {p}"
+cl = d.get("closed_loop") or {}
+if cl: s += f"\n   closed_loop {({k: cl[k] for k in cl if k in ('value', 'ms_per_step', 'generations_verified', 'picks_equal_oracle', 'scores_bitwise_equal_oracle', 'index_size', 'index_size_oracle')})}"
+rc = d.get("roofline_closed_loop") or (cl.get("roofline") if isinstance(cl, dict) else None) or {}
+if rc: s += f"\n   step parts {rc.get('step_parts_ms')}"
+h = d.get("host_path") or {}
+if h: s += "\n   host_path " + str({k: (round(v.get('decisions_per_s', v.get('decisions_per_s_p50', 0)) / 1e6, 1) if isinstance(v, dict) else v) for k, v in h.items() if k in ('staged', 'pipelined', 'pipelined_learn', 'decisions_per_s_p50')})
+    lb = (h.get("latency_by_batch") or {}).get("requests")
+    if lb: s += "\n   latency_by_batch " + str(lb)
+print(s)
+EOF
+}
+for stage in "$@"; do
+  name=${stage%%:*}; arg=""; [[ "$stage" == *:* ]] && arg=${stage#*:}
+  case $name in
+    smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
+    tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -6 | tee $OUT/pytest_${arg//[^a-zA-Z0-9]/_}.txt
+           else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt; fi ;;
+    quick) timeout 200 python scripts/dump_workload.py --config 5 --out /tmp/c5 > /dev/null 2>&1; timeout 120 ./tests/cpp/parity_quick /tmp/c5 4 2>&1 | tail -4 ;;
+    bench20)  timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; digest $OUT/bench_steps20.json ;;
+    bench200) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; digest $OUT/bench.json ;;
+    benchq20)  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/benchq20.json 2> $OUT/benchq20.err; digest $OUT/benchq20.json ;;
+    benchq200) timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref > $OUT/benchq200.json 2> $OUT/benchq200.err; digest $OUT/benchq200.json ;;
+    closed)  timeout 600 python bench.py --closed-loop > $OUT/bench_closed_loop.json 2> $OUT/bench_closed_loop.err; digest $OUT/bench_closed_loop.json ;;
+    closedq) timeout 300 python bench.py --closed-loop --cl-verify 0 > $OUT/closedq.json 2> $OUT/closedq.err; digest $OUT/closedq.json ;;
+    configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
+    routes) timeout 300 python scripts/gpu_route_times.py > $OUT/route_times.json 2> $OUT/route_times.err; tail -c 1500 $OUT/route_times.json ;;
+    small) timeout 300 python scripts/gpu_small_batch_latency.py 2>&1 | tee $OUT/small_batch_latency.txt | tail -12 ;;
+    doorbell|claim|evictloop|insertbreak)
+      bin=$name; [ $name = claim ] && bin=claimcost
+      timeout 60 ./scripts/micro/_bin/$bin $arg 2>&1 | tee $OUT/micro_$name.txt | tail -40 ;;
+    stats) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/prof_bench_under_rocprof.json 2> $OUT/prof.err )
+           head -6 $OUT/prof/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof -name "*agent_info.csv") $(find $OUT/prof -name "*kernel_trace.csv") ;;
+    stats_cl) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cl -o trace -- python $GRAFT_REPO_ROOT/bench.py --closed-loop --steps 60 --warmup 10 --no-cpu-baseline --cl-verify 0 > $OUT/prof_cl_bench_under_rocprof.json 2> $OUT/prof_cl.err )
+           head -8 $OUT/prof_cl/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof_cl -name "*agent_info.csv") $(find $OUT/prof_cl -name "*kernel_trace.csv") ;;
+    pmc|pmc_cold)
+      if [ $name = pmc ]; then ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --inflight 1"
+        CTRS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum TCC_BUSY_avr")
+      else ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --groups 262144 --zipf 0 --pods-per-group 4 --batches 4 --inflight 1"
+        CTRS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum"); fi
+      mkdir -p $OUT/$name; i=0
+      for ctrs in "${CTRS[@]}"; do i=$((i+1))     # (counters in passes of their own, with --kernel-trace only: /opt/skills/guides/MI355X_MICROARCH.md)
+        ( cd /tmp; timeout -k 5 150 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/$name -o pass$i -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/$name/bench_pass$i.json 2> $OUT/$name/pass$i.err )
+      done
+      python scripts/pmc_summary.py $OUT/$name pick_ --by-kernel | tee $OUT/${name}_summary.csv | cut -c1-200
+      rm -f $(find $OUT/$name -name "*agent_info.csv") $(find $OUT/$name -name "*kernel_trace.csv") ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+  lap $stage
+done
+du -sh $OUT

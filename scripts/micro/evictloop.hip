@@ -1,0 +1,104 @@
+// Measurement tool (not product code): the closed loop's index maintenance alone -- 64k x (16 known + 16 new) pairs per step into a
+// 16 Mi-slot index, epoch tick + eviction every second step (bench.py --closed-loop's cadence) -- with the library's own kernels, and the
+// eviction alternately by the library's index_evict_kernel and by a bare scan (claimcost.hip's E0) over the SAME index state: what of the
+// library kernel's time is the data (2 Mi victims among 16 Mi slots) and what is the kernel.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define EPPK_MAIN_UNIT 1
+#include "../../gateway-api-inference-extension_amd/csrc/eppk_kernels.hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+__global__ __launch_bounds__(256) void evict_bare(unsigned long long* keys, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch, unsigned long long* ixc) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t gone = 0;
+  for (uint32_t base = wave * 64u * U; base < slots; base += nwaves * 64u * U) {
+    unsigned long long k[U]; uint32_t st[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { k[u] = keys[base + u * 64u + lane]; st[u] = stamps[base + u * 64u + lane]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t row = base + u * 64u + lane;
+      const bool victim = (row & 7u) != 0u && k[u] != 0ull && k[u] != ~0ull && st[u] < min_epoch;
+      gone += (uint32_t)__builtin_popcountll(__ballot(victim));
+      if (victim) {
+        u32x4* Lp = (u32x4*)(lists + (size_t)row * 16u);
+        const u32x4 e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
+        keys[row] = ~0ull;
+      }
+    }
+  }
+  if (lane == 0 && gone) atomicAdd(&ixc[(wave & 63u) * 8u], (unsigned long long)(0ull - (unsigned long long)gone));
+}
+
+int main(int argc, char** argv) {
+  using LW = uint64_t;
+  const uint32_t slots = 16u << 20, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
+  const int steps = argc > 1 ? atoi(argv[1]) : 16;
+  uint32_t lg = 0; while ((1u << lg) < slots / eppk::kBucket) ++lg;
+  const uint32_t shift = 32u - lg, limit = slots / 2u;
+  const size_t rows_bytes = (((size_t)slots + 3u) * 64u * sizeof(LW) + 255u) & ~(size_t)255u, index_bytes = rows_bytes + ((size_t)slots + 2u) * 8u;
+  void* bitmaps; uint32_t *stamps, *lists, *status; unsigned long long* ixc;
+  CK(hipMalloc(&bitmaps, index_bytes)); CK(hipMemset(bitmaps, 0, index_bytes));
+  uint64_t* keys = (uint64_t*)((uint8_t*)bitmaps + rows_bytes);
+  CK(hipMalloc((void**)&stamps, ((size_t)slots + 2u) * 4u)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u));
+  const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
+  CK(hipMalloc((void**)&lists, nd * 4u));
+  hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
+  CK(hipMalloc((void**)&ixc, 64 * 64)); CK(hipMemset(ixc, 0, 64 * 64));
+  CK(hipMalloc((void**)&status, 8)); CK(hipMemset(status, 0, 8));
+  eppk::IxLaunch* d_ixl; CK(hipMalloc((void**)&d_ixl, sizeof(eppk::IxLaunch)));
+  uint32_t* d_wl; const uint32_t wl_cap = R * B; CK(hipMalloc((void**)&d_wl, (4u + (size_t)wl_cap) * 4u)); CK(hipMemset(d_wl, 0, 16));
+  uint8_t* d_rows[4]; int32_t* d_picks[4];
+  std::vector<uint8_t> rows((size_t)R * stride); std::vector<int32_t> picks(R);
+  for (int b = 0; b < 4; ++b) { CK(hipMalloc((void**)&d_rows[b], (size_t)R * stride)); CK(hipMalloc((void**)&d_picks[b], R * 4)); }
+  hipEvent_t e0, e1, e2, e3; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
+  uint32_t epoch = 1, sort_uses = 0;
+  for (int g = 0; g < steps; ++g) {
+    const int b = g & 3;
+    for (uint32_t r = 0; r < R; ++r) {           // a fresh batch: 16 hot blocks of one of 256 prefixes + 16 blocks nobody has seen
+      uint8_t* row = rows.data() + (size_t)r * stride;
+      const uint32_t grp = (uint32_t)(mix(r * 7919ull + 1 + g) % 256u);
+      ((int32_t*)row)[0] = -1; ((uint32_t*)row)[1] = 32u;
+      uint64_t* h = (uint64_t*)(row + 8);
+      for (uint32_t i = 0; i < 16; ++i) h[i] = mix(0xABCD0000ull + grp * 16u + i) | 2ull;
+      for (uint32_t i = 16; i < 32; ++i) h[i] = mix(((uint64_t)(g + 1) << 40) + (uint64_t)r * 32u + i) | 2ull;
+      picks[r] = (int32_t)((grp * 8u + (r & 7u)) % P);
+    }
+    CK(hipMemcpy(d_rows[b], rows.data(), rows.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_picks[b], picks.data(), R * 4, hipMemcpyHostToDevice));
+    const uint64_t total = (uint64_t)R * B;
+    const eppk::SortWl sw{d_wl, wl_cap, sort_uses & 1u}; ++sort_uses;
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, 0, ixc, limit, slots, (unsigned long long)total, d_ixl);
+    hipLaunchKernelGGL((eppk::index_insert_picks_kernel<LW>), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
+                       epoch, ixc, d_rows[b], stride, B, d_picks[b], R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl);
+    hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("step %2d epoch %u: update %7.1f us", g, epoch, ms * 1e3);
+    if (g & 1) {
+      ++epoch;
+      if (epoch > 2) {
+        const bool bare = ((g >> 1) & 1) != 0;
+        CK(hipEventRecord(e2));
+        if (bare) hipLaunchKernelGGL(evict_bare<4>, dim3(2048), dim3(256), 0, 0, (unsigned long long*)keys, lists, (const uint32_t*)stamps, slots, epoch - 1u, ixc);
+        else hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch - 1u, ixc);
+        CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
+        CK(hipEventElapsedTime(&ms, e2, e3));
+        unsigned long long h[64 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
+        long long live = 0; for (int s2 = 0; s2 < 64; ++s2) live += (long long)h[s2 * 8 + eppk::kIxLive];
+        printf("   evict < %u by %-7s %7.1f us   live after %lld", epoch - 1u, bare ? "bare" : "library", ms * 1e3, live);
+      }
+    }
+    printf("\n");
+  }
+  return 0;
+}
