@@ -131,6 +131,18 @@ def cpu_baseline(wl, orc, reqs, all_batches=None, passes: int = 3):
                     sample=loop["per_request_loop_what"], single_thread_value=n1 / t1, error=f"{type(e).__name__}: {e}", **loop), pm, sm
 
 
+def metric_name(headline: bool, mode: str, world: int, wl, args) -> str:
+    """BASELINE.json's metric on one GPU; at N > 1 the name says which scaling `value` is (so that an N x 64k-per-step aggregate cannot be
+    read as configs[4]'s one 64k batch, or the other way round)."""
+    if not headline:
+        return f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf}{', closed loop' if args.closed_loop else ''})"
+    if mode == "weak":
+        return f"routing decisions/sec, {world} x 64k-req x 4096-pod batches per step (request-sharded replicas, one whole batch per rank: weak scaling)"
+    if mode == "strong":
+        return f"routing decisions/sec, ONE 64k-req x 4096-pod batch per step split over {world} ranks (strong scaling)"
+    return "routing decisions/sec, 64k-req x 4096-pod batch"
+
+
 def make_batches(pkg, wl, args, n: int):
     """`n` distinct request batches against ONE snapshot + index (batch 0 = the workload's own requests)."""
     out = [wl.reqs]
@@ -174,7 +186,7 @@ class Runner:
         self.profile_every = max(1, int(getattr(args, "profile_every", 1)))
         # N > 1: completion latency of a gather bucket -- a timing event on the compute stream right before the first launch that scores
         # a bucket's batches, one on `comm` behind the collective that delivers their picks to every rank (timed region only)
-        self.lat_on, self.lat_start, self.lat_pairs = False, None, []
+        self.lat_on, self.lat_start, self.lat_pairs, self.coll_pairs = False, None, [], []
         self.host_t = {}
         self.ev_pool, self.ev_pool_used = [], 0
 
@@ -258,12 +270,20 @@ class Runner:
             views = self.gather_views[(b0, n)] = (out, src, p16, out.view(self.torch.uint8) if self.pack16 else None,
                                                   p16.view(self.torch.uint8) if self.pack16 else None)
         out, src, p16, out8, p16_8 = views
+        e_c0 = None
+        if self.lat_on:                                  # the collective alone: events around it on `comm` (timed region only)
+            e_c0 = self._timing_event()
+            e_c0.record(self.comm)
         if self.pack16:                                  # (on `comm`, the current stream, behind the kernels' completion events)
             p16.copy_(src)
             if DBG != "nogather":
                 self.dist.all_gather_into_tensor(out8, p16_8)   # (as bytes: gloo has no int16)
         elif DBG != "nogather":
             self.dist.all_gather_into_tensor(out, src)  # on `comm`, the current stream
+        if e_c0 is not None:
+            e_c1 = self._timing_event()
+            e_c1.record(self.comm)
+            self.coll_pairs.append((e_c0, e_c1))
         self.last_gather = (out, n)
         if self.lat_on and self.lat_start is not None:
             e_end = self._timing_event()
@@ -384,9 +404,9 @@ class Runner:
         # part of what the headline times.  The p99 samples (more_kernel_samples, outside the timed region) instrument every launch.
         self.pk.profile(self.profile_every)
         self.fence()
-        self.lat_on, self.lat_start, self.lat_pairs = self.use_dist and DBG != "nolat", None, []
+        self.lat_on, self.lat_start, self.lat_pairs, self.coll_pairs = self.use_dist and DBG != "nolat", None, [], []
         if self.use_dist:
-            while len(self.ev_pool) < 64:
+            while len(self.ev_pool) < 128:
                 self.ev_pool.append(self.torch.cuda.Event(enable_timing=True))
         self.ev_pool_used = 0
         self.host_t = {}
@@ -404,6 +424,7 @@ class Runner:
         self.lat_on = False
         self.bucket_latency_ms = np.asarray([a.elapsed_time(b) for a, b, _ in self.lat_pairs], dtype=np.float64)
         self.bucket_batches = [n for _, _, n in self.lat_pairs]
+        self.collective_ms = np.asarray([a.elapsed_time(b) for a, b in self.coll_pairs], dtype=np.float64)
         if self.use_dist:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -501,6 +522,9 @@ def main() -> None:
     ap.add_argument("--cl-slots", type=int, default=1 << 24, help="closed loop: index slots (live keys ~ age_every * keep_epochs * R * B/2)")
     ap.add_argument("--cl-verify", type=int, default=3, help="closed loop: generations checked against the oracle at full size before timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the closed-loop / pipelined-LEARN sub-run of the default line")
+    ap.add_argument("--closed-loop-leg", action="store_true", help="run that sub-run for a non-headline workload too")
+    ap.add_argument("--cl-steps", type=int, default=60, help="timed steps of the default line's closed-loop sub-run (warm-up: a quarter of it)")
     ap.add_argument("--no-cold-ref", action="store_true", help="skip the cold-index sub-run (roofline_cold)")
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold index)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
@@ -574,7 +598,7 @@ def main() -> None:
                         run.pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, run.streams[0])
         elapsed, kern_ms, stats = run.timed(args.steps, args.warmup, age)
         results[mode] = dict(elapsed=elapsed, kern_ms=kern_ms, stats=stats, per=run.per, launch_requests=run.launch_requests, grouped=run.grouped,
-                             bucket_latency_ms=run.bucket_latency_ms, bucket_batches=run.bucket_batches,
+                             bucket_latency_ms=run.bucket_latency_ms, bucket_batches=run.bucket_batches, collective_ms=run.collective_ms,
                              bucket=run.ring.gather_every, pack16=run.pack16,
                              value=(world if mode == "weak" else 1) * R * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps)
         if mode == modes[0]:
@@ -599,7 +623,7 @@ def main() -> None:
                     "weak": (f"one whole batch per rank per step ({world} x {R} requests per step), RCCL all-gather of all ranks' picks (buckets of {G} batches" +
                              (", int16 payload" if res.get("pack16") else "") + ") overlapped with the following kernels")}[main_mode]
         out = {
-            "metric": "routing decisions/sec, 64k-req x 4096-pod batch" if headline else f"routing decisions/sec ({wl.name}, groups={args.groups}, zipf={args.zipf}{', closed loop' if args.closed_loop else ''})",
+            "metric": metric_name(headline, main_mode, world if use_dist else 1, wl, args),
             "value": res["value"],
             "unit": "decisions/s",
             "n_gpus": world,
@@ -634,6 +658,11 @@ def main() -> None:
                 out["strong"]["completion_latency_p99_ms"] = float(np.percentile(sbl, 99))
         if use_dist:
             out["config"]["ranks_seen"] = int(dist.get_world_size())
+            cm = res.get("collective_ms")
+            out["config"]["per_rank_kernel_us"] = None      # (filled in below, once the launch durations are reduced)
+            out["config"]["collective_us"] = ({"p50": float(np.percentile(cm, 50)) * 1e3, "max": float(cm.max()) * 1e3, "collectives": int(cm.size),
+                                               "what": "one all-gather of a bucket's picks, events around it on the collective stream (rank 0, timed region)"}
+                                              if cm is not None and cm.size else None)
             bl = res["bucket_latency_ms"]
             if bl.size:
                 # BASELINE's metric names p99 pick latency: at N > 1 a batch's picks exist on every rank when the collective of its
@@ -704,6 +733,17 @@ def main() -> None:
                              "frac": roof["l2_frac_of_gather_ceiling"]})
         out["roofline"] = roof
         out["config"]["p99_step_ms"] = roof["kernel_p99_ms"]
+        if use_dist:
+            out["config"]["per_rank_kernel_us"] = avg_ms * 1e3
+            # what `value` means at N > 1, in north_star's own terms
+            out["scaling_note"] = ("north_star shards the request batch across GPUs \"only when |requests| x |pods| outgrows one device\": rank 0 scores a launch of "
+                                   f"{int(res['launch_requests'])} requests x {wl.P} pods in {avg_ms * 1e3:.1f} us here, so the 64k x 4096 batch does not outgrow one MI355X.  " +
+                                   ("`value` is therefore the aggregate of N request-sharded replicas -- every rank scores a whole 64k batch per step and all picks are "
+                                    "all-gathered (weak scaling: the unit per GPU is the shard the metric is quoted on); the strong-scaled single batch (BASELINE.json "
+                                    "configs[4]: ONE 64k batch split R/N per rank) is timed in the same invocation and printed under `strong`."
+                                    if main_mode == "weak" else
+                                    "`value` is the strong-scaled single batch (BASELINE.json configs[4]: ONE 64k batch split R/N per rank, picks all-gathered); a step is "
+                                    "then a few microseconds of kernel per rank and the collective's latency bounds it; weak scaling is printed under `weak` when timed."))
         if cl_info:
             out["closed_loop"] = cl_info
             out["roofline_closed_loop"] = closed_loop_roofline(run, wl, args, cl_state, res["ms_per_step"])
@@ -804,6 +844,19 @@ def main() -> None:
                 out["parity"] = {"gathered_picks_equal_oracle": ok, "ranks_checked": world}
     run.close()
 
+    # The path's STEADY STATE in the line the driver runs (rank 0, N = 1, headline runs): pick -> the index learns the picks -> next,
+    # different batch, ageing every other step -- its first generations verified against the oracle at full size -- and the same loop
+    # through the pipelined host entry points (EPPK_PICK_LEARN).  A context of its own (16 Mi index slots); ~3 s.
+    if rank == 0 and world == 1 and (headline or args.closed_loop_leg) and not args.closed_loop and not use_dist and not args.no_closed_loop_leg:
+        try:
+            cl = closed_loop_leg(pkg, torch, args, wl, batches)
+            out["closed_loop"] = cl["closed_loop"]
+            out["roofline_closed_loop"] = cl["roofline_closed_loop"]
+            if "host_path" in out and cl.get("pipelined_learn"):
+                out["host_path"]["pipelined_learn"] = cl["pipelined_learn"]
+        except Exception as e:  # never lose the headline line to a sub-run
+            out["closed_loop"] = {"error": repr(e)}
+
     # roofline_cold: the same kernel on an index that does not fit the caches (rank 0, N=1, headline runs only)
     if rank == 0 and world == 1 and headline and not args.no_cold_ref and not use_dist:
         try:
@@ -900,6 +953,93 @@ def group_leg(pkg, torch, args):
            "parity": {"gathered_picks_equal_oracle": same, "every_member_holds_the_same_picks": same_everywhere}}
     print(json.dumps(out), flush=True)
     g.close()
+
+
+def closed_loop_leg(pkg, torch, args, wl, batches):
+    """The closed loop as a sub-run of the default line: `closed_loop` {value, ms_per_step, generations verified against the oracle,
+    index sizes}, `roofline_closed_loop` (step parts, HBM lines per step) and `pipelined_learn` (the same loop through
+    eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end: what a host caller sees)."""
+    import copy
+    a = copy.copy(args)
+    a.closed_loop, a.inflight, a.profile_every = True, 1, 1 << 30
+    t_all = time.perf_counter()
+    run = Runner(pkg, torch, None, wl, batches, a, 0, 1, int(os.environ.get("LOCAL_RANK", "0")), index_slots=a.cl_slots, closed_loop=True)
+    try:
+        run.setup("single", 1)
+        info = closed_loop_verify(run, wl, a)
+        state = {"epoch": info["epoch"]}
+
+        def age(i, state=state):      # stream-ordered: behind the update of this step, ahead of the next pick
+            if (i + 1) % a.age_every == 0:
+                state["epoch"] = run.pk.index_advance_epoch()
+                if state["epoch"] > a.keep_epochs:
+                    run.pk.index_evict_older_device(state["epoch"] - a.keep_epochs + 1, run.streams[0])
+        steps, warm = max(8, a.cl_steps), max(4, a.cl_steps // 4)
+        elapsed, _, _ = run.timed(steps, warm, age)
+        run.pk.profile(False)
+        ms = 1e3 * elapsed / steps
+        roof = closed_loop_roofline(run, wl, a, state, ms, steps=12)
+        info.update({"value": wl.R * steps / elapsed, "unit": "decisions/s", "ms_per_step": ms, "steps": steps, "warmup": warm,
+                     "step_parts_ms": roof["step_parts_ms"], "launch_status": int(run.pk.launch_status()), "index_dropped_after": int(run.pk.index_dropped()),
+                     "what": "pick -> post-route index update (index[hash[r][i]] U= {pick[r]}) -> next, DIFFERENT batch on one stream; epoch tick + eviction of "
+                             f"hashes not re-inserted for {a.keep_epochs} epochs every {a.age_every} steps; {a.cl_slots} index slots"})
+        pl = None
+        if hasattr(run.pk, "stage_begin"):
+            pl = pipelined_learn_leg(run, wl, a, batches, state)
+        info["seconds"] = time.perf_counter() - t_all
+        return {"closed_loop": info, "roofline_closed_loop": roof, "pipelined_learn": pl}
+    finally:
+        run.close()
+
+
+def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
+    """eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over the two staging sets -- upload of batch k + 1 under the pick and the post-route
+    update of batch k -- with the shim's ageing: every `2 * age_every` batches the pipeline is drained, the epoch ticks and the hashes
+    not re-inserted for `keep_epochs` epochs go (index entry points are not issued while a set is in flight: include/eppk.h).  Rows are in
+    the pinned sets already (two different batches; building them is the caller's per-request work, as in `pipelined`)."""
+    R = wl.R
+    pk = run.pk
+    sb = [pk.stage_buffers(0)[0], pk.stage_buffers(1)[0]]
+    np.copyto(sb[0][:R], batches[0])
+    np.copyto(sb[1][:R], batches[1 % len(batches)])
+    every = 2 * args.age_every
+    lat, t_begin = [], [0.0, 0.0]
+
+    def tick():
+        state["epoch"] = pk.index_advance_epoch()
+        if state["epoch"] > args.keep_epochs:
+            pk.index_evict_older(state["epoch"] - args.keep_epochs + 1)
+
+    # warm-up: two batches through each set
+    for i in range(4):
+        pk.stage_begin(i & 1, R, learn=True)
+        pk.stage_end(i & 1)
+    tick()
+    t0 = time.perf_counter()
+    t_begin[0] = t0
+    pk.stage_begin(0, R, learn=True)
+    inflight = 0
+    for i in range(1, n_batches + 1):
+        cur, prev = i & 1, (i - 1) & 1
+        drain = i % every == 0 or i == n_batches
+        if not drain:
+            t_begin[cur] = time.perf_counter()
+            pk.stage_begin(cur, R, learn=True)
+        pk.stage_end(prev)
+        lat.append(time.perf_counter() - t_begin[prev])
+        if drain and i < n_batches:
+            tick()
+            t_begin[cur] = time.perf_counter()
+            pk.stage_begin(cur, R, learn=True)
+    run.torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    lat = np.asarray(lat) * 1e3
+    return {"batches": int(n_batches), "decisions_per_s": R * n_batches / t_all, "ms_per_batch": 1e3 * t_all / n_batches,
+            "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "pcie_floor_ms": R * run.stride / 55e9 * 1e3,
+            "ageing_every_batches": every, "index_dropped": int(pk.index_dropped()), "launch_status": int(pk.launch_status()),
+            "what": "eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over two staging sets (rows already in the pinned sets): the post-route index update "
+                    "chained on the device behind every pick; pipeline drained + epoch tick + eviction every "
+                    f"{every} batches; {args.cl_slots} index slots; wall time of the whole loop incl. the ageing pauses"}
 
 
 def closed_loop_verify(run, wl, args):

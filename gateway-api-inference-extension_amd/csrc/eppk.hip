@@ -94,7 +94,9 @@ struct eppk_ctx {
   void* bitmaps = nullptr;
   uint32_t slots = 0, shift = 0, limit = 0;
   size_t rows_bytes = 0, index_bytes = 0;   // rows | keys in one allocation
-  uint32_t* stamps = nullptr;               // [slots + 2] index epoch of the last insert of every key (ageing)
+  uint32_t* rstamps = nullptr;              // [2] exact stamps of the two reserved rows (hashes 0 / ~0: no bucket header); every other key's stamp is
+                                            // a TAG in its bucket header (eppk_kernels.hip.h: "stamps as tags")
+  uint32_t min_live = 0;                    // no live key is stamped before this epoch (the largest eviction horizon so far): the tags' window
   uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists: where a set with at most kListCap members lives (always maintained)
   bool list_routes = true;                  // EPPK_LISTS=0: the pick kernels' list routes are off (every request takes the dense route)
   uint32_t* sortwl = nullptr;               // work list of index_lists_sort_kernel: cursors[2] | lost | arrived | slots[sortwl_cap]
@@ -207,6 +209,7 @@ struct eppk_ctx {
 namespace {
 
 constexpr uint32_t kStatBanks = 4;
+constexpr uint32_t kEpochWindow = 254u;  // largest age (in index epochs) a live hash may reach: its stamp is an 8-bit tag (eppk_kernels.hip.h: kTagMod)
 constexpr uint32_t kDeferSets = 8;       // streams with a work-list buffer of their own (eppk_ctx::dsets)
 constexpr uint32_t kReportRing = 4096;   // quad launches whose deferred-count report may be outstanding (a host that enqueues far ahead of
                                          // the device: bench.py is a few hundred launches ahead; a full ring = the fast kernel for that launch)
@@ -857,8 +860,8 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     CHK(hipMalloc(&c->bitmaps, c->index_bytes));
     c->keys = (uint64_t*)((uint8_t*)c->bitmaps + c->rows_bytes);
     CHK(hipMemset(c->bitmaps, 0, c->index_bytes));
-    CHK(hipMalloc((void**)&c->stamps, ((size_t)c->slots + 2u) * 4u));
-    CHK(hipMemset(c->stamps, 0, ((size_t)c->slots + 2u) * 4u));
+    CHK(hipMalloc((void**)&c->rstamps, 2u * 4u));
+    CHK(hipMemset(c->rstamps, 0, 2u * 4u));
     const char* le = getenv("EPPK_LISTS");
     c->list_routes = !(le && atoi(le) == 0);
     {
@@ -880,7 +883,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->stamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
   (void)hipFree(c->d_at); (void)hipFree(c->d_av); (void)hipFree(c->d_sk); (void)hipFree(c->d_so);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
@@ -976,7 +979,8 @@ int eppk_index_clear(eppk_ctx* c) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   HIPCHK(c, hipMemsetAsync(c->bitmaps, 0, c->index_bytes, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->stamps, 0, ((size_t)c->slots + 2u) * 4u, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->rstamps, 0, 2u * 4u, c->stream));
+  c->min_live = c->index_epoch;            // (nothing is left that could be older)
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemsetAsync(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long), c->stream));  // key / drop counters
@@ -1008,7 +1012,7 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
   hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, c->stream, c->ixc, c->limit, c->slots, (unsigned long long)n, c->d_ixl);
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->stamps, c->slots, c->shift,
+    hipLaunchKernelGGL((index_insert_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->rstamps, c->slots, c->shift,
                        c->limit, c->index_epoch, c->ixc, (const uint64_t*)d_h, (const uint32_t*)d_p, n,
                        c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, c->d_status + (c->quiet_rows ? 1 : 0), (const eppk::IxLaunch*)c->d_ixl);
     return EPPK_OK;
@@ -1025,7 +1029,7 @@ int eppk_index_insert(eppk_ctx* c, const uint64_t* hashes, const uint32_t* pods,
 namespace {
 // The post-route update "index[hash[r][i]] U= {pick[r]}" (0602-…/README.md:101-108) for a batch whose rows and picks are on the device:
 // capacity verdict, update, re-sort of the lists it touched -- three launches on `st`.
-int learn_picks(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, hipStream_t st) {
+int learn_picks(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_t n_reqs, hipStream_t st, const uint32_t* d_learn = nullptr) {
   if (n_reqs == 0 || c->cfg.max_blocks == 0) return EPPK_OK;
   { const int rcf = learn_fence(c, st); if (rcf) return rcf; }
   const uint64_t total = (uint64_t)n_reqs * c->cfg.max_blocks;
@@ -1038,9 +1042,10 @@ int learn_picks(eppk_ctx* c, const void* d_reqs, const int32_t* d_picks, uint32_
   hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, st, c->ixc, c->limit, c->slots, (unsigned long long)total, c->d_ixl);
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->stamps, c->slots,
+    hipLaunchKernelGGL((index_insert_picks_kernel<LW>), dim3((uint32_t)grid64), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, c->rstamps, c->slots,
                        c->shift, c->limit, c->index_epoch, c->ixc, (const uint8_t*)d_reqs, c->stride, c->cfg.max_blocks, d_picks, n_reqs,
-                       c->cfg.max_pods, c->d_status + (c->quiet_rows ? 1 : 0), c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, (const eppk::IxLaunch*)c->d_ixl);
+                       c->cfg.max_pods, c->d_status + (c->quiet_rows ? 1 : 0), c->have_snapshot ? (const LW*)c->snap[c->cur].act_t : (const LW*)nullptr, sw, (const eppk::IxLaunch*)c->d_ixl,
+                       d_learn);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -1138,6 +1143,15 @@ int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
   if (c->index_epoch == 0xFFFFFFFFu) return fail(c, EPPK_ERR_LIMIT, "eppk_index_advance_epoch: epoch counter exhausted (clear the index)");
   ++c->index_epoch;
   if (new_epoch) *new_epoch = c->index_epoch;
+  // The window of the 8-bit stamp tags (SEMANTICS.md 6a): no live hash may be 255 epochs old or more.  A shim that ages its index
+  // (evict_older(epoch - keep) with a keep of a few epochs) never gets here; one that never evicts pays a scan per tick from the 255th.
+  if (c->slots && c->index_epoch > kEpochWindow && c->min_live < c->index_epoch - kEpochWindow) {
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipDeviceSynchronize());               // (index updates the caller may have in flight on streams of its own)
+    uint32_t gone = 0;
+    const int rc = eppk_index_evict_older(c, c->index_epoch - kEpochWindow, &gone);
+    if (rc) return rc;
+  }
   return EPPK_OK;
 }
 
@@ -1154,11 +1168,12 @@ int eppk_index_evict_older(eppk_ctx* c, uint32_t min_epoch, uint32_t* n_evicted)
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
-                       min_epoch, c->ixc);
+    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->rstamps, c->slots,
+                       c->index_epoch, min_epoch, c->ixc);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  { const uint32_t horizon = min_epoch < c->index_epoch ? min_epoch : c->index_epoch; if (horizon > c->min_live) c->min_live = horizon; }
   unsigned long long ev = 0;
   int rcs = ixc_sum(c, eppk::kIxEvicted, &ev);
   if (rcs) return rcs;
@@ -1187,9 +1202,9 @@ int eppk_index_trim_pods(eppk_ctx* c, uint32_t cap, uint64_t* n_removed) {
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_pod_hist_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
-                       (const uint32_t*)c->lists, (const uint32_t*)c->stamps, c->slots, c->index_epoch, hist);
+                       (const uint32_t*)c->lists, (const uint32_t*)c->rstamps, c->slots, c->index_epoch, hist);
     hipLaunchKernelGGL(index_pod_cut_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, c->cfg.max_pods, cap, cutage, over_t);
-    hipLaunchKernelGGL((index_pod_trim_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps,
+    hipLaunchKernelGGL((index_pod_trim_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->rstamps,
                        c->slots, c->index_epoch, (const uint32_t*)cutage, (const uint64_t*)over_t, c->ixc, removed);
     return EPPK_OK;
   });
@@ -1212,11 +1227,12 @@ int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream)
   if (grid > 4096u) grid = 4096u;
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
-    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->stamps, c->slots,
-                       min_epoch, c->ixc);     // (stats[0], the per-launch count of the synchronous form, just accumulates here)
+    hipLaunchKernelGGL((index_evict_kernel<LW>), dim3(grid), dim3(threads), 0, st, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->rstamps, c->slots,
+                       c->index_epoch, min_epoch, c->ixc);     // (stats[0], the per-launch count of the synchronous form, just accumulates here)
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  { const uint32_t horizon = min_epoch < c->index_epoch ? min_epoch : c->index_epoch; if (horizon > c->min_live) c->min_live = horizon; }
   return rc;
 }
 

@@ -1666,33 +1666,37 @@ struct QuadKernArgs {
   uint32_t* done_ctr; uint32_t* report;
   KChain chain;    // (MASKED tails: the exact evaluation of a request whose candidates miss the snapshot-wide QUEUE extremes needs the chain)
 };
+// (a callable function is not handed the kernarg segment pointer itself -- llvm.amdgcn.kernarg.segment.ptr is null there -- only the
+// pointer to the IMPLICIT arguments, which lie right behind the explicit ones, 8-byte aligned: walk back from there)
+static_assert(((sizeof(QuadKernArgs) + 7u) & ~(size_t)7u) == 512u, "QuadKernArgs must mirror pick_quad_kernel's parameter list (its explicit kernarg bytes: .kernarg_segment_size - 256)");
+__device__ __forceinline__ const QuadKernArgs* quad_kernargs() {
+  return (const QuadKernArgs*)((const char*)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(QuadKernArgs) + 7u) & ~(size_t)7u));
+}
+// (1) The requests THIS workgroup deferred: the work-list form of pick_fast_kernel's body over the segments of its own wavefronts (the
+//     workgroup's LDS is re-staged in that kernel's layout).  Called by a workgroup that deferred something -- rarely: the function
+//     saves and restores some fifty callee-saved registers through scratch, which every wavefront of every launch would pay otherwise.
 template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED, bool TOPK>
 __device__ __attribute__((noinline)) void quad_tail_pass(unsigned char* smem) {
-  const QuadKernArgs* a = (const QuadKernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  // this wavefront's part of the work list (and its count) has reached memory: agent-scope stores, acknowledged
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  {   // (1) the requests THIS workgroup deferred: the work-list form of pick_fast_kernel's body over its own segments (it leaves at
-      //     once when they are empty -- the common case; otherwise it re-stages the workgroup's LDS in that kernel's layout)
-    KWork wk;
-    wk.cnt = a->defer_cnt; wk.list = a->defer_list; wk.total = a->defer_total; wk.report = a->report; wk.cap = a->defer_cap; wk.n_segs = gridDim.x * (blockDim.x >> 6);
-    pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true>(
-        blockIdx.x, gridDim.x, 0u, true, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, a->n_reqs, a->pwn, a->cand_mask, a->chain, a->out_pick, a->out_score, a->stats, a->topk, wk);
-  }
-  // (2) the report (the library's feedback: how much the launch deferred) by the LAST workgroup to arrive.  "Who is last?" in two levels
-  // -- the persistent workgroups all finish within a microsecond of each other, and 512 atomics on ONE word queue up for 6 us: 16
-  // group counters (done_ctr[1 + (block & 15)]), the workgroup that completes its group bumps the top counter (done_ctr[0]), the
-  // one that completes that is the last of the launch.
-  __syncthreads();
-  if (threadIdx.x == 0u) {
-    uint32_t* done_ctr = a->done_ctr;
-    const uint32_t grp = blockIdx.x & 15u, n_grp = gridDim.x < 16u ? gridDim.x : 16u;
-    const uint32_t in_grp = (gridDim.x - grp + 15u) / 16u;                            // workgroups with this group number
-    if (atomicAdd(&done_ctr[1u + grp], 1u) == in_grp - 1u) {
-      __hip_atomic_store(&done_ctr[1u + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for this buffer set's next launch)
-      if (atomicAdd(&done_ctr[0], 1u) == n_grp - 1u) {
-        __hip_atomic_store(&done_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *a->report = __hip_atomic_load(a->defer_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (pinned host word)
-      }
+  const QuadKernArgs* a = quad_kernargs();
+  KWork wk;
+  wk.cnt = a->defer_cnt; wk.list = a->defer_list; wk.total = a->defer_total; wk.report = a->report; wk.cap = a->defer_cap; wk.n_segs = gridDim.x * (blockDim.x >> 6);
+  pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true>(
+      blockIdx.x, gridDim.x, 0u, true, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, a->n_reqs, a->pwn, a->cand_mask, a->chain, a->out_pick, a->out_score, a->stats, a->topk, wk);
+}
+// (2) The report (the library's feedback: how much the launch deferred) by the LAST workgroup to arrive.  "Who is last?" in two levels
+//     -- the persistent workgroups all finish within a microsecond of each other, and 512 atomics on ONE word queue up for 6 us: 16
+//     group counters (done_ctr[1 + (block & 15)]), the workgroup that completes its group bumps the top counter (done_ctr[0]), the
+//     one that completes that is the last of the launch.  Thread 0 of every workgroup, behind a barrier.
+__device__ __attribute__((noinline)) void quad_tail_report() {
+  const QuadKernArgs* a = quad_kernargs();
+  uint32_t* done_ctr = a->done_ctr;
+  const uint32_t grp = blockIdx.x & 15u, n_grp = gridDim.x < 16u ? gridDim.x : 16u;
+  const uint32_t in_grp = (gridDim.x - grp + 15u) / 16u;                            // workgroups with this group number
+  if (atomicAdd(&done_ctr[1u + grp], 1u) == in_grp - 1u) {
+    __hip_atomic_store(&done_ctr[1u + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for this buffer set's next launch)
+    if (atomicAdd(&done_ctr[0], 1u) == n_grp - 1u) {
+      __hip_atomic_store(&done_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *a->report = __hip_atomic_load(a->defer_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (pinned host word)
     }
   }
 }
@@ -2223,7 +2227,11 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   if constexpr (TAIL) {
     // the end of the one-launch form -- the work-list pass over what THIS workgroup deferred (rarely anything), the arrival counters and
     // the report -- lives in a function that is never inlined: the hot loop above is compiled as if it were not there
-    quad_tail_pass<LW, HAS_L, P_FIRST, MASKED, TOPK>(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's part of the work list, its count and its share of the total have
+                                                          // reached memory (agent-scope stores and atomics, acknowledged)
+    if (__syncthreads_or((int)(n_def != 0u))) quad_tail_pass<LW, HAS_L, P_FIRST, MASKED, TOPK>(smem);
+    __syncthreads();
+    if (threadIdx.x == 0u) quad_tail_report();
   }
 }
 
@@ -2902,9 +2910,11 @@ __global__ __launch_bounds__(256) void snap_top_kernel(const double* __restrict_
 //     the dense row of such a slot is ALL ZERO and nobody touches it;
 //   * its dense row (64 * sizeof(LW) bytes, one bit per pod) once a 25th pod arrived: count > kListCap ("overflowed"), the ids in
 //     the list are then unspecified.  A row that shrinks back to kListCap members returns to its list (and is zeroed).
-// Invariants (index_selfcheck_kernel checks them all): an absent key (empty word, tombstone, bucket header, the zero row) has an
-// empty list -- count 0, every id 0xFFFF -- and an all-zero row; a present key has a non-empty set; list ids are unique, below
-// 64 * bits(LW), strictly ascending after every entry point of the library; unused id positions and the three spare dwords are 0xFFFF.
+// Invariants (index_selfcheck_kernel checks them all): an EMPTY word (and a bucket header, the zero row) has an empty list -- count 0,
+// every id 0xFFFF -- and an all-zero row; a TOMBSTONE has an all-zero row and a list line whose positions from 1 on are 0xFFFF
+// (position 0 and the count may be what its previous occupant left: round 4, "stamps as tags" below); a present key has a non-empty
+// set; list ids are unique, below 64 * bits(LW), strictly ascending after every entry point of the library; unused id positions and the
+// three spare dwords are 0xFFFF.
 // Why: the post-route update of a 64k x 32-block batch makes ~1 Mi NEW keys, each a single-pod set.  With the row as the arbiter
 // ("did my atomicOr set the bit?") a new key touched four random 64-byte HBM lines (bucket, stamp, row word, list); random-line
 // atomics run at 20 G lines/s on this GPU (scripts/micro/linermw.hip), so the update could not go below ~205 us per Mi keys and the
@@ -3096,6 +3106,35 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 }
 #endif
 
+// ---- stamps as TAGS in the bucket header (round 4) -------------------------------------------------------------------
+// A key's stamp (SEMANTICS.md 6a: the index epoch of its last insert) lives in the header word of its bucket -- the line every look-up
+// of the key loads anyway -- instead of a u32 array of its own (one more random 64-byte line per new key and per known pair: 24 us of a
+// 121 us update per Mi new keys, scripts/micro/claimcost2.hip -> profiles/r04_micro_claimcost2.txt):
+//   header word = keys[bucket * 8]:  bit 0      "a key that hashed here lives in a later bucket"
+//                                    bits 1..7  FAT flag of word i: its pod set is (or was, since the flag was last cleared) more than a
+//                                               single listed pod -- two or more list entries, or the dense row
+//                                    byte i     TAG of word i, i = 1..7:  0 = no valid pod list behind this word (empty, tombstone, or a
+//                                               claim in progress), else 1 + (stamp - 1) % 255
+// A tag is written with a plain BYTE store (every writer of a launch writes the same value), never with a read-modify-write of the
+// word: the atomics that set the flag bits of byte 0 and the byte stores of the tags do not disturb each other.
+// Ages: age = (tag(epoch) - tag) mod 255 is the true age of a live key as long as that is at most 254 epochs, which
+// eppk_index_advance_epoch enforces (SEMANTICS.md 6a "window": a hash stamped 255 epochs ago or more is evicted by the tick).
+// What the tags buy beyond the line: TAG 0 IS THE "NOT READY" SIGNAL of the insert protocol (it was "count == 0" in the list line), so
+// an eviction victim's list line no longer has to be reset: a plain single-pod victim keeps its stale line -- {old pod, count 1},
+// every other position 0xFFFF -- and the next claimer's ONE 16-byte store of {pod, count 1} makes it a canonical line again; only FAT
+// victims (rare: the hot prefixes) are reset in full.  Eviction: 68 -> 40 us per Mi victims (same micro-benchmark).
+// The two reserved rows (hashes 0 / ~0: no bucket, no header) keep exact u32 stamps (rstamps[2]) and the round-3 list protocol.
+constexpr uint32_t kTagMod = 255u;
+__host__ __device__ __forceinline__ constexpr uint32_t tag_of_epoch(uint32_t epoch) { return 1u + (epoch - 1u) % kTagMod; }     // epoch >= 1
+__device__ __forceinline__ uint32_t tag_age(uint32_t cur_tag, uint32_t tag) { return (cur_tag + kTagMod - tag) % kTagMod; }    // both in 1..255
+__device__ __forceinline__ uint32_t hdr_tag(unsigned long long hdr, uint32_t i) { return (uint32_t)(hdr >> (8u * i)) & 0xFFu; }   // i = 1..7
+__device__ __forceinline__ void tag_store(uint64_t* keys, uint32_t slot, uint32_t tag) {       // (agent scope, like the atomics around it)
+  __hip_atomic_store((uint8_t*)&keys[slot & ~(kBucket - 1u)] + (slot & (kBucket - 1u)), (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long hdr_load_coherent(const uint64_t* keys, uint32_t slot) {
+  return __hip_atomic_load((const unsigned long long*)&keys[slot & ~(kBucket - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- index counters ------------------------------------------------------------------------------------------------
 // Live keys, non-empty words, dropped inserts and "evicted by this launch" are SHARDED over kIxShards cache lines
 // (ixc[shard * 8 + field]): a same-address atomic serialises at ~12 ns, and a post-pick update of a 64k x 32-block batch bumps
@@ -3178,13 +3217,15 @@ struct SortWl {
 // the following buckets for as long as the overflow flags say the chain continues -- but only after the whole chain has
 // been searched for the key itself (a tombstone may sit in front of it).  Free words only disappear while an insert kernel
 // runs (evictions are separate launches), so every inserter of one key converges on the same word: no duplicates.
-// Every insert stamps the key with the index epoch (ageing: index_evict_kernel).
-// Memory round trips per pair: one for the whole home bucket (its 8 words are loaded together), one CAS when the key is new,
-// one for {stamp, list line} together (skipped for a key this thread just claimed), one for the list CAS.
+// Every insert stamps the key with the index epoch: its TAG in the bucket header (ageing: index_evict_kernel).
+// Memory round trips per pair: one for the whole home bucket (its 8 words are loaded together: the key AND its tag), one CAS when the
+// key is new, one for the list line (skipped for a key this thread just claimed), one for the list CAS.
+// `known_only`: the pick kernel has already seen this pair's key in the index with the picked pod on its list (pick_quad_kernel's
+// learn word): all that is left to do is the stamp -- one bucket look-up, no list access.
 template <typename LW>
-__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift,
+__device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* rstamps, uint32_t slots, uint32_t shift,
                                                  uint32_t limit, uint32_t epoch, unsigned long long* ixc, const IxLaunch* il, unsigned long long* s_tmp,
-                                                 uint64_t h, uint32_t pod, bool active, const LW* act, const SortWl& sw, uint32_t* status) {
+                                                 uint64_t h, uint32_t pod, bool active, const LW* act, const SortWl& sw, uint32_t* status, bool known_only = false) {
   // a hole of the current snapshot has no cache to record: the pair is ignored (SEMANTICS.md §6b; act == null: no snapshot yet)
   if (active && act && !((act[pod & 63u] >> (pod >> 6)) & 1)) active = false;
   uint32_t slot = kNotFound;
@@ -3194,11 +3235,13 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   unsigned long long* K = (unsigned long long*)keys;
   uint32_t free_slot = kNotFound;
   unsigned long long free_val = 0ull;
+  uint32_t found_tag = 0u;                 // the tag of `slot` as the search saw it (0: unknown / not ready -- looked at again, coherently)
   // One walk of the key's bucket chain: `slot` when the key is there, else the first free word (`free_slot`, holding `free_val`).
   auto search = [&](bool coherent) {
     uint32_t bkt = home_bucket(h, shift);
     free_slot = kNotFound;
     free_val = 0ull;
+    found_tag = 0u;
     bool chain_end = false;
     for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
       unsigned long long* kb = K + (size_t)bkt * kBucket;
@@ -3214,7 +3257,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
       for (uint32_t i = 1; i < kBucket; ++i) {
         if (slot != kNotFound || chain_end) continue;
         const unsigned long long k = w[i];
-        if (k == (unsigned long long)h) { slot = bkt * kBucket + i; continue; }
+        if (k == (unsigned long long)h) { slot = bkt * kBucket + i; found_tag = hdr_tag(w[0], i); continue; }
         if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = bkt * kBucket + i; free_val = k; }
         if (k == 0ull) chain_end = true;                      // buckets fill front to back: nothing lives behind an empty word
       }
@@ -3228,6 +3271,7 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   };
   // (1) the first look (ordinary cached loads: load_line16)
   if (active && !reserved_hash) search(false);
+  if (reserved_hash || slot == kNotFound) known_only = false;      // (the pick kernel saw the key; should it be gone, the pair takes the whole path)
   // (2) the capacity regime (IxLaunch above): safe launch-wide, or every new key booked before it is claimed
   const bool safe = il->safe != 0u;        // (uniform over the launch)
   const uint32_t my_shard = blockIdx.x & (kIxShards - 1u);
@@ -3318,10 +3362,14 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   }
   bool unsorted = false;               // this thread appended behind other ids: the list needs its order back
   const bool have = active && slot != kNotFound;
-  // (1) A key this thread claimed a moment ago: its list is in the reset state and its stamp is nobody's yet -- the first id and
-  // the count go in with ONE plain 16-byte store, the stamp with another: no atomic, nothing read.  Random-line atomics cost ~50 us
-  // per Mi on this GPU whatever line they hit (a new key used to take three: bucket CAS, list CAS, count), stores ~37.
-  // This block comes BEFORE (2) for every lane of the wavefront: a lane of (2) may wait for exactly this store.
+  const uint32_t cur_tag = tag_of_epoch(epoch);
+  // (1) A key this thread claimed a moment ago.  Its word was empty (list line in the reset state) or a tombstone (list line left by
+  // the previous occupant: positions 1.. are 0xFFFF by the invariant of tag 0, position 0 and the count are stale): either way the
+  // first id and the count go in with ONE plain 16-byte store -- no atomic, nothing read -- and the TAG with a byte store into the
+  // bucket header, but only once the list store has been acknowledged: a lane of (2), in any wavefront, reads the list as soon as it
+  // sees a tag.  (Random-line atomics cost ~50 us per Mi on this GPU whatever line they hit, stores ~37; the wait costs ~2:
+  // scripts/micro/claimcost2.hip N1 / N4.)  Both steps come BEFORE (2) for every lane of the wavefront: a lane of (2) may wait for
+  // exactly this tag.  The two reserved rows have no header: exact stamp, and the list's count is their ready signal as in round 3.
   if (have && newkey) {
     uint32_t* L = lists + (size_t)slot * kListDwords;
     const u32x4_t first = {0xFFFF0000u | pod, 0xFFFFFFFFu, 0xFFFFFFFFu, 1u};
@@ -3331,31 +3379,48 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
 #ifndef EPPK_DBG_NO_LISTSTORE
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(L), "v"(first) : "memory");
 #endif
-#ifndef EPPK_DBG_NO_STAMP
-    __hip_atomic_store(&stamps[slot], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every insert of a launch carries the same epoch)
-#endif
+    if (slot >= slots) __hip_atomic_store(&rstamps[slot - slots], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // (the stores above are acknowledged before any lane of this wavefront looks at a list: no cache maintenance -- a __threadfence
-  // here, buffer_wbl2 + buffer_inv per wavefront, made the kernel four times slower)
+  // (the stores above are acknowledged before any tag goes out and before any lane of this wavefront looks at a list: no cache
+  // maintenance -- a __threadfence here, buffer_wbl2 + buffer_inv per wavefront, made the kernel four times slower)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // (2) A key that was there: stamp and list line together (one round trip), then the list protocol (list_add).
+#ifndef EPPK_DBG_NO_STAMP
+  if (have && newkey && slot < slots) tag_store(keys, slot, cur_tag);       // (every insert of a launch carries the same epoch)
+#endif
+  // (2) A key that was there.  Its tag first -- from the bucket line the search loaded; 0 = its claimer has not finished (or the
+  // search never saw the line: the slot came out of a lost compare-and-swap): look again, coherently, until the tag is there -- the
+  // claimer never waits for anybody, so it arrives.  Bounded all the same: a lane that gives up drops its pair and raises a
+  // launch-status flag instead of hanging the GPU.  An older tag is brought up to date with a byte store (every writer of the launch
+  // writes the same value).  Then the list line and the list protocol (list_add) -- unless the pick kernel has vouched for the pair.
   if (have && !newkey) {
     uint32_t* L = lists + (size_t)slot * kListDwords;
-    const uint32_t st = __hip_atomic_load(&stamps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t d[16];
-    load_line16<false>(L, d);
-    // A present key with an EMPTY list exists only between a claimer's compare-and-swap on the key word and its store above (an
-    // invariant of the index: present = non-empty): wait for that store -- the claimer never waits for anybody, so it arrives.
-    // Bounded all the same: a lane that gives up drops its pair and raises a launch-status flag instead of hanging the GPU.
-    uint32_t spins = 0;
-    while (d[3] == 0u && spins < (1u << 20)) { load_line16(L, d); ++spins; }
-    if (st < epoch) atomicMax(&stamps[slot], epoch);
-    uint32_t res = 0u, pos = 0;
-    if (d[3] == 0u) atomicOr(status, kStatusIndexStall);
-    else if (d[3] > kListCap) bitmap_set<LW>(bitmaps, slot, pod);         // overflowed: the row is the set
-    else res = list_add<false>(L, d, pod, pos);
-    if (res == 2u) list_overflow<LW>(keys, slots, bitmaps, L, slot, pod);
-    unsorted = res == 1u && pos != 0u;
+    bool ready = true;
+    if (slot < slots) {
+      uint32_t tag = found_tag, spins = 0;
+      while (tag == 0u && spins < (1u << 20)) { tag = hdr_tag(hdr_load_coherent(keys, slot), slot & (kBucket - 1u)); ++spins; }
+      ready = tag != 0u;
+#ifndef EPPK_DBG_NO_STAMP
+      if (ready && tag != cur_tag) tag_store(keys, slot, cur_tag);
+#endif
+    }
+    if (!ready) atomicOr(status, kStatusIndexStall);
+    else if (!known_only) {
+      uint32_t d[16];
+      load_line16<false>(L, d);
+      uint32_t res = 0u, pos = 0;
+      if (slot >= slots) {                                  // reserved rows: the round-3 protocol (count 0 = the claimer's store is on its way)
+        uint32_t spins = 0;
+        while (d[3] == 0u && spins < (1u << 20)) { load_line16(L, d); ++spins; }
+        if (__hip_atomic_load(&rstamps[slot - slots], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) atomicMax(&rstamps[slot - slots], epoch);
+      }
+      if (d[3] == 0u) atomicOr(status, kStatusIndexStall);
+      else if (d[3] > kListCap) bitmap_set<LW>(bitmaps, slot, pod);         // overflowed: the row is the set
+      else res = list_add<false>(L, d, pod, pos);
+      if (res == 2u) list_overflow<LW>(keys, slots, bitmaps, L, slot, pod);
+      unsorted = res == 1u && pos != 0u;
+      // the second member of a set: from here on its list line is more than {one pod, count 1} -- the eviction has to reset it in full
+      if (res == 1u && pos == 1u && slot < slots) atomicOr((unsigned long long*)&keys[slot & ~(kBucket - 1u)], 1ull << (slot & (kBucket - 1u)));
+    }
   }
   // the lists to re-sort, appended to the work list once per wavefront
   const unsigned long long um = __ballot(unsorted);
@@ -3373,25 +3438,30 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
 }
 
 template <typename LW>
-__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+__global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* rstamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                     uint32_t epoch, unsigned long long* ixc, const uint64_t* hashes, const uint32_t* pods, uint32_t n,
                                     const LW* act, SortWl sw, uint32_t* status, const IxLaunch* il) {
   __shared__ unsigned long long s_tmp[4];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, il, s_tmp, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act, sw, status);
+  index_insert_one<LW>(keys, bitmaps, lists, rstamps, slots, shift, limit, epoch, ixc, il, s_tmp, active ? hashes[i] : 0ull, active ? pods[i] : 0u, active, act, sw, status);
 }
 
-// thread (r, i): append picks[r] to hash i of request r
+// thread (r, i): append picks[r] to hash i of request r.
+// `learn` (nullable): one word per request from pick_quad_kernel<..., LEARN> -- bits 0..7 = m, the number of leading blocks of the
+// request whose keys the pick kernel found in the index (the walk of SEMANTICS.md 3 PREFIX), bit 31 = the picked pod is on the pod
+// list of every one of them.  Such a pair is in the index already: thread (r, i < m) only brings the key's stamp up to date -- one
+// bucket look-up instead of bucket + list (the 1 Mi known pairs of a 64k x 32-block closed-loop step were 38 us of its 150).
+// 0 = no information (a request that kernel deferred, or another pick route): every block takes the whole path.
 template <typename LW>
-__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* stamps, uint32_t slots, uint32_t shift, uint32_t limit,
+__global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* rstamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* ixc, const uint8_t* reqs, uint32_t stride,
                                           uint32_t max_blocks, const int32_t* picks, uint32_t n_reqs, uint32_t max_pods, uint32_t* status, const LW* act,
-                                          SortWl sw, const IxLaunch* il) {
+                                          SortWl sw, const IxLaunch* il, const uint32_t* learn) {
   __shared__ unsigned long long s_tmp[4];
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = (uint32_t)(t / max_blocks), i = (uint32_t)(t % max_blocks);
-  bool active = r < n_reqs;
+  bool active = r < n_reqs, known_only = false;
   int32_t pick = -1;
   uint64_t h = 0;
   if (active) {
@@ -3404,8 +3474,12 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     if (bad && i == 0u) atomicOr(status, (uint32_t)pick >= max_pods && pick >= 0 ? kStatusBadPick : kStatusBadRow);
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
+    if (active && learn) {
+      const uint32_t lw = learn[r];
+      known_only = (lw >> 31) != 0u && i < (lw & 0xFFu);
+    }
   }
-  index_insert_one<LW>(keys, bitmaps, lists, stamps, slots, shift, limit, epoch, ixc, il, s_tmp, h, (uint32_t)pick, active, act, sw, status);
+  index_insert_one<LW>(keys, bitmaps, lists, rstamps, slots, shift, limit, epoch, ixc, il, s_tmp, h, (uint32_t)pick, active, act, sw, status, known_only);
 }
 
 #ifdef EPPK_MAIN_UNIT
@@ -3447,6 +3521,24 @@ __global__ void index_lists_sort_kernel(uint32_t* lists, uint32_t slots, uint32_
 }
 #endif
 
+// The scanning maintenance kernels below (removal, trim, ageing) walk the table with lane = slot, 64 slots per step and chunk: the
+// header word of a slot's bucket sits in the first lane of its group of eight.
+__device__ __forceinline__ unsigned long long bucket_hdr_of_lane(unsigned long long k, uint32_t lane) {
+  const int src = (int)(lane & ~(kBucket - 1u));
+  return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(k >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)k, src);
+}
+// A slot whose pod set has become empty: the key word turns into a tombstone (reusable by later inserts; reserved rows: presence
+// cleared), its tag into 0 ("no valid list behind this word") and its FAT flag is cleared -- the caller has left the list line with
+// every position from 1 on at 0xFFFF (reset, or a plain single-pod line), which is all the next claimer relies on.  These kernels run
+// alone (no insert in flight): plain stores, an atomic only for the flag bit that neighbouring lanes may clear as well.
+__device__ __forceinline__ void slot_bury(uint64_t* keys, uint32_t slots, uint32_t row, bool fat) {
+  keys[row] = row < slots ? kTomb : 0ull;
+  if (row < slots) {
+    *((uint8_t*)&keys[row & ~(kBucket - 1u)] + (row & (kBucket - 1u))) = (uint8_t)0;
+    if (fat) atomicAnd((unsigned long long*)&keys[row & ~(kBucket - 1u)], ~(1ull << (row & (kBucket - 1u))));
+  }
+}
+
 // Remove pods from every set; a set that becomes empty gets its key tombstoned so that the hot path never meets a present key
 // with an empty pod set.  `rm` (nullable): instead of the single `pod`, every pod whose bit is set in the lane-transposed row
 // rm[64] (the holes of a snapshot: eppk_snapshot_publish scrubs them out of the index in one pass).
@@ -3469,10 +3561,10 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
   for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
     const uint32_t row = base + lane;
     bool present = false;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {     // (bucket header words are not keys)
-      const uint64_t k = keys[row];
+    const uint64_t k = row < total ? keys[row] : 0ull;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))       // (bucket header words are not keys)
       present = k != 0ull && !(row < slots && k == kTomb);
-    }
+    const bool fat = row < slots && ((bucket_hdr_of_lane(k, lane) >> (row & (kBucket - 1u))) & 1ull) != 0ull;
     bool over = false, emptied = false;
     if (present) {
       uint32_t* L = lists + (size_t)row * kListDwords;
@@ -3506,16 +3598,16 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
       if (!__any(nv != v)) continue;
       uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)nv);
       for (uint32_t dd = 32; dd; dd >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)dd);
-      if (members <= kListCap) {                       // back to the list (or gone): the row returns to all-zero
-        list_rebuild<LW>(lists, v_row, nv, lane);
+      if (members <= kListCap) {                       // back to the list (or gone): the row returns to all-zero; the slot stays FAT
+        list_rebuild<LW>(lists, v_row, nv, lane);      // unless the set is down to one pod (or gone: slot_bury)
         *w = 0;
-        if (lane == 0 && v_row < slots) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
+        if (lane == 0 && v_row < slots && members == 1u) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
         if (members == 0u && v_row == row) emptied = true;
       } else if (nv != v) {
         *w = nv;
       }
     }
-    if (emptied) keys[row] = row < slots ? kTomb : 0ull;     // reserved rows: clear presence
+    if (emptied) slot_bury(keys, slots, row, fat);
     gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   if (lane == 0 && gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
@@ -3531,8 +3623,20 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
 constexpr uint32_t kTrimBins = 64u;
 constexpr uint32_t kNoCut = 0xFFFFFFFFu;
 
+// age (in epochs, capped at kTrimBins - 1) of the present key in `row`: from its tag in the bucket header, the reserved rows from their exact stamps
+__device__ __forceinline__ uint32_t slot_age(unsigned long long hdr, const uint32_t* rstamps, uint32_t slots, uint32_t row, uint32_t epoch) {
+  uint32_t age;
+  if (row < slots) {
+    const uint32_t tag = hdr_tag(hdr, row & (kBucket - 1u));
+    age = tag ? tag_age(tag_of_epoch(epoch), tag) : 0u;
+  } else {
+    age = epoch - rstamps[row - slots];
+  }
+  return age < kTrimBins - 1u ? age : kTrimBins - 1u;
+}
+
 template <typename LW>
-__global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t epoch,
+__global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, const uint32_t* rstamps, uint32_t slots, uint32_t epoch,
                                       uint32_t* hist) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -3540,15 +3644,14 @@ __global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps,
   for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
     const uint32_t row = base + lane;
     bool present = false;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {
-      const uint64_t k = keys[row];
+    const uint64_t k = row < total ? keys[row] : 0ull;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))
       present = k != 0ull && !(row < slots && k == kTomb);
-    }
+    const unsigned long long hdr = bucket_hdr_of_lane(k, lane);
     bool over = false;
     uint32_t age = 0;
     if (present) {
-      const uint32_t st = stamps[row];
-      age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+      age = slot_age(hdr, rstamps, slots, row, epoch);
       uint32_t d[16];
       load_line16<false>(lists + (size_t)row * kListDwords, d);
       if (d[3] > kListCap) over = true;
@@ -3600,7 +3703,7 @@ __global__ __launch_bounds__(1024) void index_pod_cut_kernel(const uint32_t* his
 #endif
 
 template <typename LW>
-__global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t epoch,
+__global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* rstamps, uint32_t slots, uint32_t epoch,
                                       const uint32_t* cutage, const uint64_t* over_t, unsigned long long* ixc, unsigned long long* removed) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -3610,15 +3713,15 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
   for (uint32_t base = wave * 64u; base < total; base += nwaves * 64u) {
     const uint32_t row = base + lane;
     bool present = false;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u)) {
-      const uint64_t k = keys[row];
+    const uint64_t k = row < total ? keys[row] : 0ull;
+    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))
       present = k != 0ull && !(row < slots && k == kTomb);
-    }
+    const unsigned long long hdr = bucket_hdr_of_lane(k, lane);
+    const bool fat = row < slots && ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
     bool over = false, emptied = false;
     uint32_t age = 0;
     if (present) {
-      const uint32_t st = stamps[row];
-      age = epoch - st < kTrimBins - 1u ? epoch - st : kTrimBins - 1u;
+      age = slot_age(hdr, rstamps, slots, row, epoch);
       uint32_t* L = lists + (size_t)row * kListDwords;
       uint32_t d[16];
       load_line16<false>(L, d);                         // (a launch of its own: nothing else writes the index meanwhile)
@@ -3663,13 +3766,13 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
       if (members <= kListCap) {
         list_rebuild<LW>(lists, v_row, nv, lane);
         *w = 0;
-        if (lane == 0 && v_row < slots) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
+        if (lane == 0 && v_row < slots && members == 1u) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
         if (members == 0u && lane == src) emptied = true;
       } else if (rmw != 0) {
         *w = nv;
       }
     }
-    if (emptied) keys[row] = row < slots ? kTomb : 0ull;
+    if (emptied) slot_bury(keys, slots, row, fat);
     gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   for (int off = 32; off >= 1; off >>= 1) pairs += (uint32_t)__shfl_xor((int)pairs, off);
@@ -3680,18 +3783,21 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
 }
 
 // Ageing (SEMANTICS.md §6a; 0602-…/README.md:82 "mimicking a similar cache eviction strategy of the model server (e.g., LRU)"):
-// drop every key last stamped before min_epoch -- pod set emptied, key tombstoned (reusable by later inserts).
-// A wavefront scans 64 slots per step (lane = slot: keys -- bucket headers included -- and stamps stream in coalesced).  A LANE per
-// victim: its list line is reset by four 16-byte stores WITHOUT being read (whether the set had moved to its dense row is a bit of
-// the bucket header the scan holds already), the key word becomes a tombstone: one written line per victim beside the scan.
-// Overflowed victims get their row zeroed by the whole wavefront and their header bit cleared.
+// drop every key last stamped before min_epoch -- key tombstoned (reusable by later inserts), tag 0.
+// A wavefront scans 64 slots per step and chunk (lane = slot: the key words stream in coalesced, and with them the bucket headers that
+// hold the stamps as tags -- there is no stamp array to read).  A LANE per victim: one 8-byte store (tombstone) and one byte store
+// (tag 0) into the line the scan has just read.  Its list line is NOT touched when the slot is not FAT: {old pod, count 1} with every
+// other position 0xFFFF is exactly what the next claimer's 16-byte store overwrites (see "stamps as tags").  That was a whole random
+// 64-byte line per victim: 68 -> 40 us per Mi victims (scripts/micro/claimcost2.hip E0 / E3, tables beyond the Infinity Cache).  FAT
+// victims (two or more listed pods, or the dense row: the hot prefixes when they finally age out) get their list line reset in
+// full, their row zeroed by the whole wavefront when the set lived there, their flag cleared.
+// `keep` = epoch - min_epoch: a key is a victim iff its age exceeds it (-1: every key; >= 254: none -- ages are at most 254, which
+// eppk_index_advance_epoch sees to).  The two reserved rows: exact stamps, and the round-3 protocol (list reset in full).
 template <typename LW>
-__global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch,
+__global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* rstamps, uint32_t slots, uint32_t epoch, uint32_t min_epoch,
                                    unsigned long long* ixc) {
-  // kEvictChunks x 64 slots per wavefront and step, every chunk's key words AND stamps requested before the first is looked at.  With
-  // one chunk (and the stamp loaded only behind a live key: two dependent round trips) the scan was bound by bytes in flight; measured
-  // with 1 / 4 / 8 chunks (profiles/r03_y_evict_chunks.txt): 1 Mi victims out of 8 Mi slots 67 / 60 / 65 us standalone, ageing per
-  // step of the closed loop 70 -> 59 us (1 -> 8).
+  // kEvictChunks x 64 slots per wavefront and step, every chunk's key words requested before the first is looked at (with one chunk the
+  // scan was bound by bytes in flight; measured with 1 / 4 / 8 chunks: profiles/r03_y_evict_chunks.txt).
 #ifndef EPPK_EVICT_CHUNKS
 #define EPPK_EVICT_CHUNKS 4
 #endif
@@ -3699,15 +3805,15 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t total = slots + 2u;
+  const uint32_t cur_tag = tag_of_epoch(epoch);
+  const long long keep = (long long)epoch - (long long)min_epoch;
   uint32_t gone = 0;
   for (uint32_t base0 = wave * 64u * kEvictChunks; base0 < total; base0 += nwaves * 64u * kEvictChunks) {
     uint64_t kk[kEvictChunks];
-    uint32_t ss[kEvictChunks];
 #pragma unroll
     for (uint32_t u = 0; u < kEvictChunks; ++u) {
       const uint32_t row = base0 + u * 64u + lane;
       kk[u] = row < total ? keys[row] : 0ull;
-      ss[u] = row < total ? stamps[row] : 0u;
     }
 #pragma unroll
     for (uint32_t u = 0; u < kEvictChunks; ++u) {
@@ -3716,19 +3822,28 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
       const uint32_t row = base + lane;
       const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
       const uint64_t k = kk[u];
-      const uint32_t hdr = (uint32_t)__shfl((int)(uint32_t)k, (int)(lane & ~(kBucket - 1u)));   // this slot's bucket header (rows < slots)
-      const bool victim = row < total && !header && k != 0ull && !(row < slots && k == kTomb) && ss[u] < min_epoch;
+      const unsigned long long hdr = bucket_hdr_of_lane(k, lane);       // this slot's bucket header (rows < slots)
+      bool victim = false, fat = false;
+      if (row < slots) {
+        const uint32_t tag = hdr_tag(hdr, row & (kBucket - 1u));
+        victim = !header && k != 0ull && k != kTomb && tag != 0u && (long long)tag_age(cur_tag, tag) > keep;
+        fat = ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
+      } else if (row < total) {
+        victim = k != 0ull && rstamps[row - slots] < min_epoch;
+        fat = true;                                   // (reserved rows: always the full reset)
+      }
       gone += (uint32_t)__builtin_popcountll(__ballot(victim));
       bool whole = false;
       if (victim) {
-        u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
-        whole = row < slots ? ((hdr >> (row & (kBucket - 1u))) & 1u) != 0u : Lp[0].w > kListCap;   // (the two reserved rows have no header)
-        const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
-        keys[row] = row < slots ? kTomb : 0ull;
-        if (whole && row < slots) atomicAnd((unsigned long long*)&keys[row & ~(kBucket - 1u)], ~(1ull << (row & (kBucket - 1u))));
+        if (fat) {
+          u32x4_t* Lp = (u32x4_t*)(lists + (size_t)row * kListDwords);
+          whole = Lp[0].w > kListCap;                 // the set lives in its dense row
+          const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+          Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
+        }
+        slot_bury(keys, slots, row, fat && row < slots);
       }
-      unsigned long long vm = __ballot(whole);          // overflowed sets: the whole row, by the wavefront
+      unsigned long long vm = __ballot(whole);          // dense sets: the whole row, by the wavefront
       while (vm) {
         const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
         vm &= vm - 1ull;
@@ -3743,8 +3858,14 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
   }
 }
 
-// Diagnostic (eppk_index_selfcheck): counts the slots that break an invariant of the index (the list at the head of this section).
-// A wavefront per slot: its row word per lane, its list dwords in lanes 0..15.
+// Diagnostic (eppk_index_selfcheck): counts the slots that break an invariant of the index (the list at the head of this section, and
+// "stamps as tags").  A wavefront per slot: its row word per lane, its list dwords in lanes 0..15.  By state of the key word:
+//   empty          tag 0, not FAT, list line in the reset state (count 0, every id 0xFFFF), row all-zero
+//   tombstone      tag 0, not FAT, row all-zero; of the list line only what the next claimer relies on: count <= 1 and every position
+//                  from 1 on 0xFFFF (position 0 may still hold the previous occupant's pod)
+//   present        tag != 0; a non-empty set: listed (count <= 24: ids valid, unique, strictly ascending, nothing behind the count,
+//                  row all-zero) or dense (count > 24: more than 24 members in the row); two members or more => FAT
+//   reserved rows  (no header) absent: list reset, row zero; present: as above without tag / flag
 template <typename LW>
 __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, uint32_t slots, unsigned long long* bad) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -3752,8 +3873,13 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
   uint32_t nbad = 0;
   for (uint32_t row = wave; row < slots + 3u; row += nwaves) {
     const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
+    if (header) continue;                                                  // (wave-uniform: the header words are checked through their slots)
     const uint64_t k = row < slots + 2u ? keys[row] : 0ull;
-    const bool present = !header && row < slots + 2u && k != 0ull && !(row < slots && k == kTomb);
+    const bool tomb = row < slots && k == kTomb;
+    const bool present = row < slots + 2u && k != 0ull && !tomb;
+    const unsigned long long hdr = row < slots ? keys[row & ~(kBucket - 1u)] : 0ull;
+    const uint32_t tag = row < slots ? hdr_tag(hdr, row & (kBucket - 1u)) : 0u;
+    const bool fat = row < slots && ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
     const LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
     uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)v);
     for (uint32_t d = 32; d; d >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)d);
@@ -3764,7 +3890,8 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     const uint32_t id = ((const uint16_t*)L)[list_pos(j)], prev = j ? ((const uint16_t*)L)[list_pos(j - 1u)] : 0u;
     bool ok = true;
     if (lane < kListCap) {
-      if (count <= kListCap) {
+      if (tomb) ok = lane == 0u || id == kListNone;                        // positions 1.. (position 0: whatever the previous occupant left)
+      else if (count <= kListCap) {
         if (lane < count) ok = id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW) && (lane == 0u || prev < id);   // valid, strictly ascending
         else ok = id == kListNone;
       }
@@ -3773,11 +3900,14 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     }
     const unsigned long long notok = __ballot(!ok);
     uint32_t why = notok ? 1u : 0u;                                        // bit 0: a list entry (ballot in the record), then per state
-    if (!present) why |= (count != 0u ? 2u : 0u) | (members != 0u ? 4u : 0u);            // absent: empty list, all-zero row
+    if (tomb) why |= (count > 1u ? 2u : 0u) | (members != 0u ? 4u : 0u);                 // tombstone: a plain line at most, all-zero row
+    else if (!present) why |= (count != 0u ? 2u : 0u) | (members != 0u ? 4u : 0u);       // empty / absent reserved row: reset list, all-zero row
     else if (count <= kListCap) why |= (count == 0u ? 8u : 0u) | (members != 0u ? 16u : 0u);   // listed: non-empty, all-zero row
-    else why |= members <= kListCap ? 32u : 0u;                            // overflowed: more than kListCap members in the row
-    if (!header && row < slots)                                            // the bucket header's "overflowed" bit of this slot
-      why |= (((keys[row & ~(kBucket - 1u)] >> (row & (kBucket - 1u))) & 1ull) != 0ull) != (count > kListCap) ? 64u : 0u;
+    else why |= members <= kListCap ? 32u : 0u;                            // dense: more than kListCap members in the row
+    if (row < slots) {
+      if (!present) why |= (tag != 0u ? 128u : 0u) | (fat ? 64u : 0u);                   // no key: no tag, no flag
+      else why |= (tag == 0u ? 128u : 0u) | ((count >= 2u && !fat) ? 64u : 0u);           // a key: a tag; two members or more => FAT
+    }
     if (why) {
       ++nbad;
       // the first eight offenders in full, for eppk_index_selfcheck's EPPK_SELFCHECK_VERBOSE: bad[2 + 24 k ..] = row, why, key, members, ballot, list[16]
@@ -3786,7 +3916,7 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
       at = (unsigned long long)__shfl((long long)at, 0);
       if (at < 8ull) {
         unsigned long long* rec = bad + 2u + 24u * at;
-        if (lane == 0) { rec[0] = row; rec[1] = why; rec[2] = k; rec[3] = members; rec[4] = notok; }
+        if (lane == 0) { rec[0] = row; rec[1] = why | ((unsigned long long)tag << 32) | ((unsigned long long)fat << 40); rec[2] = k; rec[3] = members; rec[4] = notok; }
         if (lane < kListDwords) rec[5u + lane] = L[lane];
       }
     }

@@ -218,8 +218,6 @@ void orc_index_scrub_inactive(orc_index* ix, const eppk_pod_row* pods, uint32_t 
 }
 
 /* Ageing (SEMANTICS.md 6a; docs/proposals/0602-…/README.md:82 "mimicking a similar cache eviction strategy"). */
-uint32_t orc_index_advance_epoch(orc_index* ix) { return ++ix->epoch; }
-
 uint32_t orc_index_evict_older(orc_index* ix, uint32_t min_epoch) {
   uint32_t gone = 0;
   for (uint64_t i = 0; i < ix->cap; ++i) {
@@ -227,6 +225,15 @@ uint32_t orc_index_evict_older(orc_index* ix, uint32_t min_epoch) {
     if (e->used && e->n > 0 && e->stamp < min_epoch) { e->n = 0; ++gone; }
   }
   return gone;
+}
+
+/* SEMANTICS.md 6a, "window": a hash whose stamp would be 255 epochs old or more after the tick is evicted by the tick (the limit of
+ * this build: the device keeps a stamp as an 8-bit tag in the hash's bucket header). */
+#define ORC_EPOCH_WINDOW 254u
+uint32_t orc_index_advance_epoch(orc_index* ix) {
+  ++ix->epoch;
+  if (ix->epoch > ORC_EPOCH_WINDOW) orc_index_evict_older(ix, ix->epoch - ORC_EPOCH_WINDOW);
+  return ix->epoch;
 }
 
 /* SEMANTICS.md 6c.  age(h) = min(63, epoch - stamp(h)); cutage(p) = the smallest b >= 1 with #{h containing p : age(h) <= b} > cap;

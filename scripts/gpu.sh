@@ -37,7 +37,8 @@ if cl: s += f"\n   closed_loop {({k: cl[k] for k in cl if k in ('value', 'ms_per
 rc = d.get("roofline_closed_loop") or (cl.get("roofline") if isinstance(cl, dict) else None) or {}
 if rc: s += f"\n   step parts {rc.get('step_parts_ms')}"
 h = d.get("host_path") or {}
-if h: s += "\n   host_path " + str({k: (round(v.get('decisions_per_s', v.get('decisions_per_s_p50', 0)) / 1e6, 1) if isinstance(v, dict) else v) for k, v in h.items() if k in ('staged', 'pipelined', 'pipelined_learn', 'decisions_per_s_p50')})
+if h:
+    s += "\n   host_path " + str({k: (round(v.get('decisions_per_s', v.get('decisions_per_s_p50', 0)) / 1e6, 1) if isinstance(v, dict) else v) for k, v in h.items() if k in ('staged', 'pipelined', 'pipelined_learn', 'decisions_per_s_p50')})
     lb = (h.get("latency_by_batch") or {}).get("requests")
     if lb: s += "\n   latency_by_batch " + str(lb)
 print(s)
@@ -59,8 +60,8 @@ for stage in "$@"; do
     configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
     routes) timeout 300 python scripts/gpu_route_times.py > $OUT/route_times.json 2> $OUT/route_times.err; tail -c 1500 $OUT/route_times.json ;;
     small) timeout 300 python scripts/gpu_small_batch_latency.py 2>&1 | tee $OUT/small_batch_latency.txt | tail -12 ;;
-    doorbell|claim|evictloop|insertbreak)
-      bin=$name; [ $name = claim ] && bin=claimcost
+    doorbell|claim|claim2|evictloop|insertbreak)
+      bin=$name; [ $name = claim ] && bin=claimcost; [ $name = claim2 ] && bin=claimcost2
       timeout 60 ./scripts/micro/_bin/$bin $arg 2>&1 | tee $OUT/micro_$name.txt | tail -40 ;;
     stats) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/prof_bench_under_rocprof.json 2> $OUT/prof.err )
            head -6 $OUT/prof/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof -name "*agent_info.csv") $(find $OUT/prof -name "*kernel_trace.csv") ;;

@@ -1,7 +1,9 @@
 // Measurement tool (not product code): the closed loop's index maintenance alone -- 64k x (16 known + 16 new) pairs per step into a
-// 16 Mi-slot index, epoch tick + eviction every second step (bench.py --closed-loop's cadence) -- with the library's own kernels, and the
-// eviction alternately by the library's index_evict_kernel and by a bare scan (claimcost.hip's E0) over the SAME index state: what of the
-// library kernel's time is the data (2 Mi victims among 16 Mi slots) and what is the kernel.
+// 16 Mi-slot index, epoch tick + eviction every second step (bench.py --closed-loop's cadence) -- with the library's own kernels:
+// update (budget + insert + list sort) and eviction times per step, standalone.  (Round 4, first run: the eviction alternately by the
+// library kernel and by a bare scan over the same index state took the same 137-145 us -- the time is the data, 2 Mi victims among
+// 16 Mi slots beyond the Infinity Cache, not the kernel: profiles/r04_micro_evictloop_round3_protocol.txt.)
+//   evictloop [steps] [learn]     learn = 1: the update is told which pairs the pick kernel has vouched for (blocks 0..15, picked pod listed)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -14,42 +16,20 @@
 static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int U>
-__global__ __launch_bounds__(256) void evict_bare(unsigned long long* keys, uint32_t* lists, const uint32_t* stamps, uint32_t slots, uint32_t min_epoch, unsigned long long* ixc) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  uint32_t gone = 0;
-  for (uint32_t base = wave * 64u * U; base < slots; base += nwaves * 64u * U) {
-    unsigned long long k[U]; uint32_t st[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { k[u] = keys[base + u * 64u + lane]; st[u] = stamps[base + u * 64u + lane]; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t row = base + u * 64u + lane;
-      const bool victim = (row & 7u) != 0u && k[u] != 0ull && k[u] != ~0ull && st[u] < min_epoch;
-      gone += (uint32_t)__builtin_popcountll(__ballot(victim));
-      if (victim) {
-        u32x4* Lp = (u32x4*)(lists + (size_t)row * 16u);
-        const u32x4 e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
-        keys[row] = ~0ull;
-      }
-    }
-  }
-  if (lane == 0 && gone) atomicAdd(&ixc[(wave & 63u) * 8u], (unsigned long long)(0ull - (unsigned long long)gone));
-}
-
 int main(int argc, char** argv) {
   using LW = uint64_t;
   const uint32_t slots = 16u << 20, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
   const int steps = argc > 1 ? atoi(argv[1]) : 16;
+  const bool use_learn = argc > 2 && atoi(argv[2]) != 0;
+  uint32_t* d_learn; CK(hipMalloc((void**)&d_learn, 65536 * 4));
+  { std::vector<uint32_t> lw(65536, 0x80000000u | 16u); CK(hipMemcpy(d_learn, lw.data(), 65536 * 4, hipMemcpyHostToDevice)); }
   uint32_t lg = 0; while ((1u << lg) < slots / eppk::kBucket) ++lg;
   const uint32_t shift = 32u - lg, limit = slots / 2u;
   const size_t rows_bytes = (((size_t)slots + 3u) * 64u * sizeof(LW) + 255u) & ~(size_t)255u, index_bytes = rows_bytes + ((size_t)slots + 2u) * 8u;
   void* bitmaps; uint32_t *stamps, *lists, *status; unsigned long long* ixc;
   CK(hipMalloc(&bitmaps, index_bytes)); CK(hipMemset(bitmaps, 0, index_bytes));
   uint64_t* keys = (uint64_t*)((uint8_t*)bitmaps + rows_bytes);
-  CK(hipMalloc((void**)&stamps, ((size_t)slots + 2u) * 4u)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u));
+  CK(hipMalloc((void**)&stamps, 2u * 4u)); CK(hipMemset(stamps, 0, 2u * 4u));          // (the reserved rows' exact stamps; every other stamp is a header tag)
   const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
   CK(hipMalloc((void**)&lists, nd * 4u));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
@@ -79,7 +59,8 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, 0, ixc, limit, slots, (unsigned long long)total, d_ixl);
     hipLaunchKernelGGL((eppk::index_insert_picks_kernel<LW>), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
-                       epoch, ixc, d_rows[b], stride, B, d_picks[b], R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl);
+                       epoch, ixc, d_rows[b], stride, B, d_picks[b], R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl,
+                       (const uint32_t*)(use_learn && g >= 4 ? d_learn : nullptr));       // (the hot prefixes' pods are listed after a few steps)
     hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -87,15 +68,13 @@ int main(int argc, char** argv) {
     if (g & 1) {
       ++epoch;
       if (epoch > 2) {
-        const bool bare = ((g >> 1) & 1) != 0;
         CK(hipEventRecord(e2));
-        if (bare) hipLaunchKernelGGL(evict_bare<4>, dim3(2048), dim3(256), 0, 0, (unsigned long long*)keys, lists, (const uint32_t*)stamps, slots, epoch - 1u, ixc);
-        else hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch - 1u, ixc);
+        hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch, epoch - 1u, ixc);
         CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
         CK(hipEventElapsedTime(&ms, e2, e3));
         unsigned long long h[64 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
         long long live = 0; for (int s2 = 0; s2 < 64; ++s2) live += (long long)h[s2 * 8 + eppk::kIxLive];
-        printf("   evict < %u by %-7s %7.1f us   live after %lld", epoch - 1u, bare ? "bare" : "library", ms * 1e3, live);
+        printf("   evict < %u %7.1f us   live after %lld", epoch - 1u, ms * 1e3, live);
       }
     }
     printf("\n");
