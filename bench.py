@@ -183,6 +183,7 @@ class Runner:
         assert all(h != 0 for h in self.streams)
         self.comm_handle = self.comm.cuda_stream
         self.closed_loop = closed_loop
+        self.learn_api = hasattr(self.pk, "pick_learn_device") and not getattr(args, "cl_two_calls", False)
         self.profile_every = max(1, int(getattr(args, "profile_every", 1)))
         # N > 1: completion latency of a gather bucket -- a timing event on the compute stream right before the first launch that scores
         # a bucket's batches, one on `comm` behind the collective that delivers their picks to every rank (timed region only)
@@ -339,9 +340,12 @@ class Runner:
             if self.lat_on and self.use_dist and self.lat_start is None:      # first batch of a bucket
                 self.lat_start = self._timing_event()
                 self.lat_start.record(self.computes[slot % len(self.computes)])
-            self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
-            if self.closed_loop:                              # post-route index update on the same stream: the next pick sees it
-                self.pk.index_insert_picks_device(self.p_batches[b] + self.lo * self.stride, self.p_picks[slot], self.n_mine, st)
+            if self.closed_loop and self.learn_api:           # pick + post-route index update in one call: the next pick sees the update
+                self.pk.pick_learn_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
+            else:
+                self.pk.pick_device(self.p_batches[b] + self.lo * self.stride, self.n_mine, None, self.p_picks[slot], self.p_scores[slot], st)
+                if self.closed_loop:                          # (a picker without the fused entry point: the two calls, same stream)
+                    self.pk.index_insert_picks_device(self.p_batches[b] + self.lo * self.stride, self.p_picks[slot], self.n_mine, st)
         due = ring.after_batch()
         if self.grouped and due is not None:
             self._launch_group(due, b)
@@ -521,6 +525,7 @@ def main() -> None:
     ap.add_argument("--keep-epochs", type=int, default=2, help="closed loop: hashes not re-inserted during this many epochs are evicted")
     ap.add_argument("--cl-slots", type=int, default=1 << 24, help="closed loop: index slots (live keys ~ age_every * keep_epochs * R * B/2)")
     ap.add_argument("--cl-verify", type=int, default=3, help="closed loop: generations checked against the oracle at full size before timing")
+    ap.add_argument("--cl-two-calls", action="store_true", help="closed loop: eppk_pick_batch_device + eppk_index_insert_picks_device instead of eppk_pick_learn_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the closed-loop / pipelined-LEARN sub-run of the default line")
     ap.add_argument("--closed-loop-leg", action="store_true", help="run that sub-run for a non-headline workload too")
@@ -1101,13 +1106,18 @@ def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
         e0.record(st_t)
         run.pk.pick_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
         e1.record(st_t)
-        run.pk.index_insert_picks_device(run.p_batches[b] + run.lo * run.stride, run.p_picks[slot], run.n_mine, st)
+        if run.learn_api:      # the step's own call: pick + update (the pick alone, just timed, changed nothing in the index)
+            run.pk.pick_learn_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
+        else:
+            run.pk.index_insert_picks_device(run.p_batches[b] + run.lo * run.stride, run.p_picks[slot], run.n_mine, st)
         e2.record(st_t)
         run.ring.after_batch()
         run.step_no += 1
         torch.cuda.synchronize()
         size1 = run.pk.index_size()
-        t_pick.append(e0.elapsed_time(e1)); t_ins.append(e1.elapsed_time(e2)); new_keys.append(size1 - size0)
+        t_pick.append(e0.elapsed_time(e1))
+        t_ins.append(e1.elapsed_time(e2) - (e0.elapsed_time(e1) if run.learn_api else 0.0))      # (pick + update) - pick
+        new_keys.append(size1 - size0)
         if (i + 1) % args.age_every == 0:
             state["epoch"] = run.pk.index_advance_epoch()
             if state["epoch"] > args.keep_epochs:

@@ -21,7 +21,7 @@ SYMBOLS = [
     "eppk_index_clear", "eppk_index_insert", "eppk_index_insert_picks_device", "eppk_index_remove_pod",
     "eppk_index_size", "eppk_index_dropped", "eppk_index_selfcheck", "eppk_stream_wait_pick", "eppk_index_advance_epoch", "eppk_index_evict_older",
     "eppk_index_evict_older_device", "eppk_index_trim_pods",
-    "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_topk", "eppk_pick_topk_device",
+    "eppk_pick_batch", "eppk_pick_batch_device", "eppk_pick_learn_device", "eppk_pick_topk", "eppk_pick_topk_device",
     "eppk_hash_prompt", "eppk_hash_prompts_device", "eppk_xxh64", "eppk_subset_mask", "eppk_round_robin",
     "eppk_addr_fingerprint", "eppk_subset_entries", "eppk_snapshot_set_addresses", "eppk_subset_masks_device", "eppk_subset_masks",
     "eppk_pick_batch_subset", "eppk_pick_batch_candidates_device",
@@ -100,6 +100,7 @@ def load_library() -> C.CDLL:
     lib.eppk_index_trim_pods.argtypes = [vp, u32, C.POINTER(u64)]
     lib.eppk_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp]
     lib.eppk_pick_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    lib.eppk_pick_learn_device.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     lib.eppk_pick_topk.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     lib.eppk_pick_topk_device.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp]
     lib.eppk_hash_prompt.argtypes = [vp, C.c_size_t, vp, C.c_size_t, u32, vp, u32]

@@ -133,6 +133,7 @@ struct eppk_ctx {
   StageSet stage[2];
   hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update; every later pick, index update and
                                                               // publish of this context -- on whatever stream -- is ordered behind it (learn_fence)
+  uint32_t* d_learn = nullptr; size_t learn_cap = 0;          // learn words of the pick in front of a LEARN update (pick_quad_kernel<..., LEARN>)
   bool quiet_rows = false;        // a host-buffer launch is being enqueued: its kernels raise "row out of range" on a word of their own
                                   // (the call reports the row itself), not on the sticky flag of the *_device entry points
   uint32_t host_flags = 0;        // sticky launch-status flags raised by the host side (EPPK_LAUNCH_LEARN_FAILED)
@@ -321,8 +322,11 @@ int learn_fence(eppk_ctx* c, hipStream_t st) {
   return EPPK_OK;
 }
 
+// d_learn (nullable): where pick_quad_kernel<..., LEARN> leaves its learn words for the index update that follows (learn_picks);
+// *wrote_learn says whether this launch took that route and wrote them (else the update gets no words and takes the whole path).
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
-                double* d_score, hipStream_t st, uint32_t topk = 1) {
+                double* d_score, hipStream_t st, uint32_t topk = 1, uint32_t* d_learn = nullptr, bool* wrote_learn = nullptr) {
+  if (wrote_learn) *wrote_learn = false;
   const bool masked = d_mask != nullptr;
   // masked batches use the fast kernel's MASKED instantiation, indexes of 4 GiB and more its BIG one
   const bool fast = c->canonical;   // (ordered fallbacks: extra selection rounds of the same kernel; generic TOPK kernel otherwise)
@@ -387,7 +391,9 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     const bool tkq = topk > 1;
     const uint32_t qwpb = c->quad_threads / 64u;
     tail = c->quad_tail_on;
-    if (tail)
+    if (tail && d_learn && !tkq)
+      quad_fn = masked ? eppk::pick_quad_tail_learn_masked(c->lw_bytes, c->has_l, c->p_first) : eppk::pick_quad_tail_learn(c->lw_bytes, c->has_l, c->p_first);
+    else if (tail)
       quad_fn = c->lw_bytes == 2 ? eppk::pick_quad_tail_u16(c->has_l, c->p_first, masked, tkq) : c->lw_bytes == 4 ? eppk::pick_quad_tail_u32(c->has_l, c->p_first, masked, tkq)
                                                                                                                : eppk::pick_quad_tail_u64(c->has_l, c->p_first, masked, tkq);
     else
@@ -462,10 +468,12 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       uint32_t* d_list = dset->d + 32 + quad_segs;
       uint32_t* d_done = dset->d + 2;       // TAIL: workgroups that have reported in (back to zero when the launch ends)
       uint32_t* h_rep = (uint32_t*)&c->h_reports[rep_slot];
+      uint32_t* learn_arg = (tail && topk == 1) ? d_learn : nullptr;
       void* qargs[] = {&sn, &ix, &tl, &reqs8, &stride, &n_reqs, &pwn, &d_mask, &d_pick, &d_score, &stats, &d_cnt, &d_list, &defer_cap, &d_total, &d_total_next,
-                       &topk, &d_done, &h_rep, &chf};
+                       &topk, &d_done, &h_rep, &chf, &learn_arg};
       if (tail) {                           // one launch: every workgroup is its own work-list pass
         HIPCHK(c, hipExtLaunchKernel(quad_fn, dim3(quad_grid), dim3(c->quad_threads), qargs, quad_lds, st, e0, e1, 0));
+        if (wrote_learn) *wrote_learn = learn_arg != nullptr;
         ++c->quad_tail_launches;
         c->last_done = e1;
         c->last_stream = st;
@@ -535,7 +543,8 @@ int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st);
 //   k  > 1, !random   ordered fallbacks                (n * k entries; the request's pick is entry 0 of its list)
 //   random            picker "random-top-k" (§3b)      (n entries), r0 = batch index of the first request (the rule hashes it)
 int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick, double* d_score, hipStream_t st,
-             uint32_t k, bool random, uint64_t seed, uint32_t r0) {
+             uint32_t k, bool random, uint64_t seed, uint32_t r0, uint32_t* d_learn = nullptr, bool* wrote_learn = nullptr) {
+  bool all_wrote = d_learn != nullptr;       // (learn words: valid only if EVERY launch of the batch wrote its part)
   { const int rcf = learn_fence(c, st); if (rcf) return rcf; }     // (the index an earlier EPPK_PICK_LEARN batch leaves behind)
   const uint32_t E = c->assumed_epochs;
   const uint32_t per = E ? (n_reqs + E - 1u) / E : n_reqs;
@@ -563,8 +572,10 @@ int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t
                          cnt, k, seed, r0 + lo, pick, score);
       HIPCHK(c, hipGetLastError());
     } else {
-      rc = launch_pick(c, reqs, cnt, mask, pick, score, st, k);
+      bool wrote = false;
+      rc = launch_pick(c, reqs, cnt, mask, pick, score, st, k, d_learn ? d_learn + lo : nullptr, &wrote);
       if (rc) return rc;
+      all_wrote = all_wrote && wrote;
     }
     if (E) {    // the assumed load of what this epoch routed, then everything derived from the queue gauge again
       hipLaunchKernelGGL(assumed_bump_kernel, dim3((cnt + 255u) / 256u), dim3(256), 0, st, c->d_rows, (const int32_t*)pick, cnt, ok, c->n_pods);
@@ -573,6 +584,7 @@ int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t
       if (rc) return rc;
     }
   }
+  if (wrote_learn) *wrote_learn = all_wrote && !random;
   return EPPK_OK;
 }
 
@@ -910,7 +922,7 @@ void eppk_destroy(eppk_ctx* c) {
   if (c->check.h_bad) (void)hipHostFree(c->check.h_bad);
   if (c->h_reports) (void)hipHostFree((void*)c->h_reports);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
-  (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
+  (void)hipFree(c->d_rows); (void)hipFree(c->d_rm); (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score); (void)hipFree(c->d_learn);
   if (c->h_reqs) (void)hipHostFree(c->h_reqs);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_pick) (void)hipHostFree(c->h_pick);
@@ -1257,6 +1269,46 @@ int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
   return EPPK_OK;
 }
 
+namespace {
+// room for the learn words of n requests (grown behind a device synchronise: rare)
+int learn_ensure(eppk_ctx* c, size_t n) {
+  if (n <= c->learn_cap) return EPPK_OK;
+  HIPCHK(c, hipDeviceSynchronize());
+  if (c->d_learn) HIPCHK(c, hipFree(c->d_learn));
+  c->d_learn = nullptr; c->learn_cap = 0;
+  const size_t cap = n < c->cfg.max_batch ? c->cfg.max_batch : n;
+  HIPCHK(c, hipMalloc((void**)&c->d_learn, cap * 4u));
+  c->learn_cap = cap;
+  return EPPK_OK;
+}
+}  // namespace
+
+int eppk_pick_learn_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, int32_t* d_out_pick,
+                           double* d_out_score, void* stream) {
+  if (!c || ((!d_reqs || !d_out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_learn_device: null argument");
+  if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_learn_device: no snapshot published");
+  if (!c->slots) return fail(c, EPPK_ERR_ARG, "eppk_pick_learn_device: no index");
+  if (n_reqs == 0) return EPPK_OK;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  int rc = learn_ensure(c, n_reqs);
+  if (rc) return rc;
+  // (the kernels address request rows with 32-bit byte offsets: batches of 2 GiB and more in pieces, each picked and learned in turn)
+  const uint32_t per = (uint32_t)((1ull << 31) / c->stride);
+  const size_t J = (c->n_pods + 63u) / 64u;
+  for (uint32_t r0 = 0; r0 < n_reqs; r0 += per) {
+    const uint32_t n = (n_reqs - r0 < per) ? n_reqs - r0 : per;
+    const uint8_t* reqs = (const uint8_t*)d_reqs + (size_t)r0 * c->stride;
+    bool words = false;
+    rc = run_pick(c, reqs, n, d_cand_mask ? d_cand_mask + (size_t)r0 * J : nullptr, d_out_pick + r0, d_out_score ? d_out_score + r0 : nullptr, st, 1u, false, 0ull, 0u,
+                  c->d_learn, &words);
+    if (rc) return rc;
+    rc = learn_picks(c, reqs, d_out_pick + r0, n, st, words ? c->d_learn : nullptr);
+    if (rc) return rc;
+  }
+  return EPPK_OK;
+}
+
 int eppk_stream_wait_pick(eppk_ctx* c, void* waiting_stream) {
   if (!c || !waiting_stream) return fail(c, EPPK_ERR_ARG, "eppk_stream_wait_pick: null argument");
   HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1566,6 +1618,8 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
   const bool zero_copy = n_reqs <= c->zero_copy_max;
   int rc;
+  bool words = false;                        // the pick kernel left learn words for the update (pick_quad_kernel<..., LEARN>): known pairs are
+  if (learn) { rc = learn_ensure(c, n_reqs); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
   if (zero_copy) {
     // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
     // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
@@ -1591,7 +1645,8 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
       HIPCHK(c, hipEventRecord(s.copied, s.st_copy));
       s.copy_pending = true;
     }
-    rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
+    rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u,
+                  learn ? c->d_learn : nullptr, &words);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(s.picked, s.st));
     if (learn) HIPCHK(c, hipStreamWaitEvent(s.st, s.copied, 0));
@@ -1606,14 +1661,15 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
     // the pick sees the index every earlier LEARN left behind (run_pick: learn_fence; the upload above did not have to wait for it).
     // Picks and scores: written by the kernel straight into the set's pinned result buffers -- no download copies; a LEARN update reads
     // the picks from there, and only this set's next pick, ordered behind that update, writes them again.
-    rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u);
+    rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u,
+                  learn ? c->d_learn : nullptr, &words);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(s.picked, s.st));
   }
   abort_guard.armed = false;                 // the picks are on their way: from here on the call succeeds and end() delivers them
   if (learn) {
     // the post-route update, chained on the device: rows and picks are there already (eppk_pick_learn_device's second half)
-    rc = learn_picks(c, s.d_reqs, s.h_pick_dev, n_reqs, s.st);
+    rc = learn_picks(c, s.d_reqs, s.h_pick_dev, n_reqs, s.st, words ? c->d_learn : nullptr);
     if (rc == EPPK_OK && hipEventRecord(c->learned, s.st) == hipSuccess) c->learn_pending = true;
     else c->host_flags |= EPPK_LAUNCH_LEARN_FAILED;        // (eppk_last_error holds the reason; the picks stand)
   }

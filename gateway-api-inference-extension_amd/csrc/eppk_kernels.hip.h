@@ -1665,10 +1665,11 @@ struct QuadKernArgs {
   unsigned long long* stats; uint32_t* defer_cnt; uint32_t* defer_list; uint32_t defer_cap; uint32_t* defer_total; uint32_t* defer_total_next; uint32_t topk;
   uint32_t* done_ctr; uint32_t* report;
   KChain chain;    // (MASKED tails: the exact evaluation of a request whose candidates miss the snapshot-wide QUEUE extremes needs the chain)
+  uint32_t* learn_out;
 };
 // (a callable function is not handed the kernarg segment pointer itself -- llvm.amdgcn.kernarg.segment.ptr is null there -- only the
 // pointer to the IMPLICIT arguments, which lie right behind the explicit ones, 8-byte aligned: walk back from there)
-static_assert(((sizeof(QuadKernArgs) + 7u) & ~(size_t)7u) == 512u, "QuadKernArgs must mirror pick_quad_kernel's parameter list (its explicit kernarg bytes: .kernarg_segment_size - 256)");
+static_assert(((sizeof(QuadKernArgs) + 7u) & ~(size_t)7u) == 520u, "QuadKernArgs must mirror pick_quad_kernel's parameter list (its explicit kernarg bytes: .kernarg_segment_size - 256)");
 __device__ __forceinline__ const QuadKernArgs* quad_kernargs() {
   return (const QuadKernArgs*)((const char*)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(QuadKernArgs) + 7u) & ~(size_t)7u));
 }
@@ -1701,14 +1702,23 @@ __device__ __attribute__((noinline)) void quad_tail_report() {
   }
 }
 
-template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false>
+// LEARN (single picks only): the kernel also leaves one word per request for the post-route index update that follows the pick
+// (index_insert_picks_kernel: `learn`) -- bits 0..7 = m, the leading blocks of the request it found in the index; bits 8..23 = pick + 1
+// (so that the update does not have to fetch the pick from wherever the caller wanted it: pinned host memory on the staged paths);
+// bit 31 = the picked pod is on the (common) pod list of all m, i.e. those m (hash, pod) pairs are in the index already and the update
+// only has to refresh their stamps.  0 = nothing to tell (a request it deferred, or one without a pick): the update then reads picks[r]
+// and takes the whole path.  Costs the pick one 4-byte store per request; saves the update two of the three line look-ups of every
+// known pair (1 Mi per closed-loop step of a 64k x 32-block batch).
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false, bool LEARN = false>
 __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
                                                                  uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                                  int32_t* __restrict__ out_pick, double* __restrict__ out_score,
                                                                  unsigned long long* __restrict__ stats,
                                                                  uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
                                                                  uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk,
-                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report, KChain tail_chain) {
+                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report, KChain tail_chain,
+                                                                 uint32_t* __restrict__ learn_out) {
+  static_assert(!(LEARN && TOPK), "learn words go with single picks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -2137,6 +2147,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     }
     double wmax = best;
     uint32_t widx = kNoPod;
+    bool from_table = false;                                          // (LEARN: the pick is the table's candidate, not a listed pod)
     if constexpr (!TOPK) {
     // ---- argmax over the row: (total desc, pod asc)
     wmax = best;
@@ -2157,7 +2168,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     double cand_t = __hiloint2double(__shfl(__double2hiint(top_t), (int)src), __shfl(__double2loint(top_t), (int)src));
     uint32_t cand_p = (uint32_t)__shfl((int)top_p, (int)src);
     if (e == 16u) { cand_t = -__builtin_inf(); cand_p = kNoPod; }
-    if (cand_t > wmax || (cand_t == wmax && cand_p < widx)) { wmax = cand_t; widx = cand_p; }
+    if (cand_t > wmax || (cand_t == wmax && cand_p < widx)) { wmax = cand_t; widx = cand_p; from_table = true; }
     }
     // ---- store, or defer
     const bool gbad = row16(badm) != 0u;
@@ -2169,6 +2180,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
           const bool none = widx == kNoPod || no_cand;
           out_pick[r] = none ? -1 : (int32_t)widx;
           if (out_score) out_score[r] = none ? 0.0 : wmax;
+          if constexpr (LEARN) learn_out[r] = none ? 0u : (((from_table || m == 0u) ? 0u : 0x80000000u) | ((widx + 1u) << 8) | m);
         }
         if (!no_cand) {                                                 // (like pick_fast_kernel: a request without candidates is not counted)
           acc_hits += m;
@@ -2176,6 +2188,7 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
         }
       } else {
         __hip_atomic_store(&my_list[n_def + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull))], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (through to memory: TAIL)
+        if constexpr (LEARN) learn_out[r] = 0u;
       }
     }
     n_def += (uint32_t)__builtin_popcountll(dm);
@@ -3449,10 +3462,10 @@ __global__ void index_insert_kernel(uint64_t* keys, void* bitmaps, uint32_t* lis
 
 // thread (r, i): append picks[r] to hash i of request r.
 // `learn` (nullable): one word per request from pick_quad_kernel<..., LEARN> -- bits 0..7 = m, the number of leading blocks of the
-// request whose keys the pick kernel found in the index (the walk of SEMANTICS.md 3 PREFIX), bit 31 = the picked pod is on the pod
-// list of every one of them.  Such a pair is in the index already: thread (r, i < m) only brings the key's stamp up to date -- one
-// bucket look-up instead of bucket + list (the 1 Mi known pairs of a 64k x 32-block closed-loop step were 38 us of its 150).
-// 0 = no information (a request that kernel deferred, or another pick route): every block takes the whole path.
+// request whose keys the pick kernel found in the index (the walk of SEMANTICS.md 3 PREFIX), bits 8..23 = pick + 1, bit 31 = the picked
+// pod is on the pod list of every one of the m.  Such a pair is in the index already: thread (r, i < m) only brings the key's stamp up
+// to date -- one bucket look-up instead of bucket + list (the 1 Mi known pairs of a 64k x 32-block closed-loop step were 38 us of its
+// 150).  0 = no information (a request that kernel deferred, or another pick route): picks[r], and every block takes the whole path.
 template <typename LW>
 __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t* rstamps, uint32_t slots, uint32_t shift, uint32_t limit,
                                           uint32_t epoch, unsigned long long* ixc, const uint8_t* reqs, uint32_t stride,
@@ -3464,8 +3477,10 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
   bool active = r < n_reqs, known_only = false;
   int32_t pick = -1;
   uint64_t h = 0;
+  uint32_t lw = 0u;
   if (active) {
-    pick = picks[r];
+    if (learn) lw = learn[r];
+    pick = (lw & 0x00FFFF00u) ? (int32_t)((lw >> 8) & 0xFFFFu) - 1 : picks[r];
     const uint8_t* row = reqs + (size_t)r * stride;
     const uint32_t nb = ((const uint32_t*)row)[1];
     // a pick beyond the lane words (>= max_pods) would shift into other pods' bits: ignored and flagged, like a row whose block
@@ -3474,10 +3489,7 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
     if (bad && i == 0u) atomicOr(status, (uint32_t)pick >= max_pods && pick >= 0 ? kStatusBadPick : kStatusBadRow);
     active = !bad && pick >= 0 && i < nb;
     if (active) h = ((const uint64_t*)(row + 8))[i];
-    if (active && learn) {
-      const uint32_t lw = learn[r];
-      known_only = (lw >> 31) != 0u && i < (lw & 0xFFu);
-    }
+    known_only = active && (lw >> 31) != 0u && i < (lw & 0xFFu);
   }
   index_insert_one<LW>(keys, bitmaps, lists, rstamps, slots, shift, limit, epoch, ixc, il, s_tmp, h, (uint32_t)pick, active, act, sw, status, known_only);
 }

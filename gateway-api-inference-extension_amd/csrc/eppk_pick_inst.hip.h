@@ -31,6 +31,8 @@ const void* pick_quad_tail_u64(bool has_l, bool p_first, bool masked, bool topk)
 const void* pick_quad_tail_masked(int lw_bytes, bool has_l, bool p_first);
 const void* pick_quad_tail_topk(int lw_bytes, bool has_l, bool p_first);
 const void* pick_quad_tail_topk_masked(int lw_bytes, bool has_l, bool p_first);
+const void* pick_quad_tail_learn(int lw_bytes, bool has_l, bool p_first);          // LEARN instantiations (single picks; eppk_pick_quad_tail_learn[_masked].hip)
+const void* pick_quad_tail_learn_masked(int lw_bytes, bool has_l, bool p_first);
 const void* pick_fast_wl_topk_u16(bool has_l, bool p_first, bool big);          // work-list instantiations with ordered fallbacks (eppk_pick_wl_topk.hip)
 const void* pick_fast_wl_topk_u32(bool has_l, bool p_first, bool big);
 const void* pick_fast_wl_topk_u64(bool has_l, bool p_first, bool big);
@@ -80,8 +82,13 @@ namespace eppk {
 template <typename LW>
 static const void* quad_tail_unit_ptr(bool has_l, bool p_first) {
   constexpr bool M = EPPK_QUAD_TAIL_MASKED, T = EPPK_QUAD_TAIL_TOPK;
-  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true, M, T, true> : (const void*)pick_quad_kernel<LW, true, false, M, T, true>;
-  return (const void*)pick_quad_kernel<LW, false, false, M, T, true>;
+#ifdef EPPK_QUAD_TAIL_LEARN
+  constexpr bool L = true;
+#else
+  constexpr bool L = false;
+#endif
+  if (has_l) return p_first ? (const void*)pick_quad_kernel<LW, true, true, M, T, true, L> : (const void*)pick_quad_kernel<LW, true, false, M, T, true, L>;
+  return (const void*)pick_quad_kernel<LW, false, false, M, T, true, L>;
 }
 const void* EPPK_QUAD_TAIL_UNIT(int lw_bytes, bool has_l, bool p_first) {
   return lw_bytes == 2 ? quad_tail_unit_ptr<uint16_t>(has_l, p_first) : lw_bytes == 4 ? quad_tail_unit_ptr<uint32_t>(has_l, p_first) : quad_tail_unit_ptr<uint64_t>(has_l, p_first);

@@ -431,6 +431,11 @@ class BatchedPicker:
         """Device-pointer entry point (asynchronous on `stream`, a hipStream_t as int; 0 = the context's stream)."""
         self._check(self._lib.eppk_pick_batch_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_batch_device")
 
+    def pick_learn_device(self, d_reqs: int, n_reqs: int, d_mask: Optional[int], d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
+        """The pick and its post-route index update in one call (include/eppk.h eppk_pick_learn_device): pick_device followed by
+        index_insert_picks_device on `stream`, the pick kernel telling the update which pairs it has already seen in the index."""
+        self._check(self._lib.eppk_pick_learn_device(self._ctx, d_reqs, n_reqs, d_mask, d_pick, d_score, stream or None), "pick_learn_device")
+
     def pick_candidates_device(self, d_reqs: int, n_reqs: int, d_mask: int, k: int, d_pick: int, d_score: Optional[int], stream: int = 0) -> None:
         """Candidate-major kernel for masked batches with few candidates (include/eppk.h eppk_pick_batch_candidates_device):
         k = 1 the pick, k > 1 ordered fallbacks ([n_reqs, k] entries)."""

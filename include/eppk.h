@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define EPPK_ABI_VERSION 2u   /* 2: device groups, launch status, random-top-k, assumed load, holes, per-pod capacity, async eviction (additions only) */
+#define EPPK_ABI_VERSION 3u   /* 2: device groups, launch status, random-top-k, assumed load, holes, per-pod capacity, async eviction; 3: eppk_pick_learn_device,
+                               * EPPK_LAUNCH_LEARN_FAILED, the 254-epoch stamp window (additions only) */
 
 /* Limits of this build (SEMANTICS.md §limits). */
 #define EPPK_MAX_PODS      4096u /* candidate endpoints per snapshot                         */
@@ -247,6 +248,15 @@ int eppk_pick_stage_end(eppk_ctx* ctx, uint32_t set, int32_t* out_pick, double* 
 int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
                            const uint64_t* d_cand_mask, int32_t* d_out_pick, double* d_out_score,
                            void* stream);
+/* Pick + learn in ONE call: eppk_pick_batch_device followed by eppk_index_insert_picks_device on `stream` -- Scheduler.Schedule() and the
+ * post-route step of the prefix scorer ("hash(chunk i): append s", docs/proposals/0602-prefix-cache-aware-routing-proposal/README.md:101-108)
+ * for a whole batch, same picks, same scores and the same index afterwards as the two calls.  What it adds: the pick kernel has just
+ * walked every request's prefix through the index, so it tells the update which (hash, pod) pairs it has already SEEN there -- the
+ * blocks of the shared prefix with the picked pod on their list: half of a 64k x 32-block batch's 2 Mi pairs -- and the update only
+ * refreshes their stamps.  (Batches that do not take the four-requests-per-wavefront kernel get the plain update.)  The closed loop a
+ * router runs: pick -> the index learns the pick -> next batch.  EPPK_PICK_LEARN of the staged host path does the same. */
+int eppk_pick_learn_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, int32_t* d_out_pick,
+                           double* d_out_score, void* stream);
 /* Trust contract of the *_device entry points.  The host-buffer entry points check every request row and fail the call with
  * EPPK_ERR_ARG naming the row (above).  The *_device entry points return before the rows are looked at, so the KERNELS check them: a row whose
  * n_blocks exceeds max_blocks or whose adapter lies outside [-1, EPPK_MAX_ADAPTERS) is not scored -- its pick (every entry of its

@@ -16,8 +16,11 @@ def _same(picks, scores, op, osc, what=""):
     assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), what
 
 
-@pytest.mark.parametrize("R,slots,async_evict", [(65536, 1 << 24, True), (8192, 1 << 21, False)])
-def test_eight_closed_loop_generations_at_full_size(pkg, orc, R, slots, async_evict):
+@pytest.mark.parametrize("R,slots,async_evict,fused", [(65536, 1 << 24, True, False), (65536, 1 << 24, True, True), (8192, 1 << 21, False, True),
+                                                       (8192, 1 << 21, False, False)])
+def test_eight_closed_loop_generations_at_full_size(pkg, orc, R, slots, async_evict, fused):
+    """fused: eppk_pick_learn_device (one call; the pick kernel tells the update which pairs it has already seen in the index) instead of
+    eppk_pick_batch_device + eppk_index_insert_picks_device -- same picks, same scores, same index."""
     import torch
     cores = os.cpu_count() or 1
     wl = pkg.workload.make_workload(5, R=R)
@@ -34,8 +37,11 @@ def test_eight_closed_loop_generations_at_full_size(pkg, orc, R, slots, async_ev
         st = torch.cuda.Stream()
         for gen in range(8):
             b = gen % len(batches)
-            pk.pick_device(d_batches[b].data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream)
-            pk.index_insert_picks_device(d_batches[b].data_ptr(), d_pick.data_ptr(), R, st.cuda_stream)
+            if fused:
+                pk.pick_learn_device(d_batches[b].data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream)
+            else:
+                pk.pick_device(d_batches[b].data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream)
+                pk.index_insert_picks_device(d_batches[b].data_ptr(), d_pick.data_ptr(), R, st.cuda_stream)
             st.synchronize()
             op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[b], wl.B, threads=cores)
             _same(d_pick.cpu().numpy(), d_score.cpu().numpy(), op, osc, f"generation {gen}")

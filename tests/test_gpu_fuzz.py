@@ -125,10 +125,17 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
                 pk.publish(pods); oix.scrub_inactive(pods)
             elif op == "insert_picks":
                 reqs = probe_batch()
-                picks, _ = pk.pick(reqs)
-                d_reqs = torch.from_numpy(reqs.view(np.int64)).cuda(); d_picks = torch.from_numpy(picks).cuda()
-                pk.index_insert_picks_device(d_reqs.data_ptr(), d_picks.data_ptr(), R)
-                torch.cuda.synchronize()
+                d_reqs = torch.from_numpy(reqs.view(np.int64)).cuda()
+                if rng.random() < 0.5:                      # pick + learn in one call: the pick kernel's learn words steer the update
+                    d_picks = torch.empty(R, dtype=torch.int32, device="cuda")
+                    pk.pick_learn_device(d_reqs.data_ptr(), R, None, d_picks.data_ptr(), None)
+                    torch.cuda.synchronize()
+                    picks = d_picks.cpu().numpy()
+                else:
+                    picks, _ = pk.pick(reqs)
+                    d_picks = torch.from_numpy(picks).cuda()
+                    pk.index_insert_picks_device(d_reqs.data_ptr(), d_picks.data_ptr(), R)
+                    torch.cuda.synchronize()
                 op_picks, _, _ = orc.pick_batch(chain, pods, oix, reqs, B)
                 assert np.array_equal(picks, op_picks)
                 oix.insert_picks(reqs, B, op_picks)
@@ -151,3 +158,43 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
             opk, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
             assert np.array_equal(picks, opk), f"seed {seed} step {step} after {op}"
             assert np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), f"seed {seed} step {step} after {op}"
+
+
+def test_stamp_window_wraps_like_the_oracle(pkg, orc):
+    """Stamps live on the device as 8-bit tags in the bucket headers (1 + (epoch - 1) % 255): ages are exact up to 254 epochs, and a hash
+    that would be 255 epochs old is evicted by the tick itself (SEMANTICS.md 6a "window"; the oracle does the same).  600 ticks across two
+    wrap-arounds of the tag, hashes stamped at all sorts of epochs (some re-stamped again and again so that they survive), evictions with
+    horizons on either side of the wrap: live hashes, evicted counts and picks must agree throughout."""
+    rng = np.random.default_rng(77)
+    P, B, R = 300, 8, 64
+    chain = [(KV, 1), (PF, 5)]
+    pods = pkg.workload.make_pods(9, P, 128)
+    universe = rng.integers(1, 2**63, (40, B), dtype=np.uint64)
+    survivors = universe[:4].reshape(-1)                                   # re-stamped every 100 epochs: never 255 old
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=4096) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        epoch = 1
+        for tick in range(600):
+            if tick % 7 == 0:                                               # a fresh chain now and then
+                c = universe[4 + (tick // 7) % 36]
+                ip = rng.integers(0, P, c.size).astype(np.uint32)
+                pk.index_insert(c, ip); oix.insert(c, ip)
+            if tick % 100 == 0:
+                ip = rng.integers(0, P, survivors.size).astype(np.uint32)
+                pk.index_insert(survivors, ip); oix.insert(survivors, ip)
+            epoch = pk.index_advance_epoch()
+            assert epoch == oix.advance_epoch()
+            if tick in (130, 250, 256, 300, 511, 599):                      # horizons before, at and behind the wrap of the tag
+                horizon = epoch - int(rng.integers(0, 200))
+                assert pk.index_evict_older(horizon) == oix.evict_older(horizon), tick
+            if tick % 25 == 0 or 250 <= tick <= 262 or 505 <= tick <= 515:
+                assert pk.index_size() == oix.size(), tick
+                assert pk.index_selfcheck() == 0, tick
+                hs = universe[rng.integers(0, universe.shape[0], R)]
+                reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+                picks, scores = pk.pick(reqs)
+                opk, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+                assert np.array_equal(picks, opk) and np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), tick
+        assert pk.index_size() == oix.size() and pk.index_trim_pods(3) == oix.trim_pods(P, 3)
+        assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0
