@@ -1096,7 +1096,9 @@ def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
     st_t = run.computes[0]
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_pick, t_ins, t_evict, new_keys, victims = [], [], [], [], []
-    run.pk.profile(False)
+    run.pk.profile(True if run.learn_api else False)      # (fused call: the pick kernel's own duration from the events on its dispatch packet)
+    if run.learn_api:
+        run.pk.profile_drain()
     for i in range(steps):
         slot = run.ring.next_slot()
         b = run.batch_of(run.step_no)
@@ -1104,19 +1106,25 @@ def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
         size0 = run.pk.index_size()                                   # (synchronises: the step below runs alone)
         e0, e1, e2, e3 = ev(), ev(), ev(), ev()
         e0.record(st_t)
-        run.pk.pick_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
-        e1.record(st_t)
-        if run.learn_api:      # the step's own call: pick + update (the pick alone, just timed, changed nothing in the index)
+        if run.learn_api:      # the step's own call: pick + update behind one another on the stream
             run.pk.pick_learn_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
+            e1.record(st_t)
         else:
+            run.pk.pick_device(run.p_batches[b] + run.lo * run.stride, run.n_mine, None, run.p_picks[slot], run.p_scores[slot], st)
+            e1.record(st_t)
             run.pk.index_insert_picks_device(run.p_batches[b] + run.lo * run.stride, run.p_picks[slot], run.n_mine, st)
         e2.record(st_t)
         run.ring.after_batch()
         run.step_no += 1
         torch.cuda.synchronize()
         size1 = run.pk.index_size()
-        t_pick.append(e0.elapsed_time(e1))
-        t_ins.append(e1.elapsed_time(e2) - (e0.elapsed_time(e1) if run.learn_api else 0.0))      # (pick + update) - pick
+        if run.learn_api:
+            k_ms = run.pk.profile_drain()
+            pick_ms_i = float(k_ms[-1]) if len(k_ms) else 0.0
+            t_pick.append(pick_ms_i)
+            t_ins.append(e0.elapsed_time(e2) - pick_ms_i)        # (pick + update, events around the call) - the pick kernel
+        else:
+            t_pick.append(e0.elapsed_time(e1)); t_ins.append(e1.elapsed_time(e2))
         new_keys.append(size1 - size0)
         if (i + 1) % args.age_every == 0:
             state["epoch"] = run.pk.index_advance_epoch()

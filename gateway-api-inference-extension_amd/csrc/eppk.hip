@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -30,6 +31,8 @@ namespace {
 
 std::mutex g_err_mu;
 std::string g_create_err;
+std::mutex g_lds_mu;
+std::map<std::pair<int, const void*>, size_t> g_lds_limit;   // (device, kernel) -> dynamic-LDS limit set so far (occupancy_of)
 
 // One device allocation per snapshot buffer; the arrays below are views into it (fast kernel: one buffer descriptor).
 struct SnapBuf {
@@ -155,7 +158,11 @@ struct eppk_ctx {
   hipStream_t last_stream = nullptr;  // the stream of that launch
   hipEvent_t wait_ev = nullptr;       // eppk_stream_wait_pick's own event (when the launch carried none)
 
-  const void* occ_fn = nullptr; size_t occ_lds = 0; int occ_per_cu = 1;  // cached launch geometry
+  // cached launch geometry: resident workgroups per CU of every (kernel, workgroup size, LDS bytes) this context has launched.  Setting
+  // the dynamic-LDS attribute and asking for the occupancy are host calls of ~10 us each: a dispatcher that alternates between
+  // masked and unmasked batches, or between learning and plain picks, would pay them at every switch with a one-entry cache.
+  struct Occ { const void* fn; uint32_t threads; size_t lds; int per_cu; };
+  std::vector<Occ> occ;
   // pick_quad_kernel (four requests per wavefront) + the work list of what it defers to pick_fast_kernel<WL>
   // (eppk_kernels.hip.h: KWork)
   bool quad_on = true;            // EPPK_QUAD=0 switches it off (every request through pick_fast_kernel)
@@ -198,8 +205,6 @@ struct eppk_ctx {
   bool quad_tail_on = true;         // EPPK_QUAD_TAIL=0: always the two-launch form (pick_quad_kernel + work-list pass)
   uint64_t quad_tail_launches = 0;  // launches that took the one-launch form (pick_quad_kernel<TAIL>)
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
-  const void* quad_occ_fn = nullptr; size_t quad_occ_lds = 0; int quad_per_cu = 1;
-  const void* wl_occ_fn = nullptr; size_t wl_occ_lds = 0; int wl_per_cu = 1;
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
   size_t max_lds = 65536;        // LDS a workgroup may use (160 KB on gfx950)
   int max_wg_per_cu = 0;         // EPPK_MAX_WG_PER_CU: cap on resident workgroups per CU (0 = what the occupancy query allows; tuning knob)
@@ -307,6 +312,29 @@ const void* pick_kernel_ptr(const eppk_ctx* c, bool fast, bool masked, bool topk
   }
 }
 
+// Resident workgroups per CU of `fn` at this workgroup size and dynamic-LDS size (cached per context: eppk_ctx::occ); the first
+// use of a combination also raises the kernel's dynamic-LDS limit.
+int occupancy_of(eppk_ctx* c, const void* fn, uint32_t threads, size_t lds, int* per_cu_out) {
+  for (const eppk_ctx::Occ& o : c->occ)
+    if (o.fn == fn && o.threads == threads && o.lds == lds) { *per_cu_out = o.per_cu; return EPPK_OK; }
+  {   // the kernel's dynamic-LDS limit is a property of the FUNCTION on this device, shared by every context of the process: raised
+      // when a launch needs more, never lowered (another context's larger launch geometry of the same kernel stays valid)
+    std::lock_guard<std::mutex> g(g_lds_mu);
+    size_t& limit = g_lds_limit[{c->cfg.device, fn}];
+    if (lds > limit) {
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      limit = lds;
+    }
+  }
+  int per_cu = 0;
+  HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
+  if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  c->occ.push_back({fn, threads, lds, per_cu});
+  *per_cu_out = per_cu;
+  return EPPK_OK;
+}
+
 // topk == 1: the pick; topk > 1: ordered fallbacks (d_pick / d_score hold n_reqs * topk entries): extra selection rounds of the
 // fast kernel for fused chains, the TOPK generic kernel otherwise
 template <typename F> int by_lane_word(const eppk_ctx* c, F&& f);
@@ -351,15 +379,10 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     lds = (size_t)sn.J * 64u * 12u + (size_t)wpb * c->pwn * 8u + (size_t)wpb * 64u * (size_t)c->lw_bytes;   // ... | 64 lane words per wavefront (set_from_list)
   }
   // occupancy-sized persistent grid (cached per kernel/LDS size: these are host calls on the launch path)
-  if (fn != c->occ_fn || lds != c->occ_lds) {
-    if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
-    if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
-    c->occ_fn = fn; c->occ_lds = lds; c->occ_per_cu = per_cu < 1 ? 1 : per_cu;
-  }
+  int occ_per_cu = 1;
+  { const int rco = occupancy_of(c, fn, threads, lds, &occ_per_cu); if (rco) return rco; }
   uint32_t grid = (n_reqs + wpb - 1) / wpb;
-  const uint32_t cap = (uint32_t)c->num_cu * (uint32_t)c->occ_per_cu;
+  const uint32_t cap = (uint32_t)c->num_cu * (uint32_t)occ_per_cu;
   if (grid > cap) grid = cap;
   if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
   if (grid < 1) grid = 1;
@@ -406,16 +429,11 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       const size_t fast_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 64u * (size_t)c->lw_bytes + (size_t)qwpb * sn.J * 64u;
       if (fast_lds > quad_lds) quad_lds = fast_lds;
     }
-    if (quad_fn != c->quad_occ_fn || quad_lds != c->quad_occ_lds) {
-      HIPCHK(c, hipFuncSetAttribute(quad_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds));
-      int per_cu = 0;
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, quad_fn, (int)c->quad_threads, quad_lds));
-      if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
-      c->quad_occ_fn = quad_fn; c->quad_occ_lds = quad_lds; c->quad_per_cu = per_cu < 1 ? 1 : per_cu;
-    }
+    int quad_per_cu = 1;
+    { const int rco = occupancy_of(c, quad_fn, c->quad_threads, quad_lds, &quad_per_cu); if (rco) return rco; }
     const uint32_t nblk = (n_reqs + 3u) / 4u;
     quad_grid = (nblk + qwpb - 1) / qwpb;
-    const uint32_t qcap = (uint32_t)c->num_cu * (uint32_t)c->quad_per_cu;
+    const uint32_t qcap = (uint32_t)c->num_cu * (uint32_t)quad_per_cu;
     if (quad_grid > qcap) quad_grid = qcap;
     if (quad_grid > kStatSlots / qwpb) quad_grid = kStatSlots / qwpb;
     if (quad_grid < 1) quad_grid = 1;
@@ -497,14 +515,9 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
       else
         fn = c->lw_bytes == 2 ? eppk::pick_fast_wl_u16(c->has_l, c->p_first, big, masked) : c->lw_bytes == 4 ? eppk::pick_fast_wl_u32(c->has_l, c->p_first, big, masked)
                                                                                                              : eppk::pick_fast_wl_u64(c->has_l, c->p_first, big, masked);
-      if (fn != c->wl_occ_fn || lds != c->wl_occ_lds) {
-        if (lds) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int per_cu = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, lds));
-        if (c->max_wg_per_cu && per_cu > c->max_wg_per_cu) per_cu = c->max_wg_per_cu;
-        c->wl_occ_fn = fn; c->wl_occ_lds = lds; c->wl_per_cu = per_cu < 1 ? 1 : per_cu;
-      }
-      grid = (uint32_t)c->num_cu * (uint32_t)c->wl_per_cu;
+      int wl_per_cu = 1;
+      { const int rco = occupancy_of(c, fn, threads, lds, &wl_per_cu); if (rco) return rco; }
+      grid = (uint32_t)c->num_cu * (uint32_t)wl_per_cu;
       if (grid > kStatSlots / wpb) grid = kStatSlots / wpb;
       if (grid * wpb > quad_segs) grid = (quad_segs + wpb - 1) / wpb;      // one wavefront per segment at most
       // The pass is grid-stride over the segments, so ANY grid is correct; its size only has to fit what the quad kernel deferred.  A

@@ -3413,7 +3413,11 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
       while (tag == 0u && spins < (1u << 20)) { tag = hdr_tag(hdr_load_coherent(keys, slot), slot & (kBucket - 1u)); ++spins; }
       ready = tag != 0u;
 #ifndef EPPK_DBG_NO_STAMP
-      if (ready && tag != cur_tag) tag_store(keys, slot, cur_tag);
+      // An older tag: look again, COHERENTLY, before storing.  The first look was an ordinary cached load, and the copy of a hot bucket in
+      // this XCD's L2 keeps showing the old tag to every later thread of the launch: in the first update after an epoch tick all
+      // 256 pairs of every hot key stored the byte (1 Mi stores into 4096 lines: that update took 190 us instead of 106,
+      // profiles/r04_closed_loop_kernel_stats_before_recheck.csv).  The coherent load sees the first store that has landed.
+      if (ready && tag != cur_tag && hdr_tag(hdr_load_coherent(keys, slot), slot & (kBucket - 1u)) != cur_tag) tag_store(keys, slot, cur_tag);
 #endif
     }
     if (!ready) atomicOr(status, kStatusIndexStall);

@@ -176,7 +176,9 @@ int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
  * Every insert (eppk_index_insert, eppk_index_insert_picks_device) stamps its hashes with the context's index epoch
  * (starts at 1); eppk_index_advance_epoch increments it; eppk_index_evict_older drops every hash whose last stamp is
  * < min_epoch (for all pods) and makes its table word reusable.  A shim ticks the epoch once per interval and evicts
- * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches. */
+ * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches.
+ * Window (SEMANTICS.md 6a): a hash may be at most 254 epochs old -- eppk_index_advance_epoch evicts what would be older (the device
+ * keeps a stamp as an 8-bit tag in the hash's bucket header); a caller that never evicts pays a table scan per tick from the 255th on. */
 int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
 int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);
 /* Per-pod capacity (0602-…/README.md:82: the approximate index mimics the model servers' own LRU-bounded prefix caches; upstream
@@ -234,8 +236,12 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
  *     way back to the host before the update starts.  A later begin (either set) scores against the index every earlier LEARN left
  *     behind: its pick waits for that update on the device, its upload does not.
  * eppk_pick_stage_end: waits for the set's picks and copies them out (the index update of a LEARN batch may still be running).
- * Errors: EPPK_ERR_ARG for a set that is busy (begin twice) or idle (end without begin).  Snapshot publishes and the other index
- * entry points must not be issued while a set is between begin and end. */
+ * Errors: EPPK_ERR_ARG for a set that is busy (begin twice) or idle (end without begin).  A begin that FAILS has not begun: the set is
+ * idle again (whatever it had enqueued has been waited for) and end must not be called for it.  One exception: the picks were launched
+ * and only the chained LEARN update could not be enqueued -- begin then succeeds, end delivers the picks, and eppk_launch_status
+ * reports EPPK_LAUNCH_LEARN_FAILED.  The update of a LEARN batch may still be running when end returns; every later pick, index
+ * entry point and publish of the context orders itself behind it (on the device: no host wait), so a caller may issue them at once.
+ * While a set is between begin and end, snapshot publishes and index entry points must still not be issued: its pick reads both. */
 #define EPPK_STAGE_SETS 2u
 #define EPPK_PICK_LEARN 1u
 int eppk_pick_stage_buffers(eppk_ctx* ctx, uint32_t set, void** reqs, uint64_t** cand_mask);

@@ -56,7 +56,7 @@ for stage in "$@"; do
     benchq20)  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/benchq20.json 2> $OUT/benchq20.err; digest $OUT/benchq20.json ;;
     benchq200) timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref > $OUT/benchq200.json 2> $OUT/benchq200.err; digest $OUT/benchq200.json ;;
     closed)  timeout 600 python bench.py --closed-loop > $OUT/bench_closed_loop.json 2> $OUT/bench_closed_loop.err; digest $OUT/bench_closed_loop.json ;;
-    closedq) timeout 300 python bench.py --closed-loop --cl-verify 0 > $OUT/closedq.json 2> $OUT/closedq.err; digest $OUT/closedq.json ;;
+    closedq) f=$OUT/closedq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --closed-loop --cl-verify 0 $arg > $f.json 2> $f.err; digest $f.json ;;
     configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
     routes) timeout 300 python scripts/gpu_route_times.py > $OUT/route_times.json 2> $OUT/route_times.err; tail -c 1500 $OUT/route_times.json ;;
     small) timeout 300 python scripts/gpu_small_batch_latency.py 2>&1 | tee $OUT/small_batch_latency.txt | tail -12 ;;
@@ -66,7 +66,20 @@ for stage in "$@"; do
     stats) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/prof_bench_under_rocprof.json 2> $OUT/prof.err )
            head -6 $OUT/prof/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof -name "*agent_info.csv") $(find $OUT/prof -name "*kernel_trace.csv") ;;
     stats_cl) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cl -o trace -- python $GRAFT_REPO_ROOT/bench.py --closed-loop --steps 60 --warmup 10 --no-cpu-baseline --cl-verify 0 > $OUT/prof_cl_bench_under_rocprof.json 2> $OUT/prof_cl.err )
-           head -8 $OUT/prof_cl/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof_cl -name "*agent_info.csv") $(find $OUT/prof_cl -name "*kernel_trace.csv") ;;
+           head -8 $OUT/prof_cl/*kernel_stats.csv 2>/dev/null | cut -c1-200
+           python - $OUT/prof_cl <<'EOF2' | tee $OUT/prof_cl_durations.txt
+import csv, glob, sys
+import numpy as np
+for f in glob.glob(sys.argv[1] + "/*kernel_trace.csv"):
+    d = {}
+    for r in csv.DictReader(open(f)):
+        d.setdefault(r["Kernel_Name"].split("(")[0][:60], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for k, v in d.items():
+        if len(v) < 20: continue
+        v.sort(); t = np.asarray([x[1] for x in v[10:]]) / 1e3        # in launch order, warm-up launches dropped
+        print(f"{k:60s} n={t.size:4d} deciles us: " + " ".join(f"{np.percentile(t, q):6.1f}" for q in (0, 10, 25, 50, 75, 90, 100)) + f"   even/odd launches: {t[0::2].mean():6.1f} / {t[1::2].mean():6.1f}")
+EOF2
+           rm -f $(find $OUT/prof_cl -name "*agent_info.csv") $(find $OUT/prof_cl -name "*kernel_trace.csv") ;;
     pmc|pmc_cold)
       if [ $name = pmc ]; then ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --inflight 1"
         CTRS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum TCC_BUSY_avr")

@@ -18,7 +18,7 @@
 static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
 // order-independent digest of the index: per live key its pod count, stamp, list count and list ids
-__global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const uint32_t* stamps, const uint32_t* lists, uint32_t slots, unsigned long long* out) {
+__global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const uint32_t* lists, uint32_t slots, unsigned long long* out) {
   unsigned long long acc = 0;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
     if ((s & (eppk::kBucket - 1u)) == 0u) continue;
@@ -30,7 +30,8 @@ __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const 
     if (cnt > eppk::kListCap) { for (uint32_t i = 0; i < 64; ++i) pc += __popcll(rows[(size_t)s * 64u + i]); } else pc = cnt;   // (a listed set's row is all-zero)
     for (uint32_t q = 0; q < (cnt < eppk::kListCap ? cnt : eppk::kListCap); ++q) { const unsigned long long id = ((const uint16_t*)L)[eppk::list_pos(q)]; ids += (id + 1) * (id + 1); }
     unsigned long long z = k + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
-    acc += z * (1ull + pc + 7ull * stamps[s] + 13ull * cnt + 31ull * ids);
+    const unsigned long long tag = (keys[s & ~(eppk::kBucket - 1u)] >> (8u * (s & (eppk::kBucket - 1u)))) & 0xFFull;       // the stamp: a tag in the bucket header
+    acc += z * (1ull + pc + 7ull * tag + 13ull * cnt + 31ull * ids);
   }
   atomicAdd(out, acc);
 }
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
   void* bitmaps; uint32_t *stamps, *lists, *status; unsigned long long* ixc;
   CK(hipMalloc(&bitmaps, index_bytes)); CK(hipMemset(bitmaps, 0, index_bytes));
   uint64_t* keys = (uint64_t*)((uint8_t*)bitmaps + rows_bytes);
-  CK(hipMalloc((void**)&stamps, ((size_t)slots + 2u) * 4u)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u));
+  CK(hipMalloc((void**)&stamps, 2u * 4u)); CK(hipMemset(stamps, 0, 2u * 4u));          // (exact stamps of the two reserved rows only)
   const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
   CK(hipMalloc((void**)&lists, nd * 4u));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
@@ -68,7 +69,7 @@ int main(int argc, char** argv) {
   uint8_t* d_rows; int32_t* d_picks;
   CK(hipMalloc((void**)&d_rows, (size_t)R * stride)); CK(hipMalloc((void**)&d_picks, R * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*, eppk::SortWl, const eppk::IxLaunch*);
+  using Kern = void (*)(uint64_t*, void*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*, const uint8_t*, uint32_t, uint32_t, const int32_t*, uint32_t, uint32_t, uint32_t*, const LW*, eppk::SortWl, const eppk::IxLaunch*, const uint32_t*);
   eppk::IxLaunch* d_ixl; CK(hipMalloc((void**)&d_ixl, sizeof(eppk::IxLaunch)));
   uint32_t* d_wl; const uint32_t wl_cap = R * B; CK(hipMalloc((void**)&d_wl, (4u + (size_t)wl_cap) * 4u)); CK(hipMemset(d_wl, 0, 16));
   uint32_t sort_uses = 0;
@@ -84,7 +85,7 @@ int main(int argc, char** argv) {
     ++sort_uses;
     hipLaunchKernelGGL(eppk::index_budget_kernel, dim3(1), dim3(64), 0, 0, ixc, limit, slots, (unsigned long long)total, d_ixl);
     hipLaunchKernelGGL(kern, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
-                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl);
+                       epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl, (const uint32_t*)nullptr);
     CK(hipEventRecord(e1));
     hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
@@ -93,14 +94,14 @@ int main(int argc, char** argv) {
     return 0;
   };
   unsigned long long* d_dig; CK(hipMalloc((void**)&d_dig, 8));
-  using EvictKern = void (*)(uint64_t*, void*, uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*);
+  using EvictKern = void (*)(uint64_t*, void*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, unsigned long long*);
   struct V { const char* name; Kern k; EvictKern ev; uint32_t ev_grid = 4096; };
   std::vector<V> variants{{"library", eppk::index_insert_picks_kernel<LW>, eppk::index_evict_kernel<LW>}};
   for (const V& v : variants) {
     if (argc > 1) { bool want = false; for (int a = 1; a < argc; ++a) want = want || std::string(v.name).rfind(argv[a], 0) == 0; if (!want) continue; }
     printf("--- %s\n", v.name);
     kern = v.k;
-    CK(hipMemset(bitmaps, 0, index_bytes)); CK(hipMemset(stamps, 0, ((size_t)slots + 2u) * 4u)); CK(hipMemset(ixc, 0, 256 * 64));
+    CK(hipMemset(bitmaps, 0, index_bytes)); CK(hipMemset(stamps, 0, 2u * 4u)); CK(hipMemset(ixc, 0, 256 * 64));
     hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
     if (run("warm", 1, 0, 2, false)) return 1;                 // the hot prefixes enter the index
     if (run("new", 0, 10, 2, true)) return 1;
@@ -110,17 +111,17 @@ int main(int argc, char** argv) {
     unsigned long long h[256 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
     unsigned long long live = 0, dropped = 0, lost = 0; for (uint32_t s2 = 0; s2 < 256u; ++s2) { live += h[s2 * 8 + eppk::kIxLive]; dropped += h[s2 * 8 + eppk::kIxDropped]; lost += h[s2 * 8 + eppk::kIxEvicted]; }
     CK(hipMemset(d_dig, 0, 8));
-    hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, stamps, lists, slots, d_dig);
+    hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, lists, slots, d_dig);
     unsigned long long dig; CK(hipMemcpy(&dig, d_dig, 8, hipMemcpyDeviceToHost));
     printf("live keys %llu (expected %u), dropped %llu, lost claims %llu, digest %016llx\n", live, 4096u + 2u * 1048576u, dropped, lost, dig);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(v.ev, dim3(v.ev_grid), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, 3u, ixc);
+    hipLaunchKernelGGL(v.ev, dim3(v.ev_grid), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, 3u, 3u, ixc);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ems; CK(hipEventElapsedTime(&ems, e0, e1));
     CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
     unsigned long long live2 = 0, ev = 0; for (uint32_t s2 = 0; s2 < 256u; ++s2) { live2 += h[s2 * 8 + eppk::kIxLive]; ev += h[s2 * 8 + eppk::kIxEvicted]; }
     CK(hipMemset(d_dig, 0, 8));
-    hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, stamps, lists, slots, d_dig);
+    hipLaunchKernelGGL(digest_kernel, dim3(4096), dim3(256), 0, 0, keys, (const uint64_t*)bitmaps, lists, slots, d_dig);
     CK(hipMemcpy(&dig, d_dig, 8, hipMemcpyDeviceToHost));
     printf("evict    < epoch 3: %8.1f us   live keys after %llu, evicted %llu, digest %016llx\n", ems * 1e3, live2, ev - lost, dig);
   }
