@@ -30,7 +30,7 @@ SYMBOLS = [
     "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
     "eppk_group_index_remove_pod", "eppk_group_index_advance_epoch", "eppk_group_index_evict_older", "eppk_group_pick_batch",
     "eppk_group_device_picks", "eppk_group_pick_device", "eppk_group_sync", "eppk_group_stream",
-    "eppk_host_staging", "eppk_pick_batch_staged", "eppk_pick_stage_buffers", "eppk_pick_stage_begin", "eppk_pick_stage_end", "eppk_chain_is_fused", "eppk_quad_stats", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
+    "eppk_host_staging", "eppk_pick_batch_staged", "eppk_pick_stage_buffers", "eppk_pick_stage_begin", "eppk_pick_stage_end", "eppk_chain_is_fused", "eppk_quad_stats", "eppk_resident_stats", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
 
@@ -148,6 +148,7 @@ def load_library() -> C.CDLL:
     lib.eppk_group_stream.restype = vp
     lib.eppk_chain_is_fused.argtypes = [vp]
     lib.eppk_quad_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.eppk_resident_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.eppk_host_staging.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.eppk_pick_batch_staged.argtypes = [vp, u32, C.c_int, vp, vp]
     lib.eppk_pick_stage_buffers.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]

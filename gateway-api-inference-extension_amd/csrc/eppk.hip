@@ -13,6 +13,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +137,12 @@ struct eppk_ctx {
   StageSet stage[2];
   hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update; every later pick, index update and
                                                               // publish of this context -- on whatever stream -- is ordered behind it (learn_fence)
+  // The resident small-batch kernel (EPPK_RESIDENT=1; eppk_kernels.hip.h: pick_resident_kernel): pinned control block, device argument
+  // block, a stream of its own; res_seq = the last doorbell value rung.
+  bool resident_on = false, res_running = false, res_args_dirty = true;
+  uint32_t resident_max = 64, res_seq = 0;
+  eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; eppk::ResidentArgs* d_res_args = nullptr; hipStream_t res_stream = nullptr;
+  uint64_t res_batches = 0, res_starts = 0;
   uint32_t* d_learn = nullptr; size_t learn_cap = 0;          // learn words of the pick in front of a LEARN update (pick_quad_kernel<..., LEARN>)
   bool quiet_rows = false;        // a host-buffer launch is being enqueued: its kernels raise "row out of range" on a word of their own
                                   // (the call reports the row itself), not on the sticky flag of the *_device entry points
@@ -350,6 +357,8 @@ int learn_fence(eppk_ctx* c, hipStream_t st) {
   return EPPK_OK;
 }
 
+int resident_park(eppk_ctx* c);
+
 // d_learn (nullable): where pick_quad_kernel<..., LEARN> leaves its learn words for the index update that follows (learn_picks);
 // *wrote_learn says whether this launch took that route and wrote them (else the update gets no words and takes the whole path).
 int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, int32_t* d_pick,
@@ -441,6 +450,7 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     defer_cap = 4u * ((nblk + quad_segs - 1) / quad_segs);
     const size_t words = 32u + (size_t)quad_segs + (size_t)quad_segs * defer_cap;     // header: total[2] | done counters[17] (TAIL) | cnt | list
     if (words > dset->words) {             // grow this stream's buffer (rare: its first launch, or a larger batch than ever before)
+      { const int rcp = resident_park(c); if (rcp) return rcp; }      // (hipFree waits for the device)
       HIPCHK(c, hipStreamSynchronize(st));
       if (dset->d) HIPCHK(c, hipFree(dset->d));
       dset->d = nullptr; dset->words = 0;
@@ -551,6 +561,116 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
 
 int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st);
 
+int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row = 0);
+
+// ---- the resident small-batch kernel (EPPK_RESIDENT=1) ------------------------------------------------------------------------------
+// LDS of its one workgroup (pick_fast_kernel's layout for 16 wavefronts, sized for max_pods: the kernel outlives publishes); *hist =
+// the per-wave pod histogram of the list routes fits as well (else the kernel is handed an index without list routes)
+size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
+  const uint32_t wpb = 16u, J = (c->cfg.max_pods + 63u) / 64u;
+  const uint32_t pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
+  size_t lds = (size_t)J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)wpb * 64u * (size_t)c->lw_bytes;     // base | lw | pterm | scratch
+  const size_t hist = (size_t)wpb * J * 64u;
+  *hist_fits = lds + hist <= c->max_lds;
+  if (*hist_fits) lds += hist;
+  return lds;
+}
+// Park it: ring "quit" and wait for the workgroup to leave.  In front of every device-wide wait of the library's own (a
+// hipDeviceSynchronize would otherwise sit out the kernel's idle timeout), and in eppk_destroy.
+int resident_park(eppk_ctx* c) {
+  if (!c->res_running) return EPPK_OK;
+  __atomic_store_n(&c->h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
+  HIPCHK(c, hipStreamSynchronize(c->res_stream));
+  c->res_running = false;
+  return EPPK_OK;
+}
+int device_sync(eppk_ctx* c) {
+  const int rc = resident_park(c);
+  if (rc) return rc;
+  HIPCHK(c, hipDeviceSynchronize());
+  return EPPK_OK;
+}
+bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked) {
+  return c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && !masked && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
+         c->assumed_epochs == 0 && c->cfg.max_blocks >= 1;
+}
+int resident_start(eppk_ctx* c) {
+  if (c->res_running) return EPPK_OK;
+  if (!c->h_ctl) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_ctl_dev, c->h_ctl, 0));
+    std::memset(c->h_ctl, 0, sizeof(eppk::ResidentCtl));
+    HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+  }
+  const void* fn = eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first);
+  const uint32_t threads = 1024u;
+  bool hist_fits = false;
+  const size_t lds = resident_lds(c, &hist_fits);
+  int per_cu = 0;
+  { const int rco = occupancy_of(c, fn, threads, lds, &per_cu); if (rco) return rco; }
+  // the doorbell the kernel has seen last = the last one rung (a batch rung while the kernel was leaving is picked up at once)
+  const uint32_t seen = c->res_seq == 0 ? 0u : c->res_seq - 1u;
+  uint32_t bell_now = __atomic_load_n(&c->h_ctl->bell, __ATOMIC_ACQUIRE);
+  if (bell_now == eppk::kResQuit) __atomic_store_n(&c->h_ctl->bell, seen, __ATOMIC_RELEASE);
+  __atomic_store_n(&c->h_ctl->state, eppk::kResRunning, __ATOMIC_RELEASE);
+  eppk::ResidentCtl* ctl = c->h_ctl_dev;
+  const eppk::ResidentArgs* args = c->d_res_args;
+  uint32_t seen_arg = seen;
+  unsigned long long max_idle = 30000ull;                 // ~50 ms of polls over PCIe, then the workgroup leaves by itself
+  if (const char* e = getenv("EPPK_RESIDENT_IDLE_POLLS")) { const long long v = atoll(e); if (v > 0) max_idle = (unsigned long long)v; }
+  void* kargs[] = {&ctl, &args, &seen_arg, &max_idle};
+  HIPCHK(c, hipExtLaunchKernel(fn, dim3(1), dim3(threads), kargs, lds, c->res_stream, nullptr, nullptr, 0));
+  c->res_running = true;
+  ++c->res_starts;
+  return EPPK_OK;
+}
+// One small batch through the resident kernel: rows are in c->h_reqs (pinned) already; results land in c->h_pick / c->h_score.
+int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_score, const char* who) {
+  int rc = validate_rows(c, who, c->h_reqs, n_reqs, 0u);
+  if (rc) return rc;
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
+  if (c->learn_pending) HIPCHK(c, hipStreamSynchronize(c->stream));         // (the resident kernel is outside stream order: an index update still running must be over)
+  if (c->res_args_dirty) {        // a publish (or the first use): the argument block again -- between two doorbells, the kernel reads it behind the next
+    eppk::ResidentArgs a{};
+    a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail;
+    a.reqs = (const uint8_t*)c->h_reqs_dev; a.out_pick = c->h_pick_dev; a.out_score = c->h_score_dev;
+    a.stride = c->stride; a.pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
+    bool hist_fits = false;
+    (void)resident_lds(c, &hist_fits);
+    if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
+    HIPCHK(c, hipMemcpy(c->d_res_args, &a, sizeof a, hipMemcpyHostToDevice));
+    c->res_args_dirty = false;
+  }
+  rc = resident_start(c);
+  if (rc) return rc;
+  if (++c->res_seq == eppk::kResQuit || c->res_seq == 0u) c->res_seq = 1u;
+  const uint32_t seq = c->res_seq;
+  c->h_ctl->n_reqs = n_reqs;
+  __atomic_store_n(&c->h_ctl->bell, seq, __ATOMIC_RELEASE);
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (__atomic_load_n(&c->h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 1023u) == 0u) {
+      if (__atomic_load_n(&c->h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited && __atomic_load_n(&c->h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+        // the workgroup left (idle timeout) just as the doorbell rang: start it again; it sees this doorbell at once
+        HIPCHK(c, hipStreamSynchronize(c->res_stream));
+        c->res_running = false;
+        const uint32_t keep = c->res_seq;
+        c->res_seq = keep;                                  // (resident_start: seen = res_seq - 1)
+        rc = resident_start(c);
+        if (rc) return rc;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
+        return fail(c, EPPK_ERR_DEVICE, std::string(who) + ": the resident pick kernel did not answer within 5 s");
+    }
+  }
+  ++c->res_batches;
+  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
+  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
+  return EPPK_OK;
+}
+
 // One batch through the picker the caller asked for, in assumed-load epochs when those are on (SEMANTICS.md §2b):
 //   k == 1, !random   the pick                         (d_pick / d_score: n entries)
 //   k  > 1, !random   ordered fallbacks                (n * k entries; the request's pick is entry 0 of its list)
@@ -564,6 +684,7 @@ int run_pick(eppk_ctx* c, const uint8_t* d_reqs, uint32_t n_reqs, const uint64_t
   const size_t J = (c->n_pods + 63u) / 64u;
   const uint32_t ok = random ? 1u : k;                        // entries per request in the caller's arrays
   if (random && (size_t)per * k > c->rs_cap) {                // fallback lists of one epoch
+    { const int rcp = resident_park(c); if (rcp) return rcp; }
     HIPCHK(c, hipStreamSynchronize(st));
     (void)hipFree(c->d_rs_pick); (void)hipFree(c->d_rs_score);
     c->d_rs_pick = nullptr; c->d_rs_score = nullptr; c->rs_cap = 0;
@@ -617,13 +738,13 @@ int by_lane_word(const eppk_ctx* c, F&& f) {
 int sortwl_begin(eppk_ctx* c, uint64_t n_pairs, eppk::SortWl* sw) {
   const uint32_t want = (uint32_t)(n_pairs < (1ull << 24) ? n_pairs : (1ull << 24));
   if (!c->sortwl || want > c->sortwl_cap) {
-    HIPCHK(c, hipDeviceSynchronize());                 // (rare: the first insert, or a larger launch than ever before)
+    { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }                 // (rare: the first insert, or a larger launch than ever before)
     if (c->sortwl) HIPCHK(c, hipFree(c->sortwl));
     c->sortwl = nullptr; c->sortwl_cap = 0;
     const uint32_t cap = want < 4096u ? 4096u : want;
     HIPCHK(c, hipMalloc((void**)&c->sortwl, (4u + (size_t)cap) * 4u));
     HIPCHK(c, hipMemset(c->sortwl, 0, 16));
-    HIPCHK(c, hipDeviceSynchronize());
+    { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
     c->sortwl_cap = cap; c->sort_uses = 0;
   }
   sw->wl = c->sortwl; sw->cap = c->sortwl_cap; sw->which = c->sort_uses & 1u;
@@ -692,6 +813,7 @@ int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st) {
   if (rc) return rc;
   c->cur = nxt;
   c->n_pods = n_pods;
+  c->res_args_dirty = true;                  // (the resident kernel's argument block names the snapshot buffer)
   return EPPK_OK;
 }
 
@@ -708,6 +830,7 @@ int ixc_sum(eppk_ctx* c, uint32_t field, unsigned long long* out) {
 
 int ensure_tmp(eppk_ctx* c, size_t bytes) {
   if (bytes <= c->d_tmp_bytes) return EPPK_OK;
+  { const int rcp = resident_park(c); if (rcp) return rcp; }
   if (c->d_tmp) HIPCHK(c, hipFree(c->d_tmp));
   c->d_tmp = nullptr; c->d_tmp_bytes = 0;
   HIPCHK(c, hipMalloc(&c->d_tmp, bytes));
@@ -766,6 +889,9 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->fast_threads = (uint32_t)v;
   }
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
+  if (const char* rs = getenv("EPPK_RESIDENT")) c->resident_on = atoi(rs) != 0;
+  if (const char* rm = getenv("EPPK_RESIDENT_MAX")) c->resident_max = atoi(rm) > 0 ? (uint32_t)atoi(rm) : 0u;
+  if (c->resident_on && c->num_cu > 1) --c->num_cu;       // the resident workgroup holds one CU: the persistent pick kernels are sized for the rest
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
@@ -906,6 +1032,10 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
 void eppk_destroy(eppk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
+  (void)resident_park(c);
+  if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
+  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  (void)hipFree(c->d_res_args);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
@@ -1110,7 +1240,7 @@ int eppk_index_size(eppk_ctx* c, uint32_t* n_entries) {
   if (!c || !n_entries) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   unsigned long long live = 0;
-  HIPCHK(c, hipDeviceSynchronize());      // (asynchronous updates on the caller's streams included)
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }      // (asynchronous updates on the caller's streams included)
   int rc = ixc_sum(c, eppk::kIxLive, &live);   // live keys (kIxWords counts non-empty words, tombstones included)
   if (rc) return rc;
   *n_entries = (uint32_t)live;
@@ -1121,7 +1251,7 @@ int eppk_index_dropped(eppk_ctx* c, uint64_t* n_dropped) {
   if (!c || !n_dropped) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   unsigned long long d = 0;
-  HIPCHK(c, hipDeviceSynchronize());
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
   int rc = ixc_sum(c, eppk::kIxDropped, &d);
   if (rc) return rc;
   *n_dropped = (uint64_t)d;
@@ -1172,7 +1302,7 @@ int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
   // (evict_older(epoch - keep) with a keep of a few epochs) never gets here; one that never evicts pays a scan per tick from the 255th.
   if (c->slots && c->index_epoch > kEpochWindow && c->min_live < c->index_epoch - kEpochWindow) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipDeviceSynchronize());               // (index updates the caller may have in flight on streams of its own)
+    { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }               // (index updates the caller may have in flight on streams of its own)
     uint32_t gone = 0;
     const int rc = eppk_index_evict_older(c, c->index_epoch - kEpochWindow, &gone);
     if (rc) return rc;
@@ -1286,7 +1416,7 @@ namespace {
 // room for the learn words of n requests (grown behind a device synchronise: rare)
 int learn_ensure(eppk_ctx* c, size_t n) {
   if (n <= c->learn_cap) return EPPK_OK;
-  HIPCHK(c, hipDeviceSynchronize());
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
   if (c->d_learn) HIPCHK(c, hipFree(c->d_learn));
   c->d_learn = nullptr; c->learn_cap = 0;
   const size_t cap = n < c->cfg.max_batch ? c->cfg.max_batch : n;
@@ -1384,7 +1514,7 @@ int row_check_ensure(eppk_ctx* c, uint32_t** h_bad, uint32_t** h_bad_dev, hipStr
   return EPPK_OK;
 }
 
-int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row = 0) {
+int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row) {
   for (uint32_t r = 0; r < n_reqs; ++r) {
     eppk_req_hdr h;
     std::memcpy(&h, (const uint8_t*)reqs + (size_t)r * c->stride, sizeof h);
@@ -1540,6 +1670,13 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
+  if (resident_eligible(c, n_reqs, cand_mask != nullptr)) {      // the latency path of a small batch: the resident workgroup, no launch
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rcr = ensure_host_staging(c, false);
+    if (rcr) return rcr;
+    std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
+    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch");
+  }
   // (rows are validated on the host, chunk by chunk on their way to the device: never hand the kernel an out-of-range adapter / block count)
   int rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask, false, "eppk_pick_batch", true);
   if (rc) return rc;
@@ -1562,6 +1699,10 @@ int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* 
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_staged: n_reqs > max_batch");
   if (!c->h_reqs || (use_mask && !c->h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: eppk_host_staging was not called for these buffers");
   if (n_reqs == 0) return EPPK_OK;
+  if (resident_eligible(c, n_reqs, use_mask != 0)) {
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch_staged");
+  }
   int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged", true);
   if (rc) return rc;
   return pick_host_end(c, n_reqs, use_mask != 0, out_pick, out_score);
@@ -2046,7 +2187,7 @@ int eppk_hash_prompts_device(eppk_ctx* c, const void* d_prompts, uint64_t prompt
 int eppk_launch_status(eppk_ctx* c, uint32_t* flags) {
   if (!c || !flags) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipDeviceSynchronize());     // every launch of this context, on whatever stream the caller used
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }     // every launch of this context, on whatever stream the caller used
   uint32_t f = c->host_flags;
   c->host_flags = 0;
   // sticky words: d_status[0] and the last dword of either snapshot blob.  The words of the host-buffer launches (d_status[1], the
@@ -2073,10 +2214,17 @@ int eppk_chain_is_fused(const eppk_ctx* c) {
   return c->canonical ? (c->gen ? 2 : 1) : 0;
 }
 
+int eppk_resident_stats(const eppk_ctx* c, uint64_t* batches, uint64_t* starts) {
+  if (!c) return EPPK_ERR_ARG;
+  if (batches) *batches = c->res_batches;
+  if (starts) *starts = c->res_starts;
+  return c->resident_on ? 1 : 0;
+}
+
 int eppk_quad_stats(eppk_ctx* c, uint64_t* launches, uint64_t* deferred) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipDeviceSynchronize());
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
   quad_consume_reports(c);                 // (every launch has finished: every report is there)
   if (launches) *launches = c->quad_launches;
   if (deferred) *deferred = c->quad_deferred_seen;
@@ -2086,7 +2234,7 @@ int eppk_quad_stats(eppk_ctx* c, uint64_t* launches, uint64_t* deferred) {
 int eppk_profile_enable(eppk_ctx* c, int on) {
   if (!c) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipDeviceSynchronize());
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
   HIPCHK(c, hipMemset(c->stats + 4, 0, 2 * (size_t)kStatSlots * kStatBanks * sizeof(unsigned long long)));
   c->prof = on != 0;
   c->prof_every = on > 1 ? (uint32_t)on : 1u;
@@ -2115,7 +2263,7 @@ int eppk_profile_drain(eppk_ctx* c, float* ms, uint32_t cap, uint32_t* n_out) {
 int eppk_profile_bytes(eppk_ctx* c, uint64_t* bytes, uint64_t* lookups, uint32_t* launches) {
   if (!c || !bytes) return EPPK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  HIPCHK(c, hipDeviceSynchronize());
+  { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }
   std::vector<unsigned long long> slots(2 * (size_t)kStatSlots * kStatBanks);
   HIPCHK(c, hipMemcpy(slots.data(), c->stats + 4, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   unsigned long long st[2] = {0, 0};

@@ -1589,6 +1589,74 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
 
 
+// ---- RESIDENT pick kernel: the latency path of small batches (opt-in: EPPK_RESIDENT=1) -------------------------------------------
+// What a per-request caller hands over -- pkg/lwepp/handlers/request.go:141-163 calls Pick once per stream message; the reference's
+// design point is 10-1000 QPS (docs/proposals/006-scheduler/README.md:133) -- is batches of 1-64 requests, and such a batch is all
+// latency: of the 20 us a 16-request batch took host-observed in round 3, 13 were the launch and the completion signal.  This kernel
+// is launched ONCE and stays: one workgroup (a wavefront per request, 16 at a time) polls a doorbell word in pinned host memory; the
+// host writes the request rows into the context's pinned staging buffer, the count and then the doorbell; the workgroup scores the
+// batch with pick_fast_kernel's own body (same picks, same scores), writes picks and scores into the pinned result buffers, and
+// raises the completion word the host is polling.  Doorbell -> answer round trip of an empty batch: 2.7 us, with one row read over
+// PCIe 3.9 us (scripts/micro/doorbell.hip -> profiles/r04_micro_doorbell.txt).
+//   * Nothing cached before the doorbell may be trusted -- the rows were rewritten by the host, the index and the snapshot may have
+//     been updated by other kernels, and there is no kernel boundary to do it for us: system-scope acquire (vector caches) plus
+//     s_dcache_inv (the request headers and the argument block are read with scalar loads) behind every doorbell; system-scope
+//     release in front of the completion word.
+//   * The kernel leaves by itself after `max_idle_polls` polls without a doorbell (~50 ms), so that a host that has died, a device-wide
+//     synchronise of somebody else, or a caller that simply stopped cannot leave a spinning workgroup behind; the library starts it again
+//     with the next small batch.  kResQuit in the doorbell = leave now (eppk_destroy, and in front of every device-wide wait of the
+//     library's own).
+//   * It holds one CU (16 wavefronts x 128 VGPRs): the persistent pick kernels of the same context size their grids for one CU fewer.
+struct ResidentCtl {            // pinned host memory; the two directions in cache lines of their own
+  uint32_t bell;                // host -> device: sequence number of the batch to score (monotonic, never 0), or kResQuit
+  uint32_t n_reqs;              //                 written in front of the doorbell
+  uint32_t pad0[14];
+  uint32_t done;                // device -> host: sequence number of the last batch whose results are in the pinned buffers
+  uint32_t state;               //                 kResRunning while the kernel polls, kResExited when it has left
+  uint32_t pad1[14];
+};
+constexpr uint32_t kResQuit = 0xFFFFFFFFu, kResRunning = 1u, kResExited = 2u;
+struct ResidentArgs {           // device memory; rewritten by the host only between two doorbells (the kernel reads it behind each)
+  KSnap sn; KIndex ix; KTail tl;
+  const uint8_t* reqs; int32_t* out_pick; double* out_score;      // the context's pinned staging / result buffers as the device addresses them
+  uint32_t stride, pwn;
+};
+
+template <typename LW, bool HAS_L, bool P_FIRST>
+__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* args, uint32_t seen, unsigned long long max_idle_polls) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_seq, s_n;
+  for (;;) {
+    if (threadIdx.x == 0u) {
+      uint32_t v = seen;
+      for (unsigned long long polls = 0; polls < max_idle_polls; ++polls) {
+        v = __hip_atomic_load(&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v != seen) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_seq = v == seen ? kResQuit : v;                     // (idle for too long: leave; the library starts the kernel again when it needs it)
+      s_n = __hip_atomic_load(&ctl->n_reqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    const uint32_t seq = s_seq, n = s_n;
+    if (seq == kResQuit) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
+    __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
+    {
+      const ResidentArgs* a = args;
+      const KChain no_chain{};
+      const KWork no_work{};
+      pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false>(
+          0u, 1u, 0u, false, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u, no_work);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // this wavefront's picks and scores are in host memory ...
+    __syncthreads();
+    if (threadIdx.x == 0u) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the answer is
+    seen = seq;
+  }
+  if (threadIdx.x == 0u) __hip_atomic_store(&ctl->state, kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- QUAD pick kernel: FOUR requests per wavefront, every gather laid out for the vector memory pipe ------------------------
 // pick_fast_kernel spends a whole wavefront on one request (~180 vector + ~145 scalar instructions per decision).  The common
 // shape of a request -- no candidate mask, one pick, at most 32 blocks probed, every hit's pod set still in its short list, all

@@ -502,6 +502,12 @@ class BatchedPicker:
         """0 = generic per-pair kernel, 1 = fused sparse kernel, 2 = fused with an interpreted tail (include/eppk.h)."""
         return int(self._lib.eppk_chain_is_fused(self._ctx))
 
+    def resident_stats(self) -> Tuple[bool, int, int]:
+        """(switch on?, small batches answered by the resident workgroup, times it was started) -- include/eppk.h EPPK_RESIDENT."""
+        b, st = C.c_uint64(0), C.c_uint64(0)
+        on = self._lib.eppk_resident_stats(self._ctx, C.byref(b), C.byref(st))
+        return bool(on > 0), int(b.value), int(st.value)
+
     def quad_stats(self) -> Tuple[int, int]:
         """(pick launches that went through the four-requests-per-wavefront kernel, requests those launches deferred to the
         general kernel); synchronises the device (include/eppk.h eppk_quad_stats)."""

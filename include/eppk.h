@@ -220,6 +220,20 @@ int eppk_host_staging(eppk_ctx* ctx, void** reqs, uint64_t** cand_mask);
  * download (a small batch is all latency: 128 requests 33 -> 22 us host-observed). */
 int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t* out_pick, double* out_score);
 
+/* The latency path of SMALL batches (opt-in: EPPK_RESIDENT=1 in the environment when the context is created).  What a per-request
+ * caller hands over (pkg/lwepp/handlers/request.go:141-163; design point 10-1000 QPS, docs/proposals/006-scheduler/README.md:133) is
+ * batches of 1-64 requests, and such a batch is all launch and completion latency.  With the switch on, eppk_pick_batch and
+ * eppk_pick_batch_staged hand an unmasked batch of at most EPPK_RESIDENT_MAX (default 64) requests to a RESIDENT workgroup instead of
+ * launching a kernel: it polls a doorbell in pinned host memory, scores the batch with the same code as pick_fast_kernel (same picks,
+ * same scores), writes the pinned result buffers and raises a completion word the call is polling.  Costs: one CU (the persistent
+ * pick kernels of the context are sized for one fewer), and a polling host thread for the duration of the call.  The workgroup
+ * leaves by itself after ~50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next small batch; the
+ * library parks it in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel does not serve,
+ * masked batches, fallbacks and assumed load take the launched path as before.
+ * eppk_resident_stats: returns 1 when the switch is on (0 otherwise); batches = small batches answered by the resident workgroup,
+ * starts = times it was (re)started. */
+int eppk_resident_stats(const eppk_ctx* ctx, uint64_t* batches, uint64_t* starts);
+
 /* The PIPELINED host path: EPPK_STAGE_SETS staging sets, each with its own pinned rows / masks / results, device buffers and
  * stream, so that the rows of batch k + 1 cross PCIe while batch k is being scored (pkg/lwepp/handlers/request.go:141-163 is a
  * per-request caller: what it can hand over is host memory, and a 64k x 32-block batch is 17 MB -- 0.3 ms of PCIe against 20 us of

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout; tests that drive the resident kernel)")
 
 
 def _have_gpu() -> bool:
@@ -42,7 +43,7 @@ def pytest_collection_modifyitems(config, items):
 # (tests/test_gpu_quad.py sets its own switches; the full-size closed-loop / config tests run in the default mode only.)
 LIBRARY_MODES = {"default": {}, "quadmin4": {"EPPK_QUAD_MIN": "4"}, "quad0": {"EPPK_QUAD": "0"}, "lists0": {"EPPK_LISTS": "0"}}
 MODE_MODULES = {"test_gpu_parity", "test_gpu_fuzz", "test_gpu_holes", "test_gpu_pickers", "test_gpu_subset", "test_gpu_staging",
-                "test_gpu_device_rows"}
+                "test_gpu_device_rows", "test_gpu_resident"}
 
 
 def pytest_generate_tests(metafunc):
