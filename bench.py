@@ -975,7 +975,7 @@ def group_leg(pkg, torch, args):
 
 
 def resident_latency_leg(pkg, wl, batches, calls: int):
-    """Host-observed latency of eppk_pick_batch_staged for 1 / 16 / 64 requests with EPPK_RESIDENT=1 (fresh rows written into the pinned
+    """Host-observed latency of eppk_pick_batch_staged for 1 / 16 / 32 requests with EPPK_RESIDENT=1 (fresh rows written into the pinned
     staging buffer before every call, not timed), each size checked against the oracle once."""
     orc = graft.load_oracle()
     oix = orc.OracleIndex()
@@ -994,7 +994,7 @@ def resident_latency_leg(pkg, wl, batches, calls: int):
         pk.index_insert(wl.index_hashes, wl.index_pods)
         st_reqs, _ = pk.staging()
         by_n, ok = {}, True
-        for n in (1, 16, 64):
+        for n in (1, 16, 32):
             lat = []
             for i in range(calls + 10):
                 off = (i * n) % max(1, wl.R - n + 1)

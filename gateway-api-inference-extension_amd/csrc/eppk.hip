@@ -140,7 +140,7 @@ struct eppk_ctx {
   // The resident small-batch kernel (EPPK_RESIDENT=1; eppk_kernels.hip.h: pick_resident_kernel): pinned control block, device argument
   // block, a stream of its own; res_seq = the last doorbell value rung.
   bool resident_on = false, res_running = false, res_args_dirty = true;
-  uint32_t resident_max = 64, res_seq = 0;
+  uint32_t resident_max = 32, res_seq = 0, res_gen = 0;   // (16 requests per round: 1 request 12 us, 16: 14, 32: ~18, 64: 26 -- beyond 32 the launched kernels win)
   eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; eppk::ResidentArgs* d_res_args = nullptr; hipStream_t res_stream = nullptr;
   uint64_t res_batches = 0, res_starts = 0;
   uint32_t* d_learn = nullptr; size_t learn_cap = 0;          // learn words of the pick in front of a LEARN update (pick_quad_kernel<..., LEARN>)
@@ -577,10 +577,13 @@ size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
 }
 // Park it: ring "quit" and wait for the workgroup to leave.  In front of every device-wide wait of the library's own (a
 // hipDeviceSynchronize would otherwise sit out the kernel's idle timeout), and in eppk_destroy.
+#define RES_DBG(...) do { if (getenv("EPPK_RESIDENT_DEBUG")) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 int resident_park(eppk_ctx* c) {
   if (!c->res_running) return EPPK_OK;
+  RES_DBG("park: bell %u done %u state %u", c->h_ctl->bell, c->h_ctl->done, c->h_ctl->state);
   __atomic_store_n(&c->h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
   HIPCHK(c, hipStreamSynchronize(c->res_stream));
+  RES_DBG("parked: state %u", c->h_ctl->state);
   c->res_running = false;
   return EPPK_OK;
 }
@@ -594,15 +597,18 @@ bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked) {
   return c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && !masked && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
          c->assumed_epochs == 0 && c->cfg.max_blocks >= 1;
 }
+int resident_ensure(eppk_ctx* c) {            // control block, argument block, stream
+  if (c->h_ctl) return EPPK_OK;
+  HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
+  HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_ctl_dev, c->h_ctl, 0));
+  std::memset(c->h_ctl, 0, sizeof(eppk::ResidentCtl));
+  HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+  return EPPK_OK;
+}
 int resident_start(eppk_ctx* c) {
   if (c->res_running) return EPPK_OK;
-  if (!c->h_ctl) {
-    HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
-    HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_ctl_dev, c->h_ctl, 0));
-    std::memset(c->h_ctl, 0, sizeof(eppk::ResidentCtl));
-    HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
-  }
+  { const int rce = resident_ensure(c); if (rce) return rce; }
   const void* fn = eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first);
   const uint32_t threads = 1024u;
   bool hist_fits = false;
@@ -620,6 +626,7 @@ int resident_start(eppk_ctx* c) {
   unsigned long long max_idle = 30000ull;                 // ~50 ms of polls over PCIe, then the workgroup leaves by itself
   if (const char* e = getenv("EPPK_RESIDENT_IDLE_POLLS")) { const long long v = atoll(e); if (v > 0) max_idle = (unsigned long long)v; }
   void* kargs[] = {&ctl, &args, &seen_arg, &max_idle};
+  RES_DBG("start: seen %u bell %u lds %zu", seen_arg, c->h_ctl->bell, lds);
   HIPCHK(c, hipExtLaunchKernel(fn, dim3(1), dim3(threads), kargs, lds, c->res_stream, nullptr, nullptr, 0));
   c->res_running = true;
   ++c->res_starts;
@@ -631,11 +638,15 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
   if (rc) return rc;
   { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   if (c->learn_pending) HIPCHK(c, hipStreamSynchronize(c->stream));         // (the resident kernel is outside stream order: an index update still running must be over)
+  rc = resident_ensure(c);
+  if (rc) return rc;
   if (c->res_args_dirty) {        // a publish (or the first use): the argument block again -- between two doorbells, the kernel reads it behind the next
     eppk::ResidentArgs a{};
     a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail;
     a.reqs = (const uint8_t*)c->h_reqs_dev; a.out_pick = c->h_pick_dev; a.out_score = c->h_score_dev;
     a.stride = c->stride; a.pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
+    if (++c->res_gen == 0u) c->res_gen = 1u;
+    a.gen = c->res_gen;
     bool hist_fits = false;
     (void)resident_lds(c, &hist_fits);
     if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
@@ -647,6 +658,7 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
   if (++c->res_seq == eppk::kResQuit || c->res_seq == 0u) c->res_seq = 1u;
   const uint32_t seq = c->res_seq;
   c->h_ctl->n_reqs = n_reqs;
+  RES_DBG("ring %u (n = %u)", seq, n_reqs);
   __atomic_store_n(&c->h_ctl->bell, seq, __ATOMIC_RELEASE);
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
@@ -666,6 +678,7 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
     }
   }
   ++c->res_batches;
+  RES_DBG("answered %u after %u spins", seq, spins);
   std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
   if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
   return EPPK_OK;

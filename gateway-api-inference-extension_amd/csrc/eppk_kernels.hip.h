@@ -786,7 +786,9 @@ __device__ __forceinline__ uint32_t ctz_lw(LW x) {
 // real position: wavefront w of workgroup b then owns exactly the segment it filled itself -- no second launch, no waiting for any
 // other workgroup, and a burst of deferred requests is spread over the whole grid.  smem: the dynamic LDS of the calling kernel
 // (the layout below); stat_base: first probe-statistics slot of this grid's wavefronts.
-template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false>
+// RESIDENT (pick_resident_kernel): the body is called once per doorbell by a workgroup that stays; `tail` then means "the snapshot's
+// tables are in this workgroup's LDS already" (same snapshot as at the previous doorbell): only the barrier of the staging remains.
+template <typename LW, int NPL, bool HAS_L, bool HAS_P, bool P_FIRST, bool MASKED, bool BIG, bool GEN, bool TOPK, bool WL = false, bool RESIDENT = false>
 __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint32_t vgrid, const uint32_t stat_base, const bool tail, unsigned char* smem,
                                                const KSnap& sn, const KIndex& ix, const KTail& tl, const uint8_t* __restrict__ reqs,
                                                uint32_t stride, uint32_t n_reqs, uint32_t pwn,
@@ -823,15 +825,17 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
   LW* s_scr_all = (LW*)(GEN ? s_post1 + (size_t)sn.J * 64u : s_post0);                // [waves][64] lane words: set_from_list's scratch (dense route)
   uint32_t* s_hist_all = (uint32_t*)(s_scr_all + (size_t)(blockDim.x >> 6) * 64u);    // [waves][J * 16] dwords: one byte per pod
   const bool use_lists = SPARSE && ix.lists != nullptr;
-  for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
-  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct: that costs scratch)
-  if (GEN)
-    for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_post0[i] = sn.post[0][i]; s_post1[i] = sn.post[1][i]; }
-  if (pterm_tab)
-    for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
-  if (use_lists)
-    for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * sn.J * 16u; i += blockDim.x) s_hist_all[i] = 0u;
-  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * 64u; i += blockDim.x) s_scr_all[i] = (LW)0;
+  if (!(RESIDENT && tail)) {      // (the histogram and the scratch words are all-zero between two requests, so also between two doorbells)
+    for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) s_base[i] = sn.base[i];
+    if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct: that costs scratch)
+    if (GEN)
+      for (uint32_t i = threadIdx.x; i < sn.J * 64u; i += blockDim.x) { s_post0[i] = sn.post[0][i]; s_post1[i] = sn.post[1][i]; }
+    if (pterm_tab)
+      for (uint32_t i = threadIdx.x; i < pwn; i += blockDim.x) s_pterm[i] = sn.pterm[i];
+    if (use_lists)
+      for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * sn.J * 16u; i += blockDim.x) s_hist_all[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < (blockDim.x >> 6) * 64u; i += blockDim.x) s_scr_all[i] = (LW)0;
+  }
   __syncthreads();
 
   const int lane = (int)(threadIdx.x & 63u);
@@ -1620,25 +1624,36 @@ struct ResidentArgs {           // device memory; rewritten by the host only bet
   KSnap sn; KIndex ix; KTail tl;
   const uint8_t* reqs; int32_t* out_pick; double* out_score;      // the context's pinned staging / result buffers as the device addresses them
   uint32_t stride, pwn;
+  uint32_t gen, pad;              // changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
 };
 
 template <typename LW, bool HAS_L, bool P_FIRST>
-__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* args, uint32_t seen, unsigned long long max_idle_polls) {
+__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* __restrict__ args, uint32_t seen, unsigned long long max_idle_polls) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_seq, s_n;
+  // Everything the doorbell wavefront does alone is behind a WAVE-UNIFORM condition (a scalar branch).  Written as `threadIdx.x == 0`
+  // the compiler rotated the loop so that thread 0's part -- completion store, then the polling -- became an outer loop around an inner
+  // one in which the other 63 lanes of its wavefront ran ahead through the barriers with a stale sequence number: the workgroup never
+  // answered its first doorbell (round 4, found with progress marks in the control block).
+  const bool bell_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  uint32_t staged_gen = 0u;                                 // generation of the tables in LDS (0 = none: the host's generations start at 1)
   for (;;) {
-    if (threadIdx.x == 0u) {
+    if (bell_wave) {
       uint32_t v = seen;
       for (unsigned long long polls = 0; polls < max_idle_polls; ++polls) {
-        v = __hip_atomic_load(&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
         if (v != seen) break;
         __builtin_amdgcn_s_sleep(2);
       }
-      s_seq = v == seen ? kResQuit : v;                     // (idle for too long: leave; the library starts the kernel again when it needs it)
-      s_n = __hip_atomic_load(&ctl->n_reqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t n_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->n_reqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (lane0) {
+        s_seq = v == seen ? kResQuit : v;                   // (idle for too long: leave; the library starts the kernel again when it needs it)
+        s_n = n_now;
+      }
     }
     __syncthreads();
-    const uint32_t seq = s_seq, n = s_n;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
     if (seq == kResQuit) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
     __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
@@ -1646,15 +1661,22 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
       const ResidentArgs* a = args;
       const KChain no_chain{};
       const KWork no_work{};
-      pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false>(
-          0u, 1u, 0u, false, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u, no_work);
+      const uint32_t gen = a->gen;
+      pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false, /*RESIDENT*/ true>(
+          0u, 1u, 0u, /*tables staged*/ gen == staged_gen, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u,
+          no_work);
+      staged_gen = gen;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // this wavefront's picks and scores are in host memory ...
     __syncthreads();
-    if (threadIdx.x == 0u) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the answer is
+    if (bell_wave) {
+      if (lane0) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the answer is
+    }
     seen = seq;
   }
-  if (threadIdx.x == 0u) __hip_atomic_store(&ctl->state, kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (bell_wave) {
+    if (lane0) __hip_atomic_store(&ctl->state, kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- QUAD pick kernel: FOUR requests per wavefront, every gather laid out for the vector memory pipe ------------------------

@@ -1,5 +1,5 @@
 """The resident small-batch path (EPPK_RESIDENT=1; csrc/eppk_kernels.hip.h: pick_resident_kernel): eppk_pick_batch / eppk_pick_batch_staged
-of at most 64 unmasked requests are answered by a workgroup that stays on the GPU and polls a doorbell in pinned host memory -- same picks
+of at most 32 unmasked requests are answered by a workgroup that stays on the GPU and polls a doorbell in pinned host memory -- same picks
 and scores as the launched kernels (bit for bit against the oracle), across publishes and index updates (the workgroup has no kernel
 boundary to refresh its caches: it invalidates them behind every doorbell), idle time-outs and the library's own device-wide waits."""
 import time
@@ -33,7 +33,7 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         st, _ = pk.staging()
         served = 0
         for rep in range(3):
-            for n in (1, 16, 37, 64):
+            for n in (1, 16, 17, 32):
                 reqs = wl.reqs[(rep * 64) % 128:(rep * 64) % 128 + n]
                 want = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B)[:2]
                 _same(pk.pick(reqs), want, f"pick n={n}")
@@ -43,8 +43,8 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         on, b1, s1 = pk.resident_stats()
         assert b1 - b0 == served and s1 >= 1
         # beyond the limit, with a mask, or as fallbacks: the launched path as before
-        want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:65], wl.B)[:2]
-        _same(pk.pick(wl.reqs[:65]), want, "n=65")
+        want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:33], wl.B)[:2]
+        _same(pk.pick(wl.reqs[:33]), want, "n=33")
         assert pk.resident_stats()[1] == b1
         W = (P + 63) // 64
         mask = np.full((8, W), np.uint64(0xAAAAAAAAAAAAAAAA))
@@ -61,7 +61,7 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         pods2["queue"] = (pods2["queue"].astype(np.int64) * 7 + 3) % 61
         pods2["kv_util"] = 1.0 - pods2["kv_util"]
         pk.publish(pods2)
-        _same(pk.pick(wl.reqs[:48]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:48], wl.B)[:2], "after a publish")
+        _same(pk.pick(wl.reqs[:30]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:30], wl.B)[:2], "after a publish")
         e = pk.index_advance_epoch(); assert e == oix.advance_epoch()
         assert pk.index_evict_older(e) == oix.evict_older(e)                          # everything goes (a device-wide wait: the workgroup is parked)
         _same(pk.pick(wl.reqs[:20]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:20], wl.B)[:2], "after an eviction")
@@ -76,7 +76,7 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
 
 def test_the_resident_workgroup_leaves_when_idle_and_comes_back(pkg, orc, resident, monkeypatch):
     monkeypatch.setenv("EPPK_RESIDENT_IDLE_POLLS", "2000")                            # a few milliseconds of polls
-    wl = pkg.workload.make_workload(5, R=64, P=700, n_groups=8)
+    wl = pkg.workload.make_workload(5, R=32, P=700, n_groups=8)
     oix = orc.OracleIndex()
     oix.insert(wl.index_hashes, wl.index_pods)
     want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B)[:2]
