@@ -265,6 +265,10 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     assert d["scaling"] == "weak" and d["config"]["requests_per_gpu"] == 64 and d["config"]["requests_per_step"] == 128
     assert "cpu_baseline" not in d and "one whole batch per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
     assert ("int16" in d["config"]["sharding"]) == ("--pack16" in extra) and d["config"]["requests_per_launch"] == 64
+    # what `value` is: the metric names the scaling, the note quotes north_star with rank 0's measured launch time, the communicator is asked
+    assert "weak scaling" in d["metric"] and "2 x 64k" in d["metric"] if "64k" in d["metric"] else "closed loop" not in d["metric"]
+    assert "outgrows one device" in d["scaling_note"] and "weak" in d["scaling_note"]
+    assert d["config"]["per_rank_kernel_us"] > 0 and d["config"]["collective_us"]["collectives"] >= 1 and d["config"]["collective_us"]["p50"] >= 0
     cl = d["completion_latency"]                  # N > 1: when a batch's picks exist on every rank (per gather bucket)
     assert cl["buckets"] >= 1 and cl["p50_ms"] <= cl["p99_ms"] <= cl["max_ms"] and cl["batches_per_bucket"] >= 1
     assert d["parity"] == {"gathered_picks_equal_oracle": True, "ranks_checked": 2}
@@ -285,4 +289,6 @@ def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
     d = json.loads(out0[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 36 and d["config"]["requests_per_step"] == 71
     assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 4 * 36
+    assert "strong" in d["scaling_note"] and d["config"]["ranks_seen"] == 2 and d["config"]["per_rank_kernel_us"] > 0
+    assert d["completion_latency"]["p50_ms"] <= d["completion_latency"]["p99_ms"]
     assert d["parity"]["gathered_picks_equal_oracle"] is True
