@@ -395,7 +395,13 @@ class Runner:
                 for c in self.computes:
                     self.comm.wait_stream(c)                 # (a partly filled bucket: its last launches may sit on either compute stream)
             self._gather(due)                                # a partly filled bucket is flushed: every step's picks are gathered inside the timed region
+        # (Polling the streams with hipStreamQuery ahead of this synchronize -- so that the host stands at the fence when the last kernel
+        # ends instead of waking up from an interrupt -- was measured and dropped: the polling itself slows the launches down, 21.7 vs
+        # 20.2 us per step at --steps 20.  The GPU's own span of that region is 361 of its 402 us: profiles/r04_trace20_timeline.txt.)
+        t_sync = time.perf_counter()
         self.torch.cuda.synchronize()
+        if HOSTTIME and t0 is not None:
+            self.host_t["synchronize"] = time.perf_counter() - t_sync
         elapsed = None if t0 is None else time.perf_counter() - t0
         if self.use_dist:
             self.dist.barrier()
@@ -794,11 +800,13 @@ def main() -> None:
                     if n > R:
                         continue
                     l4 = []
+                    o_p, o_s = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float64)     # (result arrays and their addresses once: the timed
+                    a_p, a_s = o_p.ctypes.data, o_s.ctypes.data                               #  call is the ctypes call alone, as a cgo caller's would be)
                     for i in range(min(args.host_path, 200) + 10):
                         off = (i * n) % max(1, R - n + 1)
                         np.copyto(st_reqs[:n], batches[i % len(batches)][off:off + n])
                         t0 = time.perf_counter()
-                        run.pk.pick_staged(n)
+                        run.pk.pick_staged_into(n, a_p, a_s)
                         l4.append(time.perf_counter() - t0)
                     l4 = np.asarray(l4[10:] or l4) * 1e6
                     by_n[str(n)] = {"p50_us": float(np.percentile(l4, 50)), "p99_us": float(np.percentile(l4, 99))}
@@ -808,7 +816,12 @@ def main() -> None:
                 # the same small batches through the RESIDENT workgroup (EPPK_RESIDENT=1, opt-in: include/eppk.h): no launch, no completion
                 # signal -- a doorbell in pinned memory and a polling host.  A context of its own (the switch is read at eppk_create).
                 try:
-                    out["host_path"]["latency_by_batch_resident"] = resident_latency_leg(pkg, wl, batches, min(args.host_path, 200))
+                    res_leg = resident_latency_leg(pkg, wl, batches, min(args.host_path, 200))
+                    out["host_path"]["latency_by_batch_resident"] = res_leg
+                    lb = out["host_path"].get("latency_by_batch", {}).get("requests", {})
+                    for n_s, v in res_leg.get("requests", {}).items():          # ... and beside the launched path's figure of the same size
+                        if n_s in lb:
+                            lb[n_s]["resident_p50_us"], lb[n_s]["resident_p99_us"] = v["p50_us"], v["p99_us"]
                 except Exception as e:
                     out["host_path"]["latency_by_batch_resident"] = {"error": repr(e)}
             if hasattr(run.pk, "stage_begin"):
@@ -996,11 +1009,13 @@ def resident_latency_leg(pkg, wl, batches, calls: int):
         by_n, ok = {}, True
         for n in (1, 16, 32):
             lat = []
+            p, s = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float64)
+            a_p, a_s = p.ctypes.data, s.ctypes.data
             for i in range(calls + 10):
                 off = (i * n) % max(1, wl.R - n + 1)
                 np.copyto(st_reqs[:n], batches[i % len(batches)][off:off + n])
                 t0 = time.perf_counter()
-                p, s = pk.pick_staged(n)
+                pk.pick_staged_into(n, a_p, a_s)
                 lat.append(time.perf_counter() - t0)
             op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, st_reqs[:n].copy(), wl.B)
             ok = ok and bool(np.array_equal(p, op)) and bool(np.array_equal(s.view(np.uint64), osc.view(np.uint64)))

@@ -210,6 +210,7 @@ struct eppk_ctx {
   uint32_t quad_backoff = 0, quad_backoff_len = 0;
   uint32_t wl_hint = 0xFFFFFFFFu;   // decaying maximum of the recent launches' deferred counts (0xFFFFFFFF: no report seen yet): sizes the work-list pass
   bool quad_tail_on = true;         // EPPK_QUAD_TAIL=0: always the two-launch form (pick_quad_kernel + work-list pass)
+  bool quad_pause_on = true;        // EPPK_QUAD_PAUSE=0: a launch that deferred a large part of its batch does not pause the route (measurement knob)
   uint64_t quad_tail_launches = 0;  // launches that took the one-launch form (pick_quad_kernel<TAIL>)
   uint64_t quad_launches = 0, quad_deferred_seen = 0;
   uint32_t fast_threads = 1024;  // workgroup size of the fast kernel (EPPK_FAST_THREADS overrides: tuning knob)
@@ -242,7 +243,7 @@ void quad_consume_reports(eppk_ctx* c) {
       c->wl_hint = v > dec ? v : dec;
     }
     const uint32_t n = c->rep_n[slot];
-    if (v > (c->rep_masked[slot] ? n / 8u : n / 4u)) {
+    if (c->quad_pause_on && v > (c->rep_masked[slot] ? n / 8u : n / 4u)) {
       if (c->quad_backoff == 0) {
         c->quad_backoff_len = c->quad_backoff_len ? (c->quad_backoff_len < 4096u ? c->quad_backoff_len * 2u : 4096u) : 64u;
         c->quad_backoff = c->quad_backoff_len;
@@ -908,6 +909,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
+  if (const char* qp = getenv("EPPK_QUAD_PAUSE")) c->quad_pause_on = atoi(qp) != 0;
   if (const char* zc = getenv("EPPK_ZERO_COPY_MAX")) c->zero_copy_max = atoi(zc) > 0 ? (uint32_t)atoi(zc) : 0u;
   if (const char* hc = getenv("EPPK_HOST_CHECK_MAX")) c->host_check_max = atoi(hc) > 0 ? (uint32_t)atoi(hc) : 0u;
   if (const char* qt = getenv("EPPK_QUAD_THREADS")) {

@@ -334,6 +334,14 @@ class BatchedPicker:
         self._check(self._lib.eppk_pick_batch_staged(self._ctx, R, 1 if use_mask else 0, picks.ctypes.data, scores.ctypes.data), "pick_batch_staged")
         return picks, scores
 
+    def pick_staged_into(self, R: int, picks_ptr: int, scores_ptr: int, use_mask: bool = False) -> None:
+        """`pick_staged` into caller-owned arrays given by ADDRESS (`arr.ctypes.data`, taken once): the call a latency measurement
+        times -- without the two allocations and pointer conversions `pick_staged` does per call (3-4 us of Python, none of which a
+        cgo caller has)."""
+        rc = self._lib.eppk_pick_batch_staged(self._ctx, R, 1 if use_mask else 0, picks_ptr, scores_ptr)
+        if rc:
+            self._check(rc, "pick_batch_staged")
+
     # -- the pipelined host path (include/eppk.h eppk_pick_stage_*): two staging sets, upload of one batch under the kernel of the other
     def stage_buffers(self, which: int, with_mask: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
         """Pinned request rows [max_batch, row_words] u64 (and the flat mask buffer) of staging set `which` (0 / 1)."""

@@ -14,6 +14,8 @@
 #   doorbell claim evictloop insertbreak     scripts/micro/_bin/<name> (built in the build container)
 #   stats / stats_cl      rocprofv3 --kernel-trace --stats of the headline / the closed loop
 #   pmc / pmc_cold        the PMC passes behind profiles/pmc_*.json (then scripts/make_pmc_json.py in the build container)
+#   set:VAR=value / unset:VAR   environment for the stages that follow
+#   benchq:"<args>"       bench.py without the side legs, any arguments;  trace20 = rocprofv3 timeline of the driver-protocol region;  routes_nopause
 # Environment variables pass through (EPPK_QUAD_TAIL=0 bash scripts/gpu.sh ...).
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -47,6 +49,8 @@ EOF
 for stage in "$@"; do
   name=${stage%%:*}; arg=""; [[ "$stage" == *:* ]] && arg=${stage#*:}
   case $name in
+    set) export "$arg"; echo "export $arg" ;;
+    unset) unset "$arg" ;;
     smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
     tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -6 | tee $OUT/pytest_${arg//[^a-zA-Z0-9]/_}.txt
            else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt; fi ;;
@@ -59,6 +63,32 @@ for stage in "$@"; do
     closedq) f=$OUT/closedq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --closed-loop --cl-verify 0 $arg > $f.json 2> $f.err; digest $f.json ;;
     configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
     routes) timeout 300 python scripts/gpu_route_times.py > $OUT/route_times.json 2> $OUT/route_times.err; tail -c 1500 $OUT/route_times.json ;;
+    routes_nopause) EPPK_QUAD_PAUSE=0 timeout 300 python scripts/gpu_route_times.py > $OUT/route_times_nopause.json 2> $OUT/route_times_nopause.err; tail -c 1500 $OUT/route_times_nopause.json ;;
+    benchq) f=$OUT/benchq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --no-closed-loop-leg $arg > $f.json 2> $f.err; digest $f.json; grep "host time" $f.err ;;
+    trace20) ( cd /tmp; EPPK_BENCH_HOSTTIME=1 timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace20 -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --no-closed-loop-leg $arg > $OUT/trace20_bench.json 2> $OUT/trace20.err )
+           digest $OUT/trace20_bench.json; grep "host time" $OUT/trace20.err
+           python - $OUT/trace20 <<'EOF3' | tee $OUT/trace20_timeline.txt
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-70:]) for r in csv.DictReader(open(f))]
+    rows.sort()
+    picks = [x for x in rows if "pick_quad_kernel" in x[2]]
+    if not picks: continue
+    # the timed region = the 20 consecutive launches behind the last idle gap > 200 us that has >= 20 launches behind it ... print everything, mark gaps
+    t_first = picks[0][0]; prev_end = None
+    for s, e, n in picks:
+        gap = "" if prev_end is None else f"gap to previous END {(s - prev_end) / 1e3:8.1f} us"
+        print(f"start {(s - t_first) / 1e3:10.1f} us  dur {(e - s) / 1e3:6.1f} us  {gap}")
+        prev_end = e
+EOF3
+           rm -f $(find $OUT/trace20 -name "*agent_info.csv") ;;
+    linegather2) timeout 120 ./scripts/micro/_bin/linegather2 2>&1 | tee $OUT/micro_linegather2.txt
+      mkdir -p $OUT/lg2; i=0
+      for ctrs in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "FETCH_SIZE"; do i=$((i+1))
+        ( cd /tmp; timeout -k 5 150 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/lg2 -o pass$i -- $GRAFT_REPO_ROOT/scripts/micro/_bin/linegather2 > /dev/null 2> $OUT/lg2/pass$i.err )
+      done
+      python scripts/pmc_summary.py $OUT/lg2 gather2 --by-kernel | tee $OUT/micro_linegather2_pmc.csv | cut -c1-160
+      rm -f $(find $OUT/lg2 -name "*agent_info.csv") $(find $OUT/lg2 -name "*kernel_trace.csv") ;;
     small) timeout 300 python scripts/gpu_small_batch_latency.py 2>&1 | tee $OUT/small_batch_latency.txt | tail -12 ;;
     doorbell|claim|claim2|evictloop|insertbreak)
       bin=$name; [ $name = claim ] && bin=claimcost; [ $name = claim2 ] && bin=claimcost2
