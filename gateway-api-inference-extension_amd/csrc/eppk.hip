@@ -578,7 +578,8 @@ size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
 }
 // Park it: ring "quit" and wait for the workgroup to leave.  In front of every device-wide wait of the library's own (a
 // hipDeviceSynchronize would otherwise sit out the kernel's idle timeout), and in eppk_destroy.
-#define RES_DBG(...) do { if (getenv("EPPK_RESIDENT_DEBUG")) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
+static const bool g_res_dbg = getenv("EPPK_RESIDENT_DEBUG") != nullptr;     // (read once: the macro sits on the latency path)
+#define RES_DBG(...) do { if (g_res_dbg) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 int resident_park(eppk_ctx* c) {
   if (!c->res_running) return EPPK_OK;
   RES_DBG("park: bell %u done %u state %u", c->h_ctl->bell, c->h_ctl->done, c->h_ctl->state);
@@ -624,7 +625,7 @@ int resident_start(eppk_ctx* c) {
   eppk::ResidentCtl* ctl = c->h_ctl_dev;
   const eppk::ResidentArgs* args = c->d_res_args;
   uint32_t seen_arg = seen;
-  unsigned long long max_idle = 30000ull;                 // ~50 ms of polls over PCIe, then the workgroup leaves by itself
+  unsigned long long max_idle = 30000ull;                 // ~20-50 ms of polls over PCIe, then the workgroup leaves by itself
   if (const char* e = getenv("EPPK_RESIDENT_IDLE_POLLS")) { const long long v = atoll(e); if (v > 0) max_idle = (unsigned long long)v; }
   void* kargs[] = {&ctl, &args, &seen_arg, &max_idle};
   RES_DBG("start: seen %u bell %u lds %zu", seen_arg, c->h_ctl->bell, lds);

@@ -89,6 +89,19 @@ EOF3
       done
       python scripts/pmc_summary.py $OUT/lg2 gather2 --by-kernel | tee $OUT/micro_linegather2_pmc.csv | cut -c1-160
       rm -f $(find $OUT/lg2 -name "*agent_info.csv") $(find $OUT/lg2 -name "*kernel_trace.csv") ;;
+    dist1) # the N > 1 code path of bench.py on ONE GPU: RCCL at world size 1, through torch.distributed.run as the driver launches it
+      timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref $arg > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
+      digest $OUT/bench_force_dist.json; tail -3 $OUT/bench_force_dist.err | cut -c1-300
+      python - $OUT/bench_force_dist.json <<'EOF4'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   metric:", d["metric"]); print("   scaling_note:", d.get("scaling_note")); c = d["config"]
+    print("   ", {k: c.get(k) for k in ("ranks_seen", "per_rank_kernel_us", "collective_us", "sharding")}); print("   strong:", {k: (d.get("strong") or {}).get(k) for k in ("value", "ms_per_step")}, " completion_latency:", d.get("completion_latency"))
+except Exception as e:
+    print("   (", e, ")")
+EOF4
+      ;;
     small) timeout 300 python scripts/gpu_small_batch_latency.py 2>&1 | tee $OUT/small_batch_latency.txt | tail -12 ;;
     doorbell|claim|claim2|evictloop|insertbreak)
       bin=$name; [ $name = claim ] && bin=claimcost; [ $name = claim2 ] && bin=claimcost2
