@@ -1068,9 +1068,10 @@ def closed_loop_leg(pkg, torch, args, wl, batches):
 
 def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
     """eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over the two staging sets -- upload of batch k + 1 under the pick and the post-route
-    update of batch k -- with the shim's ageing: every `2 * age_every` batches the pipeline is drained, the epoch ticks and the hashes
-    not re-inserted for `keep_epochs` epochs go (index entry points are not issued while a set is in flight: include/eppk.h).  Rows are in
-    the pinned sets already (two different batches; building them is the caller's per-request work, as in `pipelined`)."""
+    update of batch k -- with the shim's ageing: every `2 * age_every` batches the epoch ticks and the hashes not re-inserted for
+    `keep_epochs` epochs go, stream-ordered on the device (eppk_index_evict_older_device between two begins: behind the picks and updates
+    begun before it, ahead of those begun after; the pipeline is not drained).  Rows are in the pinned sets already (two different
+    batches; building them is the caller's per-request work, as in `pipelined`)."""
     R = wl.R
     pk = run.pk
     sb = [pk.stage_buffers(0)[0], pk.stage_buffers(1)[0]]
@@ -1082,7 +1083,7 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
     def tick():
         state["epoch"] = pk.index_advance_epoch()
         if state["epoch"] > args.keep_epochs:
-            pk.index_evict_older(state["epoch"] - args.keep_epochs + 1)
+            pk.index_evict_older_device(state["epoch"] - args.keep_epochs + 1, None)
 
     # warm-up: two batches through each set
     for i in range(4):
@@ -1092,19 +1093,15 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
     t0 = time.perf_counter()
     t_begin[0] = t0
     pk.stage_begin(0, R, learn=True)
-    inflight = 0
     for i in range(1, n_batches + 1):
         cur, prev = i & 1, (i - 1) & 1
-        drain = i % every == 0 or i == n_batches
-        if not drain:
+        if i < n_batches:
             t_begin[cur] = time.perf_counter()
             pk.stage_begin(cur, R, learn=True)
+            if i % every == 0:
+                tick()                      # (set `cur` is in flight: the eviction queues behind its pick and update)
         pk.stage_end(prev)
         lat.append(time.perf_counter() - t_begin[prev])
-        if drain and i < n_batches:
-            tick()
-            t_begin[cur] = time.perf_counter()
-            pk.stage_begin(cur, R, learn=True)
     run.torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     lat = np.asarray(lat) * 1e3
@@ -1112,8 +1109,8 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "pcie_floor_ms": R * run.stride / 55e9 * 1e3,
             "ageing_every_batches": every, "index_dropped": int(pk.index_dropped()), "launch_status": int(pk.launch_status()),
             "what": "eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over two staging sets (rows already in the pinned sets): the post-route index update "
-                    "chained on the device behind every pick; pipeline drained + epoch tick + eviction every "
-                    f"{every} batches; {args.cl_slots} index slots; wall time of the whole loop incl. the ageing pauses"}
+                    "chained on the device behind every pick; epoch tick + eviction every "
+                    f"{every} batches, stream-ordered on the device between two begins (no drain); {args.cl_slots} index slots; wall time of the whole loop"}
 
 
 def closed_loop_verify(run, wl, args):

@@ -659,9 +659,9 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
   if (rc) return rc;
   if (++c->res_seq == eppk::kResQuit || c->res_seq == 0u) c->res_seq = 1u;
   const uint32_t seq = c->res_seq;
-  c->h_ctl->n_reqs = n_reqs;
   RES_DBG("ring %u (n = %u)", seq, n_reqs);
-  __atomic_store_n(&c->h_ctl->bell, seq, __ATOMIC_RELEASE);
+  static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
+  __atomic_store_n((uint64_t*)&c->h_ctl->bell, ((uint64_t)n_reqs << 32) | seq, __ATOMIC_RELEASE);      // count and doorbell in one store
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
   while (__atomic_load_n(&c->h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
@@ -680,7 +680,8 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
     }
   }
   ++c->res_batches;
-  RES_DBG("answered %u after %u spins", seq, spins);
+  RES_DBG("answered %u after %u spins; ring -> done %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
+          seq, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), c->h_ctl->pad1[0], c->h_ctl->pad1[1], c->h_ctl->pad1[2]);
   std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
   if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
   return EPPK_OK;
@@ -1393,6 +1394,13 @@ int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream)
   HIPCHK(c, hipSetDevice(c->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   { const int rcf = learn_fence(c, st); if (rcf) return rcf; }
+  // The pipelined host path may have a staging set between begin and end: the eviction queues behind that set's pick (which reads the
+  // index; its LEARN update, if any, is behind the fence above) and every later begin queues behind the eviction (the `learned` event
+  // again: run_pick's fence) -- a shim ages its index without draining the two-set pipeline.
+  for (uint32_t i = 0; i < EPPK_STAGE_SETS; ++i) {
+    eppk_ctx::StageSet& s = c->stage[i];
+    if (s.busy && s.n && s.picked && st != s.st) HIPCHK(c, hipStreamWaitEvent(st, s.picked, 0));
+  }
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
@@ -1403,6 +1411,10 @@ int eppk_index_evict_older_device(eppk_ctx* c, uint32_t min_epoch, void* stream)
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  if (c->learned) {                        // (only a context that uses the staging sets has the event: a single-stream closed loop pays nothing)
+    HIPCHK(c, hipEventRecord(c->learned, st));
+    c->learn_pending = true;
+  }
   { const uint32_t horizon = min_epoch < c->index_epoch ? min_epoch : c->index_epoch; if (horizon > c->min_live) c->min_live = horizon; }
   return rc;
 }

@@ -1611,9 +1611,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 //     with the next small batch.  kResQuit in the doorbell = leave now (eppk_destroy, and in front of every device-wide wait of the
 //     library's own).
 //   * It holds one CU (16 wavefronts x 128 VGPRs): the persistent pick kernels of the same context size their grids for one CU fewer.
-struct ResidentCtl {            // pinned host memory; the two directions in cache lines of their own
+struct alignas(64) ResidentCtl {   // pinned host memory; the two directions in cache lines of their own
   uint32_t bell;                // host -> device: sequence number of the batch to score (monotonic, never 0), or kResQuit
-  uint32_t n_reqs;              //                 written in front of the doorbell
+  uint32_t n_reqs;              //                 the batch's request count: the upper half of the SAME 8-byte word (one store, one load)
   uint32_t pad0[14];
   uint32_t done;                // device -> host: sequence number of the last batch whose results are in the pinned buffers
   uint32_t state;               //                 kResRunning while the kernel polls, kResExited when it has left
@@ -1640,23 +1640,32 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
   uint32_t staged_gen = 0u;                                 // generation of the tables in LDS (0 = none: the host's generations start at 1)
   for (;;) {
     if (bell_wave) {
-      uint32_t v = seen;
+      // doorbell and request count are ONE aligned 8-byte word, written by the host with one store and read here with one load: a
+      // second read of host memory behind the doorbell would be another ~1.2 us round trip over PCIe
+      uint32_t v = seen, n_now = 0u;
       for (unsigned long long polls = 0; polls < max_idle_polls; ++polls) {
-        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        const unsigned long long w = __hip_atomic_load((const unsigned long long*)&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        n_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
         if (v != seen) break;
         __builtin_amdgcn_s_sleep(2);
       }
-      const uint32_t n_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->n_reqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
       if (lane0) {
         s_seq = v == seen ? kResQuit : v;                   // (idle for too long: leave; the library starts the kernel again when it needs it)
         s_n = n_now;
       }
     }
+#ifdef EPPK_RESIDENT_STAMPS      // measurement build only: 100 MHz timestamps of the stages of a doorbell in the control block's spare words
+    const unsigned long long ts0 = wall_clock64();
+#endif
     __syncthreads();
     const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
     if (seq == kResQuit) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
     __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
+#ifdef EPPK_RESIDENT_STAMPS
+    const unsigned long long ts1 = wall_clock64();
+#endif
     {
       const ResidentArgs* a = args;
       const KChain no_chain{};
@@ -1667,8 +1676,17 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
           no_work);
       staged_gen = gen;
     }
+#ifdef EPPK_RESIDENT_STAMPS
+    const unsigned long long ts2 = wall_clock64();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // this wavefront's picks and scores are in host memory ...
     __syncthreads();
+#ifdef EPPK_RESIDENT_STAMPS
+    if (bell_wave && lane0) {
+      const unsigned long long ts3 = wall_clock64();
+      ctl->pad1[0] = (uint32_t)(ts1 - ts0); ctl->pad1[1] = (uint32_t)(ts2 - ts1); ctl->pad1[2] = (uint32_t)(ts3 - ts2);
+    }
+#endif
     if (bell_wave) {
       if (lane0) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the answer is
     }

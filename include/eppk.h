@@ -188,7 +188,8 @@ int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicte
 int eppk_index_trim_pods(eppk_ctx* ctx, uint32_t cap_per_pod, uint64_t* n_removed);
 /* The same eviction, asynchronous on `stream` (a hipStream_t as void*; NULL = the context's stream) and without the count: what
  * a closed loop (pick -> eppk_index_insert_picks_device -> pick ...) issues on its own stream between two batches, ordered
- * behind the inserts and ahead of the next pick, without draining the pipeline.  eppk_index_size reports the effect. */
+ * behind the inserts and ahead of the next pick, without draining the pipeline.  eppk_index_size reports the effect.  Also valid while
+ * staging sets of the pipelined host path are in flight (eppk_pick_stage_begin, below): ordered behind their picks and updates. */
 int eppk_index_evict_older_device(eppk_ctx* ctx, uint32_t min_epoch, void* stream);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
@@ -256,7 +257,11 @@ int eppk_resident_stats(const eppk_ctx* ctx, uint64_t* batches, uint64_t* starts
  * and only the chained LEARN update could not be enqueued -- begin then succeeds, end delivers the picks, and eppk_launch_status
  * reports EPPK_LAUNCH_LEARN_FAILED.  The update of a LEARN batch may still be running when end returns; every later pick, index
  * entry point and publish of the context orders itself behind it (on the device: no host wait), so a caller may issue them at once.
- * While a set is between begin and end, snapshot publishes and index entry points must still not be issued: its pick reads both. */
+ * While a set is between begin and end, snapshot publishes and index entry points must still not be issued: its pick reads both --
+ * with ONE exception, the ageing step of a router's closed loop: eppk_index_advance_epoch (host side only) followed by
+ * eppk_index_evict_older_device may be issued at any time; the eviction queues ON THE DEVICE behind the pick (and LEARN update) of
+ * every set begun before it and ahead of the pick of every set begun after it, i.e. the index ages in the order of the calls and
+ * the two-set pipeline is never drained for it. */
 #define EPPK_STAGE_SETS 2u
 #define EPPK_PICK_LEARN 1u
 int eppk_pick_stage_buffers(eppk_ctx* ctx, uint32_t set, void** reqs, uint64_t** cand_mask);

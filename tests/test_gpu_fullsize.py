@@ -219,3 +219,49 @@ def test_index_maintenance_right_behind_a_learn_batch(pkg, orc):
             assert pk.index_selfcheck() == 0
             assert pk.index_size() == oix.size()
         assert pk.launch_status() == 0 and pk.index_dropped() == 0
+
+
+@pytest.mark.parametrize("Rs,keep", [(16384, 0), (16384, 1), (512, 1)])
+def test_ageing_while_staging_sets_are_in_flight(pkg, orc, Rs, keep):
+    """The ageing step of a router's closed loop -- eppk_index_advance_epoch + eppk_index_evict_older_device -- issued BETWEEN two begins
+    of the pipelined LEARN path, a set in flight each time (include/eppk.h: the one index entry point allowed there): the eviction must
+    queue behind the pick and the update of every set begun before it and ahead of the pick of every set begun after it, i.e. the
+    index ages in the order of the calls.  The oracle replays exactly that order.  (16k requests: upload + pick_quad_kernel<LEARN>;
+    512: the zero-copy form.)"""
+    wl = pkg.workload.make_workload(5, R=Rs)
+    cores = os.cpu_count() or 1
+    n_batches = 9
+    batches = [wl.reqs] + [pkg.workload.make_requests(wl, 8800 + i) for i in range(1, 4)]
+    with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=wl.B, max_batch=Rs, index_slots=1 << 23) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        oix = orc.OracleIndex()
+        oix.insert(wl.index_hashes, wl.index_pods)
+        bufs = [pk.stage_buffers(0)[0], pk.stage_buffers(1)[0]]
+        expect = {}
+
+        def begin(b):
+            reqs = batches[b % len(batches)]
+            bufs[b & 1][:Rs] = reqs
+            pk.stage_begin(b & 1, Rs, learn=True)
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B, threads=cores)      # the oracle, in the order of the calls
+            oix.insert_picks(reqs, wl.B, op)
+            expect[b] = (op, osc)
+
+        def tick():
+            e = pk.index_advance_epoch()
+            assert oix.advance_epoch() == e
+            if e > keep:
+                pk.index_evict_older_device(e - keep)          # no count, no wait: set (b & 1) is between begin and end
+                oix.evict_older(e - keep)
+
+        begin(0)
+        for b in range(1, n_batches):
+            begin(b)
+            if b % 2 == 0:
+                tick()
+            _same(pk.stage_end((b - 1) & 1), expect.pop(b - 1), f"batch {b - 1}")
+        tick()                                                 # ... and once with the last set still in flight
+        _same(pk.stage_end((n_batches - 1) & 1), expect.pop(n_batches - 1), f"batch {n_batches - 1}")
+        assert pk.index_size() == oix.size()
+        assert pk.index_selfcheck() == 0 and pk.index_dropped() == 0 and pk.launch_status() == 0
