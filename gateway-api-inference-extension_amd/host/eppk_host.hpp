@@ -124,6 +124,10 @@ class Backend {
   // prefix index ageing: tick the epoch that stamps later inserts / drop every hash last stamped before min_epoch
   virtual int IndexAdvanceEpoch(uint32_t* new_epoch) = 0;
   virtual int IndexEvictOlder(uint32_t min_epoch, uint32_t* n_evicted) = 0;
+  // Optional: the same eviction enqueued on the device, without a count and without a wait -- allowed while a pipelined batch is
+  // between StageBegin and StageEnd (eppk_index_evict_older_device: it queues behind that batch's pick and update and ahead of the
+  // next Begin's).  EPPK_ERR_ARG = not offered: the dispatcher then collects the batch in flight first and evicts synchronously.
+  virtual int IndexEvictOlderAsync(uint32_t /*min_epoch*/) { return EPPK_ERR_ARG; }
   virtual std::string LastError() const = 0;
 };
 
@@ -158,6 +162,7 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   int IndexRemovePod(uint32_t pod) override { return eppk_index_remove_pod(ctx_, pod); }
   int IndexAdvanceEpoch(uint32_t* e) override { return eppk_index_advance_epoch(ctx_, e); }
   int IndexEvictOlder(uint32_t min_epoch, uint32_t* n) override { return eppk_index_evict_older(ctx_, min_epoch, n); }
+  int IndexEvictOlderAsync(uint32_t min_epoch) override { return eppk_index_evict_older_device(ctx_, min_epoch, nullptr); }
   std::string LastError() const override { return eppk_last_error(ctx_); }
   eppk_ctx* ctx() { return ctx_; }
 
@@ -337,7 +342,8 @@ class GpuPicker : public EndpointPicker {
   uint64_t fail_opens() const { return fail_open_count_.load(); }
   uint64_t largest_batch() const { return largest_batch_.load(); }
   uint64_t learn_drops() const { return learn_drops_.load(); }
-  uint64_t evicted() const { return evicted_.load(); }
+  uint64_t evicted() const { return evicted_.load(); }                    // hashes dropped by SYNCHRONOUS evictions (the device-side form has no count)
+  uint64_t evictions_async() const { return evictions_async_.load(); }   // evictions queued on the device behind a batch in flight
 
  private:
   struct Snapshot {
@@ -581,14 +587,28 @@ class GpuPicker : public EndpointPicker {
             next_set ^= 1u;
             if (prev.active) { bg.unlock(); Collect(prev, picks, scores); bg.lock(); }
           }
-          // ageing between two batches (the index entry points must not run while a set is in flight: collect first)
+          // Ageing between two batches.  With a batch in flight: the epoch tick is host side only and the eviction goes onto the
+          // device behind that batch (IndexEvictOlderAsync: no count, the pipeline keeps running); a backend without it -- and the
+          // synchronous form, which reports how many hashes went -- needs the pipeline empty: collect first.
           if (opt_.index_epoch_interval.count() > 0 && std::chrono::steady_clock::now() >= next_tick) {
-            if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }
             next_tick = std::chrono::steady_clock::now() + opt_.index_epoch_interval;
             uint32_t epoch = 0, gone = 0;
-            if (be_->IndexAdvanceEpoch(&epoch) == EPPK_OK && epoch > opt_.index_keep_epochs &&
-                be_->IndexEvictOlder(epoch - opt_.index_keep_epochs, &gone) == EPPK_OK)
-              evicted_.fetch_add(gone, std::memory_order_relaxed);
+            bool ticked = false, done = false;
+            if (fly.active) {
+              ticked = be_->IndexAdvanceEpoch(&epoch) == EPPK_OK;
+              if (ticked && epoch > opt_.index_keep_epochs) {
+                done = be_->IndexEvictOlderAsync(epoch - opt_.index_keep_epochs) == EPPK_OK;
+                if (done) evictions_async_.fetch_add(1, std::memory_order_relaxed);
+              } else {
+                done = ticked;
+              }
+            }
+            if (!done) {
+              if (fly.active) { bg.unlock(); Collect(fly, picks, scores); bg.lock(); }
+              if ((ticked || be_->IndexAdvanceEpoch(&epoch) == EPPK_OK) && epoch > opt_.index_keep_epochs &&
+                  be_->IndexEvictOlder(epoch - opt_.index_keep_epochs, &gone) == EPPK_OK)
+                evicted_.fetch_add(gone, std::memory_order_relaxed);
+            }
           }
         }
       }
@@ -614,7 +634,7 @@ class GpuPicker : public EndpointPicker {
   std::vector<uint32_t> free_slots_;
   uint32_t n_slots_ = 0;
   bool stop_ = false;
-  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0}, evicted_{0};
+  std::atomic<uint64_t> batches_{0}, fail_open_count_{0}, largest_batch_{0}, learn_drops_{0}, evicted_{0}, evictions_async_{0};
   std::thread th_;  // last member: started after everything above is constructed
 };
 

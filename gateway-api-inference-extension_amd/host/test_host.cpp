@@ -82,6 +82,25 @@ class FakeBackend : public Backend {
   std::atomic<bool> fail{false};
 };
 
+// ... with the pipelined form (two staging sets) and the device-side eviction: records the ORDER of the backend calls
+class PipelinedFake : public FakeBackend {
+ public:
+  void* StageRows(uint32_t set) override { return buf[set & 1u].data(); }
+  int StageBegin(uint32_t set, uint32_t n, bool) override { log("B" + std::to_string(set)); n_[set & 1u] = n; return EPPK_OK; }
+  int StageEnd(uint32_t set, int32_t* picks, double* scores) override {
+    log("E" + std::to_string(set));
+    return PickBatch(nullptr, n_[set & 1u], nullptr, picks, scores);
+  }
+  int IndexAdvanceEpoch(uint32_t* e) override { log("T"); return FakeBackend::IndexAdvanceEpoch(e); }
+  int IndexEvictOlder(uint32_t m, uint32_t* n) override { log("S"); return FakeBackend::IndexEvictOlder(m, n); }
+  int IndexEvictOlderAsync(uint32_t m) override { log("A" + std::to_string(m)); return EPPK_OK; }
+  void log(const std::string& op) { std::lock_guard<std::mutex> g(log_mu); ops.push_back(op); }
+  std::mutex log_mu;
+  std::vector<std::string> ops;
+  std::vector<unsigned char> buf[2] = {std::vector<unsigned char>(1 << 16), std::vector<unsigned char>(1 << 16)};
+  uint32_t n_[2] = {0, 0};
+};
+
 static std::vector<Endpoint> make_endpoints(int n) {
   std::vector<Endpoint> v;
   for (int i = 0; i < n; ++i) {
@@ -317,6 +336,34 @@ static int run_cpu() {
     CHECK(fk->epoch.load() == 5u);
     CHECK(fk->evict_calls.size() == 3 && fk->evict_calls[0] == 1u && fk->evict_calls[1] == 2u && fk->evict_calls[2] == 3u);
     CHECK(gp.evicted() == 9u);
+  }
+  {  // ... and with a pipelined backend that offers the device-side eviction: the tick lands while a batch is between Begin and End
+     // (no collect in front of it), the eviction is the asynchronous one, and the synchronous form is never called
+    GpuPickerOptions opt;
+    opt.max_pods = 8; opt.max_blocks = 4; opt.max_batch = 4;
+    opt.index_epoch_interval = std::chrono::microseconds(1);
+    opt.index_keep_epochs = 1;
+    auto fk = new PipelinedFake();
+    GpuPicker gp(std::unique_ptr<Backend>(fk), opt);
+    auto eps = make_endpoints(2);
+    std::vector<eppk_pod_row> rows(2);
+    std::memset(rows.data(), 0, rows.size() * sizeof(eppk_pod_row));
+    CHECK(gp.PublishSnapshot(eps, rows, {}, 1).ok());
+    std::vector<const Endpoint*> c{&eps[0], &eps[1]};
+    PickResult r;
+    for (int i = 0; i < 4; ++i) {
+      CHECK(gp.Pick({}, c, &r).ok() && !r.endpoint.empty());
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    std::lock_guard<std::mutex> g(fk->log_mu);
+    int in_flight = 0, async = 0;
+    for (const std::string& op : fk->ops) {
+      if (op[0] == 'B') ++in_flight;
+      if (op[0] == 'E') --in_flight;
+      CHECK(op[0] != 'S');                                   // never the synchronous eviction
+      if (op[0] == 'A') { ++async; CHECK(in_flight >= 1); }   // ... and the asynchronous one with a batch in flight
+    }
+    CHECK(async >= 2 && gp.evictions_async() == (uint64_t)async && gp.evicted() == 0u);
   }
   return 0;
 }
