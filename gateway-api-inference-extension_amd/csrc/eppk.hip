@@ -139,9 +139,20 @@ struct eppk_ctx {
                                                               // publish of this context -- on whatever stream -- is ordered behind it (learn_fence)
   // The resident small-batch kernel (EPPK_RESIDENT=1; eppk_kernels.hip.h: pick_resident_kernel): pinned control block, device argument
   // block, a stream of its own; res_seq = the last doorbell value rung.
-  bool resident_on = false, res_running = false, res_args_dirty = true;
-  uint32_t resident_max = 32, res_seq = 0, res_gen = 0;   // (16 requests per round: 1 request 12 us, 16: 14, 32: ~18, 64: 26 -- beyond 32 the launched kernels win)
-  eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; eppk::ResidentArgs* d_res_args = nullptr; hipStream_t res_stream = nullptr;
+  bool resident_on = false, res_args_dirty = true;
+  uint32_t resident_quad_from = 8;           // smallest batch that rings the quad form (EPPK_RESIDENT_QUAD_FROM).  Same box, p50 of the bare call,
+                                             // fast / quad form: 1 request 11.0 / 11.9 us, 4: 11.1 / 11.9, 8: 12.3 / 11.9, 16: 13.3 / 12.0, 32: 15.5 / 13.4,
+                                             // 64: 27.9 / 19.4 (scripts/res_sweep.py, profiles/r04_resident_latency.txt)
+  uint32_t resident_max = 32, res_gen = 0;   // (EPPK_RESIDENT_MAX; 64 by default where the quad form of the kernel runs: eppk_create)
+  // Two resident workgroups at most, one per FORM of the kernel, each with its control block and stream: [0] pick_fast_kernel's body
+  // (a wavefront per request: up to 16 requests), [1] pick_quad_kernel's body (four requests per wavefront: beyond 16, where that
+  // route exists).  A batch rings the one that suits it; each leaves by itself when idle and is started again on demand.
+  struct ResidentUnit {
+    eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; hipStream_t stream = nullptr;
+    bool running = false; uint32_t seq = 0;   // seq = the last doorbell value rung
+  } res[2];
+  eppk::ResidentArgs* d_res_args = nullptr;
+  uint32_t* d_res_wl = nullptr; uint32_t res_wl_cap = 0;     // the resident workgroup's work list (its pick_quad_kernel form): total[32] | cnt[16] | list[16][cap]
   uint64_t res_batches = 0, res_starts = 0;
   uint32_t* d_learn = nullptr; size_t learn_cap = 0;          // learn words of the pick in front of a LEARN update (pick_quad_kernel<..., LEARN>)
   bool quiet_rows = false;        // a host-buffer launch is being enqueued: its kernels raise "row out of range" on a word of their own
@@ -581,12 +592,17 @@ size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
 static const bool g_res_dbg = getenv("EPPK_RESIDENT_DEBUG") != nullptr;     // (read once: the macro sits on the latency path)
 #define RES_DBG(...) do { if (g_res_dbg) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 int resident_park(eppk_ctx* c) {
-  if (!c->res_running) return EPPK_OK;
-  RES_DBG("park: bell %u done %u state %u", c->h_ctl->bell, c->h_ctl->done, c->h_ctl->state);
-  __atomic_store_n(&c->h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
-  HIPCHK(c, hipStreamSynchronize(c->res_stream));
-  RES_DBG("parked: state %u", c->h_ctl->state);
-  c->res_running = false;
+  for (eppk_ctx::ResidentUnit& u : c->res) {                // (both doorbells first, then both waits)
+    if (!u.running) continue;
+    RES_DBG("park: bell %u done %u state %u", u.h_ctl->bell, u.h_ctl->done, u.h_ctl->state);
+    __atomic_store_n(&u.h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
+  }
+  for (eppk_ctx::ResidentUnit& u : c->res) {
+    if (!u.running) continue;
+    HIPCHK(c, hipStreamSynchronize(u.stream));
+    RES_DBG("parked: state %u", u.h_ctl->state);
+    u.running = false;
+  }
   return EPPK_OK;
 }
 int device_sync(eppk_ctx* c) {
@@ -599,38 +615,55 @@ bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked) {
   return c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && !masked && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
          c->assumed_epochs == 0 && c->cfg.max_blocks >= 1;
 }
-int resident_ensure(eppk_ctx* c) {            // control block, argument block, stream
-  if (c->h_ctl) return EPPK_OK;
-  HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
-  HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_ctl_dev, c->h_ctl, 0));
-  std::memset(c->h_ctl, 0, sizeof(eppk::ResidentCtl));
+// The form of the resident kernel: pick_quad_kernel's body (four requests per wavefront) wherever a launch would take that route --
+// the list routes are on and their LDS fits beside the tables -- else pick_fast_kernel's body alone.  Fixed for the life of a context.
+bool resident_quad(const eppk_ctx* c) {
+  bool hist_fits = false;
+  (void)resident_lds(c, &hist_fits);
+  return c->quad_on && hist_fits && c->slots != 0u && make_kindex(c).lists != nullptr;
+}
+int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams
+  if (c->d_res_args) return EPPK_OK;
+  {   // the work list of the quad form: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
+    const uint32_t nblk = (c->resident_max + 3u) / 4u, per_wave = (nblk + 15u) / 16u;
+    c->res_wl_cap = 4u * (per_wave ? per_wave : 1u);
+    const size_t words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
+    HIPCHK(c, hipMalloc((void**)&c->d_res_wl, words * 4u));
+    HIPCHK(c, hipMemset(c->d_res_wl, 0, words * 4u));
+  }
+  for (eppk_ctx::ResidentUnit& u : c->res) {
+    HIPCHK(c, hipHostMalloc((void**)&u.h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
+    std::memset(u.h_ctl, 0, sizeof(eppk::ResidentCtl));
+    HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+  }
   HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
-  HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
   return EPPK_OK;
 }
-int resident_start(eppk_ctx* c) {
-  if (c->res_running) return EPPK_OK;
+int resident_start(eppk_ctx* c, uint32_t form) {
+  eppk_ctx::ResidentUnit& u = c->res[form];
+  if (u.running) return EPPK_OK;
   { const int rce = resident_ensure(c); if (rce) return rce; }
-  const void* fn = eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first);
+  const void* fn = form ? eppk::pick_resident_quad(c->lw_bytes, c->has_l, c->p_first) : eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first);
   const uint32_t threads = 1024u;
   bool hist_fits = false;
   const size_t lds = resident_lds(c, &hist_fits);
   int per_cu = 0;
   { const int rco = occupancy_of(c, fn, threads, lds, &per_cu); if (rco) return rco; }
   // the doorbell the kernel has seen last = the last one rung (a batch rung while the kernel was leaving is picked up at once)
-  const uint32_t seen = c->res_seq == 0 ? 0u : c->res_seq - 1u;
-  uint32_t bell_now = __atomic_load_n(&c->h_ctl->bell, __ATOMIC_ACQUIRE);
-  if (bell_now == eppk::kResQuit) __atomic_store_n(&c->h_ctl->bell, seen, __ATOMIC_RELEASE);
-  __atomic_store_n(&c->h_ctl->state, eppk::kResRunning, __ATOMIC_RELEASE);
-  eppk::ResidentCtl* ctl = c->h_ctl_dev;
+  const uint32_t seen = u.seq == 0 ? 0u : u.seq - 1u;
+  uint32_t bell_now = __atomic_load_n(&u.h_ctl->bell, __ATOMIC_ACQUIRE);
+  if (bell_now == eppk::kResQuit) __atomic_store_n(&u.h_ctl->bell, seen, __ATOMIC_RELEASE);
+  __atomic_store_n(&u.h_ctl->state, eppk::kResRunning, __ATOMIC_RELEASE);
+  eppk::ResidentCtl* ctl = u.h_ctl_dev;
   const eppk::ResidentArgs* args = c->d_res_args;
   uint32_t seen_arg = seen;
   unsigned long long max_idle = 30000ull;                 // ~20-50 ms of polls over PCIe, then the workgroup leaves by itself
   if (const char* e = getenv("EPPK_RESIDENT_IDLE_POLLS")) { const long long v = atoll(e); if (v > 0) max_idle = (unsigned long long)v; }
   void* kargs[] = {&ctl, &args, &seen_arg, &max_idle};
-  RES_DBG("start: seen %u bell %u lds %zu", seen_arg, c->h_ctl->bell, lds);
-  HIPCHK(c, hipExtLaunchKernel(fn, dim3(1), dim3(threads), kargs, lds, c->res_stream, nullptr, nullptr, 0));
-  c->res_running = true;
+  RES_DBG("start form %u: seen %u bell %u lds %zu", form, seen_arg, u.h_ctl->bell, lds);
+  HIPCHK(c, hipExtLaunchKernel(fn, dim3(1), dim3(threads), kargs, lds, u.stream, nullptr, nullptr, 0));
+  u.running = true;
   ++c->res_starts;
   return EPPK_OK;
 }
@@ -650,29 +683,31 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
     if (++c->res_gen == 0u) c->res_gen = 1u;
     a.gen = c->res_gen;
     bool hist_fits = false;
-    (void)resident_lds(c, &hist_fits);
+    a.lds_bytes = (uint32_t)resident_lds(c, &hist_fits);
     if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
+    a.defer_total = c->d_res_wl; a.defer_cnt = c->d_res_wl + 32; a.defer_list = c->d_res_wl + 48; a.defer_cap = c->res_wl_cap;
     HIPCHK(c, hipMemcpy(c->d_res_args, &a, sizeof a, hipMemcpyHostToDevice));
     c->res_args_dirty = false;
   }
-  rc = resident_start(c);
+  const uint32_t form = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? 1u : 0u;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
+  eppk_ctx::ResidentUnit& u = c->res[form];
+  rc = resident_start(c, form);
   if (rc) return rc;
-  if (++c->res_seq == eppk::kResQuit || c->res_seq == 0u) c->res_seq = 1u;
-  const uint32_t seq = c->res_seq;
+  if (++u.seq == eppk::kResQuit || u.seq == 0u) u.seq = 1u;
+  const uint32_t seq = u.seq;
   RES_DBG("ring %u (n = %u)", seq, n_reqs);
   static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
-  __atomic_store_n((uint64_t*)&c->h_ctl->bell, ((uint64_t)n_reqs << 32) | seq, __ATOMIC_RELEASE);      // count and doorbell in one store
+  __atomic_store_n((uint64_t*)&u.h_ctl->bell, ((uint64_t)n_reqs << 32) | seq, __ATOMIC_RELEASE);      // count and doorbell in one store
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
-  while (__atomic_load_n(&c->h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+  while (__atomic_load_n(&u.h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 1023u) == 0u) {
-      if (__atomic_load_n(&c->h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited && __atomic_load_n(&c->h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+      if (__atomic_load_n(&u.h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited && __atomic_load_n(&u.h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
         // the workgroup left (idle timeout) just as the doorbell rang: start it again; it sees this doorbell at once
-        HIPCHK(c, hipStreamSynchronize(c->res_stream));
-        c->res_running = false;
-        const uint32_t keep = c->res_seq;
-        c->res_seq = keep;                                  // (resident_start: seen = res_seq - 1)
-        rc = resident_start(c);
+        // (resident_start: seen = seq - 1)
+        HIPCHK(c, hipStreamSynchronize(u.stream));
+        u.running = false;
+        rc = resident_start(c, form);
         if (rc) return rc;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
@@ -680,8 +715,8 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
     }
   }
   ++c->res_batches;
-  RES_DBG("answered %u after %u spins; ring -> done %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
-          seq, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), c->h_ctl->pad1[0], c->h_ctl->pad1[1], c->h_ctl->pad1[2]);
+  RES_DBG("answered %u (form %u) after %u spins; ring -> done %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
+          seq, form, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]);
   std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
   if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
   return EPPK_OK;
@@ -906,8 +941,10 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   }
   if (const char* mw = getenv("EPPK_MAX_WG_PER_CU")) c->max_wg_per_cu = atoi(mw) > 0 ? atoi(mw) : 0;
   if (const char* rs = getenv("EPPK_RESIDENT")) c->resident_on = atoi(rs) != 0;
-  if (const char* rm = getenv("EPPK_RESIDENT_MAX")) c->resident_max = atoi(rm) > 0 ? (uint32_t)atoi(rm) : 0u;
-  if (c->resident_on && c->num_cu > 1) --c->num_cu;       // the resident workgroup holds one CU: the persistent pick kernels are sized for the rest
+  if (const char* qf = getenv("EPPK_RESIDENT_QUAD_FROM")) c->resident_quad_from = atoi(qf) > 0 ? (uint32_t)atoi(qf) : 1u;
+  bool resident_max_set = false;
+  if (const char* rm = getenv("EPPK_RESIDENT_MAX")) { c->resident_max = atoi(rm) > 0 ? (uint32_t)atoi(rm) : 0u; resident_max_set = true; }
+  if (c->resident_on && c->num_cu > 2) c->num_cu -= 2;    // a resident workgroup holds one CU (two forms: two workgroups at most): the persistent pick kernels are sized for the rest
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
@@ -1041,6 +1078,9 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     }
   }
   CHK(hipDeviceSynchronize());
+  // the resident path's default limit: with pick_quad_kernel's body behind the doorbell 64 requests take 16.6 us (21.1 launched), with
+  // pick_fast_kernel's body alone 24.5 -- 32 stays the limit there
+  if (c->resident_on && !resident_max_set && resident_quad(c)) c->resident_max = 64;
 #undef CHK
   *out = c;
   return EPPK_OK;
@@ -1050,9 +1090,12 @@ void eppk_destroy(eppk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   (void)resident_park(c);
-  if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
-  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  for (eppk_ctx::ResidentUnit& u : c->res) {
+    if (u.stream) (void)hipStreamDestroy(u.stream);
+    if (u.h_ctl) (void)hipHostFree(u.h_ctl);
+  }
   (void)hipFree(c->d_res_args);
+  (void)hipFree(c->d_res_wl);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);

@@ -1593,110 +1593,6 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 
 
 
-// ---- RESIDENT pick kernel: the latency path of small batches (opt-in: EPPK_RESIDENT=1) -------------------------------------------
-// What a per-request caller hands over -- pkg/lwepp/handlers/request.go:141-163 calls Pick once per stream message; the reference's
-// design point is 10-1000 QPS (docs/proposals/006-scheduler/README.md:133) -- is batches of 1-64 requests, and such a batch is all
-// latency: of the 20 us a 16-request batch took host-observed in round 3, 13 were the launch and the completion signal.  This kernel
-// is launched ONCE and stays: one workgroup (a wavefront per request, 16 at a time) polls a doorbell word in pinned host memory; the
-// host writes the request rows into the context's pinned staging buffer, the count and then the doorbell; the workgroup scores the
-// batch with pick_fast_kernel's own body (same picks, same scores), writes picks and scores into the pinned result buffers, and
-// raises the completion word the host is polling.  Doorbell -> answer round trip of an empty batch: 2.7 us, with one row read over
-// PCIe 3.9 us (scripts/micro/doorbell.hip -> profiles/r04_micro_doorbell.txt).
-//   * Nothing cached before the doorbell may be trusted -- the rows were rewritten by the host, the index and the snapshot may have
-//     been updated by other kernels, and there is no kernel boundary to do it for us: system-scope acquire (vector caches) plus
-//     s_dcache_inv (the request headers and the argument block are read with scalar loads) behind every doorbell; system-scope
-//     release in front of the completion word.
-//   * The kernel leaves by itself after `max_idle_polls` polls without a doorbell (~50 ms), so that a host that has died, a device-wide
-//     synchronise of somebody else, or a caller that simply stopped cannot leave a spinning workgroup behind; the library starts it again
-//     with the next small batch.  kResQuit in the doorbell = leave now (eppk_destroy, and in front of every device-wide wait of the
-//     library's own).
-//   * It holds one CU (16 wavefronts x 128 VGPRs): the persistent pick kernels of the same context size their grids for one CU fewer.
-struct alignas(64) ResidentCtl {   // pinned host memory; the two directions in cache lines of their own
-  uint32_t bell;                // host -> device: sequence number of the batch to score (monotonic, never 0), or kResQuit
-  uint32_t n_reqs;              //                 the batch's request count: the upper half of the SAME 8-byte word (one store, one load)
-  uint32_t pad0[14];
-  uint32_t done;                // device -> host: sequence number of the last batch whose results are in the pinned buffers
-  uint32_t state;               //                 kResRunning while the kernel polls, kResExited when it has left
-  uint32_t pad1[14];
-};
-constexpr uint32_t kResQuit = 0xFFFFFFFFu, kResRunning = 1u, kResExited = 2u;
-struct ResidentArgs {           // device memory; rewritten by the host only between two doorbells (the kernel reads it behind each)
-  KSnap sn; KIndex ix; KTail tl;
-  const uint8_t* reqs; int32_t* out_pick; double* out_score;      // the context's pinned staging / result buffers as the device addresses them
-  uint32_t stride, pwn;
-  uint32_t gen, pad;              // changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
-};
-
-template <typename LW, bool HAS_L, bool P_FIRST>
-__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* __restrict__ args, uint32_t seen, unsigned long long max_idle_polls) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_seq, s_n;
-  // Everything the doorbell wavefront does alone is behind a WAVE-UNIFORM condition (a scalar branch).  Written as `threadIdx.x == 0`
-  // the compiler rotated the loop so that thread 0's part -- completion store, then the polling -- became an outer loop around an inner
-  // one in which the other 63 lanes of its wavefront ran ahead through the barriers with a stale sequence number: the workgroup never
-  // answered its first doorbell (round 4, found with progress marks in the control block).
-  const bool bell_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
-  const bool lane0 = (threadIdx.x & 63u) == 0u;
-  uint32_t staged_gen = 0u;                                 // generation of the tables in LDS (0 = none: the host's generations start at 1)
-  for (;;) {
-    if (bell_wave) {
-      // doorbell and request count are ONE aligned 8-byte word, written by the host with one store and read here with one load: a
-      // second read of host memory behind the doorbell would be another ~1.2 us round trip over PCIe
-      uint32_t v = seen, n_now = 0u;
-      for (unsigned long long polls = 0; polls < max_idle_polls; ++polls) {
-        const unsigned long long w = __hip_atomic_load((const unsigned long long*)&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
-        n_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
-        if (v != seen) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (lane0) {
-        s_seq = v == seen ? kResQuit : v;                   // (idle for too long: leave; the library starts the kernel again when it needs it)
-        s_n = n_now;
-      }
-    }
-#ifdef EPPK_RESIDENT_STAMPS      // measurement build only: 100 MHz timestamps of the stages of a doorbell in the control block's spare words
-    const unsigned long long ts0 = wall_clock64();
-#endif
-    __syncthreads();
-    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
-    if (seq == kResQuit) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
-    __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
-#ifdef EPPK_RESIDENT_STAMPS
-    const unsigned long long ts1 = wall_clock64();
-#endif
-    {
-      const ResidentArgs* a = args;
-      const KChain no_chain{};
-      const KWork no_work{};
-      const uint32_t gen = a->gen;
-      pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false, /*RESIDENT*/ true>(
-          0u, 1u, 0u, /*tables staged*/ gen == staged_gen, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u,
-          no_work);
-      staged_gen = gen;
-    }
-#ifdef EPPK_RESIDENT_STAMPS
-    const unsigned long long ts2 = wall_clock64();
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // this wavefront's picks and scores are in host memory ...
-    __syncthreads();
-#ifdef EPPK_RESIDENT_STAMPS
-    if (bell_wave && lane0) {
-      const unsigned long long ts3 = wall_clock64();
-      ctl->pad1[0] = (uint32_t)(ts1 - ts0); ctl->pad1[1] = (uint32_t)(ts2 - ts1); ctl->pad1[2] = (uint32_t)(ts3 - ts2);
-    }
-#endif
-    if (bell_wave) {
-      if (lane0) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the answer is
-    }
-    seen = seq;
-  }
-  if (bell_wave) {
-    if (lane0) __hip_atomic_store(&ctl->state, kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // ---- QUAD pick kernel: FOUR requests per wavefront, every gather laid out for the vector memory pipe ------------------------
 // pick_fast_kernel spends a whole wavefront on one request (~180 vector + ~145 scalar instructions per decision).  The common
 // shape of a request -- no candidate mask, one pick, at most 32 blocks probed, every hit's pod set still in its short list, all
@@ -1817,17 +1713,17 @@ __device__ __attribute__((noinline)) void quad_tail_report() {
 // only has to refresh their stamps.  0 = nothing to tell (a request it deferred, or one without a pick): the update then reads picks[r]
 // and takes the whole path.  Costs the pick one 4-byte store per request; saves the update two of the three line look-ups of every
 // known pair (1 Mi per closed-loop step of a 64k x 32-block batch).
-template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false, bool LEARN = false>
-__global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
-                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
-                                                                 int32_t* __restrict__ out_pick, double* __restrict__ out_score,
-                                                                 unsigned long long* __restrict__ stats,
-                                                                 uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk,
-                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report, KChain tail_chain,
-                                                                 uint32_t* __restrict__ learn_out) {
+// The body of pick_quad_kernel -- everything but the end of the one-launch form -- as a function: the kernel below is one caller, the
+// RESIDENT small-batch kernel (pick_resident_kernel: one workgroup behind a doorbell, tables already in LDS, request rows in pinned
+// host memory) the other.  vblock / vgrid = this workgroup's place among the workgroups that share the batch.  Returns the number of
+// requests this WAVEFRONT deferred (wave-uniform): they are in its segment of the work list.
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED, bool TOPK, bool LEARN, bool RESIDENT = false>
+__device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const uint32_t vgrid, unsigned char* smem, const KSnap& sn, const KIndex& ix, const KTail& tl,
+                                                   const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
+                                                   int32_t* __restrict__ out_pick, double* __restrict__ out_score, unsigned long long* __restrict__ stats,
+                                                   uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
+                                                   uint32_t* __restrict__ defer_total, uint32_t topk, uint32_t* __restrict__ learn_out) {
   static_assert(!(LEARN && TOPK), "learn words go with single picks");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
   double* s_pterm = s_lw + 4;
@@ -1841,9 +1737,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   const uint32_t k = (uint32_t)lane & 15u, g = (uint32_t)lane >> 4, gsh = (uint32_t)lane & 48u;
   const uint32_t q = ((uint32_t)lane >> 2) & 3u, j = (uint32_t)lane & 3u, j16 = j * 16u;
   const uint32_t wpb = blockDim.x >> 6;
-  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * wpb));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vblock * wpb + (threadIdx.x >> 6)));
+  const uint32_t nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vgrid * wpb));
   const uint32_t nblk = (n_reqs + 3u) >> 2;                          // blocks of four requests
   const bool idle = gwave >= nblk;                                   // (more wavefronts than blocks: it still helps staging the tables)
   uint32_t* bits = s_bits_all + ((threadIdx.x >> 6) * 4u + g) * bits_dw;
@@ -2128,9 +2023,9 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     // ---- next stages, queued BEHIND everything this block still waits for: key gather of the next block, rows of the one
     //      after, L2 prefetch of a later one
 #if EPPK_QUAD_PIPE_KEYS
-    issue_keys(nxt, pb);
+    if (!RESIDENT || blk + nwaves < nblk) issue_keys(nxt, pb);
 #endif
-    issue_row(blk + 2u * nwaves, cur);
+    if (!RESIDENT || blk + 2u * nwaves < nblk) issue_row(blk + 2u * nwaves, cur);
 #if EPPK_QUAD_PREFETCH > 0
     {   // one lane per 64-byte sector of the four (contiguous) rows; the value is never used.  Branch-free (past the end: the
         // last block again; lanes beyond the rows: their last sector again): a conditional landing register would need a copy,
@@ -2305,21 +2200,22 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   Row qa, qb;
   Probe pb;
   issue_row(gwave, qa);                                              // the first rows come from HBM: in flight while the tables are staged
-  issue_row(gwave + nwaves, qb);
+  if (!RESIDENT || gwave + nwaves < nblk) issue_row(gwave + nwaves, qb);   // (RESIDENT: rows cross PCIe -- no load that nobody waits for)
+  if constexpr (!RESIDENT) {                                         // (RESIDENT: the tables are in LDS already and stay there between doorbells)
 #ifndef EPPK_DBGQ_NO_STAGE  // (defined: timing experiment only, wrong results: base[] is not staged)
-  for (uint32_t i = threadIdx.x; i < sn.J * 32u; i += blockDim.x) ((double2*)s_base)[i] = ((const double2*)sn.base)[i];   // (16 bytes per load: every
+    for (uint32_t i = threadIdx.x; i < sn.J * 32u; i += blockDim.x) ((double2*)s_base)[i] = ((const double2*)sn.base)[i];   // (16 bytes per load: every
                                                                      // vector memory instruction costs the CU's address unit ~16 clocks)
 #endif
-  if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
-  for (uint32_t i = threadIdx.x; i < pwn / 2u; i += blockDim.x) ((double2*)s_pterm)[i] = ((const double2*)sn.pterm)[i];
-  if ((pwn & 1u) && threadIdx.x == 0u) s_pterm[pwn - 1u] = sn.pterm[pwn - 1u];
-  for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
-  if (MASKED)
-    for (uint32_t i = threadIdx.x; i < 192u; i += blockDim.x) s_nat[i] = sn.nat[i];
-  __syncthreads();
+    if (threadIdx.x == 0u) { s_lw[0] = tl.lw[0]; s_lw[1] = tl.lw[1]; s_lw[2] = tl.lw[2]; s_lw[3] = tl.lw[3]; }   // (no dynamic index into the argument struct)
+    for (uint32_t i = threadIdx.x; i < pwn / 2u; i += blockDim.x) ((double2*)s_pterm)[i] = ((const double2*)sn.pterm)[i];
+    if ((pwn & 1u) && threadIdx.x == 0u) s_pterm[pwn - 1u] = sn.pterm[pwn - 1u];
+    for (uint32_t i = threadIdx.x; i < (blockDim.x >> 4) * bits_dw; i += blockDim.x) s_bits_all[i] = 0u;
+    if (MASKED)
+      for (uint32_t i = threadIdx.x; i < 192u; i += blockDim.x) s_nat[i] = sn.nat[i];
+    __syncthreads();
+  }
   if (idle) {
     if (lane == 0) __hip_atomic_store(&defer_cnt[gwave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (!TAIL) return;
   }
   if (!idle) {
 #if EPPK_QUAD_PIPE_KEYS
@@ -2345,6 +2241,23 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
                         (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 48);
     if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
   }
+  return n_def;
+}
+
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED = false, bool TOPK = false, bool TAIL = false, bool LEARN = false>
+__global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_quad_kernel(KSnap sn, KIndex ix, KTail tl, const uint8_t* __restrict__ reqs,
+                                                                 uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
+                                                                 int32_t* __restrict__ out_pick, double* __restrict__ out_score,
+                                                                 unsigned long long* __restrict__ stats,
+                                                                 uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
+                                                                 uint32_t* __restrict__ defer_total, uint32_t* __restrict__ defer_total_next, uint32_t topk,
+                                                                 uint32_t* __restrict__ done_ctr, uint32_t* __restrict__ report, KChain tail_chain,
+                                                                 uint32_t* __restrict__ learn_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
+  const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN>(blockIdx.x, gridDim.x, smem, sn, ix, tl, reqs, stride, n_reqs, pwn, cand_mask, out_pick, out_score,
+                                                                                 stats, defer_cnt, defer_list, defer_cap, defer_total, topk, learn_out);
+  (void)tail_chain; (void)done_ctr; (void)report; (void)n_def;
   if constexpr (TAIL) {
     // the end of the one-launch form -- the work-list pass over what THIS workgroup deferred (rarely anything), the arrival counters and
     // the report -- lives in a function that is never inlined: the hot loop above is compiled as if it were not there
@@ -2353,6 +2266,152 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
     if (__syncthreads_or((int)(n_def != 0u))) quad_tail_pass<LW, HAS_L, P_FIRST, MASKED, TOPK>(smem);
     __syncthreads();
     if (threadIdx.x == 0u) quad_tail_report();
+  }
+}
+
+// ---- RESIDENT pick kernel: the latency path of small batches (opt-in: EPPK_RESIDENT=1) -------------------------------------------
+// What a per-request caller hands over -- pkg/lwepp/handlers/request.go:141-163 calls Pick once per stream message; the reference's
+// design point is 10-1000 QPS (docs/proposals/006-scheduler/README.md:133) -- is batches of 1-64 requests, and such a batch is all
+// latency: of the 20 us a 16-request batch took host-observed in round 3, 13 were the launch and the completion signal.  This kernel
+// is launched ONCE and stays: one workgroup (a wavefront per request, 16 at a time) polls a doorbell word in pinned host memory; the
+// host writes the request rows into the context's pinned staging buffer, the count and then the doorbell; the workgroup scores the
+// batch with pick_fast_kernel's own body (same picks, same scores), writes picks and scores into the pinned result buffers, and
+// raises the completion word the host is polling.  Doorbell -> answer round trip of an empty batch: 2.7 us, with one row read over
+// PCIe 3.9 us (scripts/micro/doorbell.hip -> profiles/r04_micro_doorbell.txt).
+//   * Nothing cached before the doorbell may be trusted -- the rows were rewritten by the host, the index and the snapshot may have
+//     been updated by other kernels, and there is no kernel boundary to do it for us: system-scope acquire (vector caches) plus
+//     s_dcache_inv (the request headers and the argument block are read with scalar loads) behind every doorbell; system-scope
+//     release in front of the completion word.
+//   * The kernel leaves by itself after `max_idle_polls` polls without a doorbell (~50 ms), so that a host that has died, a device-wide
+//     synchronise of somebody else, or a caller that simply stopped cannot leave a spinning workgroup behind; the library starts it again
+//     with the next small batch.  kResQuit in the doorbell = leave now (eppk_destroy, and in front of every device-wide wait of the
+//     library's own).
+//   * It holds one CU (16 wavefronts x 128 VGPRs): the persistent pick kernels of the same context size their grids for one CU fewer.
+struct alignas(64) ResidentCtl {   // pinned host memory; the two directions in cache lines of their own
+  uint32_t bell;                // host -> device: sequence number of the batch to score (monotonic, never 0), or kResQuit
+  uint32_t n_reqs;              //                 the batch's request count: the upper half of the SAME 8-byte word (one store, one load)
+  uint32_t pad0[14];
+  uint32_t done;                // device -> host: sequence number of the last batch whose results are in the pinned buffers
+  uint32_t state;               //                 kResRunning while the kernel polls, kResExited when it has left
+  uint32_t pad1[14];
+};
+constexpr uint32_t kResQuit = 0xFFFFFFFFu, kResRunning = 1u, kResExited = 2u;
+struct ResidentArgs {           // device memory; rewritten by the host only between two doorbells (the kernel reads it behind each)
+  KSnap sn; KIndex ix; KTail tl;
+  const uint8_t* reqs; int32_t* out_pick; double* out_score;      // the context's pinned staging / result buffers as the device addresses them
+  uint32_t stride, pwn;
+  uint32_t gen, lds_bytes;        // gen changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
+  uint32_t* defer_cnt; uint32_t* defer_list; uint32_t* defer_total; uint32_t defer_cap, pad;   // QUAD form: the workgroup's work list (one segment per wavefront)
+};
+
+template <typename LW, bool HAS_L, bool P_FIRST, bool QUAD>
+__global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* __restrict__ args, uint32_t seen, unsigned long long max_idle_polls) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_seq, s_n;
+  // Everything the doorbell wavefront does alone is behind a WAVE-UNIFORM condition (a scalar branch).  Written as `threadIdx.x == 0`
+  // the compiler rotated the loop so that thread 0's part -- completion store, then the polling -- became an outer loop around an inner
+  // one in which the other 63 lanes of its wavefront ran ahead through the barriers with a stale sequence number: the workgroup never
+  // answered its first doorbell (round 4, found with progress marks in the control block).
+  const bool bell_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  uint32_t staged_gen = 0u;                                 // generation of the tables in LDS (0 = none: the host's generations start at 1)
+  for (;;) {
+    if (bell_wave) {
+      // doorbell and request count are ONE aligned 8-byte word, written by the host with one store and read here with one load: a
+      // second read of host memory behind the doorbell would be another ~1.2 us round trip over PCIe
+      uint32_t v = seen, n_now = 0u;
+      for (unsigned long long polls = 0; polls < max_idle_polls; ++polls) {
+        const unsigned long long w = __hip_atomic_load((const unsigned long long*)&ctl->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        n_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+        if (v != seen) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lane0) {
+        s_seq = v == seen ? kResQuit : v;                   // (idle for too long: leave; the library starts the kernel again when it needs it)
+        s_n = n_now;
+      }
+    }
+#ifdef EPPK_RESIDENT_STAMPS      // measurement build only: 100 MHz timestamps of the stages of a doorbell in the control block's spare words
+    const unsigned long long ts0 = wall_clock64();
+#endif
+    __syncthreads();
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
+    if (seq == kResQuit) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
+    __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
+#ifdef EPPK_RESIDENT_STAMPS
+    const unsigned long long ts1 = wall_clock64();
+#endif
+    if constexpr (QUAD) {
+      // The form for batches of 8 requests and more (the library keeps one resident workgroup of each form and rings the one that suits
+      // the batch: a request's latency is its chain of dependent loads -- row over PCIe, buckets, lists, tables -- and pick_quad_kernel's
+      // body has one link more, the tier words of the listed pods: 11.9 against 11.0 us for one request, but a flat 12 us up to 16
+      // requests, 13.4 against 15.5 for 32 and 19.4 against 27.9 for 64; scripts/res_sweep.py).
+      // pick_quad_kernel's body -- four requests per wavefront, a third of the instructions per request -- and, for what it defers
+      // (differing or overflowed lists, reserved hashes, an exhausted table ...), the work-list form of pick_fast_kernel's body over
+      // this workgroup's own segments, exactly as pick_quad_kernel<TAIL> ends.  The two bodies share the front of the LDS layout
+      // (base | lw | pterm) and both keep everything behind it all-zero between two requests, so the tables are staged ONCE per
+      // snapshot generation, here, and both bodies are told that they are there.
+      const ResidentArgs* a = args;
+      const uint32_t gen = a->gen;
+      if (gen != staged_gen) {
+        double* s_base = (double*)smem;
+        double* s_lw = s_base + (size_t)a->sn.J * 64u;
+        double* s_pterm = s_lw + 4;
+        for (uint32_t i = threadIdx.x; i < a->sn.J * 64u; i += blockDim.x) s_base[i] = a->sn.base[i];
+        if (threadIdx.x < 4u) s_lw[threadIdx.x] = threadIdx.x == 0u ? a->tl.lw[0] : threadIdx.x == 1u ? a->tl.lw[1] : threadIdx.x == 2u ? a->tl.lw[2] : a->tl.lw[3];
+        for (uint32_t i = threadIdx.x; i < a->pwn; i += blockDim.x) s_pterm[i] = a->sn.pterm[i];
+        uint32_t* rest = (uint32_t*)(s_pterm + a->pwn);
+        const uint32_t n_rest = (a->lds_bytes - (uint32_t)((unsigned char*)rest - smem)) / 4u;
+        for (uint32_t i = threadIdx.x; i < n_rest; i += blockDim.x) rest[i] = 0u;
+        __syncthreads();
+        staged_gen = gen;
+      }
+      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, /*MASKED*/ false, /*TOPK*/ false, /*LEARN*/ false, /*RESIDENT*/ true>(
+          0u, 1u, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, a->out_pick, a->out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
+          a->defer_total, 1u, nullptr);
+      // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
+      // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also
+      // asks "did anybody defer?".  Only then the work-list pass, and a second release + barrier behind it.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      if (__syncthreads_or((int)(n_def != 0u))) {
+        const KChain no_chain{};
+        KWork wk;
+        wk.cnt = a->defer_cnt; wk.list = a->defer_list; wk.total = a->defer_total; wk.report = a->defer_total; wk.cap = a->defer_cap; wk.n_segs = blockDim.x >> 6;
+        pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ true, /*RESIDENT*/ true>(
+            0u, 1u, 0u, /*tables staged*/ true, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u, wk);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+      }
+    } else {
+      const ResidentArgs* a = args;
+      const KChain no_chain{};
+      const KWork no_work{};
+      const uint32_t gen = a->gen;
+      pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false, /*RESIDENT*/ true>(
+          0u, 1u, 0u, /*tables staged*/ gen == staged_gen, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u,
+          no_work);
+      staged_gen = gen;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // this wavefront's picks and scores are in host memory ...
+      __syncthreads();
+    }
+#ifdef EPPK_RESIDENT_STAMPS
+    const unsigned long long ts2 = wall_clock64();
+#endif
+#ifdef EPPK_RESIDENT_STAMPS
+    if (bell_wave && lane0) {
+      const unsigned long long ts3 = wall_clock64();
+      ctl->pad1[0] = (uint32_t)(ts1 - ts0); ctl->pad1[1] = (uint32_t)(ts2 - ts1); ctl->pad1[2] = (uint32_t)(ts3 - ts2);   // (ts2: behind body, release and barrier)
+    }
+#endif
+    if (bell_wave) {
+      if (lane0) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... (every wavefront's, behind the barrier) before the answer is
+    }
+    seen = seq;
+  }
+  if (bell_wave) {
+    if (lane0) __hip_atomic_store(&ctl->state, kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -10,10 +10,11 @@ wl = pkg.workload.make_workload(5, R=4096)
 oix = orc.OracleIndex(); oix.insert(wl.index_hashes, wl.index_pods)
 for resident in ("1", "0"):
     os.environ["EPPK_RESIDENT"] = resident
-    pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=64, index_slots=wl.index_slots)
+    os.environ.setdefault("EPPK_RESIDENT_MAX", "128")
+    pk = pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=256, index_slots=wl.index_slots)
     pk.publish(wl.pods); pk.index_insert(wl.index_hashes, wl.index_pods)
     st, _ = pk.staging()
-    for n in (1, 16, 32, 64):
+    for n in (1, 16, 17, 32, 64, 128):
         lat = []
         for i in range(420):
             off = (i * n) % (wl.R - n)

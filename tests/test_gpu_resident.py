@@ -1,5 +1,5 @@
 """The resident small-batch path (EPPK_RESIDENT=1; csrc/eppk_kernels.hip.h: pick_resident_kernel): eppk_pick_batch / eppk_pick_batch_staged
-of at most 32 unmasked requests are answered by a workgroup that stays on the GPU and polls a doorbell in pinned host memory -- same picks
+of at most 32 / 64 unmasked requests are answered by a workgroup that stays on the GPU and polls a doorbell in pinned host memory -- same picks
 and scores as the launched kernels (bit for bit against the oracle), across publishes and index updates (the workgroup has no kernel
 boundary to refresh its caches: it invalidates them behind every doorbell), idle time-outs and the library's own device-wide waits."""
 import time
@@ -31,20 +31,23 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         on, b0, s0 = pk.resident_stats()
         assert on
         st, _ = pk.staging()
+        # two forms of the resident kernel: a wavefront per request below 8 requests, four requests per wavefront from 8 on (where
+        # pick_quad_kernel's route exists: not with EPPK_QUAD=0 / EPPK_LISTS=0) -- the default limit is 64 there, else 32
+        limit = 64 if eppk_mode in ("default", "quadmin4") else 32
         served = 0
         for rep in range(3):
-            for n in (1, 16, 17, 32):
+            for n in (1, 7, 8, 9, 16, 17, 32, 33, 61, 64):
                 reqs = wl.reqs[(rep * 64) % 128:(rep * 64) % 128 + n]
                 want = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B)[:2]
                 _same(pk.pick(reqs), want, f"pick n={n}")
                 st[:n] = reqs
                 _same(pk.pick_staged(n), want, f"pick_staged n={n}")
-                served += 2
+                served += 2 if n <= limit else 0
         on, b1, s1 = pk.resident_stats()
-        assert b1 - b0 == served and s1 >= 1
+        assert b1 - b0 == served and s1 >= 1, (b1 - b0, served, s1)
         # beyond the limit, with a mask, or as fallbacks: the launched path as before
-        want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:33], wl.B)[:2]
-        _same(pk.pick(wl.reqs[:33]), want, "n=33")
+        want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:65], wl.B)[:2]
+        _same(pk.pick(wl.reqs[:65]), want, "n=65")
         assert pk.resident_stats()[1] == b1
         W = (P + 63) // 64
         mask = np.full((8, W), np.uint64(0xAAAAAAAAAAAAAAAA))
@@ -62,6 +65,18 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         pods2["kv_util"] = 1.0 - pods2["kv_util"]
         pk.publish(pods2)
         _same(pk.pick(wl.reqs[:30]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:30], wl.B)[:2], "after a publish")
+        # requests pick_quad_kernel's body cannot finish itself (reserved hashes 0 / ~0 among their blocks, lists that differ since the
+        # insert above): behind the doorbell they take the work-list pass of pick_fast_kernel's body, inside the same resident workgroup
+        odd = wl.reqs[:40].copy()
+        odd[3, 1 + 2] = np.uint64(0)
+        odd[7, 1 + 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        odd[21, 1 + wl.B - 1] = np.uint64(0)
+        rh = np.array([0, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        rp = np.array([3 % P, 9 % P], dtype=np.uint32)
+        pk.index_insert(rh, rp); oix.insert(rh, rp)
+        _same(pk.pick(odd), orc.pick_batch(wl.chain, pods2, oix, odd, wl.B)[:2], "reserved hashes and differing lists, 40 requests")
+        _same(pk.pick(odd[:9]), orc.pick_batch(wl.chain, pods2, oix, odd[:9], wl.B)[:2], "reserved hashes, 9 requests")
+        _same(pk.pick(odd[:5]), orc.pick_batch(wl.chain, pods2, oix, odd[:5], wl.B)[:2], "reserved hashes, 5 requests (the other form)")
         e = pk.index_advance_epoch(); assert e == oix.advance_epoch()
         assert pk.index_evict_older(e) == oix.evict_older(e)                          # everything goes (a device-wide wait: the workgroup is parked)
         _same(pk.pick(wl.reqs[:20]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:20], wl.B)[:2], "after an eviction")
