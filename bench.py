@@ -988,8 +988,9 @@ def group_leg(pkg, torch, args):
 
 
 def resident_latency_leg(pkg, wl, batches, calls: int):
-    """Host-observed latency of eppk_pick_batch_staged for 1 / 16 / 32 requests with EPPK_RESIDENT=1 (fresh rows written into the pinned
-    staging buffer before every call, not timed), each size checked against the oracle once."""
+    """Host-observed latency of eppk_pick_batch_staged for 1 / 4 / 16 / 32 / 64 requests with EPPK_RESIDENT=1 (fresh rows written into the
+    pinned staging buffer before every call, not timed), each size checked against the oracle once.  Below 8 requests the resident
+    workgroup with pick_fast_kernel's body answers, from 8 on the one with pick_quad_kernel's."""
     orc = graft.load_oracle()
     oix = orc.OracleIndex()
     oix.insert(wl.index_hashes, wl.index_pods)
@@ -1007,7 +1008,7 @@ def resident_latency_leg(pkg, wl, batches, calls: int):
         pk.index_insert(wl.index_hashes, wl.index_pods)
         st_reqs, _ = pk.staging()
         by_n, ok = {}, True
-        for n in (1, 16, 32):
+        for n in (1, 4, 16, 32, 64):
             lat = []
             p, s = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float64)
             a_p, a_s = p.ctypes.data, s.ctypes.data
@@ -1023,8 +1024,9 @@ def resident_latency_leg(pkg, wl, batches, calls: int):
             by_n[str(n)] = {"p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99))}
         on, served, starts = pk.resident_stats()
         return {"requests": by_n, "picks_and_scores_equal_oracle": ok, "batches_answered_by_the_resident_workgroup": served, "kernel_starts": starts,
-                "what": "eppk_pick_batch_staged with EPPK_RESIDENT=1 (opt-in): a resident workgroup polls a doorbell in pinned host memory, scores the batch with "
-                        "pick_fast_kernel's body and raises a completion word the call polls -- no launch, no completion signal; one CU is held"}
+                "what": "eppk_pick_batch_staged with EPPK_RESIDENT=1 (opt-in): a resident workgroup polls a doorbell in pinned host memory, scores the batch "
+                        "(below 8 requests with pick_fast_kernel's body, from 8 on with pick_quad_kernel's: one workgroup of each form) and raises a completion "
+                        "word the call polls -- no launch, no completion signal; a CU is held per form in use"}
     finally:
         pk.close()
 

@@ -224,13 +224,15 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
 /* The latency path of SMALL batches (opt-in: EPPK_RESIDENT=1 in the environment when the context is created).  What a per-request
  * caller hands over (pkg/lwepp/handlers/request.go:141-163; design point 10-1000 QPS, docs/proposals/006-scheduler/README.md:133) is
  * batches of a few dozen requests at most, and such a batch is all launch and completion latency.  With the switch on, eppk_pick_batch and
- * eppk_pick_batch_staged hand an unmasked batch of at most EPPK_RESIDENT_MAX (default 32) requests to a RESIDENT workgroup instead of
- * launching a kernel: it polls a doorbell in pinned host memory, scores the batch with the same code as pick_fast_kernel (same picks,
- * same scores), writes the pinned result buffers and raises a completion word the call is polling (host-observed: 1 request 12 us,
- * 16 requests 14 us, against 19-21 us through a launch: profiles/r04_resident_latency.txt).  Costs: one CU (the persistent
- * pick kernels of the context are sized for one fewer), and a polling host thread for the duration of the call.  The workgroup
- * leaves by itself after ~50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next small batch; the
- * library parks it in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel does not serve,
+ * eppk_pick_batch_staged hand an unmasked batch of at most EPPK_RESIDENT_MAX requests (default 64; 32 where the four-requests-per-
+ * wavefront kernel does not apply) to a RESIDENT workgroup instead of launching a kernel: it polls a doorbell in pinned host memory,
+ * scores the batch with the same code as the launched kernels (pick_fast_kernel's body below EPPK_RESIDENT_QUAD_FROM = 8 requests,
+ * pick_quad_kernel's from there on: one resident workgroup of each form, same picks, same scores), writes the pinned result buffers
+ * and raises a completion word the call is polling (host-observed: 1 request 11 us, 16 requests 12 us, 32: 13.4, 64: 17-19, against
+ * 19-21 us through a launch: profiles/r04_resident_latency.txt).  Costs: a CU per form in use (the persistent pick kernels of the
+ * context are sized for two fewer), and a polling host thread for the duration of the call.  A workgroup leaves by itself after
+ * ~20-50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next batch of its kind; the library parks
+ * both in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel does not serve,
  * masked batches, fallbacks and assumed load take the launched path as before.
  * eppk_resident_stats: returns 1 when the switch is on (0 otherwise); batches = small batches answered by the resident workgroup,
  * starts = times it was (re)started. */
