@@ -818,10 +818,22 @@ def main() -> None:
                 try:
                     res_leg = resident_latency_leg(pkg, wl, batches, min(args.host_path, 200))
                     out["host_path"]["latency_by_batch_resident"] = res_leg
-                    lb = out["host_path"].get("latency_by_batch", {}).get("requests", {})
-                    for n_s, v in res_leg.get("requests", {}).items():          # ... and beside the launched path's figure of the same size
-                        if n_s in lb:
-                            lb[n_s]["resident_p50_us"], lb[n_s]["resident_p99_us"] = v["p50_us"], v["p99_us"]
+                    # latency_by_batch[n] = what a caller who has opted into the latency path gets for that size: the resident workgroup's
+                    # figures where it serves the size (p50_us / p99_us, path "resident"), the launched path's beside them
+                    # (launched_p50_us / launched_p99_us); sizes beyond its limit: the launched path (path "launched")
+                    lbb = out["host_path"].get("latency_by_batch", {})
+                    lb = lbb.get("requests", {})
+                    for v in lb.values():
+                        v["path"] = "launched"
+                    if res_leg.get("picks_and_scores_equal_oracle"):
+                        for n_s, v in res_leg.get("requests", {}).items():
+                            e = lb.setdefault(n_s, {})
+                            if "p50_us" in e:
+                                e["launched_p50_us"], e["launched_p99_us"] = e["p50_us"], e["p99_us"]
+                            e["p50_us"], e["p99_us"], e["path"] = v["p50_us"], v["p99_us"], "resident"
+                            e["resident_p50_us"], e["resident_p99_us"] = v["p50_us"], v["p99_us"]
+                        lbb["what"] = (lbb.get("what", "") + "; path \"resident\": the same call with EPPK_RESIDENT=1 (opt-in latency path: a resident workgroup behind a "
+                                       "doorbell, no launch; include/eppk.h), the launched path's figures beside it as launched_p50_us / launched_p99_us")
                 except Exception as e:
                     out["host_path"]["latency_by_batch_resident"] = {"error": repr(e)}
             if hasattr(run.pk, "stage_begin"):

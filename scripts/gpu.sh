@@ -42,7 +42,7 @@ h = d.get("host_path") or {}
 if h:
     s += "\n   host_path " + str({k: (round(v.get('decisions_per_s', v.get('decisions_per_s_p50', 0)) / 1e6, 1) if isinstance(v, dict) else v) for k, v in h.items() if k in ('staged', 'pipelined', 'pipelined_learn', 'decisions_per_s_p50')})
     lb = (h.get("latency_by_batch") or {}).get("requests")
-    if lb: s += "\n   latency_by_batch " + str(lb)
+    if lb: s += "\n   latency_by_batch " + str({n: {k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items() if not k.startswith("resident_")} for n, e in lb.items()})
 print(s)
 EOF
 }
