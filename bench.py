@@ -825,7 +825,7 @@ def main() -> None:
                     lb = lbb.get("requests", {})
                     for v in lb.values():
                         v["path"] = "launched"
-                    if res_leg.get("picks_and_scores_equal_oracle"):
+                    if res_leg.get("picks_and_scores_equal_oracle") and res_leg.get("batches_answered_by_the_resident_workgroup", 0) > 0:
                         for n_s, v in res_leg.get("requests", {}).items():
                             e = lb.setdefault(n_s, {})
                             if "p50_us" in e:
