@@ -81,7 +81,8 @@ typedef struct eppk_cfg {
   uint32_t max_blocks;    /* B: u64 hash slots in every request row (row stride = 8 + 8*B) */
   uint32_t max_batch;     /* largest n_reqs for the host-buffer entry point */
   uint32_t index_slots;   /* prefix table capacity: power of two in [64, 2^28], 0 = no prefix index.  Holds at most
-                           * index_slots/2 live hashes (EPPK_ERR_INDEX_FULL beyond); size it at >= 4x the expected
+                           * index_slots/2 live hashes (EPPK_ERR_INDEX_FULL beyond; the two reserved hash values 0 and ~0 have
+                           * rows of their own behind the table and are always admitted); size it at >= 4x the expected
                            * number (load <= 0.25).  Memory: index_slots * (64 * lane-word bytes + 12) */
   uint32_t n_scorers;     /* <= EPPK_MAX_SCORERS; order fixes the fp summation order */
   uint32_t reserved;

@@ -85,7 +85,7 @@ def test_fuzz_pick(pkg, orc, seed):
     assert np.array_equal(ts.view(np.uint64), ots.view(np.uint64)), info + f" topk {k}"
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(120))
 def test_fuzz_index_maintenance(pkg, orc, seed):
     """Random sequences of index operations (bulk insert, post-pick insert on device, pod removal, epoch ticks, eviction) applied
     to the device index and to the oracle's; after every operation the picks of a probe batch, their scores and the number of
@@ -198,3 +198,79 @@ def test_stamp_window_wraps_like_the_oracle(pkg, orc):
                 assert np.array_equal(picks, opk) and np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), tick
         assert pk.index_size() == oix.size() and pk.index_trim_pods(3) == oix.trim_pods(P, 3)
         assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0
+
+
+@pytest.mark.parametrize("slots,pods_per_key", [(64, 3), (128, 2), (256, 4), (1024, 1)])
+def test_a_launch_that_fills_the_table_to_its_limit_drops_nothing(pkg, orc, slots, pods_per_key):
+    """slots / 2 distinct hashes in ONE insert launch (several pairs per hash, spread over wavefronts): the launch as a whole might not
+    fit, so every new key is booked before it is claimed -- and lanes of several wavefronts book the same key.  The surplus bookings
+    come back as soon as their lanes see the key; a lane waiting for one of them must let them get there (round 4: it used to spin in
+    a loop of its own while the holder, a lane of the same wavefront, could not move, and the launch dropped pairs that fit).  One hash
+    more is then refused, exactly."""
+    rng = np.random.default_rng(slots * 10 + pods_per_key)
+    n_keys = slots // 2
+    keys = rng.integers(1, 2**63, n_keys, dtype=np.uint64)
+    if slots >= 128:                                       # the two reserved hashes (rows of their own behind the table) count as keys too
+        keys[0], keys[1] = np.uint64(0), np.uint64(0xFFFFFFFFFFFFFFFF)
+    ih = np.repeat(keys, pods_per_key)
+    rng.shuffle(ih)                                        # pairs of one hash land in different wavefronts
+    ip = rng.integers(0, 200, ih.size).astype(np.uint32)
+    chain = [(KV, 1), (PF, 3)]
+    pods = pkg.workload.make_pods(7, 200, 128)
+    for rep in range(6):                                   # (the old failure was not deterministic)
+        with pkg.BatchedPicker(chain, max_pods=200, max_blocks=4, max_batch=8, index_slots=slots) as pk:
+            pk.publish(pods)
+            pk.index_insert(ih, ip)
+            assert pk.index_size() == n_keys and pk.index_dropped() == 0 and pk.index_selfcheck() == 0
+            with pytest.raises(Exception, match="INDEX_FULL"):
+                pk.index_insert(np.array([12345], dtype=np.uint64), np.array([1], dtype=np.uint32))
+            assert pk.index_size() == n_keys
+
+
+def test_many_requests_teach_the_same_new_keys_the_same_pod(pkg, orc):
+    """The post-route update of a batch whose requests share their block chains AND their picks, on an index that was emptied just
+    before (every key new, every slot a reclaimed tombstone): hundreds of lanes append the same pod to the same fresh key while its
+    claimer's store is on its way.  An appender's first look at the list line must be coherent -- the L2 line is 128 bytes, two list
+    lines: a cached copy taken in through the neighbouring slot earlier in the launch does not show the claimer's pod, and the lane
+    appended it a second time (found by scripts/gpu_fuzz_campaign.py; one in twenty repetitions of this loop body)."""
+    import torch
+    rng = np.random.default_rng(77)
+    P, B, R = 300, 16, 96
+    chain = [(Q, 1), (KV, 2), (L, 1), (PF, 4)]
+    pods = pkg.workload.make_pods(99, P, 128)
+    universe = rng.integers(1, 2**63, (24, B), dtype=np.uint64)
+
+    def batch():
+        hs = universe[rng.integers(0, universe.shape[0], R)].copy()
+        for r in range(R):
+            if rng.random() < 0.5:
+                cut = int(rng.integers(0, B))
+                hs[r, cut:] = rng.integers(1, 2**63, B - cut, dtype=np.uint64)
+        return pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=8192) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        for it in range(120):
+            reqs = batch()
+            d_reqs = torch.from_numpy(reqs.view(np.int64)).cuda()
+            d_picks = torch.empty(R, dtype=torch.int32, device="cuda")
+            if it % 2:
+                pk.pick_learn_device(d_reqs.data_ptr(), R, None, d_picks.data_ptr(), None)
+            else:
+                pk.pick_device(d_reqs.data_ptr(), R, None, d_picks.data_ptr(), None)
+                pk.index_insert_picks_device(d_reqs.data_ptr(), d_picks.data_ptr(), R)
+            torch.cuda.synchronize()
+            op, _, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+            assert np.array_equal(d_picks.cpu().numpy(), op), f"iteration {it}"
+            oix.insert_picks(reqs, B, op)
+            assert pk.index_selfcheck() == 0, f"iteration {it}"
+            assert pk.index_size() == oix.size(), f"iteration {it}"
+            probe = batch()
+            got = pk.pick(probe)
+            want = orc.pick_batch(chain, pods, oix, probe, B)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)), f"iteration {it}"
+            if it % 3 == 2:                                 # empty the index: the next update claims tombstones
+                e = pk.index_advance_epoch()
+                assert e == oix.advance_epoch()
+                assert pk.index_evict_older(e) == oix.evict_older(e)
