@@ -12,7 +12,7 @@ wl = pkg.workload.make_workload(5, R=R)
 batches = [wl.reqs] + [pkg.workload.make_requests(wl, 6000 + i) for i in range(5)]
 keep = 2
 t0 = time.time()
-with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=1 << 22) as pk:
+with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=max(1 << 22, 1 << int(np.ceil(np.log2(256 * R))))) as pk:   # (room for the hashes of keep + 2 generations at load <= 1/4)
     pk.publish(wl.pods); pk.index_insert(wl.index_hashes, wl.index_pods)
     oix = orc.OracleIndex(); oix.insert(wl.index_hashes, wl.index_pods)
     d_b = [torch.from_numpy(b.view(np.int64)).cuda() for b in batches]
