@@ -622,20 +622,26 @@ bool resident_quad(const eppk_ctx* c) {
   (void)resident_lds(c, &hist_fits);
   return c->quad_on && hist_fits && c->slots != 0u && make_kindex(c).lists != nullptr;
 }
-int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams
+int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams (each made once: a call that failed half-way is resumed)
   if (c->d_res_args) return EPPK_OK;
-  {   // the work list of the quad form: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
+  if (!c->d_res_wl) {   // the work list of the quad form: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
     const uint32_t nblk = (c->resident_max + 3u) / 4u, per_wave = (nblk + 15u) / 16u;
     c->res_wl_cap = 4u * (per_wave ? per_wave : 1u);
     const size_t words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
-    HIPCHK(c, hipMalloc((void**)&c->d_res_wl, words * 4u));
-    HIPCHK(c, hipMemset(c->d_res_wl, 0, words * 4u));
+    uint32_t* wl = nullptr;
+    HIPCHK(c, hipMalloc((void**)&wl, words * 4u));
+    if (hipMemset(wl, 0, words * 4u) != hipSuccess) { (void)hipFree(wl); return fail(c, EPPK_ERR_DEVICE, "resident path: hipMemset of the work list failed"); }
+    c->d_res_wl = wl;
   }
   for (eppk_ctx::ResidentUnit& u : c->res) {
-    HIPCHK(c, hipHostMalloc((void**)&u.h_ctl, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
-    HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
-    std::memset(u.h_ctl, 0, sizeof(eppk::ResidentCtl));
-    HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+    if (!u.h_ctl) {
+      eppk::ResidentCtl* h = nullptr;
+      HIPCHK(c, hipHostMalloc((void**)&h, sizeof(eppk::ResidentCtl), hipHostMallocDefault));
+      std::memset(h, 0, sizeof(eppk::ResidentCtl));
+      u.h_ctl = h;
+    }
+    if (!u.h_ctl_dev) HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
+    if (!u.stream) HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
   }
   HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
   return EPPK_OK;
