@@ -269,7 +269,7 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     assert "cpu_baseline" not in d and "one whole batch per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
     assert ("int16" in d["config"]["sharding"]) == ("--pack16" in extra) and d["config"]["requests_per_launch"] == 64
     # what `value` is: the metric names the scaling, the note quotes north_star with rank 0's measured launch time, the communicator is asked
-    assert "weak scaling" in d["metric"] and "2 x 64k" in d["metric"] if "64k" in d["metric"] else "closed loop" not in d["metric"]
+    assert "closed loop" not in d["metric"]        # (a reduced workload here: the headline's names are checked in test_metric_names_say_which_scaling)
     assert "outgrows one device" in d["scaling_note"] and "weak" in d["scaling_note"]
     assert d["config"]["per_rank_kernel_us"] > 0 and d["config"]["collective_us"]["collectives"] >= 1 and d["config"]["collective_us"]["p50"] >= 0
     cl = d["completion_latency"]                  # N > 1: when a batch's picks exist on every rank (per gather bucket)
@@ -295,3 +295,20 @@ def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
     assert "strong" in d["scaling_note"] and d["config"]["ranks_seen"] == 2 and d["config"]["per_rank_kernel_us"] > 0
     assert d["completion_latency"]["p50_ms"] <= d["completion_latency"]["p99_ms"]
     assert d["parity"]["gathered_picks_equal_oracle"] is True
+
+
+def test_metric_names_say_which_scaling():
+    """At N > 1 the line's `metric` must not be readable as BASELINE.json configs[4]'s ONE 64k batch when `value` is the aggregate of N
+    replicas, nor the other way round (round-3 verdict item 4)."""
+    import types
+    import bench
+    wl = types.SimpleNamespace(name="C5 64kx4096 full chain + prefix B=32")
+    args = types.SimpleNamespace(groups=256, zipf=1.0, closed_loop=False)
+    one = bench.metric_name(True, "single", 1, wl, args)
+    weak = bench.metric_name(True, "weak", 8, wl, args)
+    strong = bench.metric_name(True, "strong", 8, wl, args)
+    assert one == "routing decisions/sec, 64k-req x 4096-pod batch"
+    assert "8 x 64k-req" in weak and "weak scaling" in weak and "replicas" in weak
+    assert "ONE 64k-req" in strong and "8 ranks" in strong and "strong scaling" in strong
+    assert len({one, weak, strong}) == 3
+    assert "C5" in bench.metric_name(False, "weak", 8, wl, args)          # a reduced workload never carries the headline's name
