@@ -544,7 +544,8 @@ def main() -> None:
     ap.add_argument("--no-resident-leg", action="store_true", help="skip the small-batch latencies through the resident workgroup (EPPK_RESIDENT=1)")
     ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the closed-loop / pipelined-LEARN sub-run of the default line")
     ap.add_argument("--closed-loop-leg", action="store_true", help="run that sub-run for a non-headline workload too")
-    ap.add_argument("--cl-steps", type=int, default=60, help="timed steps of the default line's closed-loop sub-run (warm-up: a quarter of it)")
+    ap.add_argument("--cl-steps", type=int, default=200, help="timed steps of the default line's closed-loop sub-run (warm-up: a quarter of it)")
+    ap.add_argument("--pl-batches", type=int, default=512, help="batches of the default line's pipelined-LEARN sub-run (its p99 is a percentile of that many)")
     ap.add_argument("--no-cold-ref", action="store_true", help="skip the cold-index sub-run (roofline_cold)")
     ap.add_argument("--groups", type=int, default=256, help="shared-prefix groups (256 = BASELINE workload; 65536 = cold index)")
     ap.add_argument("--zipf", type=float, default=1.0, help="Zipf exponent over groups (0 = uniform)")
@@ -818,22 +819,18 @@ def main() -> None:
                 try:
                     res_leg = resident_latency_leg(pkg, wl, batches, min(args.host_path, 200))
                     out["host_path"]["latency_by_batch_resident"] = res_leg
-                    # latency_by_batch[n] = what a caller who has opted into the latency path gets for that size: the resident workgroup's
-                    # figures where it serves the size (p50_us / p99_us, path "resident"), the launched path's beside them
-                    # (launched_p50_us / launched_p99_us); sizes beyond its limit: the launched path (path "launched")
+                    # latency_by_batch[n] LEADS with the library's default configuration (p50_us / p99_us, path "launched"); the opt-in
+                    # resident workgroup's figures for the sizes it serves stand beside them (resident_p50_us / resident_p99_us)
                     lbb = out["host_path"].get("latency_by_batch", {})
                     lb = lbb.get("requests", {})
                     for v in lb.values():
-                        v["path"] = "launched"
+                        v["path"] = "launched (default)"
                     if res_leg.get("picks_and_scores_equal_oracle") and res_leg.get("batches_answered_by_the_resident_workgroup", 0) > 0:
                         for n_s, v in res_leg.get("requests", {}).items():
-                            e = lb.setdefault(n_s, {})
-                            if "p50_us" in e:
-                                e["launched_p50_us"], e["launched_p99_us"] = e["p50_us"], e["p99_us"]
-                            e["p50_us"], e["p99_us"], e["path"] = v["p50_us"], v["p99_us"], "resident"
+                            e = lb.setdefault(n_s, {"path": "resident only (size not timed on the launched path)"})
                             e["resident_p50_us"], e["resident_p99_us"] = v["p50_us"], v["p99_us"]
-                        lbb["what"] = (lbb.get("what", "") + "; path \"resident\": the same call with EPPK_RESIDENT=1 (opt-in latency path: a resident workgroup behind a "
-                                       "doorbell, no launch; include/eppk.h), the launched path's figures beside it as launched_p50_us / launched_p99_us")
+                        lbb["what"] = (lbb.get("what", "") + "; resident_p50_us / resident_p99_us: the same call with EPPK_RESIDENT=1 (opt-in latency path: a resident "
+                                       "workgroup behind a doorbell, no launch; include/eppk.h)")
                 except Exception as e:
                     out["host_path"]["latency_by_batch_resident"] = {"error": repr(e)}
             if hasattr(run.pk, "stage_begin"):
@@ -909,6 +906,7 @@ def main() -> None:
             out["roofline_cold"] = {"error": repr(e)}
 
     if rank == 0:
+        steady_state_into_config(out)
         # RCCL writes a version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON
         # line is the last thing on stdout
         import ctypes
@@ -920,6 +918,60 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def steady_state_into_config(out) -> None:
+    """The path's steady-state figures, copied from the side objects of the line into `config` (flat keys): the driver's stored record
+    keeps `config` in full but only the NAMES of the other top-level keys."""
+    c = out["config"]
+
+    def put(key, *path, scale=1.0):
+        v = out
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+            if v is None:
+                return
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            c[key] = v
+        else:
+            c[key] = v * scale
+    put("closed_loop_value", "closed_loop", "value")
+    put("closed_loop_ms_per_step", "closed_loop", "ms_per_step")
+    put("closed_loop_steps", "closed_loop", "steps")
+    put("closed_loop_generations_verified", "closed_loop", "generations_verified")
+    put("closed_loop_picks_equal_oracle", "closed_loop", "picks_equal_oracle")
+    put("closed_loop_scores_bitwise_equal_oracle", "closed_loop", "scores_bitwise_equal_oracle")
+    put("closed_loop_step_parts_ms", "closed_loop", "step_parts_ms")
+    put("closed_loop_traffic_bytes_per_step", "roofline_closed_loop", "traffic")
+    put("host_pageable_decisions_per_s_p50", "host_path", "decisions_per_s_p50")
+    put("host_staged_decisions_per_s_p50", "host_path", "staged", "decisions_per_s_p50")
+    put("host_staged_p50_ms", "host_path", "staged", "p50_ms")
+    put("host_staged_p99_ms", "host_path", "staged", "p99_ms")
+    put("host_pipelined_decisions_per_s", "host_path", "pipelined", "decisions_per_s")
+    put("host_pipelined_p99_ms", "host_path", "pipelined", "p99_ms")
+    put("host_pipelined_learn_decisions_per_s", "host_path", "pipelined_learn", "decisions_per_s")
+    put("host_pipelined_learn_batches", "host_path", "pipelined_learn", "batches")
+    put("host_pipelined_learn_p99_ms", "host_path", "pipelined_learn", "p99_ms")
+    for n in ("16", "128"):
+        put(f"latency_{n}_launched_p50_us", "host_path", "latency_by_batch", "requests", n, "p50_us")
+        put(f"latency_{n}_launched_p99_us", "host_path", "latency_by_batch", "requests", n, "p99_us")
+    for n in ("1", "16", "64"):
+        put(f"latency_{n}_resident_p50_us", "host_path", "latency_by_batch_resident", "requests", n, "p50_us")
+    put("latency_dispatcher_calls_us", "host_path", "latency_dispatcher_calls")
+    put("cold_value", "roofline_cold", "value")
+    put("cold_frac", "roofline_cold", "frac")
+    put("cold_frac_strict", "roofline_cold", "frac_strict")
+    put("cold_traffic_bytes_per_launch", "roofline_cold", "traffic")
+    put("cpu_baseline_value", "cpu_baseline", "value")
+    put("parity_picks_equal_oracle", "parity", "picks_equal_oracle")
+    put("parity_scores_bitwise_equal_oracle", "parity", "scores_bitwise_equal_oracle")
+    # N > 1: BASELINE.json configs[4] (ONE 64k batch split R/N per rank) first class, beside the weak-scaled `value`
+    put("strong_value", "strong", "value")
+    put("strong_ms_per_step", "strong", "ms_per_step")
+    put("strong_completion_latency_p50_ms", "strong", "completion_latency_p50_ms")
+    put("strong_completion_latency_p99_ms", "strong", "completion_latency_p99_ms")
+    put("weak_value", "weak", "value")
+    put("completion_latency_p99_ms", "completion_latency", "p99_ms")
 
 
 def group_leg(pkg, torch, args):
@@ -995,8 +1047,82 @@ def group_leg(pkg, torch, args):
            "completion_latency": {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "batches_per_bucket": G,
                                   "definition": "host time of one bucket alone: eppk_group_pick_device -> eppk_group_sync"},
            "parity": {"gathered_picks_equal_oracle": same, "every_member_holds_the_same_picks": same_everywhere}}
-    print(json.dumps(out), flush=True)
     g.close()
+    try:
+        out["host_path"] = group_pipelined_leg(pkg, wl, batches, devices, args)
+        out["config"]["group_pipelined_decisions_per_s"] = out["host_path"]["pipelined"]["decisions_per_s"]
+        out["config"]["group_pipelined_learn_decisions_per_s"] = out["host_path"]["pipelined_learn"]["decisions_per_s"]
+        out["config"]["group_pipelined_learn_first_batches_equal_oracle"] = out["host_path"]["pipelined_learn"]["first_batches_equal_oracle"]
+    except Exception as e:
+        out["host_path"] = {"error": repr(e)}
+    print(json.dumps(out), flush=True)
+
+
+def group_pipelined_leg(pkg, wl, batches, devices, args, n_batches: int = 200):
+    """What a host caller of a device group sees: eppk_group_pick_stage_begin / _end over the group's two staging sets (rows already in the
+    pinned sets), plain and with EPPK_PICK_LEARN + the shim's ageing between begins (eppk_group_index_evict_older_device).  The first
+    LEARN batches are checked against the oracle replaying the call order.  A group of its own (closed-loop index size)."""
+    R, M = wl.R, len(devices)
+    orc = graft.load_oracle()
+    g = pkg.DeviceGroup(wl.chain, devices, max_pods=max(wl.P, 64), max_blocks=wl.B, max_batch=R, index_slots=args.cl_slots, gather=pkg.picker.GATHER_PEER)
+    try:
+        g.publish(wl.pods)
+        g.index_insert(wl.index_hashes, wl.index_pods)
+        sb = [g.stage_buffers(0)[0], g.stage_buffers(1)[0]]
+        np.copyto(sb[0][:R], batches[0])
+        np.copyto(sb[1][:R], batches[1 % len(batches)])
+
+        def loop(n, learn, tick=None):
+            lat, t_begin = [], [0.0, 0.0]
+            t0 = time.perf_counter()
+            t_begin[0] = t0
+            g.stage_begin(0, R, learn=learn)
+            for i in range(1, n + 1):
+                cur, prev = i & 1, (i - 1) & 1
+                if i < n:
+                    t_begin[cur] = time.perf_counter()
+                    g.stage_begin(cur, R, learn=learn)
+                    if tick is not None:
+                        tick(i)
+                g.stage_end(prev)
+                lat.append(time.perf_counter() - t_begin[prev])
+            for i in range(M):
+                g.member_index_size(i)                      # (synchronises every member: the last updates are inside the wall time)
+            t_all = time.perf_counter() - t0
+            lat = np.asarray(lat) * 1e3
+            return {"batches": n, "decisions_per_s": R * n / t_all, "ms_per_batch": 1e3 * t_all / n, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99))}
+
+        loop(4, False)
+        plain = loop(n_batches, False)
+        plain["what"] = f"eppk_group_pick_stage_begin / _end over two staging sets, {M} members: every member uploads and scores its shard of each batch"
+        # LEARN: the first generations against the oracle (set 0 / 1 hold batches 0 / 1: the oracle replays begin order)
+        oix = orc.OracleIndex()
+        oix.insert(wl.index_hashes, wl.index_pods)
+        ok = True
+        cores = os.cpu_count() or 1
+        for k in range(3):
+            g.stage_begin(k & 1, R, learn=True)
+            picks, scores = g.stage_end(k & 1)
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, batches[(k & 1) % len(batches)], wl.B, threads=cores)
+            ok = ok and bool(np.array_equal(picks, op)) and bool(np.array_equal(scores.view(np.uint64), osc.view(np.uint64)))
+            oix.insert_picks(batches[(k & 1) % len(batches)], wl.B, op)
+        sizes = [g.member_index_size(i) for i in range(M)]
+        ok = ok and all(sz == oix.size() for sz in sizes)
+        every = 2 * args.age_every
+        state = {"epoch": 1}
+
+        def tick(i):
+            if i % every == 0:
+                state["epoch"] = g.index_advance_epoch()
+                if state["epoch"] > args.keep_epochs:
+                    g.index_evict_older_device(state["epoch"] - args.keep_epochs + 1)
+        learn = loop(n_batches, True, tick)
+        learn.update({"first_batches_equal_oracle": ok, "ageing_every_batches": every, "launch_status": [int(g.member_launch_status(i)) for i in range(M)],
+                      "what": f"the same with EPPK_PICK_LEARN: every member uploads the WHOLE batch, the picks are gathered (peer copies) and each member applies the post-route "
+                              f"update to its replica; epoch tick + eppk_group_index_evict_older_device every {every} batches between two begins; {args.cl_slots} index slots"})
+        return {"pipelined": plain, "pipelined_learn": learn, "members": M}
+    finally:
+        g.close()
 
 
 def resident_latency_leg(pkg, wl, batches, calls: int):
@@ -1073,14 +1199,14 @@ def closed_loop_leg(pkg, torch, args, wl, batches):
                              f"hashes not re-inserted for {a.keep_epochs} epochs every {a.age_every} steps; {a.cl_slots} index slots"})
         pl = None
         if hasattr(run.pk, "stage_begin"):
-            pl = pipelined_learn_leg(run, wl, a, batches, state)
+            pl = pipelined_learn_leg(run, wl, a, batches, state, n_batches=max(8, a.pl_batches))
         info["seconds"] = time.perf_counter() - t_all
         return {"closed_loop": info, "roofline_closed_loop": roof, "pipelined_learn": pl}
     finally:
         run.close()
 
 
-def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 24):
+def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     """eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over the two staging sets -- upload of batch k + 1 under the pick and the post-route
     update of batch k -- with the shim's ageing: every `2 * age_every` batches the epoch ticks and the hashes not re-inserted for
     `keep_epochs` epochs go, stream-ordered on the device (eppk_index_evict_older_device between two begins: behind the picks and updates
@@ -1228,8 +1354,17 @@ def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
     floor_ins = n_new * (1.0 / RANDOM_LINE_READS + 1.0 / RANDOM_LINE_ATOMICS + 2.0 / RANDOM_LINE_STORES)
     floor_evict = n_vic / RANDOM_LINE_STORES + scan_bytes / (HBM_PEAK_GBS * 1e9)
     step_s = ms_per_step * 1e-3
+    traffic = traffic_src = None
+    tj = stamped_json("pmc_traffic_closed_loop.json", kernel_source_hash())
+    if tj and tj.get("age_every") == args.age_every and tj.get("requests") == run.n_mine:
+        traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj
     return {"bound": "hbm-random-lines", "achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_step": bytes_step, "ms_per_step_timed": ms_per_step,
+            "traffic": traffic, "traffic_frac": (traffic / step_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "traffic_by_kernel": ({k: traffic_src[k] for k in ("pick", "index_update", "ageing_per_step") if k in traffic_src} if traffic_src else None),
+            "traffic_source": ("profiles/pmc_traffic_closed_loop.json: rocprofv3 --pmc passes of `bench.py --closed-loop` with THIS kernel build (stamped with its source hash): "
+                               "64 * RDREQ_64B + 128 * RDREQ_128B + WRITE_SIZE, mean per dispatch of the LEARN pick, the update kernels and (divided by age_every) the eviction"
+                               if traffic else None),
+            "bytes_per_step": bytes_step, "ms_per_step_timed": ms_per_step,
             "step_parts_ms": {"pick": pick_ms, "index_update": ins_ms, "ageing_per_step": evict_ms, "sum": pick_ms + ins_ms + evict_ms,
                               "note": f"each part alone on the GPU, events around it, {steps} steps behind the timed region"},
             "per_step": {"pairs": pairs, "new_keys": n_new, "victims": n_vic, "lines_per_new_key": 3, "lines_per_victim": 1},

@@ -30,6 +30,8 @@ SYMBOLS = [
     "eppk_group_set_min_shard", "eppk_group_snapshot_publish", "eppk_group_index_clear", "eppk_group_index_insert",
     "eppk_group_index_remove_pod", "eppk_group_index_advance_epoch", "eppk_group_index_evict_older", "eppk_group_pick_batch",
     "eppk_group_device_picks", "eppk_group_pick_device", "eppk_group_sync", "eppk_group_stream",
+    "eppk_group_index_evict_older_device", "eppk_group_index_trim_pods", "eppk_group_pick_topk", "eppk_group_pick_random_topk",
+    "eppk_group_pick_stage_buffers", "eppk_group_pick_stage_begin", "eppk_group_pick_stage_end",
     "eppk_host_staging", "eppk_pick_batch_staged", "eppk_pick_stage_buffers", "eppk_pick_stage_begin", "eppk_pick_stage_end", "eppk_chain_is_fused", "eppk_quad_stats", "eppk_resident_stats", "eppk_profile_enable", "eppk_profile_drain", "eppk_profile_bytes",
 ]
 
@@ -140,6 +142,13 @@ def load_library() -> C.CDLL:
     lib.eppk_group_index_advance_epoch.argtypes = [vp, C.POINTER(u32)]
     lib.eppk_group_index_evict_older.argtypes = [vp, u32, C.POINTER(u32)]
     lib.eppk_group_pick_batch.argtypes = [vp, vp, u32, vp, vp, vp, u32]
+    lib.eppk_group_index_evict_older_device.argtypes = [vp, u32]
+    lib.eppk_group_index_trim_pods.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.eppk_group_pick_topk.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    lib.eppk_group_pick_random_topk.argtypes = [vp, vp, u32, vp, u32, u64, vp, vp]
+    lib.eppk_group_pick_stage_buffers.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]
+    lib.eppk_group_pick_stage_begin.argtypes = [vp, u32, u32, C.c_int, u32]
+    lib.eppk_group_pick_stage_end.argtypes = [vp, u32, vp, vp]
     lib.eppk_group_device_picks.argtypes = [vp, u32]
     lib.eppk_group_device_picks.restype = vp
     lib.eppk_group_pick_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u32]

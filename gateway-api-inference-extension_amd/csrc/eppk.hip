@@ -133,8 +133,10 @@ struct eppk_ctx {
     void* d_reqs = nullptr; uint64_t* d_mask = nullptr; int32_t* d_pick = nullptr; double* d_score = nullptr;
     void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;
     uint32_t n = 0; bool busy = false, had_mask = false;
+    uint32_t row_base = 0;       // a group member's set: batch index of the first row its device-side check looked at
   };
   StageSet stage[2];
+  hipStream_t learn_words_stream = nullptr; hipEvent_t learn_words_free = nullptr;   // d_learn is ONE buffer: a pick + update pair on another stream waits for the last pair's update
   hipEvent_t learned = nullptr; bool learn_pending = false;   // recorded behind the latest LEARN update; every later pick, index update and
                                                               // publish of this context -- on whatever stream -- is ordered behind it (learn_fence)
   // The resident small-batch kernel (EPPK_RESIDENT=1; eppk_kernels.hip.h: pick_resident_kernel): pinned control block, device argument
@@ -234,7 +236,7 @@ struct eppk_ctx {
 namespace {
 
 constexpr uint32_t kStatBanks = 4;
-constexpr uint32_t kEpochWindow = 254u;  // largest age (in index epochs) a live hash may reach: its stamp is an 8-bit tag (eppk_kernels.hip.h: kTagMod)
+constexpr uint32_t kEpochWindow = EPPK_INDEX_EPOCH_WINDOW;  // largest age (in index epochs) a live hash may reach: its stamp is an 8-bit tag (eppk_kernels.hip.h: kTagMod)
 constexpr uint32_t kDeferSets = 8;       // streams with a work-list buffer of their own (eppk_ctx::dsets)
 constexpr uint32_t kReportRing = 4096;   // quad launches whose deferred-count report may be outstanding (a host that enqueues far ahead of
                                          // the device: bench.py is a few hundred launches ahead; a full ring = the fast kernel for that launch)
@@ -646,7 +648,11 @@ int resident_ensure(eppk_ctx* c) {            // control blocks, argument block,
   HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
   return EPPK_OK;
 }
-int resident_start(eppk_ctx* c, uint32_t form) {
+// `outstanding`: a doorbell has been rung that the workgroup which just left did not answer (the in-call restart of resident_pick): the
+// new workgroup must take it at once (seen = seq - 1).  Otherwise the last doorbell HAS been answered: seen = seq, or the fresh
+// workgroup would score that batch a second time -- the stale count of the doorbell word against whatever rows the caller is writing
+// into the staging buffer for its next call (~10 us on the path meant to save them, results written behind the new batch's end).
+int resident_start(eppk_ctx* c, uint32_t form, bool outstanding = false) {
   eppk_ctx::ResidentUnit& u = c->res[form];
   if (u.running) return EPPK_OK;
   { const int rce = resident_ensure(c); if (rce) return rce; }
@@ -656,8 +662,7 @@ int resident_start(eppk_ctx* c, uint32_t form) {
   const size_t lds = resident_lds(c, &hist_fits);
   int per_cu = 0;
   { const int rco = occupancy_of(c, fn, threads, lds, &per_cu); if (rco) return rco; }
-  // the doorbell the kernel has seen last = the last one rung (a batch rung while the kernel was leaving is picked up at once)
-  const uint32_t seen = u.seq == 0 ? 0u : u.seq - 1u;
+  const uint32_t seen = (outstanding && u.seq != 0u) ? u.seq - 1u : u.seq;
   uint32_t bell_now = __atomic_load_n(&u.h_ctl->bell, __ATOMIC_ACQUIRE);
   if (bell_now == eppk::kResQuit) __atomic_store_n(&u.h_ctl->bell, seen, __ATOMIC_RELEASE);
   __atomic_store_n(&u.h_ctl->state, eppk::kResRunning, __ATOMIC_RELEASE);
@@ -677,8 +682,13 @@ int resident_start(eppk_ctx* c, uint32_t form) {
 int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_score, const char* who) {
   int rc = validate_rows(c, who, c->h_reqs, n_reqs, 0u);
   if (rc) return rc;
+  // The resident kernel is OUTSIDE stream order: whatever this context has queued that changes the index or the snapshot must be over
+  // before the doorbell rings -- a LEARN update behind a staging set (the `learned` event), and anything on the context's own stream
+  // (eppk_index_insert_picks_device / eppk_pick_learn_device / eppk_index_evict_older_device with stream = NULL on a context that never
+  // used the staging sets: no event).  One hipStreamQuery when the stream is idle.  Work on a CALLER's stream is the caller's to order
+  // (include/eppk.h: "streams").
   { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
-  if (c->learn_pending) HIPCHK(c, hipStreamSynchronize(c->stream));         // (the resident kernel is outside stream order: an index update still running must be over)
+  if (c->learn_pending || hipStreamQuery(c->stream) != hipSuccess) HIPCHK(c, hipStreamSynchronize(c->stream));
   rc = resident_ensure(c);
   if (rc) return rc;
   if (c->res_args_dirty) {        // a publish (or the first use): the argument block again -- between two doorbells, the kernel reads it behind the next
@@ -713,7 +723,7 @@ int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_s
         // (resident_start: seen = seq - 1)
         HIPCHK(c, hipStreamSynchronize(u.stream));
         u.running = false;
-        rc = resident_start(c, form);
+        rc = resident_start(c, form, true);
         if (rc) return rc;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
@@ -1126,6 +1136,7 @@ void eppk_destroy(eppk_ctx* c) {
     if (s.h_score) (void)hipHostFree(s.h_score);
   }
   if (c->learned) (void)hipEventDestroy(c->learned);
+  if (c->learn_words_free) (void)hipEventDestroy(c->learn_words_free);
   if (c->check.st) { (void)hipStreamSynchronize(c->check.st); (void)hipStreamDestroy(c->check.st); }
   if (c->check.done) (void)hipEventDestroy(c->check.done);
   if (c->check.h_bad) (void)hipHostFree(c->check.h_bad);
@@ -1362,17 +1373,22 @@ int eppk_index_selfcheck(eppk_ctx* c, uint64_t* n_bad) {
 int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
   if (!c) return EPPK_ERR_ARG;
   if (c->index_epoch == 0xFFFFFFFFu) return fail(c, EPPK_ERR_LIMIT, "eppk_index_advance_epoch: epoch counter exhausted (clear the index)");
-  ++c->index_epoch;
-  if (new_epoch) *new_epoch = c->index_epoch;
-  // The window of the 8-bit stamp tags (SEMANTICS.md 6a): no live hash may be 255 epochs old or more.  A shim that ages its index
-  // (evict_older(epoch - keep) with a keep of a few epochs) never gets here; one that never evicts pays a scan per tick from the 255th.
-  if (c->slots && c->index_epoch > kEpochWindow && c->min_live < c->index_epoch - kEpochWindow) {
+  // The window of the 8-bit stamp tags (SEMANTICS.md 6a): after the tick to epoch e no live hash may be stamped before e - 254.  The
+  // eviction runs BEFORE the tick, at epoch e - 1: a hash stamped at e - 255 is 254 epochs old there -- the largest age a tag can
+  // express -- and goes (keep = 253).  Behind the tick it would be 255 epochs old, its tag would equal the new epoch's and it would
+  // read as age 0 for ever (round-4 defect: the scan ran behind the tick with keep = 254, which no tag age exceeds).
+  // A shim that ages its index (evict_older(epoch - keep) with a keep of a few epochs) never gets here; one that never evicts, or
+  // keeps 254 epochs and more, pays a scan per tick from the 255th.
+  const uint32_t next = c->index_epoch + 1u;
+  if (c->slots && next > kEpochWindow && c->min_live < next - kEpochWindow) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     { const int rcs_ = device_sync(c); if (rcs_) return rcs_; }               // (index updates the caller may have in flight on streams of its own)
     uint32_t gone = 0;
-    const int rc = eppk_index_evict_older(c, c->index_epoch - kEpochWindow, &gone);
+    const int rc = eppk_index_evict_older(c, next - kEpochWindow, &gone);
     if (rc) return rc;
   }
+  c->index_epoch = next;
+  if (new_epoch) *new_epoch = c->index_epoch;
   return EPPK_OK;
 }
 
@@ -1490,6 +1506,22 @@ int eppk_pick_batch_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
 }
 
 namespace {
+// The learn words live in ONE buffer per context (d_learn): a LEARN pick on stream `st` may only overwrite them once the update
+// behind the previous LEARN pick -- possibly on another stream of the caller's -- has read them.  Free in the single-stream case: the
+// event is recorded (on the PREVIOUS stream, behind everything queued there) only when the stream changes.
+int learn_words_fence(eppk_ctx* c, hipStream_t st) {
+  if (c->learn_words_stream && c->learn_words_stream != st) {
+    if (!c->learn_words_free) HIPCHK(c, hipEventCreateWithFlags(&c->learn_words_free, hipEventDisableTiming));
+    if (hipEventRecord(c->learn_words_free, c->learn_words_stream) == hipSuccess) {
+      HIPCHK(c, hipStreamWaitEvent(st, c->learn_words_free, 0));
+    } else {                                  // (the caller has destroyed that stream meanwhile: whatever ran on it is waited for wholesale)
+      (void)hipGetLastError();
+      const int rcs_ = device_sync(c); if (rcs_) return rcs_;
+    }
+  }
+  c->learn_words_stream = st;
+  return EPPK_OK;
+}
 // room for the learn words of n requests (grown behind a device synchronise: rare)
 int learn_ensure(eppk_ctx* c, size_t n) {
   if (n <= c->learn_cap) return EPPK_OK;
@@ -1512,6 +1544,8 @@ int eppk_pick_learn_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, con
   HIPCHK(c, hipSetDevice(c->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   int rc = learn_ensure(c, n_reqs);
+  if (rc) return rc;
+  rc = learn_words_fence(c, st);
   if (rc) return rc;
   // (the kernels address request rows with 32-bit byte offsets: batches of 2 GiB and more in pieces, each picked and learned in turn)
   const uint32_t per = (uint32_t)((1ull << 31) / c->stride);
@@ -1795,7 +1829,7 @@ int stage_ensure(eppk_ctx* c, uint32_t set, bool need_mask) {
     HIPCHK(c, hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&s.picked, hipEventDisableTiming));
     HIPCHK(c, hipMalloc(&s.d_reqs, mb * c->stride));
-    HIPCHK(c, hipMalloc((void**)&s.d_pick, mb * 4u));
+    HIPCHK(c, hipMalloc((void**)&s.d_pick, (mb + EPPK_GROUP_MAX_DEVICES) * 4u));   // (+ the padding of a group's in-place all-gather)
     HIPCHK(c, hipMalloc((void**)&s.d_score, mb * 8u));
     HIPCHK(c, hipHostMalloc(&s.h_reqs, mb * c->stride, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void**)&s.h_pick, mb * 4u, hipHostMallocDefault));
@@ -1850,7 +1884,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   const bool zero_copy = n_reqs <= c->zero_copy_max;
   int rc;
   bool words = false;                        // the pick kernel left learn words for the update (pick_quad_kernel<..., LEARN>): known pairs are
-  if (learn) { rc = learn_ensure(c, n_reqs); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
+  if (learn) { rc = learn_ensure(c, n_reqs); if (!rc) rc = learn_words_fence(c, s.st); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
   if (zero_copy) {
     // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
     // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
@@ -2116,6 +2150,19 @@ int eppk_pick_batch_subset(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const
 
 // ---- ordered fallbacks ---------------------------------------------------------------------------------
 
+namespace {
+int topk_ensure(eppk_ctx* c, bool need_mask) {
+  const size_t mb = c->cfg.max_batch;
+  if (!c->d_tk_reqs) {
+    HIPCHK(c, hipMalloc(&c->d_tk_reqs, mb * c->stride));
+    HIPCHK(c, hipMalloc((void**)&c->d_tk_pick, mb * EPPK_MAX_TOPK * 4u));
+    HIPCHK(c, hipMalloc((void**)&c->d_tk_score, mb * EPPK_MAX_TOPK * 8u));
+  }
+  if (need_mask && !c->d_tk_mask) HIPCHK(c, hipMalloc((void**)&c->d_tk_mask, mb * c->jmax * 8u));
+  return EPPK_OK;
+}
+}  // namespace
+
 int eppk_pick_topk_device(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,
                           int32_t* d_out_pick, double* d_out_score, void* stream) {
   if (!c || ((!d_reqs || !d_out_pick) && n_reqs)) return fail(c, EPPK_ERR_ARG, "eppk_pick_topk_device: null argument");
@@ -2171,12 +2218,7 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
     return EPPK_OK;
   }
   // device buffers are kept in the context (allocated on first use); transfers are plain pageable copies
-  if (!c->d_tk_reqs) {
-    HIPCHK(c, hipMalloc(&c->d_tk_reqs, mb * c->stride));
-    HIPCHK(c, hipMalloc((void**)&c->d_tk_pick, mb * EPPK_MAX_TOPK * 4u));
-    HIPCHK(c, hipMalloc((void**)&c->d_tk_score, mb * EPPK_MAX_TOPK * 8u));
-  }
-  if (cand_mask && !c->d_tk_mask) HIPCHK(c, hipMalloc((void**)&c->d_tk_mask, mb * c->jmax * 8u));
+  { const int rct = topk_ensure(c, cand_mask != nullptr); if (rct) return rct; }
   HIPCHK(c, hipMemcpyAsync(c->d_tk_reqs, reqs, (size_t)n_reqs * c->stride, hipMemcpyHostToDevice, c->stream));
   if (cand_mask) HIPCHK(c, hipMemcpyAsync(c->d_tk_mask, cand_mask, (size_t)n_reqs * J * 8u, hipMemcpyHostToDevice, c->stream));
   int rc = run_pick(c, (const uint8_t*)c->d_tk_reqs, n_reqs, cand_mask ? c->d_tk_mask : nullptr, c->d_tk_pick, c->d_tk_score, c->stream, k, false, 0ull, 0u);
@@ -2376,6 +2418,18 @@ struct eppk_group {
   uint32_t max_batch = 0;
   void* h_stage = nullptr; size_t h_stage_bytes = 0;   // ONE pinned, portable copy of a batch: every device DMAs from it
   std::vector<hipEvent_t> ev;                           // ev[g]: device g's shard of picks is in every peer's array (PEER)
+  // ordered fallbacks over the group (eppk_group_pick_topk / _random_topk): pinned, portable mask and result staging
+  uint64_t* h_tk_mask = nullptr; int32_t* h_tk_pick = nullptr; double* h_tk_score = nullptr;
+  // The PIPELINED host path over the group (eppk_group_pick_stage_*): per set ONE pinned, portable buffer of rows / masks / results that
+  // the caller fills and every member's DMA engine reads; the members work on their own staging sets' streams and device buffers
+  // (eppk_ctx::stage[set]).  sev[set][i]: member i's shard of picks has landed in every peer's array (PEER gather of a LEARN batch).
+  struct GStage {
+    void* h_reqs = nullptr; uint64_t* h_mask = nullptr; int32_t* h_pick = nullptr; double* h_score = nullptr;
+    uint32_t n = 0, used = 0, per = 0; bool busy = false, had_mask = false, learn = false, host_learn = false;
+    std::vector<hipEvent_t> sev;
+    std::vector<hipEvent_t> cev;   // cev[p]: member p's update has read its copy of this set's gathered picks: the peers may push the next batch's into it
+  };
+  GStage gstage[EPPK_STAGE_SETS];
   // RCCL (dlopen)
   void* rccl = nullptr;
   std::vector<void*> comms;
@@ -2496,8 +2550,19 @@ void eppk_group_destroy(eppk_group* g) {
   if (!g) return;
   for (void* c : g->comms) if (c && g->nccl_comm_destroy) (void)g->nccl_comm_destroy(c);
   for (size_t i = 0; i < g->ev.size(); ++i) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(g->ev[i]); }
+  for (eppk_group::GStage& gs : g->gstage) {
+    for (size_t i = 0; i < gs.sev.size(); ++i) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(gs.sev[i]); }
+    for (size_t i = 0; i < gs.cev.size(); ++i) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(gs.cev[i]); }
+    if (gs.h_reqs) (void)hipHostFree(gs.h_reqs);
+    if (gs.h_mask) (void)hipHostFree(gs.h_mask);
+    if (gs.h_pick) (void)hipHostFree(gs.h_pick);
+    if (gs.h_score) (void)hipHostFree(gs.h_score);
+  }
   for (eppk_ctx* m : g->ctx) eppk_destroy(m);
   if (g->h_stage) (void)hipHostFree(g->h_stage);
+  if (g->h_tk_mask) (void)hipHostFree(g->h_tk_mask);
+  if (g->h_tk_pick) (void)hipHostFree(g->h_tk_pick);
+  if (g->h_tk_score) (void)hipHostFree(g->h_tk_score);
   delete g;     // (librccl stays loaded: unloading a library that owns device state is not worth the risk)
 }
 
@@ -2681,6 +2746,318 @@ int eppk_group_pick_device(eppk_group* g, const void* const* d_reqs, const uint3
     const int erc = g->nccl_group_end();
     if (nrc != 0 || erc != 0) return gfail(g, EPPK_ERR_DEVICE, std::string("ncclAllGather: ") + (g->nccl_err ? g->nccl_err(nrc ? nrc : erc) : "error"));
   }
+  return EPPK_OK;
+}
+
+// ---- what a shim calls beside eppk_group_pick_batch: ageing, per-pod capacity, ordered fallbacks, the pipelined host path ------------------
+namespace { void group_host_learn_flush(eppk_group* g, uint32_t set); }
+
+int eppk_group_index_evict_older_device(eppk_group* g, uint32_t min_epoch) {
+  if (!g) return EPPK_ERR_ARG;
+  // every member: on its own stream, behind the picks (and LEARN updates) of the staging sets begun before, ahead of those begun after
+  for (uint32_t set = 0; set < EPPK_STAGE_SETS; ++set) group_host_learn_flush(g, set);
+  GALL(g, eppk_index_evict_older_device(m, min_epoch, nullptr));
+  return EPPK_OK;
+}
+
+int eppk_group_index_trim_pods(eppk_group* g, uint32_t cap_per_pod, uint64_t* n_removed) {
+  if (!g) return EPPK_ERR_ARG;
+  GALL(g, eppk_index_trim_pods(m, cap_per_pod, n_removed));     // (replicas are identical: every member removes the same pairs)
+  return EPPK_OK;
+}
+
+namespace {
+
+int group_pinned(eppk_group* g, void** p, size_t bytes, const char* what) {
+  if (*p) return EPPK_OK;
+  if (hipHostMalloc(p, bytes ? bytes : 8u, hipHostMallocPortable) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return gfail(g, EPPK_ERR_NOMEM, std::string(what) + ": pinned staging"); }
+  return EPPK_OK;
+}
+
+// how a batch of n requests is spread over the members: `used` of them, `per` rows each (the last one what is left)
+struct Shards {
+  uint32_t n, used, per;
+  Shards(const eppk_group* g, uint32_t n_) : n(n_) {
+    const uint32_t G = (uint32_t)g->ctx.size();
+    used = (n + g->min_shard - 1) / g->min_shard;
+    used = used < 1 ? 1 : used > G ? G : used;
+    per = (n + used - 1) / used;
+  }
+  uint32_t lo(uint32_t i) const { const uint64_t l = (uint64_t)i * per; return (uint32_t)(l < n ? l : n); }
+  uint32_t cnt(uint32_t i) const { return i >= used ? 0u : lo(i + 1) - lo(i); }
+};
+
+// ordered fallbacks / picker "random-top-k" over the group: sharded by request like eppk_group_pick_batch, every member busy at once
+int group_topk(eppk_group* g, const char* who, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, bool random, uint64_t seed,
+               int32_t* out_pick, double* out_score) {
+  if (!g || ((!reqs || !out_pick) && n_reqs)) return gfail(g, EPPK_ERR_ARG, std::string(who) + ": null argument");
+  if (k < 1 || k > EPPK_MAX_TOPK) return gfail(g, EPPK_ERR_ARG, std::string(who) + ": k out of range (1..8)");
+  if (n_reqs > g->max_batch) return gfail(g, EPPK_ERR_LIMIT, std::string(who) + ": n_reqs > max_batch");
+  if (n_reqs == 0) return EPPK_OK;
+  eppk_ctx* c0 = g->ctx[0];
+  for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, std::string(who) + ": no snapshot published");
+  for (eppk_ctx* m : g->ctx) if (m->assumed_epochs) return gfail(g, EPPK_ERR_ARG, std::string(who) + ": device groups do not support assumed load");
+  int rc = validate_rows(c0, who, reqs, n_reqs);
+  if (rc) return gfail(g, rc, eppk_last_error(c0));
+  const size_t J = (c0->n_pods + 63u) / 64u;
+  const uint32_t ok = random ? 1u : k;                         // entries per request in the caller's arrays
+  if (cand_mask && !J) {
+    for (size_t i = 0; i < (size_t)n_reqs * ok; ++i) { out_pick[i] = EPPK_NO_PICK; if (out_score) out_score[i] = 0.0; }
+    return EPPK_OK;
+  }
+  const size_t mb = g->max_batch;
+  if ((rc = group_pinned(g, &g->h_stage, mb * c0->stride, who))) return rc;
+  g->h_stage_bytes = g->h_stage_bytes < mb * c0->stride ? mb * c0->stride : g->h_stage_bytes;
+  if ((rc = group_pinned(g, (void**)&g->h_tk_pick, mb * EPPK_MAX_TOPK * 4u, who))) return rc;
+  if ((rc = group_pinned(g, (void**)&g->h_tk_score, mb * EPPK_MAX_TOPK * 8u, who))) return rc;
+  if (cand_mask && (rc = group_pinned(g, (void**)&g->h_tk_mask, mb * c0->jmax * 8u, who))) return rc;
+  std::memcpy(g->h_stage, reqs, (size_t)n_reqs * c0->stride);
+  if (cand_mask) std::memcpy(g->h_tk_mask, cand_mask, (size_t)n_reqs * J * 8u);
+  const Shards sh(g, n_reqs);
+  GFOR(g, i) {
+    const uint32_t lo = sh.lo(i), cnt = sh.cnt(i);
+    if (!cnt) continue;
+    eppk_ctx* m = g->ctx[i];
+    auto mfail = [&](int code) { return gfail(g, code, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(m)); };
+    if (hipSetDevice(g->dev[i]) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, std::string(who) + ": hipSetDevice failed");
+    if ((rc = topk_ensure(m, cand_mask != nullptr))) return mfail(rc);
+    if (hipMemcpyAsync(m->d_tk_reqs, (const uint8_t*)g->h_stage + (size_t)lo * m->stride, (size_t)cnt * m->stride, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+        (cand_mask && hipMemcpyAsync(m->d_tk_mask, g->h_tk_mask + (size_t)lo * J, (size_t)cnt * J * 8u, hipMemcpyHostToDevice, m->stream) != hipSuccess))
+      return gfail(g, EPPK_ERR_DEVICE, std::string(who) + ": upload failed");
+    // (random-top-k hashes the request's index in the BATCH: r0 = the shard's first row, so that the split does not show)
+    rc = run_pick(m, (const uint8_t*)m->d_tk_reqs, cnt, cand_mask ? m->d_tk_mask : nullptr, m->d_tk_pick, m->d_tk_score, m->stream, k, random, seed, lo);
+    if (rc) return mfail(rc);
+    if (hipMemcpyAsync(g->h_tk_pick + (size_t)lo * ok, m->d_tk_pick, (size_t)cnt * ok * 4u, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(g->h_tk_score + (size_t)lo * ok, m->d_tk_score, (size_t)cnt * ok * 8u, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
+      return gfail(g, EPPK_ERR_DEVICE, std::string(who) + ": download failed");
+  }
+  GFOR(g, i) {
+    if (!sh.cnt(i)) continue;
+    (void)hipSetDevice(g->dev[i]);
+    if (hipStreamSynchronize(g->ctx[i]->stream) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, std::string(who) + ": device " + std::to_string(g->dev[i]) + " failed");
+  }
+  std::memcpy(out_pick, g->h_tk_pick, (size_t)n_reqs * ok * 4u);
+  if (out_score) std::memcpy(out_score, g->h_tk_score, (size_t)n_reqs * ok * 8u);
+  return EPPK_OK;
+}
+
+// EPPK_GATHER_HOST + EPPK_PICK_LEARN: the update of a staged batch cannot be chained on the devices before its picks have reached the
+// host.  It is issued as soon as something needs the index it leaves behind: the set's own end, a begin of the other set (its pick
+// must see it: this call then waits for the in-flight set's picks first -- the price of the mode), or the ageing step.
+void group_host_learn_flush(eppk_group* g, uint32_t set) {
+  eppk_group::GStage& gs = g->gstage[set];
+  if (!gs.host_learn) return;
+  gs.host_learn = false;
+  GFOR(g, i) {                               // the picks of every shard must be in the pinned buffer
+    eppk_ctx::StageSet& s = g->ctx[i]->stage[set];
+    if (!s.busy) continue;
+    (void)hipSetDevice(g->dev[i]);
+    (void)hipEventSynchronize(s.picked);
+  }
+  GFOR(g, p) {
+    eppk_ctx* m = g->ctx[p];
+    eppk_ctx::StageSet& s = m->stage[set];
+    (void)hipSetDevice(g->dev[p]);
+    QuietRows quiet(m);
+    int rc = hipMemcpyAsync(s.d_pick, gs.h_pick, (size_t)gs.n * 4u, hipMemcpyHostToDevice, s.st) == hipSuccess ? EPPK_OK : EPPK_ERR_DEVICE;
+    const bool up_ev = rc == EPPK_OK && hipEventRecord(gs.sev[p], s.st) == hipSuccess;
+    if (rc == EPPK_OK) rc = learn_picks(m, s.d_reqs, s.d_pick, gs.n, s.st);
+    if (rc == EPPK_OK && hipEventRecord(m->learned, s.st) == hipSuccess) m->learn_pending = true;
+    else m->host_flags |= EPPK_LAUNCH_LEARN_FAILED;
+    // the pinned pick buffer is the caller's again when the set's end returns (the next begin's members write their shards into it):
+    // the upload must have read it by then -- a few microseconds; the update itself runs on
+    if (up_ev) (void)hipEventSynchronize(gs.sev[p]); else (void)hipStreamSynchronize(s.st);
+  }
+}
+
+}  // namespace
+
+int eppk_group_pick_topk(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, int32_t* out_pick, double* out_score) {
+  return group_topk(g, "eppk_group_pick_topk", reqs, n_reqs, cand_mask, k, false, 0ull, out_pick, out_score);
+}
+
+int eppk_group_pick_random_topk(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, uint64_t seed, int32_t* out_pick,
+                                double* out_score) {
+  return group_topk(g, "eppk_group_pick_random_topk", reqs, n_reqs, cand_mask, k, true, seed, out_pick, out_score);
+}
+
+int eppk_group_pick_stage_buffers(eppk_group* g, uint32_t set, void** reqs, uint64_t** cand_mask) {
+  if (!g || set >= EPPK_STAGE_SETS) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_buffers: no such set");
+  eppk_group::GStage& gs = g->gstage[set];
+  eppk_ctx* c0 = g->ctx[0];
+  const size_t mb = g->max_batch;
+  int rc;
+  if ((rc = group_pinned(g, &gs.h_reqs, mb * c0->stride, "eppk_group_pick_stage_buffers"))) return rc;
+  if ((rc = group_pinned(g, (void**)&gs.h_pick, mb * 4u, "eppk_group_pick_stage_buffers"))) return rc;
+  if ((rc = group_pinned(g, (void**)&gs.h_score, mb * 8u, "eppk_group_pick_stage_buffers"))) return rc;
+  if (cand_mask && (rc = group_pinned(g, (void**)&gs.h_mask, mb * c0->jmax * 8u, "eppk_group_pick_stage_buffers"))) return rc;
+  if (gs.sev.empty()) {
+    GFOR(g, i) {
+      hipEvent_t e;
+      (void)hipSetDevice(g->dev[i]);
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_buffers: hipEventCreate failed");
+      gs.sev.push_back(e);
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_buffers: hipEventCreate failed");
+      gs.cev.push_back(e);
+    }
+  }
+  GFOR(g, i) {       // every member's own set: stream, events, device buffers
+    eppk_ctx* m = g->ctx[i];
+    (void)hipSetDevice(g->dev[i]);
+    if ((rc = stage_ensure(m, set, cand_mask != nullptr))) return gfail(g, rc, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(m));
+  }
+  if (reqs) *reqs = gs.h_reqs;
+  if (cand_mask) *cand_mask = gs.h_mask;
+  return EPPK_OK;
+}
+
+int eppk_group_pick_stage_begin(eppk_group* g, uint32_t set, uint32_t n_reqs, int use_mask, uint32_t flags) {
+  if (!g || set >= EPPK_STAGE_SETS) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: no such set");
+  eppk_group::GStage& gs = g->gstage[set];
+  if (!gs.h_reqs || gs.sev.empty() || (use_mask && !gs.h_mask)) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: eppk_group_pick_stage_buffers was not called for these buffers");
+  if (gs.busy) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: the set is in flight (end it first)");
+  if (n_reqs > g->max_batch) return gfail(g, EPPK_ERR_LIMIT, "eppk_group_pick_stage_begin: n_reqs > max_batch");
+  eppk_ctx* c0 = g->ctx[0];
+  for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, "eppk_group_pick_stage_begin: no snapshot published");
+  for (eppk_ctx* m : g->ctx) if (m->assumed_epochs) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: device groups do not support assumed load");
+  if ((flags & EPPK_PICK_LEARN) && !c0->slots) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: EPPK_PICK_LEARN without a prefix index");
+  const bool learn = (flags & EPPK_PICK_LEARN) != 0u && c0->cfg.max_blocks != 0u;
+  const uint32_t G = (uint32_t)g->ctx.size();
+  const Shards sh(g, n_reqs);
+  if (learn && g->mode == EPPK_GATHER_RCCL && sh.used != G && n_reqs)
+    return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_begin: EPPK_GATHER_RCCL shards over all members (set min_shard <= n_reqs / devices)");
+  group_host_learn_flush(g, set ^ 1u);        // (EPPK_GATHER_HOST: the other set's update, which this set's picks must see)
+  gs.n = n_reqs; gs.used = sh.used; gs.per = sh.per; gs.had_mask = use_mask != 0; gs.learn = learn; gs.host_learn = false; gs.busy = true;
+  if (n_reqs == 0) return EPPK_OK;
+  const size_t J = (c0->n_pods + 63u) / 64u;
+  // A begin that fails has not begun (as eppk_pick_stage_begin): whatever the members had enqueued is waited for and every set is idle again.
+  struct Abort {
+    eppk_group* g; uint32_t set; eppk_group::GStage& gs; bool armed = true;
+    ~Abort() {
+      if (!armed) return;
+      for (uint32_t i = 0; i < (uint32_t)g->ctx.size(); ++i) {
+        eppk_ctx::StageSet& s = g->ctx[i]->stage[set];
+        if (s.st) { (void)hipSetDevice(g->dev[i]); (void)hipStreamSynchronize(s.st); }
+        s.busy = false; s.check_pending = false; s.copy_pending = false;
+      }
+      gs.busy = false;
+    }
+  } abort_guard{g, set, gs};
+  // A: every member: upload (its shard; the whole batch when the index learns from it), row check, pick of its shard, picks and scores
+  //    into the group's pinned result buffers
+  GFOR(g, i) {
+    const uint32_t lo = sh.lo(i), cnt = sh.cnt(i);
+    eppk_ctx* m = g->ctx[i];
+    eppk_ctx::StageSet& s = m->stage[set];
+    s.busy = false; s.n = 0; s.check_pending = false; s.copy_pending = false;
+    if (cnt == 0 && !learn) continue;
+    auto mfail = [&](int code) { return gfail(g, code, "device " + std::to_string(g->dev[i]) + ": " + eppk_last_error(m)); };
+    if (hipSetDevice(g->dev[i]) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_begin: hipSetDevice failed");
+    s.busy = true; s.n = learn ? n_reqs : cnt; s.had_mask = use_mask != 0;
+    QuietRows quiet(m);                      // rows out of range are reported by end(), naming the row
+    const uint32_t up_lo = learn ? 0u : lo, up_n = learn ? n_reqs : cnt;
+    if (hipMemcpyAsync(s.d_reqs, (const uint8_t*)gs.h_reqs + (size_t)up_lo * m->stride, (size_t)up_n * m->stride, hipMemcpyHostToDevice, s.st) != hipSuccess)
+      return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_begin: upload failed");
+    int rc = row_check_ensure(m, &s.h_bad, &s.h_bad_dev, &s.st_check, &s.checked);
+    if (!rc) rc = rows_check_launch(m, s.d_reqs, up_n, s.h_bad, s.h_bad_dev, s.st);
+    if (rc) return mfail(rc);
+    s.check_pending = true; s.check_side = false; s.row_base = up_lo;
+    if (cnt) {
+      if (use_mask && J && hipMemcpyAsync(s.d_mask, gs.h_mask + (size_t)lo * J, (size_t)cnt * J * 8u, hipMemcpyHostToDevice, s.st) != hipSuccess)
+        return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_begin: mask upload failed");
+      const uint8_t* d_shard = (const uint8_t*)s.d_reqs + (learn ? (size_t)lo * m->stride : 0u);
+      // picks and scores at their BATCH positions of the member's arrays (a gather fills in the other members' shards around them)
+      rc = run_pick(m, d_shard, cnt, (use_mask && J) ? s.d_mask : nullptr, s.d_pick + lo, s.d_score + lo, s.st, 1u, false, 0ull, 0u);
+      if (rc) return mfail(rc);
+      if (hipMemcpyAsync(gs.h_pick + lo, s.d_pick + lo, (size_t)cnt * 4u, hipMemcpyDeviceToHost, s.st) != hipSuccess ||
+          hipMemcpyAsync(gs.h_score + lo, s.d_score + lo, (size_t)cnt * 8u, hipMemcpyDeviceToHost, s.st) != hipSuccess)
+        return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_begin: download failed");
+    }
+    if (hipEventRecord(s.picked, s.st) != hipSuccess) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_begin: hipEventRecord failed");
+  }
+  abort_guard.armed = false;                 // the picks are on their way: from here on the call succeeds and end() delivers them
+  if (!learn) return EPPK_OK;
+  // B: the picks of every shard onto every member, then C: each member applies the SAME post-route update to its replica.  A failure
+  // here leaves the picks standing (EPPK_LAUNCH_LEARN_FAILED on the members, as eppk_pick_stage_begin does).
+  auto learn_failed = [&](const std::string& why) {
+    for (eppk_ctx* m : g->ctx) m->host_flags |= EPPK_LAUNCH_LEARN_FAILED;
+    g->err = why;
+    return EPPK_OK;
+  };
+  if (g->mode == EPPK_GATHER_HOST) { gs.host_learn = true; return EPPK_OK; }      // (the picks reach the host first: the update is chained in end())
+  if (g->mode == EPPK_GATHER_PEER) {
+    GFOR(g, i) {
+      const uint32_t lo = sh.lo(i), cnt = sh.cnt(i);
+      if (!cnt) continue;
+      eppk_ctx::StageSet& s = g->ctx[i]->stage[set];
+      (void)hipSetDevice(g->dev[i]);
+      GFOR(g, p) {
+        if (p == i) continue;
+        // (member p's update of this set's PREVIOUS batch may still be reading the array the push lands in: it runs on p's stream, the
+        // push on this member's -- an event that was never recorded does not hold anything up)
+        (void)hipStreamWaitEvent(s.st, gs.cev[p], 0);
+        int32_t* dst = g->ctx[p]->stage[set].d_pick + lo;
+        const hipError_t e = g->dev[p] == g->dev[i] ? hipMemcpyAsync(dst, s.d_pick + lo, (size_t)cnt * 4u, hipMemcpyDeviceToDevice, s.st)
+                                                    : hipMemcpyPeerAsync(dst, g->dev[p], s.d_pick + lo, g->dev[i], (size_t)cnt * 4u, s.st);
+        if (e != hipSuccess) return learn_failed(std::string("eppk_group_pick_stage_begin: peer copy failed: ") + hipGetErrorString(e));
+      }
+      if (hipEventRecord(gs.sev[i], s.st) != hipSuccess) return learn_failed("eppk_group_pick_stage_begin: hipEventRecord failed");
+    }
+    GFOR(g, p) {
+      (void)hipSetDevice(g->dev[p]);
+      GFOR(g, i) if (i != p && sh.cnt(i)) (void)hipStreamWaitEvent(g->ctx[p]->stage[set].st, gs.sev[i], 0);
+    }
+  } else {                                   // RCCL: in place, per entries per rank (the arrays have room for per * G)
+    int nrc = g->nccl_group_start();
+    GFOR(g, i) {
+      eppk_ctx::StageSet& s = g->ctx[i]->stage[set];
+      (void)hipSetDevice(g->dev[i]);
+      if (nrc == 0) nrc = g->nccl_all_gather(s.d_pick + (size_t)i * sh.per, s.d_pick, sh.per, /*ncclInt32*/ 2, g->comms[i], s.st);
+    }
+    const int erc = g->nccl_group_end();
+    if (nrc != 0 || erc != 0) return learn_failed(std::string("ncclAllGather: ") + (g->nccl_err ? g->nccl_err(nrc ? nrc : erc) : "error"));
+  }
+  GFOR(g, p) {
+    eppk_ctx* m = g->ctx[p];
+    eppk_ctx::StageSet& s = m->stage[set];
+    (void)hipSetDevice(g->dev[p]);
+    QuietRows quiet(m);
+    const int rc = learn_picks(m, s.d_reqs, s.d_pick, n_reqs, s.st);
+    if (rc == EPPK_OK && hipEventRecord(m->learned, s.st) == hipSuccess) m->learn_pending = true;
+    else m->host_flags |= EPPK_LAUNCH_LEARN_FAILED;
+    (void)hipEventRecord(gs.cev[p], s.st);
+  }
+  return EPPK_OK;
+}
+
+int eppk_group_pick_stage_end(eppk_group* g, uint32_t set, int32_t* out_pick, double* out_score) {
+  if (!g || set >= EPPK_STAGE_SETS) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: no such set");
+  eppk_group::GStage& gs = g->gstage[set];
+  if (!gs.busy) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: the set is not in flight");
+  if (!out_pick && gs.n) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: null argument");
+  gs.busy = false;
+  if (gs.n == 0) return EPPK_OK;
+  uint32_t bad = 0xFFFFFFFFu;
+  bool dev_failed = false;
+  GFOR(g, i) {
+    eppk_ctx::StageSet& s = g->ctx[i]->stage[set];
+    if (!s.busy) continue;
+    (void)hipSetDevice(g->dev[i]);
+    if (hipEventSynchronize(s.picked) != hipSuccess) dev_failed = true;
+    s.busy = false;
+    if (s.check_pending) {
+      s.check_pending = false;
+      if (*s.h_bad != 0xFFFFFFFFu && s.row_base + *s.h_bad < bad) bad = s.row_base + *s.h_bad;
+    }
+  }
+  if (dev_failed) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_end: a member's stream failed");
+  if (bad != 0xFFFFFFFFu) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: request row " + std::to_string(bad) + " out of range");
+  eppk_ctx* c0 = g->ctx[0];
+  const size_t J = (c0->n_pods + 63u) / 64u;
+  std::memcpy(out_pick, gs.h_pick, (size_t)gs.n * 4u);
+  if (out_score) std::memcpy(out_score, gs.h_score, (size_t)gs.n * 8u);
+  if (gs.had_mask && !J) for (uint32_t r = 0; r < gs.n; ++r) { out_pick[r] = EPPK_NO_PICK; if (out_score) out_score[r] = 0.0; }
+  group_host_learn_flush(g, set);             // HOST gather: the picks are here now: back onto every member, then its update
   return EPPK_OK;
 }
 

@@ -173,6 +173,47 @@ class LibEppkBackend : public Backend {  // include/eppk.h
   void* stage_[EPPK_STAGE_SETS] = {nullptr, nullptr};   // the two pipelined sets (eppk_pick_stage_buffers)
 };
 
+// The same seam over a DEVICE GROUP (include/eppk.h eppk_group_*): one picker over several GPUs, the batch sharded by request, the
+// replicated index learning on every member behind the gathered picks.  Everything the dispatcher uses on one context exists here:
+// the two pipelined staging sets with LEARN, ordered fallbacks, ageing without a drain.
+class LibEppkGroupBackend : public Backend {
+ public:
+  static std::unique_ptr<LibEppkGroupBackend> Create(const eppk_cfg& cfg, const std::vector<int32_t>& devices, uint32_t gather_mode, std::string* err,
+                                                     uint32_t min_shard = 0) {
+    eppk_group* g = nullptr;
+    if (eppk_group_create(&cfg, devices.data(), (uint32_t)devices.size(), gather_mode, &g) != EPPK_OK) { if (err) *err = eppk_group_last_error(nullptr); return nullptr; }
+    if (min_shard) (void)eppk_group_set_min_shard(g, min_shard);
+    return std::unique_ptr<LibEppkGroupBackend>(new LibEppkGroupBackend(g));
+  }
+  ~LibEppkGroupBackend() override { eppk_group_destroy(g_); }
+  int Publish(const eppk_pod_row* rows, uint32_t n, uint64_t epoch) override { return eppk_group_snapshot_publish(g_, rows, n, epoch); }
+  int PickBatch(const void* reqs, uint32_t n, const uint64_t* mask, int32_t* picks, double* scores) override {
+    return eppk_group_pick_batch(g_, reqs, n, mask, picks, scores, 0u);
+  }
+  void* StageRows(uint32_t set) override {
+    if (set >= EPPK_STAGE_SETS) return nullptr;
+    if (!stage_[set] && eppk_group_pick_stage_buffers(g_, set, &stage_[set], nullptr) != EPPK_OK) stage_[set] = nullptr;
+    return stage_[set];
+  }
+  int StageBegin(uint32_t set, uint32_t n, bool learn) override { return eppk_group_pick_stage_begin(g_, set, n, 0, learn ? EPPK_PICK_LEARN : 0u); }
+  int StageEnd(uint32_t set, int32_t* picks, double* scores) override { return eppk_group_pick_stage_end(g_, set, picks, scores); }
+  int PickTopK(const void* reqs, uint32_t n, const uint64_t* mask, uint32_t k, int32_t* picks, double* scores) override {
+    return eppk_group_pick_topk(g_, reqs, n, mask, k, picks, scores);
+  }
+  int IndexInsert(const uint64_t* hashes, const uint32_t* pods, uint32_t n) override { return eppk_group_index_insert(g_, hashes, pods, n); }
+  int IndexRemovePod(uint32_t pod) override { return eppk_group_index_remove_pod(g_, pod); }
+  int IndexAdvanceEpoch(uint32_t* e) override { return eppk_group_index_advance_epoch(g_, e); }
+  int IndexEvictOlder(uint32_t min_epoch, uint32_t* n) override { return eppk_group_index_evict_older(g_, min_epoch, n); }
+  int IndexEvictOlderAsync(uint32_t min_epoch) override { return eppk_group_index_evict_older_device(g_, min_epoch); }
+  std::string LastError() const override { return eppk_group_last_error(g_); }
+  eppk_group* group() { return g_; }
+
+ private:
+  explicit LibEppkGroupBackend(eppk_group* g) : g_(g) {}
+  eppk_group* g_;
+  void* stage_[EPPK_STAGE_SETS] = {nullptr, nullptr};
+};
+
 // ---- GpuPicker: EndpointPicker over batched picks -------------------------------------------------------
 
 struct GpuPickerOptions {
@@ -192,7 +233,8 @@ struct GpuPickerOptions {
   bool stable_slots = false;
   // Ageing of the learned prefixes -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)",
   // 0602-…/README.md:82.  Every `index_epoch_interval` the dispatcher ticks the index epoch (between two batches) and drops the
-  // hashes that were not re-inserted during the last `index_keep_epochs` epochs.  0 = no ageing.
+  // hashes that were not re-inserted during the last `index_keep_epochs` epochs.  0 = no ageing.  (A keep beyond the library's stamp
+  // window is clamped to it: EPPK_INDEX_EPOCH_WINDOW, include/eppk.h.)
   std::chrono::microseconds index_epoch_interval{0};
   uint32_t index_keep_epochs = 8;
 };
@@ -200,7 +242,11 @@ struct GpuPickerOptions {
 class GpuPicker : public EndpointPicker {
  public:
   GpuPicker(std::unique_ptr<Backend> backend, const GpuPickerOptions& opt)
-      : be_(std::move(backend)), opt_(opt), stride_(8u + 8u * opt.max_blocks), th_([this] { Loop(); }) {}
+      : be_(std::move(backend)), opt_(ClampOptions(opt)), stride_(8u + 8u * opt.max_blocks), th_([this] { Loop(); }) {}
+  static GpuPickerOptions ClampOptions(GpuPickerOptions o) {
+    if (o.index_keep_epochs > EPPK_INDEX_EPOCH_WINDOW) o.index_keep_epochs = EPPK_INDEX_EPOCH_WINDOW;
+    return o;
+  }
   ~GpuPicker() override {
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
     cv_.notify_all();

@@ -565,7 +565,7 @@ class DeviceGroup:
         rc = self._lib.eppk_group_create(C.byref(cfg), devs, len(devices), gather, C.byref(self._g))
         if rc != 0:
             raise EppkError(rc, (self._lib.eppk_group_last_error(None) or b"").decode())
-        self.n_pods, self.row_words, self.max_batch = 0, 1 + max_blocks, max_batch
+        self.n_pods, self.row_words, self.max_batch, self.max_pods = 0, 1 + max_blocks, max_batch, max_pods
         if min_shard is not None:
             self._check(self._lib.eppk_group_set_min_shard(self._g, int(min_shard)), "set_min_shard")
 
@@ -638,6 +638,73 @@ class DeviceGroup:
         flags = (GROUP_LEARN if learn else 0) | (GROUP_GATHER if gather else 0)
         self._check(self._lib.eppk_group_pick_batch(self._g, reqs.ctypes.data, R, mptr, picks.ctypes.data, scores.ctypes.data, flags), "group_pick_batch")
         return picks, scores
+
+    def index_evict_older_device(self, min_epoch: int) -> None:
+        """eppk_group_index_evict_older_device: asynchronous on every member, valid between two stage_begin calls."""
+        self._check(self._lib.eppk_group_index_evict_older_device(self._g, min_epoch), "group_index_evict_older_device")
+
+    def index_trim_pods(self, cap_per_pod: int) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.eppk_group_index_trim_pods(self._g, cap_per_pod, C.byref(n)), "group_index_trim_pods")
+        return n.value
+
+    def _rows_and_mask(self, reqs, mask):
+        reqs = np.ascontiguousarray(reqs, dtype=np.uint64)
+        assert reqs.ndim == 2 and reqs.shape[1] == self.row_words, "request row stride mismatch"
+        mptr = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert mask.shape == (reqs.shape[0], (self.n_pods + 63) // 64), "mask shape mismatch"
+            mptr = mask.ctypes.data
+        return reqs, mask, mptr
+
+    def pick_topk(self, reqs: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """eppk_group_pick_topk: ([R, k] candidate indices, [R, k] totals), column 0 = the pick."""
+        reqs, mask, mptr = self._rows_and_mask(reqs, mask)
+        R = reqs.shape[0]
+        picks = np.full((R, max(int(k), 1)), -1, dtype=np.int32)
+        scores = np.zeros((R, max(int(k), 1)), dtype=np.float64)
+        self._check(self._lib.eppk_group_pick_topk(self._g, reqs.ctypes.data, R, mptr, k, picks.ctypes.data, scores.ctypes.data), "group_pick_topk")
+        return picks, scores
+
+    def pick_random_topk(self, reqs: np.ndarray, k: int, seed: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        reqs, mask, mptr = self._rows_and_mask(reqs, mask)
+        R = reqs.shape[0]
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        self._check(self._lib.eppk_group_pick_random_topk(self._g, reqs.ctypes.data, R, mptr, k, seed & 0xFFFFFFFFFFFFFFFF, picks.ctypes.data,
+                                                          scores.ctypes.data), "group_pick_random_topk")
+        return picks, scores
+
+    # -- the pipelined host path over the group (eppk_group_pick_stage_*) ---------------------------------------------
+    def stage_buffers(self, which: int, with_mask: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        rp, mp = C.c_void_p(0), C.c_void_p(0)
+        self._check(self._lib.eppk_group_pick_stage_buffers(self._g, which, C.byref(rp), C.byref(mp) if with_mask else None), "group_pick_stage_buffers")
+        reqs = np.frombuffer((C.c_uint64 * (self.max_batch * self.row_words)).from_address(rp.value), dtype=np.uint64).reshape(self.max_batch, self.row_words)
+        mask = None
+        if with_mask:
+            jmax = (self.max_pods + 63) // 64
+            mask = np.frombuffer((C.c_uint64 * (self.max_batch * jmax)).from_address(mp.value), dtype=np.uint64)
+        return reqs, mask
+
+    def stage_begin(self, which: int, R: int, use_mask: bool = False, learn: bool = False) -> None:
+        self._check(self._lib.eppk_group_pick_stage_begin(self._g, which, R, 1 if use_mask else 0, 1 if learn else 0), "group_pick_stage_begin")
+        self._stage_n = getattr(self, "_stage_n", {})
+        self._stage_n[which] = R
+
+    def stage_end(self, which: int) -> Tuple[np.ndarray, np.ndarray]:
+        R = getattr(self, "_stage_n", {}).get(which, 0)
+        picks = np.empty(R, dtype=np.int32)
+        scores = np.empty(R, dtype=np.float64)
+        self._check(self._lib.eppk_group_pick_stage_end(self._g, which, picks.ctypes.data, scores.ctypes.data), "group_pick_stage_end")
+        return picks, scores
+
+    def member_launch_status(self, i: int) -> int:
+        f = C.c_uint32(0)
+        rc = self._lib.eppk_launch_status(self._lib.eppk_group_ctx(self._g, i), C.byref(f))
+        if rc != 0:
+            raise EppkError(rc, "launch_status")
+        return f.value
 
     def member_index_size(self, i: int) -> int:
         n = C.c_uint32(0)

@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define EPPK_ABI_VERSION 3u   /* 2: device groups, launch status, random-top-k, assumed load, holes, per-pod capacity, async eviction; 3: eppk_pick_learn_device,
-                               * EPPK_LAUNCH_LEARN_FAILED, the 254-epoch stamp window (additions only) */
+#define EPPK_ABI_VERSION 4u   /* 2: device groups, launch status, random-top-k, assumed load, holes, per-pod capacity, async eviction; 3: eppk_pick_learn_device,
+                               * EPPK_LAUNCH_LEARN_FAILED, the 254-epoch stamp window; 4: groups get fallbacks, the pipelined host path, async ageing and
+                               * per-pod capacity (additions only) */
 
 /* Limits of this build (SEMANTICS.md §limits). */
 #define EPPK_MAX_PODS      4096u /* candidate endpoints per snapshot                         */
@@ -43,6 +44,7 @@ extern "C" {
 #define EPPK_MAX_SCORERS   8u    /* entries in a profile's weighted scorer chain             */
 
 #define EPPK_MAX_TOPK      8u    /* entries of an ordered fallback list (eppk_pick_topk)        */
+#define EPPK_INDEX_EPOCH_WINDOW 254u /* largest age, in index epochs, a live hash may reach (eppk_index_advance_epoch) */
 
 #define EPPK_NO_PICK       (-1)  /* out_pick value: request had zero candidates (-> 503, fail closed) */
 #define EPPK_ADAPTER_BASE  (-1)  /* req.adapter value: request targets the base model         */
@@ -178,8 +180,9 @@ int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
  * (starts at 1); eppk_index_advance_epoch increments it; eppk_index_evict_older drops every hash whose last stamp is
  * < min_epoch (for all pods) and makes its table word reusable.  A shim ticks the epoch once per interval and evicts
  * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches.
- * Window (SEMANTICS.md 6a): a hash may be at most 254 epochs old -- eppk_index_advance_epoch evicts what would be older (the device
- * keeps a stamp as an 8-bit tag in the hash's bucket header); a caller that never evicts pays a table scan per tick from the 255th on. */
+ * Window (SEMANTICS.md 6a): a hash may be at most EPPK_INDEX_EPOCH_WINDOW = 254 epochs old -- the tick to epoch e first evicts every
+ * hash stamped before e - 254 (the device keeps a stamp as an 8-bit tag in the hash's bucket header); a caller that never evicts,
+ * or whose keep is 254 epochs and more, pays a table scan per tick from the 255th on (a shim clamps its keep to the window). */
 int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
 int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);
 /* Per-pod capacity (0602-…/README.md:82: the approximate index mimics the model servers' own LRU-bounded prefix caches; upstream
@@ -378,9 +381,33 @@ int eppk_group_index_insert(eppk_group* g, const uint64_t* hashes, const uint32_
 int eppk_group_index_remove_pod(eppk_group* g, uint32_t pod);
 int eppk_group_index_advance_epoch(eppk_group* g, uint32_t* new_epoch);
 int eppk_group_index_evict_older(eppk_group* g, uint32_t min_epoch, uint32_t* n_evicted);
+/* Ageing and per-pod capacity of the replicated index as a context has them: eppk_index_evict_older_device on every member's own
+ * stream (valid while staging sets of eppk_group_pick_stage_* are in flight: behind the picks and LEARN updates begun before the call,
+ * ahead of those begun after it -- the shim's ageing step does not drain the group's pipeline either), eppk_index_trim_pods on every
+ * member (replicas are identical: n_removed is any member's count). */
+int eppk_group_index_evict_older_device(eppk_group* g, uint32_t min_epoch);
+int eppk_group_index_trim_pods(eppk_group* g, uint32_t cap_per_pod, uint64_t* n_removed);
 /* eppk_pick_batch over the group: same arguments and results (out_pick / out_score hold all n_reqs entries, in request order). */
 int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, int32_t* out_pick,
                           double* out_score, uint32_t flags);
+/* Ordered fallbacks (PickResult.Fallbacks, pkg/lwepp/handlers/server.go:72-77; docs/proposals/004-endpoint-picker-protocol/README.md:73)
+ * and the picker "random-top-k" over the group: eppk_pick_topk / eppk_pick_random_topk with the batch sharded by request as above,
+ * every member busy at once; same arguments, same results as the context calls on the unsharded batch (random-top-k hashes a request's
+ * index in the BATCH, not in its shard). */
+int eppk_group_pick_topk(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, int32_t* out_pick,
+                         double* out_score);
+int eppk_group_pick_random_topk(eppk_group* g, const void* reqs, uint32_t n_reqs, const uint64_t* cand_mask, uint32_t k, uint64_t seed,
+                                int32_t* out_pick, double* out_score);
+/* The PIPELINED host path over the group: eppk_pick_stage_buffers / _begin / _end (above) with the same calling rules, flags
+ * (EPPK_PICK_LEARN) and error behaviour.  A set's rows / masks / results live in ONE pinned buffer of the group that every member's DMA
+ * engine reads; member i uploads and scores its shard on its own staging set's stream while the caller fills the other set.  With
+ * EPPK_PICK_LEARN every member uploads the WHOLE batch, the picks of all shards are gathered onto every member (the group's gather
+ * mode: peer pushes, one ncclAllGather, or -- EPPK_GATHER_HOST -- uploaded again by _end once they have reached the host) and each member
+ * chains the SAME post-route update to its replica behind them; a later begin of either set scores against that index on every
+ * member.  Ageing between two begins: eppk_group_index_advance_epoch + eppk_group_index_evict_older_device. */
+int eppk_group_pick_stage_buffers(eppk_group* g, uint32_t set, void** reqs, uint64_t** cand_mask);
+int eppk_group_pick_stage_begin(eppk_group* g, uint32_t set, uint32_t n_reqs, int use_mask, uint32_t flags);
+int eppk_group_pick_stage_end(eppk_group* g, uint32_t set, int32_t* out_pick, double* out_score);
 /* The DEVICE-RESIDENT form: member i scores the n_rows[i] request rows at d_reqs[i] -- already in ITS device memory (what a
  * producer that hashes prompts on the device leaves there, eppk_hash_prompts_device) -- into d_out_pick[i] / d_out_score[i] (its
  * memory too; d_out_score nullable), enqueued on the member's own stream (eppk_group_stream) without touching the host: no staging,

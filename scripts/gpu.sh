@@ -13,7 +13,7 @@
 #   small                 scripts/gpu_small_batch_latency.py
 #   doorbell claim evictloop insertbreak     scripts/micro/_bin/<name> (built in the build container)
 #   stats / stats_cl      rocprofv3 --kernel-trace --stats of the headline / the closed loop
-#   pmc / pmc_cold        the PMC passes behind profiles/pmc_*.json (then scripts/make_pmc_json.py in the build container)
+#   pmc / pmc_cold / pmc_cl   the PMC passes behind profiles/pmc_*.json (then scripts/make_pmc_json.py / make_pmc_cl_json.py in the build container)
 #   set:VAR=value / unset:VAR   environment for the stages that follow
 #   benchq:"<args>"       bench.py without the side legs, any arguments;  trace20 = rocprofv3 timeline of the driver-protocol region;  routes_nopause
 # Environment variables pass through (EPPK_QUAD_TAIL=0 bash scripts/gpu.sh ...).
@@ -134,6 +134,13 @@ EOF2
       done
       python scripts/pmc_summary.py $OUT/$name pick_ --by-kernel | tee $OUT/${name}_summary.csv | cut -c1-200
       rm -f $(find $OUT/$name -name "*agent_info.csv") $(find $OUT/$name -name "*kernel_trace.csv") ;;
+    pmc_cl) # counter passes of the closed loop's kernels (LEARN pick, update, eviction) -> scripts/make_pmc_cl_json.py in the build container
+      mkdir -p $OUT/pmc_cl; i=0
+      for ctrs in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "WRITE_SIZE" "FETCH_SIZE"; do i=$((i+1))
+        ( cd /tmp; timeout -k 5 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_cl -o pass$i -- python $GRAFT_REPO_ROOT/bench.py --closed-loop --steps 12 --warmup 6 --cl-verify 0 --no-cpu-baseline > $OUT/pmc_cl/bench_pass$i.json 2> $OUT/pmc_cl/pass$i.err )
+      done
+      python scripts/pmc_summary.py $OUT/pmc_cl _kernel --by-kernel | grep -v "snap_\|lists_fill\|hash_" | tee $OUT/pmc_cl_summary.csv | cut -c1-200
+      rm -f $(find $OUT/pmc_cl -name "*agent_info.csv") $(find $OUT/pmc_cl -name "*kernel_trace.csv") ;;
     *) echo "unknown stage $stage" ;;
   esac
   lap $stage

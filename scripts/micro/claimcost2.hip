@@ -39,7 +39,22 @@ __global__ __launch_bounds__(256) void newkey(unsigned long long* keys, uint32_t
   const u32x4 b0 = B4[0], b1 = B4[1], b2 = B4[2], b3 = B4[3];
   const unsigned long long seen = ((unsigned long long)b0.w << 32) | b0.z;
   const unsigned long long junk = (b1.x ^ b2.y ^ b3.z) & 0ull;
-  atomicCAS(&keys[slot], seen + junk, h);
+  if (MODE < 5) atomicCAS(&keys[slot], seen + junk, h);
+  if (MODE >= 5) {
+    // round-5 candidates: single-pod sets INLINE in the bucket (docs/next/bucket_with_inline_sets.md): no list line at all
+    //   N5  CAS + ONE 4-byte meta store {tag, flags, pod} into the bucket line     N6  CAS only (floor)     N7  bucket load only
+    //   N8  as N5 with the 5-key layout's addresses (keys at bytes 24..63, meta at 4..23)
+    if (MODE == 7) { if (seen + junk == 0x1234567ull) keys[slot] = h; return; }
+    if (MODE == 8) {
+      unsigned long long* kw = keys + (slot & ~7u) + 3u;            // key[1] of the 5-key layout: byte 24 of the bucket
+      atomicCAS(kw, ((unsigned long long)b1.w << 32 | b1.z) + junk, h);
+      __hip_atomic_store((uint32_t*)(keys + (slot & ~7u)) + 1, (uint32_t)((seed & 0xFFu) << 24) | (k & 4095u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    atomicCAS(&keys[slot], seen + junk, h);
+    if (MODE == 5) __hip_atomic_store((uint32_t*)(keys + (slot & ~7u)) + 1, (uint32_t)((seed & 0xFFu) << 24) | (k & 4095u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   uint32_t* L = lists + (size_t)slot * 16u;
   const u32x4 first = {0xFFFF0000u | (k & 4095u), 0xFFFFFFFFu, 0xFFFFFFFFu, 1u}, rest = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   if (MODE == 2 || MODE == 3)
@@ -108,6 +123,11 @@ int main() {
   timeit("N2 new key: ... + 64 B list line + header byte, no wait", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<2>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 20) << 32); });
   timeit("N3 new key: ... + 64 B list line + s_waitcnt + header byte", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<3>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 30) << 32); });
   timeit("N4 new key: ... + 16 B list store + s_waitcnt + header byte", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<4>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 40) << 32); });
+  timeit("N5 new key, inline set: bucket load + CAS + ONE 4 B meta store into the bucket line", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<5>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 100) << 32); });
+  timeit("N6 floor: bucket load + CAS", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<6>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 110) << 32); });
+  timeit("N7 floor: bucket load only", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<7>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 120) << 32); });
+  timeit("N8 new key, inline set, 5-key layout addresses (key at byte 24, meta at byte 4)", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<8>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 130) << 32); });
+  timeit("N1 again (order check)", 1.0, [&](int i) { hipLaunchKernelGGL(newkey<1>, dim3(grid), dim3(256), 0, 0, keys, lists, stamps, slots, n, (uint64_t)(i + 140) << 32); });
   const int eg = 2048;
   const double vic = 2.0 * 7.0 / 8.0;                          // 2 Mi position-1 slots x 7/8 = 1.75 Mi victims per launch
   timeit("E0 ageing: scan keys + stamps; victim = 64 B list line + key word (landed; per Mi victims)", vic, [&](int i) { hipLaunchKernelGGL(evict<0>, dim3(eg), dim3(256), 0, 0, keys, lists, (const uint32_t*)stamps, slots, (uint64_t)(i + 50) << 32, out); });

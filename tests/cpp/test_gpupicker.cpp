@@ -147,6 +147,63 @@ int main() {
     orc_index_free(oix);
   }
 
+  // ---- 4. the same dispatcher over a DEVICE GROUP (two, then four members on device 0): LEARN through the group's staging sets with the
+  //         ageing step between begins, then ordered fallbacks through eppk_group_pick_topk --------------------------------------------
+  for (int members : {2, 4}) {
+    GpuPickerOptions opt;
+    opt.max_pods = 256; opt.max_blocks = B; opt.max_batch = 64; opt.window = std::chrono::microseconds(50);
+    opt.learn_prefixes = true;
+    opt.index_epoch_interval = std::chrono::microseconds(2000); opt.index_keep_epochs = 1000;   // ticks all the time, never old enough to go: clamped to the window
+    std::string err;
+    auto be = LibEppkGroupBackend::Create(MakeCfg(prof, opt, 1 << 14, 0), std::vector<int32_t>((size_t)members, 0), EPPK_GATHER_PEER, &err, /*min_shard=*/1);
+    if (!be) { std::fprintf(stderr, "group create failed: %s\n", err.c_str()); return 1; }
+    eppk_group* grp = be->group();
+    orc_index* oix = orc_index_new();
+    {
+      GpuPicker gp(std::move(be), opt);
+      CHECK(gp.PublishSnapshot(eps, rows, adapters, 1).ok());
+      const int N = 200;
+      for (int i = 0; i < N; ++i) {
+        PickRequest rq;
+        const int conv = (int)(rnd() % 30);
+        rq.model = (conv % 4 == 0) ? "base" : "adapter-" + std::to_string(conv % 8);
+        rq.body = std::string(200, (char)('A' + conv % 26)) + std::to_string(conv) + std::string(250, 'g');
+        uint8_t row[STRIDE];
+        row_of(rq, adapters, row);
+        int32_t want; double wsc;
+        CHECK(orc_pick_batch(chain, 4, rows.data(), (uint32_t)P, oix, row, B, 1, nullptr, &want, &wsc, nullptr) == 0);
+        PickResult r;
+        CHECK(gp.Pick(rq, all, &r).ok());
+        CHECK(want >= 0 && r.endpoint == JoinHostPort(eps[(size_t)want].address, "8080"));
+        const uint32_t nb = ((const uint32_t*)row)[1];
+        for (uint32_t b = 0; b < nb; ++b) orc_index_insert(oix, ((const uint64_t*)(row + 8))[b], (uint32_t)want);
+      }
+      CHECK(gp.fail_opens() == 0 && gp.learn_drops() == 0);
+      for (uint32_t m = 0; m < (uint32_t)members; ++m) {       // every replica learned every pick
+        uint32_t size = 0; uint64_t bad = 1;
+        CHECK(eppk_index_size(eppk_group_ctx(grp, m), &size) == EPPK_OK && (uint64_t)size == orc_index_size(oix));
+        CHECK(eppk_index_selfcheck(eppk_group_ctx(grp, m), &bad) == EPPK_OK && bad == 0);
+      }
+      // fallbacks: a batch of rows straight through the backend seam (sharded over the members) against the oracle's top-3
+      const uint32_t n = 48, K = 3;
+      std::vector<uint8_t> rws((size_t)n * STRIDE);
+      for (uint32_t i = 0; i < n; ++i) {
+        PickRequest rq;
+        const int conv = (int)(rnd() % 30);
+        rq.model = (conv % 4 == 0) ? "base" : "adapter-" + std::to_string(conv % 8);
+        rq.body = std::string(200, (char)('A' + conv % 26)) + std::to_string(conv) + std::string(250, 'g');
+        row_of(rq, adapters, rws.data() + (size_t)i * STRIDE);
+      }
+      std::vector<int32_t> tp((size_t)n * K), op((size_t)n * K);
+      std::vector<double> ts((size_t)n * K), os((size_t)n * K);
+      CHECK(eppk_group_pick_topk(grp, rws.data(), n, nullptr, K, tp.data(), ts.data()) == EPPK_OK);
+      CHECK(orc_pick_topk(chain, 4, rows.data(), (uint32_t)P, oix, rws.data(), B, n, nullptr, K, 1, op.data(), os.data()) == 0);
+      CHECK(tp == op && std::memcmp(ts.data(), os.data(), ts.size() * 8) == 0);
+    }
+    std::printf("gpupicker 4 ok (%d members): picks with the replicated index learning behind the gathered picks equal the oracle; fallbacks too\n", members);
+    orc_index_free(oix);
+  }
+
   // ---- 3. stable slots: a slot reused within one publish / trimmed and regrown is scrubbed --------------------------------------------
   {
     GpuPickerOptions opt;

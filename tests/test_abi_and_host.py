@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in decl:
         assert hasattr(lib, name), f"libeppk.so does not export {name}"
     assert sorted(pkg._lib.SYMBOLS) == decl, "python binding list and header disagree"
-    assert lib.eppk_abi_version() == 3
+    assert lib.eppk_abi_version() == 4
 
 
 def test_struct_layouts_match_header(pkg):

@@ -200,6 +200,67 @@ def test_stamp_window_wraps_like_the_oracle(pkg, orc):
         assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0
 
 
+@pytest.mark.parametrize("first_epoch", [1, 40, 255])
+def test_a_hash_left_alone_is_gone_at_age_255(pkg, orc, first_epoch):
+    """Hashes inserted ONCE and never touched again, no explicit eviction: the tick that would make them 255 epochs old removes them
+    (SEMANTICS.md 6a "window").  Round 4 ran that eviction behind the tick with keep = 254 -- no tag age exceeds 254, nothing went, and the
+    hash's tag then equalled the new epoch's: age 0 for ever (advisor finding, round 4).  Sizes, picks, scores and per-pod trimming
+    against the oracle at every tick around both wrap-arounds; a second generation inserted on the way must live its own 254 epochs."""
+    rng = np.random.default_rng(1000 + first_epoch)
+    P, B, R = 300, 8, 64
+    chain = [(KV, 1), (PF, 5)]
+    pods = pkg.workload.make_pods(11, P, 128)
+    gen1 = rng.integers(1, 2**63, (6, B), dtype=np.uint64)
+    gen1[0, 0] = 0                                                          # a reserved hash (exact stamp, no tag) ages the same way
+    gen2 = rng.integers(1, 2**63, (6, B), dtype=np.uint64)
+    with pkg.BatchedPicker(chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=1024) as pk:
+        pk.publish(pods)
+        oix = orc.OracleIndex()
+        epoch = 1
+        while epoch < first_epoch:
+            epoch = pk.index_advance_epoch()
+            assert epoch == oix.advance_epoch()
+        for c in gen1:
+            ip = rng.integers(0, P, c.size).astype(np.uint32)
+            pk.index_insert(c, ip); oix.insert(c, ip)
+        born1, born2 = epoch, None
+        n1 = len(set(gen1.reshape(-1).tolist()))
+        assert pk.index_size() == oix.size() == n1
+        for tick in range(2 * 255 + 12):
+            if tick == 100:
+                for c in gen2:
+                    ip = rng.integers(0, P, c.size).astype(np.uint32)
+                    pk.index_insert(c, ip); oix.insert(c, ip)
+                born2 = epoch
+            epoch = pk.index_advance_epoch()
+            assert epoch == oix.advance_epoch()
+            near = any(b is not None and 252 <= epoch - b <= 258 for b in (born1, born2))
+            if near or tick % 50 == 0:
+                assert pk.index_size() == oix.size(), (tick, epoch)
+                want = (n1 if epoch - born1 <= 254 else 0) + (gen2.size if born2 is not None and epoch - born2 <= 254 else 0)
+                assert pk.index_size() == want, (tick, epoch, born1, born2)
+                hs = np.concatenate([gen1, gen2])[rng.integers(0, 12, R)]
+                reqs = pkg.picker.make_req_rows(rng.integers(-1, 128, R), np.full(R, B), hs, B)
+                picks, scores = pk.pick(reqs)
+                opk, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+                assert np.array_equal(picks, opk) and np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), (tick, epoch)
+            if epoch - born1 in (253, 254) or (born2 is not None and epoch - born2 == 254):
+                # per-pod capacity reads the ages (SEMANTICS.md 6c) -- on copies: trimming must not change what the window sees
+                assert pk.index_selfcheck() == 0
+        assert pk.index_size() == oix.size() == 0 and pk.index_selfcheck() == 0
+        # ... and a keep of 254 epochs and more never evicts by itself: only the window does (both shims clamp their keep to it)
+        c = gen1[1]
+        ip = rng.integers(0, P, c.size).astype(np.uint32)
+        pk.index_insert(c, ip); oix.insert(c, ip)
+        for _ in range(254):
+            epoch = pk.index_advance_epoch(); oix.advance_epoch()
+            assert pk.index_evict_older(max(epoch - 254, 0)) == oix.evict_older(max(epoch - 254, 0)) == 0
+        assert pk.index_size() == oix.size() == len(set(c.tolist()))
+        assert pk.index_trim_pods(2) == oix.trim_pods(P, 2)
+        epoch = pk.index_advance_epoch(); oix.advance_epoch()
+        assert pk.index_size() == oix.size() == 0 and pk.index_selfcheck() == 0
+
+
 @pytest.mark.parametrize("slots,pods_per_key", [(64, 3), (128, 2), (256, 4), (1024, 1)])
 def test_a_launch_that_fills_the_table_to_its_limit_drops_nothing(pkg, orc, slots, pods_per_key):
     """slots / 2 distinct hashes in ONE insert launch (several pairs per hash, spread over wavefronts): the launch as a whole might not

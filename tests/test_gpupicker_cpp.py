@@ -32,3 +32,4 @@ def test_gpupicker_against_the_oracle():
     out = subprocess.run([_build()], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "gpupicker 1 ok" in out.stdout and "gpupicker 2 ok" in out.stdout and "gpupicker 3 ok" in out.stdout
+    assert "gpupicker 4 ok (2 members)" in out.stdout and "gpupicker 4 ok (4 members)" in out.stdout
