@@ -1108,7 +1108,7 @@ def group_pipelined_leg(pkg, wl, batches, devices, args, n_batches: int = 200):
             oix.insert_picks(batches[(k & 1) % len(batches)], wl.B, op)
         sizes = [g.member_index_size(i) for i in range(M)]
         ok = ok and all(sz == oix.size() for sz in sizes)
-        every = 2 * args.age_every
+        every = args.age_every
         state = {"epoch": 1}
 
         def tick(i):
@@ -1217,7 +1217,7 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     sb = [pk.stage_buffers(0)[0], pk.stage_buffers(1)[0]]
     np.copyto(sb[0][:R], batches[0])
     np.copyto(sb[1][:R], batches[1 % len(batches)])
-    every = 2 * args.age_every
+    every = args.age_every                  # (the closed loop's own policy: the index holds the same ~4 Mi hashes in both legs)
     lat, t_begin = [], [0.0, 0.0]
 
     def tick():
@@ -1247,7 +1247,7 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     lat = np.asarray(lat) * 1e3
     return {"batches": int(n_batches), "decisions_per_s": R * n_batches / t_all, "ms_per_batch": 1e3 * t_all / n_batches,
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "pcie_floor_ms": R * run.stride / 55e9 * 1e3,
-            "ageing_every_batches": every, "index_dropped": int(pk.index_dropped()), "launch_status": int(pk.launch_status()),
+            "ageing_every_batches": every, "index_dropped": int(pk.index_dropped()), "launch_status": int(pk.launch_status()), "index_size_after": int(pk.index_size()),
             "what": "eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over two staging sets (rows already in the pinned sets): the post-route index update "
                     "chained on the device behind every pick; epoch tick + eviction every "
                     f"{every} batches, stream-ordered on the device between two begins (no drain); {args.cl_slots} index slots; wall time of the whole loop"}

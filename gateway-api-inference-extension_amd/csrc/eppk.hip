@@ -134,6 +134,7 @@ struct eppk_ctx {
     void* h_reqs_dev = nullptr; uint64_t* h_mask_dev = nullptr; int32_t* h_pick_dev = nullptr; double* h_score_dev = nullptr;
     uint32_t n = 0; bool busy = false, had_mask = false;
     uint32_t row_base = 0;       // a group member's set: batch index of the first row its device-side check looked at
+    bool resident = false; uint32_t res_unit = 0, res_seq = 0;   // the batch between begin and end was rung into a resident workgroup (no launch)
   };
   StageSet stage[2];
   hipStream_t learn_words_stream = nullptr; hipEvent_t learn_words_free = nullptr;   // d_learn is ONE buffer: a pick + update pair on another stream waits for the last pair's update
@@ -149,10 +150,12 @@ struct eppk_ctx {
   // Two resident workgroups at most, one per FORM of the kernel, each with its control block and stream: [0] pick_fast_kernel's body
   // (a wavefront per request: up to 16 requests), [1] pick_quad_kernel's body (four requests per wavefront: beyond 16, where that
   // route exists).  A batch rings the one that suits it; each leaves by itself when idle and is started again on demand.
+  static constexpr uint32_t kResUnits = 5u;
   struct ResidentUnit {
     eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; hipStream_t stream = nullptr;
     bool running = false; uint32_t seq = 0;   // seq = the last doorbell value rung
-  } res[2];
+    bool pending = false; uint32_t pending_seq = 0;   // a doorbell rung (eppk_pick_stage_begin) and not collected yet
+  } res[kResUnits];
   eppk::ResidentArgs* d_res_args = nullptr;
   uint32_t* d_res_wl = nullptr; uint32_t res_wl_cap = 0;     // the resident workgroup's work list (its pick_quad_kernel form): total[32] | cnt[16] | list[16][cap]
   uint64_t res_batches = 0, res_starts = 0;
@@ -364,7 +367,11 @@ template <typename F> int by_lane_word(const eppk_ctx* c, F&& f);
 // may still be running when eppk_pick_stage_end returns.  Whatever touches the index or reads it afterwards -- a pick, an insert, an
 // eviction, a removal, a trim, a clear, a publish (index scrub), the self check -- is ordered behind it here, on the stream it is
 // about to use: the update's kernels assume that nothing disappears while they run and share one sort work list and capacity verdict.
+int resident_drain(eppk_ctx* c);
 int learn_fence(eppk_ctx* c, hipStream_t st) {
+  // (a small batch rung into a resident workgroup by eppk_pick_stage_begin and not collected yet reads index and snapshot OUTSIDE
+  // stream order: it is answered before anything of this context is launched that could change them)
+  if (c->resident_on) { const int rcd = resident_drain(c); if (rcd) return rcd; }
   if (!c->learn_pending) return EPPK_OK;
   if (hipEventQuery(c->learned) == hipSuccess) { c->learn_pending = false; return EPPK_OK; }
   HIPCHK(c, hipStreamWaitEvent(st, c->learned, 0));
@@ -577,24 +584,34 @@ int rebuild_snapshot(eppk_ctx* c, uint32_t n_pods, hipStream_t st);
 
 int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_reqs, uint32_t first_row = 0);
 
-// ---- the resident small-batch kernel (EPPK_RESIDENT=1) ------------------------------------------------------------------------------
-// LDS of its one workgroup (pick_fast_kernel's layout for 16 wavefronts, sized for max_pods: the kernel outlives publishes); *hist =
-// the per-wave pod histogram of the list routes fits as well (else the kernel is handed an index without list routes)
+// ---- the resident small-batch kernels (EPPK_RESIDENT=1) ------------------------------------------------------------------------------
+// Units (eppk_ctx::res[]): 0 = pick_fast_kernel's body (plain picks below EPPK_RESIDENT_QUAD_FROM requests), 1 = pick_quad_kernel's body
+// (plain picks), 2 = ... with candidate masks, 3 = ... with ordered fallbacks, 4 = both.  Each is a kernel of its own behind a doorbell
+// of its own, started by the first batch that needs it; an idle one leaves by itself.
+constexpr uint32_t kResFast = 0u, kResQuad = 1u, kResMasked = 2u, kResTopk = 3u, kResTopkMasked = 4u;
+// LDS of a resident workgroup (sized for max_pods: the kernels outlive publishes; ONE size for every unit -- the argument block
+// carries it): pick_fast_kernel's layout for 16 wavefronts, or pick_quad_kernel<MASKED>'s where that is larger.  *hist_fits = the
+// per-wave pod histogram of the list routes fits as well (else the kernel is handed an index without list routes).
 size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
   const uint32_t wpb = 16u, J = (c->cfg.max_pods + 63u) / 64u;
   const uint32_t pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
-  size_t lds = (size_t)J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)wpb * 64u * (size_t)c->lw_bytes;     // base | lw | pterm | scratch
+  const size_t front = (size_t)J * 64u * 8u + 32u + (size_t)pwn * 8u;                                       // base | lw | pterm
+  size_t lds = front + (size_t)wpb * 64u * (size_t)c->lw_bytes;                                             // | scratch
   const size_t hist = (size_t)wpb * J * 64u;
   *hist_fits = lds + hist <= c->max_lds;
   if (*hist_fits) lds += hist;
+  const size_t quad_masked = front + (size_t)wpb * 4u * J * 8u + 192u * 8u + (size_t)wpb * 4u * J * 8u;     // | listed bits | natural sets | candidate words
+  if (*hist_fits && quad_masked > lds && quad_masked <= c->max_lds) lds = quad_masked;
   return lds;
 }
-// Park it: ring "quit" and wait for the workgroup to leave.  In front of every device-wide wait of the library's own (a
-// hipDeviceSynchronize would otherwise sit out the kernel's idle timeout), and in eppk_destroy.
+// Park them: ring "quit" and wait for the workgroups to leave.  In front of every device-wide wait of the library's own (a
+// hipDeviceSynchronize would otherwise sit out the kernels' idle timeout), and in eppk_destroy.
 static const bool g_res_dbg = getenv("EPPK_RESIDENT_DEBUG") != nullptr;     // (read once: the macro sits on the latency path)
 #define RES_DBG(...) do { if (g_res_dbg) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
+int resident_drain(eppk_ctx* c);
 int resident_park(eppk_ctx* c) {
-  for (eppk_ctx::ResidentUnit& u : c->res) {                // (both doorbells first, then both waits)
+  { const int rcd = resident_drain(c); if (rcd) return rcd; }       // (a batch rung by eppk_pick_stage_begin and not yet collected is answered first)
+  for (eppk_ctx::ResidentUnit& u : c->res) {                // (every doorbell first, then the waits)
     if (!u.running) continue;
     RES_DBG("park: bell %u done %u state %u", u.h_ctl->bell, u.h_ctl->done, u.h_ctl->state);
     __atomic_store_n(&u.h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
@@ -613,26 +630,30 @@ int device_sync(eppk_ctx* c) {
   HIPCHK(c, hipDeviceSynchronize());
   return EPPK_OK;
 }
-bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked) {
-  return c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && !masked && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
-         c->assumed_epochs == 0 && c->cfg.max_blocks >= 1;
-}
-// The form of the resident kernel: pick_quad_kernel's body (four requests per wavefront) wherever a launch would take that route --
-// the list routes are on and their LDS fits beside the tables -- else pick_fast_kernel's body alone.  Fixed for the life of a context.
+// The form of the resident kernels: pick_quad_kernel's body (four requests per wavefront) wherever a launch would take that route --
+// the list routes are on and their LDS fits beside the tables -- else pick_fast_kernel's body alone (plain picks only).  Fixed for the
+// life of a context.
 bool resident_quad(const eppk_ctx* c) {
   bool hist_fits = false;
   (void)resident_lds(c, &hist_fits);
   return c->quad_on && hist_fits && c->slots != 0u && make_kindex(c).lists != nullptr;
 }
+// k = entries per request (1: the pick)
+bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k = 1u) {
+  if (!(c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
+        c->assumed_epochs == 0 && c->cfg.max_blocks >= 1)) return false;
+  if (!masked && k == 1u) return true;
+  return k <= EPPK_MAX_TOPK && n_reqs <= 255u && resident_quad(c);     // the variants exist for the quad form
+}
 int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams (each made once: a call that failed half-way is resumed)
   if (c->d_res_args) return EPPK_OK;
-  if (!c->d_res_wl) {   // the work list of the quad form: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
+  if (!c->d_res_wl) {   // the work list of the quad forms: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
     const uint32_t nblk = (c->resident_max + 3u) / 4u, per_wave = (nblk + 15u) / 16u;
     c->res_wl_cap = 4u * (per_wave ? per_wave : 1u);
     const size_t words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
     uint32_t* wl = nullptr;
-    HIPCHK(c, hipMalloc((void**)&wl, words * 4u));
-    if (hipMemset(wl, 0, words * 4u) != hipSuccess) { (void)hipFree(wl); return fail(c, EPPK_ERR_DEVICE, "resident path: hipMemset of the work list failed"); }
+    HIPCHK(c, hipMalloc((void**)&wl, words * 4u * eppk_ctx::kResUnits));      // (one work list per unit: two units may be scoring at once)
+    if (hipMemset(wl, 0, words * 4u * eppk_ctx::kResUnits) != hipSuccess) { (void)hipFree(wl); return fail(c, EPPK_ERR_DEVICE, "resident path: hipMemset of the work lists failed"); }
     c->d_res_wl = wl;
   }
   for (eppk_ctx::ResidentUnit& u : c->res) {
@@ -645,18 +666,20 @@ int resident_ensure(eppk_ctx* c) {            // control blocks, argument block,
     if (!u.h_ctl_dev) HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
     if (!u.stream) HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
   }
-  HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs)));
+  HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs) * eppk_ctx::kResUnits));
   return EPPK_OK;
 }
-// `outstanding`: a doorbell has been rung that the workgroup which just left did not answer (the in-call restart of resident_pick): the
+// `outstanding`: a doorbell has been rung that the workgroup which just left did not answer (the in-call restart of resident_wait): the
 // new workgroup must take it at once (seen = seq - 1).  Otherwise the last doorbell HAS been answered: seen = seq, or the fresh
 // workgroup would score that batch a second time -- the stale count of the doorbell word against whatever rows the caller is writing
 // into the staging buffer for its next call (~10 us on the path meant to save them, results written behind the new batch's end).
-int resident_start(eppk_ctx* c, uint32_t form, bool outstanding = false) {
-  eppk_ctx::ResidentUnit& u = c->res[form];
+int resident_start(eppk_ctx* c, uint32_t unit, bool outstanding = false) {
+  eppk_ctx::ResidentUnit& u = c->res[unit];
   if (u.running) return EPPK_OK;
   { const int rce = resident_ensure(c); if (rce) return rce; }
-  const void* fn = form ? eppk::pick_resident_quad(c->lw_bytes, c->has_l, c->p_first) : eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first);
+  const void* fn = unit == kResFast ? eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first)
+                 : unit == kResQuad ? eppk::pick_resident_quad(c->lw_bytes, c->has_l, c->p_first)
+                                    : eppk::pick_resident_quad_variant(c->lw_bytes, c->has_l, c->p_first, unit == kResMasked || unit == kResTopkMasked, unit == kResTopk || unit == kResTopkMasked);
   const uint32_t threads = 1024u;
   bool hist_fits = false;
   const size_t lds = resident_lds(c, &hist_fits);
@@ -667,74 +690,125 @@ int resident_start(eppk_ctx* c, uint32_t form, bool outstanding = false) {
   if (bell_now == eppk::kResQuit) __atomic_store_n(&u.h_ctl->bell, seen, __ATOMIC_RELEASE);
   __atomic_store_n(&u.h_ctl->state, eppk::kResRunning, __ATOMIC_RELEASE);
   eppk::ResidentCtl* ctl = u.h_ctl_dev;
-  const eppk::ResidentArgs* args = c->d_res_args;
+  const eppk::ResidentArgs* args = c->d_res_args + unit;
   uint32_t seen_arg = seen;
   unsigned long long max_idle = 30000ull;                 // ~20-50 ms of polls over PCIe, then the workgroup leaves by itself
   if (const char* e = getenv("EPPK_RESIDENT_IDLE_POLLS")) { const long long v = atoll(e); if (v > 0) max_idle = (unsigned long long)v; }
   void* kargs[] = {&ctl, &args, &seen_arg, &max_idle};
-  RES_DBG("start form %u: seen %u bell %u lds %zu", form, seen_arg, u.h_ctl->bell, lds);
+  RES_DBG("start unit %u: seen %u bell %u lds %zu", unit, seen_arg, u.h_ctl->bell, lds);
   HIPCHK(c, hipExtLaunchKernel(fn, dim3(1), dim3(threads), kargs, lds, u.stream, nullptr, nullptr, 0));
   u.running = true;
   ++c->res_starts;
   return EPPK_OK;
 }
-// One small batch through the resident kernel: rows are in c->h_reqs (pinned) already; results land in c->h_pick / c->h_score.
-int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_score, const char* who) {
-  int rc = validate_rows(c, who, c->h_reqs, n_reqs, 0u);
-  if (rc) return rc;
-  // The resident kernel is OUTSIDE stream order: whatever this context has queued that changes the index or the snapshot must be over
-  // before the doorbell rings -- a LEARN update behind a staging set (the `learned` event), and anything on the context's own stream
-  // (eppk_index_insert_picks_device / eppk_pick_learn_device / eppk_index_evict_older_device with stream = NULL on a context that never
-  // used the staging sets: no event).  One hipStreamQuery when the stream is idle.  Work on a CALLER's stream is the caller's to order
-  // (include/eppk.h: "streams").
-  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
-  if (c->learn_pending || hipStreamQuery(c->stream) != hipSuccess) HIPCHK(c, hipStreamSynchronize(c->stream));
-  rc = resident_ensure(c);
-  if (rc) return rc;
-  if (c->res_args_dirty) {        // a publish (or the first use): the argument block again -- between two doorbells, the kernel reads it behind the next
-    eppk::ResidentArgs a{};
-    a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail;
-    a.reqs = (const uint8_t*)c->h_reqs_dev; a.out_pick = c->h_pick_dev; a.out_score = c->h_score_dev;
-    a.stride = c->stride; a.pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
-    if (++c->res_gen == 0u) c->res_gen = 1u;
-    a.gen = c->res_gen;
-    bool hist_fits = false;
-    a.lds_bytes = (uint32_t)resident_lds(c, &hist_fits);
-    if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
-    a.defer_total = c->d_res_wl; a.defer_cnt = c->d_res_wl + 32; a.defer_list = c->d_res_wl + 48; a.defer_cap = c->res_wl_cap;
-    HIPCHK(c, hipMemcpy(c->d_res_args, &a, sizeof a, hipMemcpyHostToDevice));
-    c->res_args_dirty = false;
-  }
-  const uint32_t form = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? 1u : 0u;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
-  eppk_ctx::ResidentUnit& u = c->res[form];
-  rc = resident_start(c, form);
-  if (rc) return rc;
-  if (++u.seq == eppk::kResQuit || u.seq == 0u) u.seq = 1u;
-  const uint32_t seq = u.seq;
-  RES_DBG("ring %u (n = %u)", seq, n_reqs);
-  static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
-  __atomic_store_n((uint64_t*)&u.h_ctl->bell, ((uint64_t)n_reqs << 32) | seq, __ATOMIC_RELEASE);      // count and doorbell in one store
+// Wait for the answer to doorbell `seq` of `unit` (restarting a workgroup that left just as the doorbell rang).
+int resident_wait(eppk_ctx* c, uint32_t unit, uint32_t seq, const char* who) {
+  eppk_ctx::ResidentUnit& u = c->res[unit];
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
-  while (__atomic_load_n(&u.h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+  // (doorbells of a unit are answered in order: `done` may already be past `seq` when a later batch of the same unit was rung and
+  // collected first -- sequence numbers compare modulo 2^32)
+  auto reached = [&]() { return (int32_t)(__atomic_load_n(&u.h_ctl->done, __ATOMIC_ACQUIRE) - seq) >= 0; };
+  while (!reached()) {
     if ((++spins & 1023u) == 0u) {
-      if (__atomic_load_n(&u.h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited && __atomic_load_n(&u.h_ctl->done, __ATOMIC_ACQUIRE) != seq) {
+      if (__atomic_load_n(&u.h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited && !reached()) {
         // the workgroup left (idle timeout) just as the doorbell rang: start it again; it sees this doorbell at once
-        // (resident_start: seen = seq - 1)
         HIPCHK(c, hipStreamSynchronize(u.stream));
         u.running = false;
-        rc = resident_start(c, form, true);
+        const int rc = resident_start(c, unit, true);
         if (rc) return rc;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
         return fail(c, EPPK_ERR_DEVICE, std::string(who) + ": the resident pick kernel did not answer within 5 s");
     }
   }
+  if (u.pending && u.pending_seq == seq) u.pending = false;
+  RES_DBG("answered %u (unit %u) after %u spins; wait %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
+          seq, unit, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]);
+  return EPPK_OK;
+}
+// Every doorbell that has been rung and not collected yet (eppk_pick_stage_begin rings, _end collects) is answered: in front of
+// whatever CHANGES what the resident workgroups read -- the argument blocks, the index, the snapshot -- and of parking them.
+int resident_drain(eppk_ctx* c) {
+  for (uint32_t unit = 0; unit < eppk_ctx::kResUnits; ++unit) {
+    eppk_ctx::ResidentUnit& u = c->res[unit];
+    if (!u.pending) continue;
+    const int rc = resident_wait(c, unit, u.pending_seq, "resident path");
+    u.pending = false;
+    if (rc) return rc;
+  }
+  return EPPK_OK;
+}
+// Ring a small batch in: its rows (and mask rows) are in buffer set `bufset` (0 = the context's pinned staging buffers, 1 + s = staging
+// set s) already and have been validated; the results land in that set's pinned result buffers.  *unit_out / *seq_out: what to wait for.
+int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_t bufset, uint32_t* unit_out, uint32_t* seq_out) {
+  { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
+  // The resident kernels are OUTSIDE stream order: whatever this context has queued that changes the index or the snapshot must be over
+  // before the doorbell rings -- a LEARN update behind a staging set (the `learned` event), and anything on the context's own stream
+  // (eppk_index_insert_picks_device / eppk_pick_learn_device / eppk_index_evict_older_device with stream = NULL on a context that never
+  // used the staging sets: no event).  One hipStreamQuery when the stream is idle.  Work on a CALLER's stream is the caller's to order
+  // (include/eppk.h: "streams").
+  if (c->learn_pending || hipStreamQuery(c->stream) != hipSuccess) HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipGetLastError();
+  int rc = resident_ensure(c);
+  if (rc) return rc;
+  if (c->res_args_dirty) {        // a publish, new staging buffers (or the first use): the argument blocks again -- with no doorbell outstanding
+    rc = resident_drain(c);
+    if (rc) return rc;
+    eppk::ResidentArgs a{};
+    a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail;
+    a.buf[0] = {(const uint8_t*)c->h_reqs_dev, c->h_mask_dev, c->h_pick_dev, c->h_score_dev};
+    for (uint32_t sset = 0; sset < EPPK_STAGE_SETS; ++sset) {
+      const eppk_ctx::StageSet& ss = c->stage[sset];
+      a.buf[1u + sset] = {(const uint8_t*)ss.h_reqs_dev, ss.h_mask_dev, ss.h_pick_dev, ss.h_score_dev};
+    }
+    a.stride = c->stride; a.pwn = (c->cfg.max_blocks + 1u) * c->pterm_ld;
+    if (++c->res_gen == 0u) c->res_gen = 1u;
+    a.gen = c->res_gen;
+    bool hist_fits = false;
+    a.lds_bytes = (uint32_t)resident_lds(c, &hist_fits);
+    if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
+    eppk::ResidentArgs all[eppk_ctx::kResUnits];
+    const size_t wl_words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
+    for (uint32_t unit = 0; unit < eppk_ctx::kResUnits; ++unit) {
+      all[unit] = a;
+      uint32_t* wl = c->d_res_wl + unit * wl_words;
+      all[unit].defer_total = wl; all[unit].defer_cnt = wl + 32; all[unit].defer_list = wl + 48; all[unit].defer_cap = c->res_wl_cap;
+    }
+    HIPCHK(c, hipMemcpy(c->d_res_args, all, sizeof all, hipMemcpyHostToDevice));
+    c->res_args_dirty = false;
+  }
+  uint32_t unit;
+  if (!masked && k == 1u) unit = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? kResQuad : kResFast;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
+  else unit = k > 1u ? (masked ? kResTopkMasked : kResTopk) : kResMasked;
+  eppk_ctx::ResidentUnit& u = c->res[unit];
+  if (u.pending) {                  // one doorbell per unit at a time (the other staging set's batch of the same kind): answered first
+    rc = resident_wait(c, unit, u.pending_seq, "resident path");
+    if (rc) return rc;
+  }
+  rc = resident_start(c, unit);
+  if (rc) return rc;
+  if (++u.seq == eppk::kResQuit || u.seq == 0u) u.seq = 1u;
+  RES_DBG("ring %u (unit %u, n = %u, k = %u, buffers %u)", u.seq, unit, n_reqs, k, bufset);
+  static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
+  __atomic_store_n((uint64_t*)&u.h_ctl->bell, ((uint64_t)eppk::res_bell_hi(n_reqs, k, bufset) << 32) | u.seq, __ATOMIC_RELEASE);      // count and doorbell in one store
+  u.pending = true; u.pending_seq = u.seq;
+  *unit_out = unit; *seq_out = u.seq;
   ++c->res_batches;
-  RES_DBG("answered %u (form %u) after %u spins; ring -> done %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
-          seq, form, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]);
-  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * 4u);
-  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * 8u);
+  return EPPK_OK;
+}
+// One small batch through a resident kernel, synchronously: rows (and mask) are in c->h_reqs / c->h_mask (pinned) already; results land in
+// c->h_pick / c->h_score (n * k entries with ordered fallbacks).
+int resident_pick(eppk_ctx* c, uint32_t n_reqs, int32_t* out_pick, double* out_score, const char* who, bool masked = false, uint32_t k = 1u) {
+  int rc = validate_rows(c, who, c->h_reqs, n_reqs, 0u);
+  if (rc) return rc;
+  uint32_t unit = 0, seq = 0;
+  rc = resident_ring(c, n_reqs, masked, k, 0u, &unit, &seq);
+  if (rc) return rc;
+  rc = resident_wait(c, unit, seq, who);
+  if (rc) return rc;
+  std::memcpy(out_pick, c->h_pick, (size_t)n_reqs * k * 4u);
+  if (out_score) std::memcpy(out_score, c->h_score, (size_t)n_reqs * k * 8u);
   return EPPK_OK;
 }
 
@@ -1648,11 +1722,13 @@ int ensure_host_staging(eppk_ctx* c, bool need_mask) {
     HIPCHK(c, hipHostGetDevicePointer(&c->h_reqs_dev, c->h_reqs, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_pick_dev, c->h_pick, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_score_dev, c->h_score, 0));
+    c->res_args_dirty = true;                // (the resident kernels' argument blocks name these buffers)
   }
   if (need_mask && !c->d_mask) {
     HIPCHK(c, hipMalloc((void**)&c->d_mask, mb * c->jmax * 8u));
     HIPCHK(c, hipHostMalloc((void**)&c->h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->h_mask_dev, c->h_mask, 0));
+    c->res_args_dirty = true;
   }
   return EPPK_OK;
 }
@@ -1781,12 +1857,13 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
-  if (resident_eligible(c, n_reqs, cand_mask != nullptr)) {      // the latency path of a small batch: the resident workgroup, no launch
+  if (c->n_pods != 0u && resident_eligible(c, n_reqs, cand_mask != nullptr)) {      // the latency path of a small batch: a resident workgroup, no launch
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rcr = ensure_host_staging(c, false);
+    int rcr = ensure_host_staging(c, cand_mask != nullptr);
     if (rcr) return rcr;
     std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
-    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch");
+    if (cand_mask) std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * ((c->n_pods + 63u) / 64u) * 8u);
+    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch", cand_mask != nullptr);
   }
   // (rows are validated on the host, chunk by chunk on their way to the device: never hand the kernel an out-of-range adapter / block count)
   int rc = pick_host_begin(c, (const uint8_t*)reqs, false, n_reqs, 0u, n_reqs, false, cand_mask, false, "eppk_pick_batch", true);
@@ -1810,9 +1887,9 @@ int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* 
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_staged: n_reqs > max_batch");
   if (!c->h_reqs || (use_mask && !c->h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: eppk_host_staging was not called for these buffers");
   if (n_reqs == 0) return EPPK_OK;
-  if (resident_eligible(c, n_reqs, use_mask != 0)) {
+  if (c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0)) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch_staged");
+    return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch_staged", use_mask != 0);
   }
   int rc = pick_host_begin(c, (const uint8_t*)c->h_reqs, true, n_reqs, 0u, n_reqs, false, use_mask ? c->h_mask : nullptr, false, "eppk_pick_batch_staged", true);
   if (rc) return rc;
@@ -1837,11 +1914,13 @@ int stage_ensure(eppk_ctx* c, uint32_t set, bool need_mask) {
     HIPCHK(c, hipHostGetDevicePointer(&s.h_reqs_dev, s.h_reqs, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_pick_dev, s.h_pick, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_score_dev, s.h_score, 0));
+    c->res_args_dirty = true;                // (the resident kernels' argument blocks name these buffers)
   }
   if (need_mask && !s.d_mask) {
     HIPCHK(c, hipMalloc((void**)&s.d_mask, mb * c->jmax * 8u));
     HIPCHK(c, hipHostMalloc((void**)&s.h_mask, mb * c->jmax * 8u, hipHostMallocDefault));
     HIPCHK(c, hipHostGetDevicePointer((void**)&s.h_mask_dev, s.h_mask, 0));
+    c->res_args_dirty = true;
   }
   if (!c->learned) HIPCHK(c, hipEventCreateWithFlags(&c->learned, hipEventDisableTiming));
   return EPPK_OK;
@@ -1867,7 +1946,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   if (s.busy) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: the set is in flight (end it first)");
   if ((flags & EPPK_PICK_LEARN) && !c->slots) return fail(c, EPPK_ERR_ARG, "eppk_pick_stage_begin: EPPK_PICK_LEARN without a prefix index");
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true; s.check_pending = false;
+  s.n = n_reqs; s.had_mask = use_mask != 0; s.busy = true; s.check_pending = false; s.resident = false;
   if (n_reqs == 0) return EPPK_OK;
   // A begin that fails has NOT begun: whatever it had enqueued on the set's stream is waited for and the set is idle again (both
   // shims treat a failed begin that way and never call end for it; a set left busy would fail every later begin).  One exception: the
@@ -1883,6 +1962,17 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
   const bool zero_copy = n_reqs <= c->zero_copy_max;
   int rc;
+  if (!learn && c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0)) {
+    // the latency path of a small batch (EPPK_RESIDENT=1): rung into a resident workgroup, which reads the set's pinned rows (and mask
+    // rows) and writes its pinned results; end() polls the completion word -- no launch, no event
+    rc = validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
+    if (rc) return rc;
+    rc = resident_ring(c, n_reqs, use_mask != 0, 1u, 1u + set, &s.res_unit, &s.res_seq);
+    if (rc) return rc;
+    s.resident = true;
+    abort_guard.armed = false;
+    return EPPK_OK;
+  }
   bool words = false;                        // the pick kernel left learn words for the update (pick_quad_kernel<..., LEARN>): known pairs are
   if (learn) { rc = learn_ensure(c, n_reqs); if (!rc) rc = learn_words_fence(c, s.st); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
   if (zero_copy) {
@@ -1949,6 +2039,14 @@ int eppk_pick_stage_end(eppk_ctx* c, uint32_t set, int32_t* out_pick, double* ou
   HIPCHK(c, hipSetDevice(c->cfg.device));
   s.busy = false;
   if (s.n == 0) return EPPK_OK;
+  if (s.resident) {
+    s.resident = false;
+    const int rcw = resident_wait(c, s.res_unit, s.res_seq, "eppk_pick_stage_end");
+    if (rcw) return rcw;
+    std::memcpy(out_pick, s.h_pick, (size_t)s.n * 4u);
+    if (out_score) std::memcpy(out_score, s.h_score, (size_t)s.n * 8u);
+    return EPPK_OK;
+  }
   HIPCHK(c, hipEventSynchronize(s.picked));
   if (s.copy_pending) { HIPCHK(c, hipEventSynchronize(s.copied)); s.copy_pending = false; }   // (the caller may refill the rows now)
   if (s.check_pending) {
@@ -2210,6 +2308,8 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
     if (rc) return rc;
     if (reqs != c->h_reqs) std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
     if (cand_mask && cand_mask != c->h_mask) std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
+    // the latency path of a dispatcher that asks for fallback lists (every one of its batches comes through here): a resident workgroup
+    if (resident_eligible(c, n_reqs, cand_mask != nullptr, k)) return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_topk", cand_mask != nullptr, k);
     rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n_reqs, cand_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, k, false, 0ull, 0u);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2571,25 +2671,34 @@ eppk_ctx* eppk_group_ctx(eppk_group* g, uint32_t i) { return (g && i < g->ctx.si
 int eppk_group_ranks_seen(const eppk_group* g) { return g ? g->ranks_seen : EPPK_ERR_ARG; }
 int eppk_group_set_min_shard(eppk_group* g, uint32_t n) { if (!g || n == 0) return EPPK_ERR_ARG; g->min_shard = n; return EPPK_OK; }
 
+// (EPPK_GATHER_HOST: a staged LEARN batch whose update is still owed is given it before anything else touches the replicas, the epoch
+// counter included -- the update is stamped with the epoch of ITS begin's place in the call order)
+namespace { void group_host_learn_flush(eppk_group* g, uint32_t set); }
+#define GFLUSH(g) do { for (uint32_t set_ = 0; set_ < EPPK_STAGE_SETS; ++set_) group_host_learn_flush((g), set_); } while (0)
+
 int eppk_group_snapshot_publish(eppk_group* g, const eppk_pod_row* rows, uint32_t n_pods, uint64_t epoch) {
   if (!g) return EPPK_ERR_ARG;
+  GFLUSH(g);
   GALL(g, eppk_snapshot_publish(m, rows, n_pods, epoch));
   return EPPK_OK;
 }
-int eppk_group_index_clear(eppk_group* g) { if (!g) return EPPK_ERR_ARG; GALL(g, eppk_index_clear(m)); return EPPK_OK; }
+int eppk_group_index_clear(eppk_group* g) { if (!g) return EPPK_ERR_ARG; GFLUSH(g); GALL(g, eppk_index_clear(m)); return EPPK_OK; }
 int eppk_group_index_insert(eppk_group* g, const uint64_t* hashes, const uint32_t* pods, uint32_t n) {
   if (!g) return EPPK_ERR_ARG;
+  GFLUSH(g);
   GALL(g, eppk_index_insert(m, hashes, pods, n));
   return EPPK_OK;
 }
-int eppk_group_index_remove_pod(eppk_group* g, uint32_t pod) { if (!g) return EPPK_ERR_ARG; GALL(g, eppk_index_remove_pod(m, pod)); return EPPK_OK; }
+int eppk_group_index_remove_pod(eppk_group* g, uint32_t pod) { if (!g) return EPPK_ERR_ARG; GFLUSH(g); GALL(g, eppk_index_remove_pod(m, pod)); return EPPK_OK; }
 int eppk_group_index_advance_epoch(eppk_group* g, uint32_t* new_epoch) {
   if (!g) return EPPK_ERR_ARG;
+  GFLUSH(g);
   GALL(g, eppk_index_advance_epoch(m, new_epoch));
   return EPPK_OK;
 }
 int eppk_group_index_evict_older(eppk_group* g, uint32_t min_epoch, uint32_t* n_evicted) {
   if (!g) return EPPK_ERR_ARG;
+  GFLUSH(g);
   GALL(g, eppk_index_evict_older(m, min_epoch, n_evicted));     // (replicas are identical: every member evicts the same hashes)
   return EPPK_OK;
 }
@@ -2599,6 +2708,7 @@ int eppk_group_pick_batch(eppk_group* g, const void* reqs, uint32_t n_reqs, cons
   if (!g || ((!reqs || !out_pick) && n_reqs)) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_batch: null argument");
   if (n_reqs > g->max_batch) return gfail(g, EPPK_ERR_LIMIT, "eppk_group_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
+  GFLUSH(g);
   const uint32_t G = (uint32_t)g->ctx.size();
   eppk_ctx* c0 = g->ctx[0];
   for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, "eppk_group_pick_batch: no snapshot published");
@@ -2708,6 +2818,7 @@ int eppk_group_pick_device(eppk_group* g, const void* const* d_reqs, const uint3
   if (gather && !d_gathered) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: EPPK_GROUP_GATHER without d_gathered");
   if (gather && g->mode == EPPK_GATHER_HOST) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_device: a device-resident gather needs EPPK_GATHER_PEER or EPPK_GATHER_RCCL");
   for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, "eppk_group_pick_device: no snapshot published");
+  GFLUSH(g);
   const uint32_t G = (uint32_t)g->ctx.size();
   std::vector<size_t> off(G + 1, 0);
   GFOR(g, i) off[i + 1] = off[i] + n_rows[i];
@@ -2750,18 +2861,18 @@ int eppk_group_pick_device(eppk_group* g, const void* const* d_reqs, const uint3
 }
 
 // ---- what a shim calls beside eppk_group_pick_batch: ageing, per-pod capacity, ordered fallbacks, the pipelined host path ------------------
-namespace { void group_host_learn_flush(eppk_group* g, uint32_t set); }
 
 int eppk_group_index_evict_older_device(eppk_group* g, uint32_t min_epoch) {
   if (!g) return EPPK_ERR_ARG;
   // every member: on its own stream, behind the picks (and LEARN updates) of the staging sets begun before, ahead of those begun after
-  for (uint32_t set = 0; set < EPPK_STAGE_SETS; ++set) group_host_learn_flush(g, set);
+  GFLUSH(g);
   GALL(g, eppk_index_evict_older_device(m, min_epoch, nullptr));
   return EPPK_OK;
 }
 
 int eppk_group_index_trim_pods(eppk_group* g, uint32_t cap_per_pod, uint64_t* n_removed) {
   if (!g) return EPPK_ERR_ARG;
+  GFLUSH(g);
   GALL(g, eppk_index_trim_pods(m, cap_per_pod, n_removed));     // (replicas are identical: every member removes the same pairs)
   return EPPK_OK;
 }
@@ -2794,6 +2905,7 @@ int group_topk(eppk_group* g, const char* who, const void* reqs, uint32_t n_reqs
   if (k < 1 || k > EPPK_MAX_TOPK) return gfail(g, EPPK_ERR_ARG, std::string(who) + ": k out of range (1..8)");
   if (n_reqs > g->max_batch) return gfail(g, EPPK_ERR_LIMIT, std::string(who) + ": n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
+  GFLUSH(g);
   eppk_ctx* c0 = g->ctx[0];
   for (eppk_ctx* m : g->ctx) if (!m->have_snapshot) return gfail(g, EPPK_ERR_NO_SNAPSHOT, std::string(who) + ": no snapshot published");
   for (eppk_ctx* m : g->ctx) if (m->assumed_epochs) return gfail(g, EPPK_ERR_ARG, std::string(who) + ": device groups do not support assumed load");

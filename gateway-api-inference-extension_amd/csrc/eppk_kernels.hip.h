@@ -2296,16 +2296,26 @@ struct alignas(64) ResidentCtl {   // pinned host memory; the two directions in 
   uint32_t pad1[14];
 };
 constexpr uint32_t kResQuit = 0xFFFFFFFFu, kResRunning = 1u, kResExited = 2u;
+// The upper half of the doorbell word: bits 0..7 the batch's request count, 8..11 k (entries per request: 1 = the pick), 12..13 the
+// buffer set the rows / masks / results of this batch live in (0 = the context's staging buffers, 1 + s = staging set s of the
+// pipelined host path).
+constexpr uint32_t kResBufSets = 3u;
+__host__ __device__ __forceinline__ constexpr uint32_t res_bell_hi(uint32_t n, uint32_t k, uint32_t bufset) { return n | (k << 8) | (bufset << 12); }
+struct ResidentBuf { const uint8_t* reqs; const uint64_t* mask; int32_t* out_pick; double* out_score; };   // pinned host memory as the device addresses it (null: never used)
 struct ResidentArgs {           // device memory; rewritten by the host only between two doorbells (the kernel reads it behind each)
   KSnap sn; KIndex ix; KTail tl;
-  const uint8_t* reqs; int32_t* out_pick; double* out_score;      // the context's pinned staging / result buffers as the device addresses them
+  ResidentBuf buf[kResBufSets];
   uint32_t stride, pwn;
   uint32_t gen, lds_bytes;        // gen changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
   uint32_t* defer_cnt; uint32_t* defer_list; uint32_t* defer_total; uint32_t defer_cap, pad;   // QUAD form: the workgroup's work list (one segment per wavefront)
 };
 
-template <typename LW, bool HAS_L, bool P_FIRST, bool QUAD>
+// MASKED / TOPK (QUAD form only): the variants a dispatcher issues beside plain picks -- a batch with candidate masks (the subset filter,
+// pkg/lwepp/handlers/request.go:104-133), ordered fallbacks (PickResult.Fallbacks, handlers/server.go:72-77) -- each a kernel of its own
+// behind a doorbell of its own (the library starts the one a call needs; an idle one leaves by itself).
+template <typename LW, bool HAS_L, bool P_FIRST, bool QUAD, bool MASKED = false, bool TOPK = false>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* __restrict__ args, uint32_t seen, unsigned long long max_idle_polls) {
+  static_assert(QUAD || !(MASKED || TOPK), "the variants exist for the quad form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_seq, s_n;
   // Everything the doorbell wavefront does alone is behind a WAVE-UNIFORM condition (a scalar branch).  Written as `threadIdx.x == 0`
@@ -2336,7 +2346,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
     const unsigned long long ts0 = wall_clock64();
 #endif
     __syncthreads();
-    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq), n_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n);
+    const uint32_t n = n_word & 0xFFu, kk = (n_word >> 8) & 0xFu, bufset = (n_word >> 12) & 3u;
     if (seq == kResQuit) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope: the vector caches forget what they held before the doorbell
     __builtin_amdgcn_s_dcache_inv();                        // ... and the scalar cache (request headers, the argument block)
@@ -2365,12 +2376,18 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         uint32_t* rest = (uint32_t*)(s_pterm + a->pwn);
         const uint32_t n_rest = (a->lds_bytes - (uint32_t)((unsigned char*)rest - smem)) / 4u;
         for (uint32_t i = threadIdx.x; i < n_rest; i += blockDim.x) rest[i] = 0u;
+        if constexpr (MASKED) {   // the snapshot's three natural-layout sets, where pick_quad_body<MASKED> keeps them: behind the "listed" bits of all rows
+          __syncthreads();
+          uint64_t* s_nat = (uint64_t*)(rest + (blockDim.x >> 4) * (a->sn.J * 2u));
+          for (uint32_t i = threadIdx.x; i < 192u; i += blockDim.x) s_nat[i] = a->sn.nat[i];
+        }
         __syncthreads();
         staged_gen = gen;
       }
-      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, /*MASKED*/ false, /*TOPK*/ false, /*LEARN*/ false, /*RESIDENT*/ true>(
-          0u, 1u, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, a->out_pick, a->out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
-          a->defer_total, 1u, nullptr);
+      const ResidentBuf rb = a->buf[bufset];
+      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, /*LEARN*/ false, /*RESIDENT*/ true>(
+          0u, 1u, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, rb.out_pick, rb.out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
+          a->defer_total, TOPK ? kk : 1u, nullptr);
       // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
       // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also
       // asks "did anybody defer?".  Only then the work-list pass, and a second release + barrier behind it.
@@ -2379,8 +2396,13 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         const KChain no_chain{};
         KWork wk;
         wk.cnt = a->defer_cnt; wk.list = a->defer_list; wk.total = a->defer_total; wk.report = a->defer_total; wk.cap = a->defer_cap; wk.n_segs = blockDim.x >> 6;
-        pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ true, /*RESIDENT*/ true>(
-            0u, 1u, 0u, /*tables staged*/ true, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u, wk);
+        // (MASKED: the quad layout keeps the snapshot's natural sets and the rows' candidate words where the fast body expects its all-zero
+        // histogram: the rare pass over deferred requests stages its own layout -- "tables staged" false -- and the next doorbell stages the
+        // quad layout again)
+        pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true, /*RESIDENT*/ true>(
+            0u, 1u, 0u, /*tables staged*/ !MASKED, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, no_chain, rb.out_pick, rb.out_score, nullptr,
+            TOPK ? kk : 1u, wk);
+        if constexpr (MASKED) staged_gen = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __syncthreads();
       }
@@ -2389,8 +2411,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
       const KChain no_chain{};
       const KWork no_work{};
       const uint32_t gen = a->gen;
+      const ResidentBuf rb = a->buf[bufset];
+      (void)kk;
       pick_fast_body<LW, 6, HAS_L, true, P_FIRST, /*MASKED*/ false, /*BIG*/ true, /*GEN*/ false, /*TOPK*/ false, /*WL*/ false, /*RESIDENT*/ true>(
-          0u, 1u, 0u, /*tables staged*/ gen == staged_gen, smem, a->sn, a->ix, a->tl, a->reqs, a->stride, n, a->pwn, nullptr, no_chain, a->out_pick, a->out_score, nullptr, 1u,
+          0u, 1u, 0u, /*tables staged*/ gen == staged_gen, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, nullptr, no_chain, rb.out_pick, rb.out_score, nullptr, 1u,
           no_work);
       staged_gen = gen;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // this wavefront's picks and scores are in host memory ...

@@ -6,6 +6,12 @@
 #define EPPK_RESIDENT_QUAD false
 #define EPPK_RESIDENT_FN pick_resident
 #endif
+#ifndef EPPK_RESIDENT_MASKED      // the variants of the quad form (eppk_pick_resident_quad_{masked,topk,topk_masked}.hip)
+#define EPPK_RESIDENT_MASKED false
+#endif
+#ifndef EPPK_RESIDENT_TOPK
+#define EPPK_RESIDENT_TOPK false
+#endif
 #include "eppk_kernels.hip.h"
 #include "eppk_pick_inst.hip.h"
 
@@ -13,8 +19,9 @@ namespace eppk {
 
 template <typename LW>
 static const void* resident_ptr(bool has_l, bool p_first) {
-  if (has_l) return p_first ? (const void*)pick_resident_kernel<LW, true, true, EPPK_RESIDENT_QUAD> : (const void*)pick_resident_kernel<LW, true, false, EPPK_RESIDENT_QUAD>;
-  return (const void*)pick_resident_kernel<LW, false, false, EPPK_RESIDENT_QUAD>;
+  constexpr bool Q = EPPK_RESIDENT_QUAD, M = EPPK_RESIDENT_MASKED, T = EPPK_RESIDENT_TOPK;
+  if (has_l) return p_first ? (const void*)pick_resident_kernel<LW, true, true, Q, M, T> : (const void*)pick_resident_kernel<LW, true, false, Q, M, T>;
+  return (const void*)pick_resident_kernel<LW, false, false, Q, M, T>;
 }
 const void* EPPK_RESIDENT_FN(int lw_bytes, bool has_l, bool p_first) {
   return lw_bytes == 2 ? resident_ptr<uint16_t>(has_l, p_first) : lw_bytes == 4 ? resident_ptr<uint32_t>(has_l, p_first) : resident_ptr<uint64_t>(has_l, p_first);

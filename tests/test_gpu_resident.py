@@ -45,7 +45,7 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
                 served += 2 if n <= limit else 0
         on, b1, s1 = pk.resident_stats()
         assert b1 - b0 == served and s1 >= 1, (b1 - b0, served, s1)
-        # beyond the limit, with a mask, or as fallbacks: the launched path as before
+        # beyond the limit: the launched path as before; with a mask: the masked resident workgroup where pick_quad_kernel's route exists
         want = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:65], wl.B)[:2]
         _same(pk.pick(wl.reqs[:65]), want, "n=65")
         assert pk.resident_stats()[1] == b1
@@ -54,7 +54,7 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         if P % 64:
             mask[:, -1] &= np.uint64((1 << (P % 64)) - 1)
         _same(pk.pick(wl.reqs[:8], mask), orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs[:8], wl.B, mask)[:2], "masked")
-        assert pk.resident_stats()[1] == b1
+        assert pk.resident_stats()[1] == b1 + (1 if limit == 64 else 0)
         # the index and the snapshot change under the resident workgroup: it must see both at the next doorbell
         extra_h = wl.reqs[:32, 1 + wl.B // 2:1 + wl.B].reshape(-1).copy()             # the unique tails of 32 requests, now cached on pod 5
         extra_p = np.full(extra_h.size, 5 % P, dtype=np.uint32)
@@ -87,6 +87,80 @@ def test_small_batches_through_the_resident_workgroup(pkg, orc, resident, eppk_m
         with pytest.raises(Exception):
             pk.pick(bad)
         _same(pk.pick(wl.reqs[:4]), orc.pick_batch(wl.chain, pods2, oix, wl.reqs[:4], wl.B)[:2], "after a refused batch")
+
+
+@pytest.mark.parametrize("P,B", [(4096, 32), (1000, 8)])
+def test_what_a_dispatcher_issues_through_the_resident_workgroups(pkg, orc, resident, eppk_mode, P, B):
+    """The variants beside plain picks (a resident workgroup each, started on first use): batches with candidate masks (the subset filter,
+    handlers/request.go:104-133), ordered fallbacks (PickResult.Fallbacks, handlers/server.go:72-77) with and without masks, and the two
+    staging sets of the pipelined host path (eppk_pick_stage_begin rings the doorbell, _end polls the completion word) -- picks, lists and
+    scores against the oracle, across an index update and a publish, with requests the quad body defers (reserved hashes) among them."""
+    quad = eppk_mode in ("default", "quadmin4")
+    wl = pkg.workload.make_workload(5, R=256, P=P, n_groups=16, B=B, masked=True)
+    wl.mask[3, :] = 0                                                                 # a request without candidates
+    wl.mask[11, :] = 0; wl.mask[11, 0] = np.uint64(2)                                 # ... with exactly one
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=wl.B, max_batch=256, index_slots=wl.index_slots * 4) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        pods = wl.pods
+        sb = [pk.stage_buffers(0, with_mask=True), pk.stage_buffers(1, with_mask=True)]
+        W = (P + 63) // 64
+
+        def round_(tag, reqs_all):
+            b0 = pk.resident_stats()[1]
+            served = 0
+            for n in (1, 5, 16, 33, 64):
+                reqs, mask = reqs_all[:n], wl.mask[:n]
+                _same(pk.pick(reqs, mask), orc.pick_batch(wl.chain, pods, oix, reqs, wl.B, mask)[:2], f"{tag}: masked n={n}")
+                served += 1 if quad else 0
+                for k in (2, 4):
+                    for m in (None, mask):
+                        tp, ts = pk.pick_topk(reqs, k, m)
+                        op, osc = orc.pick_topk_batch(wl.chain, pods, oix, reqs, wl.B, k, m)
+                        assert np.array_equal(tp, op), f"{tag}: top-{k} n={n} masked={m is not None}"
+                        assert np.array_equal(ts.view(np.uint64), osc.view(np.uint64)), f"{tag}: top-{k} scores n={n} masked={m is not None}"
+                        served += 1 if quad else 0
+                # the two staging sets: plain in set 0, masked in set 1, both in flight
+                sb[0][0][:n] = reqs
+                sb[1][0][:n] = reqs_all[64:64 + n]
+                sb[1][1][:n * W] = wl.mask[64:64 + n].reshape(-1)
+                pk.stage_begin(0, n)
+                pk.stage_begin(1, n, use_mask=True)
+                _same(pk.stage_end(0), orc.pick_batch(wl.chain, pods, oix, reqs, wl.B)[:2], f"{tag}: staged n={n}")
+                _same(pk.stage_end(1), orc.pick_batch(wl.chain, pods, oix, reqs_all[64:64 + n], wl.B, wl.mask[64:64 + n])[:2], f"{tag}: staged masked n={n}")
+                served += 1 + (1 if quad else 0) if n <= (64 if quad else 32) else 0
+            assert pk.resident_stats()[1] - b0 == served, (tag, pk.resident_stats()[1] - b0, served)
+
+        round_("fresh", wl.reqs)
+        # the index changes (an update launched on the context's stream), then the snapshot: the next doorbells must see both
+        extra_h = wl.reqs[:32, 1 + wl.B // 2:1 + wl.B].reshape(-1).copy()
+        extra_p = np.full(extra_h.size, 5 % P, dtype=np.uint32)
+        pk.index_insert(extra_h, extra_p); oix.insert(extra_h, extra_p)
+        pods = wl.pods.copy()
+        pods["queue"] = (pods["queue"].astype(np.int64) * 5 + 1) % 59
+        pk.publish(pods)
+        round_("after insert + publish", wl.reqs)
+        # requests the quad body defers: reserved hashes among their blocks -> the work-list pass inside the same resident workgroup
+        odd = wl.reqs.copy()
+        odd[2, 1 + 1] = np.uint64(0)
+        odd[9, 1 + 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        odd[70, 1 + wl.B - 1] = np.uint64(0)
+        rh = np.array([0, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        rp = np.array([3 % P, 9 % P], dtype=np.uint32)
+        pk.index_insert(rh, rp); oix.insert(rh, rp)
+        round_("deferred requests", odd)
+        round_("deferred requests again", odd)                                        # (the masked form stages its LDS layout again behind a work-list pass)
+        # a row out of range is refused by name (begin: small batches are checked on the host), nothing is delivered, the set stays usable
+        sb[0][0][:4] = wl.reqs[:4]
+        sb[0][0][2, 0] = np.uint64(1000) << np.uint64(32)
+        with pytest.raises(Exception):
+            pk.stage_begin(0, 4)
+        sb[0][0][:4] = wl.reqs[:4]
+        pk.stage_begin(0, 4)
+        _same(pk.stage_end(0), orc.pick_batch(wl.chain, pods, oix, wl.reqs[:4], wl.B)[:2], "after a refused begin")
+        assert pk.index_selfcheck() == 0 and pk.launch_status() == 0
 
 
 def test_the_resident_workgroup_leaves_when_idle_and_comes_back(pkg, orc, resident, monkeypatch):
