@@ -756,7 +756,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
     rc = resident_drain(c);
     if (rc) return rc;
     eppk::ResidentArgs a{};
-    a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail;
+    a.sn = make_ksnap(c); a.ix = make_kindex(c); a.tl = c->tail; a.chain = c->kchain;
     a.buf[0] = {(const uint8_t*)c->h_reqs_dev, c->h_mask_dev, c->h_pick_dev, c->h_score_dev};
     for (uint32_t sset = 0; sset < EPPK_STAGE_SETS; ++sset) {
       const eppk_ctx::StageSet& ss = c->stage[sset];

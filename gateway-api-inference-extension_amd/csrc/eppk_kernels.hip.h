@@ -2305,6 +2305,7 @@ struct ResidentBuf { const uint8_t* reqs; const uint64_t* mask; int32_t* out_pic
 struct ResidentArgs {           // device memory; rewritten by the host only between two doorbells (the kernel reads it behind each)
   KSnap sn; KIndex ix; KTail tl;
   ResidentBuf buf[kResBufSets];
+  KChain chain;                   // the whole weighted chain: the exact evaluation of a MASKED request whose candidates miss a QUEUE extreme (work-list pass)
   uint32_t stride, pwn;
   uint32_t gen, lds_bytes;        // gen changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
   uint32_t* defer_cnt; uint32_t* defer_list; uint32_t* defer_total; uint32_t defer_cap, pad;   // QUAD form: the workgroup's work list (one segment per wavefront)
@@ -2400,8 +2401,8 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         // histogram: the rare pass over deferred requests stages its own layout -- "tables staged" false -- and the next doorbell stages the
         // quad layout again)
         pick_fast_body<LW, 6, HAS_L, true, P_FIRST, MASKED, /*BIG*/ true, /*GEN*/ false, TOPK, /*WL*/ true, /*RESIDENT*/ true>(
-            0u, 1u, 0u, /*tables staged*/ !MASKED, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, no_chain, rb.out_pick, rb.out_score, nullptr,
-            TOPK ? kk : 1u, wk);
+            0u, 1u, 0u, /*tables staged*/ !MASKED, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, MASKED ? a->chain : no_chain, rb.out_pick,
+            rb.out_score, nullptr, TOPK ? kk : 1u, wk);
         if constexpr (MASKED) staged_gen = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __syncthreads();

@@ -52,7 +52,7 @@ for stage in "$@"; do
     set) export "$arg"; echo "export $arg" ;;
     unset) unset "$arg" ;;
     smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
-    tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -6 | tee $OUT/pytest_${arg//[^a-zA-Z0-9]/_}.txt
+    tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -k "$arg" 2>&1 | tail -30 | cut -c1-400 | tee $OUT/pytest_${arg//[^a-zA-Z0-9]/_}.txt
            else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt; fi ;;
     quick) timeout 200 python scripts/dump_workload.py --config 5 --out /tmp/c5 > /dev/null 2>&1; timeout 120 ./tests/cpp/parity_quick /tmp/c5 4 2>&1 | tail -4 ;;
     bench20)  timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; digest $OUT/bench_steps20.json ;;
