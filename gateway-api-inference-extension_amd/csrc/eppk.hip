@@ -150,11 +150,13 @@ struct eppk_ctx {
   // Two resident workgroups at most, one per FORM of the kernel, each with its control block and stream: [0] pick_fast_kernel's body
   // (a wavefront per request: up to 16 requests), [1] pick_quad_kernel's body (four requests per wavefront: beyond 16, where that
   // route exists).  A batch rings the one that suits it; each leaves by itself when idle and is started again on demand.
-  static constexpr uint32_t kResUnits = 5u;
+  static constexpr uint32_t kResUnits = 7u;
+  uint8_t* d_res_rows = nullptr; uint32_t* d_res_learn = nullptr; uint32_t* d_res_sortwl = nullptr;   // LEARN units: row copies, learn words, sort work lists (per unit)
   struct ResidentUnit {
     eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; hipStream_t stream = nullptr;
     bool running = false; uint32_t seq = 0;   // seq = the last doorbell value rung
     bool pending = false; uint32_t pending_seq = 0;   // a doorbell rung (eppk_pick_stage_begin) and not collected yet
+    bool updating = false; uint32_t update_seq = 0;   // LEARN units: the index update behind that doorbell has not been seen finished yet
   } res[kResUnits];
   eppk::ResidentArgs* d_res_args = nullptr;
   uint32_t* d_res_wl = nullptr; uint32_t res_wl_cap = 0;     // the resident workgroup's work list (its pick_quad_kernel form): total[32] | cnt[16] | list[16][cap]
@@ -586,9 +588,10 @@ int validate_rows(eppk_ctx* c, const char* who, const void* reqs, uint32_t n_req
 
 // ---- the resident small-batch kernels (EPPK_RESIDENT=1) ------------------------------------------------------------------------------
 // Units (eppk_ctx::res[]): 0 = pick_fast_kernel's body (plain picks below EPPK_RESIDENT_QUAD_FROM requests), 1 = pick_quad_kernel's body
-// (plain picks), 2 = ... with candidate masks, 3 = ... with ordered fallbacks, 4 = both.  Each is a kernel of its own behind a doorbell
-// of its own, started by the first batch that needs it; an idle one leaves by itself.
-constexpr uint32_t kResFast = 0u, kResQuad = 1u, kResMasked = 2u, kResTopk = 3u, kResTopkMasked = 4u;
+// (plain picks), 2 = ... with candidate masks, 3 = ... with ordered fallbacks, 4 = both, 5 / 6 = single picks (plain / masked) followed by
+// the post-route index update, applied by the resident workgroup itself (EPPK_PICK_LEARN).  Each is a kernel of its own behind a
+// doorbell of its own, started by the first batch that needs it; an idle one leaves by itself.
+constexpr uint32_t kResFast = 0u, kResQuad = 1u, kResMasked = 2u, kResTopk = 3u, kResTopkMasked = 4u, kResLearn = 5u, kResLearnMasked = 6u;
 // LDS of a resident workgroup (sized for max_pods: the kernels outlive publishes; ONE size for every unit -- the argument block
 // carries it): pick_fast_kernel's layout for 16 wavefronts, or pick_quad_kernel<MASKED>'s where that is larger.  *hist_fits = the
 // per-wave pod histogram of the list routes fits as well (else the kernel is handed an index without list routes).
@@ -638,11 +641,12 @@ bool resident_quad(const eppk_ctx* c) {
   (void)resident_lds(c, &hist_fits);
   return c->quad_on && hist_fits && c->slots != 0u && make_kindex(c).lists != nullptr;
 }
-// k = entries per request (1: the pick)
-bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k = 1u) {
+// k = entries per request (1: the pick); learn: the post-route index update chained behind the pick (single picks)
+bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k = 1u, bool learn = false) {
   if (!(c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
         c->assumed_epochs == 0 && c->cfg.max_blocks >= 1)) return false;
-  if (!masked && k == 1u) return true;
+  if (!masked && k == 1u && !learn) return true;
+  if (learn && (k != 1u || !c->slots || !c->have_snapshot)) return false;
   return k <= EPPK_MAX_TOPK && n_reqs <= 255u && resident_quad(c);     // the variants exist for the quad form
 }
 int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams (each made once: a call that failed half-way is resumed)
@@ -666,6 +670,16 @@ int resident_ensure(eppk_ctx* c) {            // control blocks, argument block,
     if (!u.h_ctl_dev) HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
     if (!u.stream) HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
   }
+  if (c->slots && !c->d_res_sortwl) {       // LEARN units (two at most): a device copy of a batch's rows, its learn words, a sort work list each
+    const size_t rm = c->resident_max ? c->resident_max : 1u;
+    HIPCHK(c, hipMalloc((void**)&c->d_res_rows, 2u * rm * c->stride));
+    HIPCHK(c, hipMalloc((void**)&c->d_res_learn, 2u * rm * 4u));
+    const size_t wl_words = 4u + rm * (c->cfg.max_blocks ? c->cfg.max_blocks : 1u);
+    uint32_t* wl = nullptr;
+    HIPCHK(c, hipMalloc((void**)&wl, 2u * wl_words * 4u));
+    if (hipMemset(wl, 0, 2u * wl_words * 4u) != hipSuccess) { (void)hipFree(wl); return fail(c, EPPK_ERR_DEVICE, "resident path: hipMemset of the sort work lists failed"); }
+    c->d_res_sortwl = wl;
+  }
   HIPCHK(c, hipMalloc((void**)&c->d_res_args, sizeof(eppk::ResidentArgs) * eppk_ctx::kResUnits));
   return EPPK_OK;
 }
@@ -679,6 +693,7 @@ int resident_start(eppk_ctx* c, uint32_t unit, bool outstanding = false) {
   { const int rce = resident_ensure(c); if (rce) return rce; }
   const void* fn = unit == kResFast ? eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first)
                  : unit == kResQuad ? eppk::pick_resident_quad(c->lw_bytes, c->has_l, c->p_first)
+                 : unit >= kResLearn ? eppk::pick_resident_quad_learn(c->lw_bytes, c->has_l, c->p_first, unit == kResLearnMasked)
                                     : eppk::pick_resident_quad_variant(c->lw_bytes, c->has_l, c->p_first, unit == kResMasked || unit == kResTopkMasked, unit == kResTopk || unit == kResTopkMasked);
   const uint32_t threads = 1024u;
   bool hist_fits = false;
@@ -732,16 +747,26 @@ int resident_wait(eppk_ctx* c, uint32_t unit, uint32_t seq, const char* who) {
 int resident_drain(eppk_ctx* c) {
   for (uint32_t unit = 0; unit < eppk_ctx::kResUnits; ++unit) {
     eppk_ctx::ResidentUnit& u = c->res[unit];
-    if (!u.pending) continue;
-    const int rc = resident_wait(c, unit, u.pending_seq, "resident path");
-    u.pending = false;
-    if (rc) return rc;
+    if (u.pending) {
+      const int rc = resident_wait(c, unit, u.pending_seq, "resident path");
+      u.pending = false;
+      if (rc) return rc;
+    }
+    if (u.updating) {               // a LEARN unit: the index update behind its last answer (microseconds; the workgroup cannot leave in between)
+      const auto t0 = std::chrono::steady_clock::now();
+      uint32_t spins = 0;
+      while ((int32_t)(__atomic_load_n(&u.h_ctl->updated, __ATOMIC_ACQUIRE) - u.update_seq) < 0) {
+        if ((++spins & 4095u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
+          return fail(c, EPPK_ERR_DEVICE, "resident path: the index update of a small LEARN batch did not finish within 5 s");
+      }
+      u.updating = false;
+    }
   }
   return EPPK_OK;
 }
 // Ring a small batch in: its rows (and mask rows) are in buffer set `bufset` (0 = the context's pinned staging buffers, 1 + s = staging
 // set s) already and have been validated; the results land in that set's pinned result buffers.  *unit_out / *seq_out: what to wait for.
-int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_t bufset, uint32_t* unit_out, uint32_t* seq_out) {
+int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_t bufset, uint32_t* unit_out, uint32_t* seq_out, bool learn = false) {
   { const int rcf = learn_fence(c, c->stream); if (rcf) return rcf; }
   // The resident kernels are OUTSIDE stream order: whatever this context has queued that changes the index or the snapshot must be over
   // before the doorbell rings -- a LEARN update behind a staging set (the `learned` event), and anything on the context's own stream
@@ -768,18 +793,30 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
     bool hist_fits = false;
     a.lds_bytes = (uint32_t)resident_lds(c, &hist_fits);
     if (!hist_fits) a.ix.lists = nullptr;                 // (no room for the list routes' histogram in the 160 KB: dense rows only)
+    if (c->slots) {               // what the LEARN units' own index update needs (eppk.hip: learn_picks passes the same to its launches)
+      a.keys_w = c->keys; a.bitmaps_w = c->bitmaps; a.lists_w = c->lists; a.rstamps = c->rstamps; a.ixc = c->ixc; a.status = c->d_status + 1;   // (rows are validated on the host: the quiet word)
+      a.act = c->have_snapshot ? c->snap[c->cur].act_t : nullptr;
+      a.limit = c->limit; a.epoch = c->index_epoch; a.max_blocks = c->cfg.max_blocks; a.max_pods = c->cfg.max_pods;
+    }
     eppk::ResidentArgs all[eppk_ctx::kResUnits];
     const size_t wl_words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
+    const size_t rm = c->resident_max ? c->resident_max : 1u, sort_words = 4u + rm * (c->cfg.max_blocks ? c->cfg.max_blocks : 1u);
     for (uint32_t unit = 0; unit < eppk_ctx::kResUnits; ++unit) {
       all[unit] = a;
       uint32_t* wl = c->d_res_wl + unit * wl_words;
       all[unit].defer_total = wl; all[unit].defer_cnt = wl + 32; all[unit].defer_list = wl + 48; all[unit].defer_cap = c->res_wl_cap;
+      if (unit >= kResLearn && c->d_res_sortwl) {
+        const uint32_t lu = unit - kResLearn;
+        all[unit].rows_copy = c->d_res_rows + lu * rm * c->stride; all[unit].learn = c->d_res_learn + lu * rm;
+        all[unit].sort_wl = c->d_res_sortwl + lu * sort_words; all[unit].sort_cap = (uint32_t)(sort_words - 4u);
+      }
     }
     HIPCHK(c, hipMemcpy(c->d_res_args, all, sizeof all, hipMemcpyHostToDevice));
     c->res_args_dirty = false;
   }
   uint32_t unit;
-  if (!masked && k == 1u) unit = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? kResQuad : kResFast;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
+  if (learn) unit = masked ? kResLearnMasked : kResLearn;
+  else if (!masked && k == 1u) unit = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? kResQuad : kResFast;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
   else unit = k > 1u ? (masked ? kResTopkMasked : kResTopk) : kResMasked;
   eppk_ctx::ResidentUnit& u = c->res[unit];
   if (u.pending) {                  // one doorbell per unit at a time (the other staging set's batch of the same kind): answered first
@@ -793,6 +830,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
   static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
   __atomic_store_n((uint64_t*)&u.h_ctl->bell, ((uint64_t)eppk::res_bell_hi(n_reqs, k, bufset) << 32) | u.seq, __ATOMIC_RELEASE);      // count and doorbell in one store
   u.pending = true; u.pending_seq = u.seq;
+  if (learn) { u.updating = true; u.update_seq = u.seq; }
   *unit_out = unit; *seq_out = u.seq;
   ++c->res_batches;
   return EPPK_OK;
@@ -1186,6 +1224,7 @@ void eppk_destroy(eppk_ctx* c) {
   }
   (void)hipFree(c->d_res_args);
   (void)hipFree(c->d_res_wl);
+  (void)hipFree(c->d_res_rows); (void)hipFree(c->d_res_learn); (void)hipFree(c->d_res_sortwl);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
   (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
@@ -1462,6 +1501,7 @@ int eppk_index_advance_epoch(eppk_ctx* c, uint32_t* new_epoch) {
     if (rc) return rc;
   }
   c->index_epoch = next;
+  c->res_args_dirty = true;                  // (the LEARN resident units stamp with the epoch of their argument block)
   if (new_epoch) *new_epoch = c->index_epoch;
   return EPPK_OK;
 }
@@ -1962,12 +2002,13 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
   const bool zero_copy = n_reqs <= c->zero_copy_max;
   int rc;
-  if (!learn && c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0)) {
+  if (c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0, 1u, learn)) {
     // the latency path of a small batch (EPPK_RESIDENT=1): rung into a resident workgroup, which reads the set's pinned rows (and mask
-    // rows) and writes its pinned results; end() polls the completion word -- no launch, no event
+    // rows) and writes its pinned results; end() polls the completion word -- no launch, no event.  With LEARN the workgroup applies
+    // the post-route index update itself, right behind the answer (it has copied the rows: the caller may refill the set after end()).
     rc = validate_rows(c, "eppk_pick_stage_begin", s.h_reqs, n_reqs, 0u);
     if (rc) return rc;
-    rc = resident_ring(c, n_reqs, use_mask != 0, 1u, 1u + set, &s.res_unit, &s.res_seq);
+    rc = resident_ring(c, n_reqs, use_mask != 0, 1u, 1u + set, &s.res_unit, &s.res_seq, learn);
     if (rc) return rc;
     s.resident = true;
     abort_guard.armed = false;

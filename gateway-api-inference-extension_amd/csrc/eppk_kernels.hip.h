@@ -2293,7 +2293,8 @@ struct alignas(64) ResidentCtl {   // pinned host memory; the two directions in 
   uint32_t pad0[14];
   uint32_t done;                // device -> host: sequence number of the last batch whose results are in the pinned buffers
   uint32_t state;               //                 kResRunning while the kernel polls, kResExited when it has left
-  uint32_t pad1[14];
+  uint32_t updated;             //                 LEARN units: sequence number of the last batch whose post-route index update is in the index
+  uint32_t pad1[13];
 };
 constexpr uint32_t kResQuit = 0xFFFFFFFFu, kResRunning = 1u, kResExited = 2u;
 // The upper half of the doorbell word: bits 0..7 the batch's request count, 8..11 k (entries per request: 1 = the pick), 12..13 the
@@ -2309,14 +2310,30 @@ struct ResidentArgs {           // device memory; rewritten by the host only bet
   uint32_t stride, pwn;
   uint32_t gen, lds_bytes;        // gen changes whenever the block is rewritten (a publish): the workgroup stages the snapshot's tables into LDS again
   uint32_t* defer_cnt; uint32_t* defer_list; uint32_t* defer_total; uint32_t defer_cap, pad;   // QUAD form: the workgroup's work list (one segment per wavefront)
+  // LEARN units: the post-route update index[hash[r][i]] U= {pick[r]} is applied by the resident workgroup itself, right behind the answer
+  uint8_t* rows_copy;             // device copy of the batch's request rows (the caller may refill the pinned rows as soon as it has the picks)
+  uint32_t* learn;                // learn words of the batch (pick_quad_kernel<..., LEARN>)
+  uint64_t* keys_w; void* bitmaps_w; uint32_t* lists_w; uint32_t* rstamps; unsigned long long* ixc; uint32_t* status; const void* act;
+  uint32_t* sort_wl; uint32_t sort_cap;      // a work list of the unit's own for the lists to re-sort (SortWl layout)
+  uint32_t limit, epoch, max_blocks, max_pods, pad2;
 };
 
 // MASKED / TOPK (QUAD form only): the variants a dispatcher issues beside plain picks -- a batch with candidate masks (the subset filter,
 // pkg/lwepp/handlers/request.go:104-133), ordered fallbacks (PickResult.Fallbacks, handlers/server.go:72-77) -- each a kernel of its own
 // behind a doorbell of its own (the library starts the one a call needs; an idle one leaves by itself).
-template <typename LW, bool HAS_L, bool P_FIRST, bool QUAD, bool MASKED = false, bool TOPK = false>
+// LEARN (QUAD form, single picks): what eppk_pick_stage_begin(EPPK_PICK_LEARN) issues.  The workgroup first copies the batch's rows
+// from pinned host memory into device memory (one PCIe round trip, which the pick body then does not pay again: it reads the copy),
+// answers the picks, and then applies the post-route index update ITSELF (resident_learn_update, behind the index maintenance code
+// below): budget, one index_insert_one per (block, pick) pair, re-sort of the lists it touched -- the three launches of the
+// launched path, without a launch.  The next doorbell of this unit is looked at only behind the update; every other reader or writer of the
+// index waits for the `updated` word (eppk.hip: resident_drain).
+template <typename LW>
+__device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const ResidentBuf& rb, uint32_t n);
+
+template <typename LW, bool HAS_L, bool P_FIRST, bool QUAD, bool MASKED = false, bool TOPK = false, bool LEARN = false>
 __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel(ResidentCtl* ctl, const ResidentArgs* __restrict__ args, uint32_t seen, unsigned long long max_idle_polls) {
-  static_assert(QUAD || !(MASKED || TOPK), "the variants exist for the quad form");
+  static_assert(QUAD || !(MASKED || TOPK || LEARN), "the variants exist for the quad form");
+  static_assert(!(LEARN && TOPK), "learn words go with single picks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_seq, s_n;
   // Everything the doorbell wavefront does alone is behind a WAVE-UNIFORM condition (a scalar branch).  Written as `threadIdx.x == 0`
@@ -2385,10 +2402,19 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         __syncthreads();
         staged_gen = gen;
       }
-      const ResidentBuf rb = a->buf[bufset];
-      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, /*LEARN*/ false, /*RESIDENT*/ true>(
+      ResidentBuf rb = a->buf[bufset];
+      if constexpr (LEARN) {
+        // the rows into device memory (8-byte words, the whole batch at once: every load in flight together), and the pick reads them there
+        const unsigned long long* src = (const unsigned long long*)rb.reqs;
+        unsigned long long* dst = (unsigned long long*)a->rows_copy;
+        const uint32_t n_words = n * (a->stride / 8u);
+        for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
+        __syncthreads();
+        rb.reqs = a->rows_copy;
+      }
+      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN, /*RESIDENT*/ true>(
           0u, 1u, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, rb.out_pick, rb.out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
-          a->defer_total, TOPK ? kk : 1u, nullptr);
+          a->defer_total, TOPK ? kk : 1u, LEARN ? a->learn : nullptr);
       // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
       // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also
       // asks "did anybody defer?".  Only then the work-list pass, and a second release + barrier behind it.
@@ -2432,6 +2458,19 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
 #endif
     if (bell_wave) {
       if (lane0) __hip_atomic_store(&ctl->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... (every wavefront's, behind the barrier) before the answer is
+    }
+    if constexpr (LEARN) {
+      const ResidentArgs* a = args;
+      ResidentBuf rb = a->buf[bufset];
+      rb.reqs = a->rows_copy;
+      resident_learn_update<LW>(a, rb, n);
+      // (the update's stores and atomics are at agent scope; the word tells the HOST that they have all been issued and acknowledged)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (bell_wave) {
+        if (lane0) __hip_atomic_store(&ctl->updated, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // the quad layout's all-zero regions are untouched by the update (it uses static LDS of its own)
     }
     seen = seq;
   }
@@ -4141,6 +4180,84 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     }
   }
   if (lane == 0 && nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+
+
+// The post-route index update of ONE small batch by the resident workgroup that has just answered it (pick_resident_kernel<..., LEARN>):
+// what learn_picks (eppk.hip) launches as index_budget_kernel + index_insert_picks_kernel + index_lists_sort_kernel, here by the
+// 1024 threads of the workgroup, in place.  Nothing else touches the index meanwhile (the library orders every other reader and
+// writer behind the unit's `updated` word), so the protocol of index_insert_one holds as in a launch of its own.
+template <typename LW>
+__device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const ResidentBuf& rb, uint32_t n) {
+  __shared__ IxLaunch s_il;
+  __shared__ unsigned long long s_tmp[4];
+  const uint32_t max_blocks = a->max_blocks, slots = a->ix.slots;
+  const uint32_t total = n * max_blocks;
+  unsigned long long* ixc = a->ixc;
+  // (1) the capacity verdict (index_budget_kernel): the first wavefront, lane = shard
+  if (threadIdx.x < 64u) {
+    const uint32_t l = threadIdx.x;
+    unsigned long long lv = __hip_atomic_load(&ixc[l * 8u + kIxLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long wd = __hip_atomic_load(&ixc[l * 8u + kIxWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ixc[l * 8u + kIxReserved], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off >= 1; off >>= 1) { lv += __shfl_xor((long long)lv, off); wd += __shfl_xor((long long)wd, off); }
+    if (l == 0u) {
+      const long long live = (long long)lv, words = (long long)wd;
+      long long left = (long long)a->limit - live;
+      const long long left_w = (long long)(slots / 4u * 3u) - words;
+      if (left_w < left) left = left_w;
+      s_il.left = left;
+      s_il.safe = (live >= 0 && (unsigned long long)live + total < (unsigned long long)a->limit && (unsigned long long)words + total < (unsigned long long)(slots / 4u * 3u)) ? 1u : 0u;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (the zeroed booking words, before any lane books)
+  __syncthreads();
+  // (2) a thread per (request, block) pair, in rounds of the workgroup's size (index_insert_picks_kernel)
+  SortWl sw;
+  sw.wl = a->sort_wl; sw.cap = a->sort_cap; sw.which = 0u;
+  const LW* act = (const LW*)a->act;
+  for (uint32_t base = 0; base < total; base += blockDim.x) {           // (uniform: every thread calls index_insert_one in every round)
+    const uint32_t t = base + threadIdx.x;
+    const uint32_t r = t / max_blocks, i = t % max_blocks;
+    bool active = t < total, known_only = false;
+    int32_t pick = -1;
+    uint64_t h = 0;
+    if (active) {
+      const uint32_t lw = a->learn[r];
+      pick = (lw & 0x00FFFF00u) ? (int32_t)((lw >> 8) & 0xFFFFu) - 1 : __hip_atomic_load(&rb.out_pick[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint8_t* row = rb.reqs + (size_t)r * a->stride;
+      const uint32_t nb = ((const uint32_t*)row)[1];
+      const bool bad = (pick >= 0 && (uint32_t)pick >= a->max_pods) || nb > max_blocks;     // (the host has validated the rows: never, as a rule)
+      if (bad && i == 0u) atomicOr(a->status, (uint32_t)pick >= a->max_pods && pick >= 0 ? kStatusBadPick : kStatusBadRow);
+      active = !bad && pick >= 0 && i < nb;
+      if (active) h = ((const uint64_t*)(row + 8))[i];
+      known_only = active && (lw >> 31) != 0u && i < (lw & 0xFFu);
+    }
+    index_insert_one<LW>(a->keys_w, a->bitmaps_w, a->lists_w, a->rstamps, slots, a->ix.shift, a->limit, a->epoch, ixc, &s_il, s_tmp, h, (uint32_t)pick, active, act, sw,
+                         a->status, known_only);
+  }
+  // (3) the lists that got an id appended behind others go back to ascending order (index_lists_sort_kernel)
+  __threadfence();
+  __syncthreads();
+  uint32_t* wl = a->sort_wl;
+  const uint32_t n_listed_raw = __hip_atomic_load(&wl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t n_listed = n_listed_raw < a->sort_cap ? n_listed_raw : a->sort_cap;
+  for (uint32_t i = threadIdx.x; i < n_listed; i += blockDim.x) {
+    const uint32_t slot = __hip_atomic_load(&wl[4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* L = a->lists_w + (size_t)slot * kListDwords;
+    const uint32_t cnt = __hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt < 2u || cnt > kListCap) continue;
+    if (atomicCAS(&L[3], cnt, cnt | kListBusy) != cnt) continue;
+    uint32_t d[16];
+    load_line16(L, d);
+    list_sort_line(d);
+    d[3] = cnt | kListBusy;
+    store_line16(L, d);
+    __threadfence();
+    __hip_atomic_store(&L[3], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0u) __hip_atomic_store(&wl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the cursor, for the next batch)
 }
 
 }  // namespace eppk

@@ -39,6 +39,8 @@ const void* pick_resident_quad_masked(int lw_bytes, bool has_l, bool p_first);  
 const void* pick_resident_quad_topk(int lw_bytes, bool has_l, bool p_first);
 const void* pick_resident_quad_topk_masked(int lw_bytes, bool has_l, bool p_first);
 const void* pick_resident_quad_variant(int lw_bytes, bool has_l, bool p_first, bool masked, bool topk);
+const void* pick_resident_quad_learn(int lw_bytes, bool has_l, bool p_first, bool masked);        // ... followed by the index update (eppk_pick_resident_quad_learn*.hip)
+const void* pick_resident_quad_learn_masked(int lw_bytes, bool has_l, bool p_first);
 const void* pick_fast_wl_topk_u16(bool has_l, bool p_first, bool big);          // work-list instantiations with ordered fallbacks (eppk_pick_wl_topk.hip)
 const void* pick_fast_wl_topk_u32(bool has_l, bool p_first, bool big);
 const void* pick_fast_wl_topk_u64(bool has_l, bool p_first, bool big);

@@ -163,6 +163,73 @@ def test_what_a_dispatcher_issues_through_the_resident_workgroups(pkg, orc, resi
         assert pk.index_selfcheck() == 0 and pk.launch_status() == 0
 
 
+@pytest.mark.parametrize("P,B", [(4096, 32), (700, 8)])
+def test_small_learn_batches_update_the_index_inside_the_resident_workgroup(pkg, orc, resident, eppk_mode, P, B):
+    """eppk_pick_stage_begin(EPPK_PICK_LEARN) of a small batch: the resident workgroup answers the picks and applies the post-route update
+    index[hash[r][i]] U= {pick[r]} itself (0602-prefix-cache-aware-routing-proposal/README.md:101-108), right behind the answer -- no launch.
+    A closed loop of small batches (both staging sets, plain and masked, 1 .. 64 requests, returning conversations, requests the quad
+    body defers), the oracle replaying the call order; between them what a shim does: epoch ticks, evictions on the device, a trim, a
+    publish, a LARGE launched LEARN batch -- every one of them ordered behind the resident update and ahead of the next doorbell."""
+    quad = eppk_mode in ("default", "quadmin4")
+    wl = pkg.workload.make_workload(5, R=512, P=P, n_groups=24, B=B, masked=True)
+    rng = np.random.default_rng(P + B)
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=wl.B, max_batch=512, index_slots=1 << 16) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        pods = wl.pods
+        sb = [pk.stage_buffers(0, with_mask=True), pk.stage_buffers(1, with_mask=True)]
+        W = (P + 63) // 64
+        b0 = pk.resident_stats()[1]
+        served = 0
+        epoch = 1
+        odd = wl.reqs.copy()
+        odd[5, 1 + 1] = np.uint64(0)                                                 # reserved hashes: deferred by the quad body, learned all the same
+        odd[40, 1 + 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        for step in range(60):
+            n = int(rng.choice([1, 2, 7, 8, 16, 31, 48, 64]))
+            lo = int(rng.integers(0, 512 - n))
+            src = odd if step % 7 == 3 else wl.reqs
+            reqs = src[lo:lo + n]
+            masked = step % 3 == 2
+            mask = wl.mask[lo:lo + n] if masked else None
+            which = step & 1
+            sb[which][0][:n] = reqs
+            if masked:
+                sb[which][1][:n * W] = mask.reshape(-1)
+            pk.stage_begin(which, n, use_mask=masked, learn=True)
+            op, osc, _ = orc.pick_batch(wl.chain, pods, oix, reqs, wl.B, mask)
+            oix.insert_picks(reqs, wl.B, op)
+            got = pk.stage_end(which)
+            sb[which][0][:n] = np.uint64(0xDEAD)                                       # the caller refills the set right after end(): the update must not read it
+            _same(got, (op, osc), f"step {step} n={n} masked={masked}")
+            served += 1 if quad else 0
+            if step % 10 == 4:                                                        # the shim's ageing between two batches
+                epoch = pk.index_advance_epoch(); assert epoch == oix.advance_epoch()
+                if epoch > 2:
+                    pk.index_evict_older_device(epoch - 2)
+                    oix.evict_older(epoch - 2)
+            if step % 16 == 9:
+                assert pk.index_size() == oix.size(), step
+                assert pk.index_trim_pods(300) == oix.trim_pods(P, 300), step
+            if step == 25:
+                pods = wl.pods.copy()
+                pods["queue"] = (pods["queue"].astype(np.int64) * 3 + 2) % 53
+                pk.publish(pods)
+            if step % 20 == 11:                                                       # a launched LEARN batch (beyond the resident limit) in between
+                big = wl.reqs[:200]
+                sb[which ^ 1][0][:200] = big
+                pk.stage_begin(which ^ 1, 200, learn=True)
+                op, osc, _ = orc.pick_batch(wl.chain, pods, oix, big, wl.B)
+                oix.insert_picks(big, wl.B, op)
+                _same(pk.stage_end(which ^ 1), (op, osc), f"step {step}: launched LEARN batch")
+        assert pk.resident_stats()[1] - b0 == served
+        assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0 and pk.index_dropped() == 0 and pk.launch_status() == 0
+        # every hash the oracle holds is listed with the same pods: one more (plain) batch over everything
+        _same(pk.pick(wl.reqs[:64]), orc.pick_batch(wl.chain, pods, oix, wl.reqs[:64], wl.B)[:2], "after the loop")
+
+
 def test_the_resident_workgroup_leaves_when_idle_and_comes_back(pkg, orc, resident, monkeypatch):
     monkeypatch.setenv("EPPK_RESIDENT_IDLE_POLLS", "2000")                            # a few milliseconds of polls
     wl = pkg.workload.make_workload(5, R=32, P=700, n_groups=8)
