@@ -833,6 +833,11 @@ def main() -> None:
                                        "workgroup behind a doorbell, no launch; include/eppk.h)")
                 except Exception as e:
                     out["host_path"]["latency_by_batch_resident"] = {"error": repr(e)}
+            if hasattr(run.pk, "resident_stats") and not args.no_resident_leg:
+                try:
+                    out["host_path"]["latency_dispatcher_calls"] = dispatcher_latency_leg(pkg, wl, batches, min(args.host_path, 200))
+                except Exception as e:
+                    out["host_path"]["latency_dispatcher_calls"] = {"error": repr(e)}
             if hasattr(run.pk, "stage_begin"):
                 # PIPELINED: two staging sets -- the rows of batch k + 1 cross PCIe while batch k is scored (eppk_pick_stage_*).  Same
                 # convention as `staged`: the rows are in the pinned buffers already (two different batches, one per set; building them
@@ -957,7 +962,10 @@ def steady_state_into_config(out) -> None:
         put(f"latency_{n}_launched_p99_us", "host_path", "latency_by_batch", "requests", n, "p99_us")
     for n in ("1", "16", "64"):
         put(f"latency_{n}_resident_p50_us", "host_path", "latency_by_batch_resident", "requests", n, "p50_us")
-    put("latency_dispatcher_calls_us", "host_path", "latency_dispatcher_calls")
+    for mode in ("launched", "resident"):
+        for call in ("pick", "pick_masked", "top4", "pick_learn", "pick_learn_after_60us_idle"):
+            put(f"latency_16_{call}_{mode}_p50_us", "host_path", "latency_dispatcher_calls", mode, call, "p50_us")
+        put(f"latency_16_dispatcher_calls_{mode}_equal_oracle", "host_path", "latency_dispatcher_calls", mode, "equal_oracle")
     put("cold_value", "roofline_cold", "value")
     put("cold_frac", "roofline_cold", "frac")
     put("cold_frac_strict", "roofline_cold", "frac_strict")
@@ -1167,6 +1175,110 @@ def resident_latency_leg(pkg, wl, batches, calls: int):
                         "word the call polls -- no launch, no completion signal; a CU is held per form in use"}
     finally:
         pk.close()
+
+
+def dispatcher_latency_leg(pkg, wl, batches, calls: int, n: int = 16):
+    """Host-observed latency of what the Go / C++ dispatcher really issues for a small batch (integration patch: eppk_pick_stage_begin with
+    EPPK_PICK_LEARN, eppk_pick_topk for PickResult.Fallbacks, masked batches), `n` requests per call, with the library's defaults
+    ("launched") and with EPPK_RESIDENT=1 ("resident": a resident workgroup per variant behind a doorbell).  Rows are written into the
+    pinned buffers before every call (not timed).  Every variant is checked against the oracle once; the LEARN loop against the oracle's
+    index size at the end."""
+    orc = graft.load_oracle()
+    out = {}
+    P, B = wl.P, wl.B
+    W = (P + 63) // 64
+    rng = np.random.default_rng(5)
+    mask = rng.integers(0, 2**63, (n, W), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (n, W), dtype=np.uint64)
+    for mode in ("launched", "resident"):
+        old = os.environ.get("EPPK_RESIDENT")
+        if mode == "resident":
+            os.environ["EPPK_RESIDENT"] = "1"
+        else:
+            os.environ.pop("EPPK_RESIDENT", None)
+        try:
+            pk = pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=B, max_batch=256, index_slots=1 << 20)
+        finally:
+            if old is None:
+                os.environ.pop("EPPK_RESIDENT", None)
+            else:
+                os.environ["EPPK_RESIDENT"] = old
+        try:
+            pk.publish(wl.pods)
+            pk.index_insert(wl.index_hashes, wl.index_pods)
+            oix = orc.OracleIndex()
+            oix.insert(wl.index_hashes, wl.index_pods)
+            st, stm = pk.staging(with_mask=True)
+            sb, sbm = pk.stage_buffers(0, with_mask=True)
+            res, ok = {}, True
+
+            def rows(i):
+                off = (i * n) % max(1, wl.R - n + 1)
+                return batches[i % len(batches)][off:off + n]
+
+            def timed(fill, call):
+                lat, t_start = [], 0.0
+                for i in range(calls + 10):
+                    if i == 10:
+                        t_start = time.perf_counter()
+                    fill(i)
+                    t0 = time.perf_counter()
+                    call()
+                    lat.append(time.perf_counter() - t0)
+                cycle = (time.perf_counter() - t_start) * 1e6 / calls
+                lat = np.asarray(lat[10:]) * 1e6
+                return {"p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)), "cycle_us": cycle}
+
+            p, sc = np.empty(n * 4, dtype=np.int32), np.empty(n * 4, dtype=np.float64)
+            a_p, a_s = p.ctypes.data, sc.ctypes.data
+            lib, ctx = pk._lib, pk._ctx
+            res["pick"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: pk.pick_staged_into(n, a_p, a_s))
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, st[:n].copy(), B)
+            ok = ok and bool(np.array_equal(p[:n], op)) and bool(np.array_equal(sc[:n].view(np.uint64), osc.view(np.uint64)))
+            stm[:n * W] = mask.reshape(-1)
+            res["pick_masked"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: pk.pick_staged_into(n, a_p, a_s, use_mask=True))
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, mask)
+            ok = ok and bool(np.array_equal(p[:n], op)) and bool(np.array_equal(sc[:n].view(np.uint64), osc.view(np.uint64)))
+            st_ptr = st.ctypes.data
+            res["top4"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: lib.eppk_pick_topk(ctx, st_ptr, n, None, 4, a_p, a_s))
+            op, osc = orc.pick_topk_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, 4)
+            ok = ok and bool(np.array_equal(p.reshape(n, 4), op)) and bool(np.array_equal(sc.view(np.uint64).reshape(n, 4), osc.view(np.uint64)))
+            # pick + LEARN through a staging set: begin -> end is what the request waits for; the update runs on behind it, and the
+            # next begin waits for it on the device (launched) / on the completion word of the resident update
+            learned = []
+
+            def learn_call():
+                lib.eppk_pick_stage_begin(ctx, 0, n, 0, 1)
+                lib.eppk_pick_stage_end(ctx, 0, a_p, a_s)
+
+            def learn_fill(i):
+                np.copyto(sb[:n], rows(i))
+                learned.append(rows(i))
+            res["pick_learn"] = timed(learn_fill, learn_call)      # (cycle_us: back to back: fill, begin, end, fill, ...)
+            t_sync = time.perf_counter()
+            pk.index_size()
+            res["pick_learn"]["sync_after_loop_us"] = (time.perf_counter() - t_sync) * 1e6
+            # the same with the device idle between two batches (a dispatcher at 10-1000 QPS: docs/proposals/006-scheduler/README.md:133):
+            # the previous batch's index update is long over when the next one arrives
+            def idle_fill(i):
+                learn_fill(i + calls + 16)              # (other rows than the loop above has just taught the index: not revisits)
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 60e-6:
+                    pass
+            res["pick_learn_after_60us_idle"] = timed(idle_fill, learn_call)
+            for rws in learned:                           # the oracle replays the loop: same index at the end
+                o_p, _, _ = orc.pick_batch(wl.chain, wl.pods, oix, rws, B)
+                oix.insert_picks(rws, B, o_p)
+            ok = ok and pk.index_size() == oix.size() and bool(np.array_equal(p[:n], o_p)) and pk.index_selfcheck() == 0
+            res["equal_oracle"] = ok
+            if mode == "resident":
+                res["batches_answered_by_resident_workgroups"] = int(pk.resident_stats()[1])
+            out[mode] = res
+        finally:
+            pk.close()
+    out["requests"] = n
+    out["what"] = ("eppk_pick_batch_staged (plain / masked), eppk_pick_topk (k = 4) and eppk_pick_stage_begin(EPPK_PICK_LEARN) + _end for one small batch, host-observed; "
+                   "\"launched\" = the library's defaults, \"resident\" = EPPK_RESIDENT=1 (opt-in; a resident workgroup per variant)")
+    return out
 
 
 def closed_loop_leg(pkg, torch, args, wl, batches):

@@ -150,13 +150,17 @@ struct eppk_ctx {
   // Two resident workgroups at most, one per FORM of the kernel, each with its control block and stream: [0] pick_fast_kernel's body
   // (a wavefront per request: up to 16 requests), [1] pick_quad_kernel's body (four requests per wavefront: beyond 16, where that
   // route exists).  A batch rings the one that suits it; each leaves by itself when idle and is started again on demand.
-  static constexpr uint32_t kResUnits = 7u;
+  static constexpr uint32_t kResUnits = 7u, kResSlots = 4u;
+  hipStream_t res_slot_stream[kResSlots] = {nullptr, nullptr, nullptr, nullptr};   // high-priority streams: one hardware queue per running resident kernel
+  int32_t res_slot_unit[kResSlots] = {-1, -1, -1, -1};                               // which unit runs on the slot (-1: free)
+  uint64_t res_clock = 0;                                                            // LRU clock of the units (ResidentUnit::last_rung)
   uint8_t* d_res_rows = nullptr; uint32_t* d_res_learn = nullptr; uint32_t* d_res_sortwl = nullptr;   // LEARN units: row copies, learn words, sort work lists (per unit)
   struct ResidentUnit {
     eppk::ResidentCtl* h_ctl = nullptr; eppk::ResidentCtl* h_ctl_dev = nullptr; hipStream_t stream = nullptr;
     bool running = false; uint32_t seq = 0;   // seq = the last doorbell value rung
     bool pending = false; uint32_t pending_seq = 0;   // a doorbell rung (eppk_pick_stage_begin) and not collected yet
     bool updating = false; uint32_t update_seq = 0;   // LEARN units: the index update behind that doorbell has not been seen finished yet
+    int32_t slot = -1; uint64_t last_rung = 0;        // the stream slot it runs on; when it was last rung (the slots are handed out LRU)
   } res[kResUnits];
   eppk::ResidentArgs* d_res_args = nullptr;
   uint32_t* d_res_wl = nullptr; uint32_t res_wl_cap = 0;     // the resident workgroup's work list (its pick_quad_kernel form): total[32] | cnt[16] | list[16][cap]
@@ -609,7 +613,12 @@ size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
 }
 // Park them: ring "quit" and wait for the workgroups to leave.  In front of every device-wide wait of the library's own (a
 // hipDeviceSynchronize would otherwise sit out the kernels' idle timeout), and in eppk_destroy.
-static const bool g_res_dbg = getenv("EPPK_RESIDENT_DEBUG") != nullptr;     // (read once: the macro sits on the latency path)
+static const bool g_res_dbg = getenv("EPPK_RESIDENT_DEBUG") != nullptr && atoi(getenv("EPPK_RESIDENT_DEBUG")) != 2;     // (read once: the macro sits on the latency path)
+// EPPK_RESIDENT_DEBUG=2: nothing is printed on the latency path (a write(2) between two doorbells changes what is measured); the waits and the
+// device stamps of the last doorbells are kept and printed by eppk_destroy
+static const bool g_res_log = getenv("EPPK_RESIDENT_DEBUG") != nullptr && atoi(getenv("EPPK_RESIDENT_DEBUG")) == 2;
+struct ResLog { uint32_t unit, seq; float wait_us; uint32_t st[4]; };
+static std::vector<ResLog> g_res_logs;
 #define RES_DBG(...) do { if (g_res_dbg) { std::fprintf(stderr, "[eppk resident] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 int resident_drain(eppk_ctx* c);
 int resident_park(eppk_ctx* c) {
@@ -624,7 +633,19 @@ int resident_park(eppk_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(u.stream));
     RES_DBG("parked: state %u", u.h_ctl->state);
     u.running = false;
+    if (u.slot >= 0) { c->res_slot_unit[u.slot] = -1; u.slot = -1; }
   }
+  return EPPK_OK;
+}
+// ONE unit leaves (its slot goes to another): answered and updated first, then "quit".
+int resident_park_one(eppk_ctx* c, uint32_t unit) {
+  eppk_ctx::ResidentUnit& u = c->res[unit];
+  if (!u.running) return EPPK_OK;
+  { const int rcd = resident_drain(c); if (rcd) return rcd; }
+  __atomic_store_n(&u.h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
+  HIPCHK(c, hipStreamSynchronize(u.stream));
+  u.running = false;
+  if (u.slot >= 0) { c->res_slot_unit[u.slot] = -1; u.slot = -1; }
   return EPPK_OK;
 }
 int device_sync(eppk_ctx* c) {
@@ -668,7 +689,21 @@ int resident_ensure(eppk_ctx* c) {            // control blocks, argument block,
       u.h_ctl = h;
     }
     if (!u.h_ctl_dev) HIPCHK(c, hipHostGetDevicePointer((void**)&u.h_ctl_dev, u.h_ctl, 0));
-    if (!u.stream) HIPCHK(c, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+  }
+  // The streams the resident kernels are launched on: kResSlots of them, at the HIGHEST stream priority.  The runtime multiplexes the
+  // streams of one priority class over a few hardware queues (four by default), and a kernel that never ends blocks its queue: a second
+  // resident kernel -- or an ordinary launch of this context -- that lands on the same hardware queue starts when the first one
+  // leaves, i.e. after its idle time-out (measured: 38 ms instead of 12 us, round 5).  Streams of another priority class come from a
+  // pool of their own: the first kResSlots high-priority streams each get a hardware queue to themselves, away from every launched kernel.
+  // More units than slots may never be alive at once (resident_start parks the least recently rung one).
+  for (hipStream_t& st : c->res_slot_stream) {
+    if (st) continue;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) {
+      (void)hipGetLastError();
+      st = nullptr;
+      HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    }
   }
   if (c->slots && !c->d_res_sortwl) {       // LEARN units (two at most): a device copy of a batch's rows, its learn words, a sort work list each
     const size_t rm = c->resident_max ? c->resident_max : 1u;
@@ -691,6 +726,25 @@ int resident_start(eppk_ctx* c, uint32_t unit, bool outstanding = false) {
   eppk_ctx::ResidentUnit& u = c->res[unit];
   if (u.running) return EPPK_OK;
   { const int rce = resident_ensure(c); if (rce) return rce; }
+  if (u.slot < 0) {                 // a stream slot: a free one (a unit that left by itself still holds its slot: taken back first), else the least recently rung unit's
+    for (uint32_t sl = 0; sl < eppk_ctx::kResSlots; ++sl) {
+      const int32_t other = c->res_slot_unit[sl];
+      if (other >= 0 && c->res[other].running && !c->res[other].pending && __atomic_load_n(&c->res[other].h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited) {
+        HIPCHK(c, hipStreamSynchronize(c->res[other].stream));
+        c->res[other].running = false; c->res[other].slot = -1; c->res_slot_unit[sl] = -1;
+      }
+    }
+    int32_t pick = -1;
+    for (uint32_t sl = 0; sl < eppk_ctx::kResSlots && pick < 0; ++sl) if (c->res_slot_unit[sl] < 0) pick = (int32_t)sl;
+    if (pick < 0) {
+      uint32_t lru = 0; uint64_t best = ~0ull;
+      for (uint32_t sl = 0; sl < eppk_ctx::kResSlots; ++sl) { const uint64_t t = c->res[c->res_slot_unit[sl]].last_rung; if (t < best) { best = t; lru = sl; } }
+      const int rcp = resident_park_one(c, (uint32_t)c->res_slot_unit[lru]);
+      if (rcp) return rcp;
+      pick = (int32_t)lru;
+    }
+    u.slot = pick; c->res_slot_unit[pick] = (int32_t)unit; u.stream = c->res_slot_stream[pick];
+  }
   const void* fn = unit == kResFast ? eppk::pick_resident(c->lw_bytes, c->has_l, c->p_first)
                  : unit == kResQuad ? eppk::pick_resident_quad(c->lw_bytes, c->has_l, c->p_first)
                  : unit >= kResLearn ? eppk::pick_resident_quad_learn(c->lw_bytes, c->has_l, c->p_first, unit == kResLearnMasked)
@@ -738,8 +792,10 @@ int resident_wait(eppk_ctx* c, uint32_t unit, uint32_t seq, const char* who) {
     }
   }
   if (u.pending && u.pending_seq == seq) u.pending = false;
-  RES_DBG("answered %u (unit %u) after %u spins; wait %.2f us; device stamps (10 ns ticks, measurement builds only): bell seen -> caches invalidated %u, -> body done %u, -> released %u",
-          seq, unit, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]);
+  if (g_res_log && g_res_logs.size() < 65536u)
+    g_res_logs.push_back({unit, seq, (float)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()), {u.h_ctl->pad1[3], u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]}});
+  RES_DBG("answered %u (unit %u) after %u spins; wait %.2f us; device stamps (10 ns ticks, measurement builds only): rows copied %u; bell seen -> caches invalidated %u, -> body done %u, -> released %u",
+          seq, unit, spins, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), u.h_ctl->pad1[3], u.h_ctl->pad1[0], u.h_ctl->pad1[1], u.h_ctl->pad1[2]);
   return EPPK_OK;
 }
 // Every doorbell that has been rung and not collected yet (eppk_pick_stage_begin rings, _end collects) is answered: in front of
@@ -829,7 +885,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
   RES_DBG("ring %u (unit %u, n = %u, k = %u, buffers %u)", u.seq, unit, n_reqs, k, bufset);
   static_assert(offsetof(eppk::ResidentCtl, n_reqs) == offsetof(eppk::ResidentCtl, bell) + 4u && offsetof(eppk::ResidentCtl, bell) % 8u == 0u, "doorbell + count: one aligned 8-byte word");
   __atomic_store_n((uint64_t*)&u.h_ctl->bell, ((uint64_t)eppk::res_bell_hi(n_reqs, k, bufset) << 32) | u.seq, __ATOMIC_RELEASE);      // count and doorbell in one store
-  u.pending = true; u.pending_seq = u.seq;
+  u.pending = true; u.pending_seq = u.seq; u.last_rung = ++c->res_clock;
   if (learn) { u.updating = true; u.update_seq = u.seq; }
   *unit_out = unit; *seq_out = u.seq;
   ++c->res_batches;
@@ -1072,7 +1128,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* qf = getenv("EPPK_RESIDENT_QUAD_FROM")) c->resident_quad_from = atoi(qf) > 0 ? (uint32_t)atoi(qf) : 1u;
   bool resident_max_set = false;
   if (const char* rm = getenv("EPPK_RESIDENT_MAX")) { c->resident_max = atoi(rm) > 0 ? (uint32_t)atoi(rm) : 0u; resident_max_set = true; }
-  if (c->resident_on && c->num_cu > 2) c->num_cu -= 2;    // a resident workgroup holds one CU (two forms: two workgroups at most): the persistent pick kernels are sized for the rest
+  if (c->resident_on && c->num_cu > (int)eppk_ctx::kResSlots) c->num_cu -= (int)eppk_ctx::kResSlots;    // a resident workgroup holds one CU (kResSlots of them at most): the persistent pick kernels are sized for the rest
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
   if (const char* qt = getenv("EPPK_QUAD_TAIL")) c->quad_tail_on = atoi(qt) != 0;
@@ -1216,12 +1272,19 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
 
 void eppk_destroy(eppk_ctx* c) {
   if (!c) return;
+  if (g_res_log && !g_res_logs.empty()) {
+    const size_t from = g_res_logs.size() > 24u ? g_res_logs.size() - 24u : 0u;
+    for (size_t i = from; i < g_res_logs.size(); ++i) {
+      const ResLog& l = g_res_logs[i];
+      std::fprintf(stderr, "[eppk resident] unit %u seq %u: wait %.2f us; stamps (10 ns ticks, measurement builds): rows copied %u, bell seen -> caches invalidated %u, -> body done %u, -> released %u\n",
+                   l.unit, l.seq, l.wait_us, l.st[0], l.st[1], l.st[2], l.st[3]);
+    }
+    g_res_logs.clear();
+  }
   (void)hipSetDevice(c->cfg.device);
   (void)resident_park(c);
-  for (eppk_ctx::ResidentUnit& u : c->res) {
-    if (u.stream) (void)hipStreamDestroy(u.stream);
-    if (u.h_ctl) (void)hipHostFree(u.h_ctl);
-  }
+  for (eppk_ctx::ResidentUnit& u : c->res) if (u.h_ctl) (void)hipHostFree(u.h_ctl);
+  for (hipStream_t st : c->res_slot_stream) if (st) (void)hipStreamDestroy(st);
   (void)hipFree(c->d_res_args);
   (void)hipFree(c->d_res_wl);
   (void)hipFree(c->d_res_rows); (void)hipFree(c->d_res_learn); (void)hipFree(c->d_res_sortwl);
@@ -2015,7 +2078,9 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
     return EPPK_OK;
   }
   bool words = false;                        // the pick kernel left learn words for the update (pick_quad_kernel<..., LEARN>): known pairs are
-  if (learn) { rc = learn_ensure(c, n_reqs); if (!rc) rc = learn_words_fence(c, s.st); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
+  if (learn) { rc = learn_ensure(c, n_reqs); if (rc) return rc; }     // skipped, and the picks come out of those words instead of pinned host memory
+  // (learn_words_fence goes in right in front of the pick: NOT ahead of the upload, which must not wait for the other set's update --
+  // the point of the two sets is that the rows of batch k + 1 cross PCIe while batch k is scored and learned)
   if (zero_copy) {
     // ZERO-COPY (a small batch, as eppk_pick_batch_staged does it): one launch that reads the pinned set and writes its result buffers.
     // With LEARN the index update runs on behind `picked`, and the caller may refill the set as soon as _end has returned: the update
@@ -2041,6 +2106,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
       HIPCHK(c, hipEventRecord(s.copied, s.st_copy));
       s.copy_pending = true;
     }
+    if (learn) { rc = learn_words_fence(c, s.st); if (rc) return rc; }
     rc = run_pick(c, (const uint8_t*)s.h_reqs_dev, n_reqs, (use_mask && J) ? s.h_mask_dev : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u,
                   learn ? c->d_learn : nullptr, &words);
     if (rc) return rc;
@@ -2057,6 +2123,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
     // the pick sees the index every earlier LEARN left behind (run_pick: learn_fence; the upload above did not have to wait for it).
     // Picks and scores: written by the kernel straight into the set's pinned result buffers -- no download copies; a LEARN update reads
     // the picks from there, and only this set's next pick, ordered behind that update, writes them again.
+    if (learn) { rc = learn_words_fence(c, s.st); if (rc) return rc; }
     rc = run_pick(c, (const uint8_t*)s.d_reqs, n_reqs, (use_mask && J) ? s.d_mask : nullptr, s.h_pick_dev, s.h_score_dev, s.st, 1u, false, 0ull, 0u,
                   learn ? c->d_learn : nullptr, &words);
     if (rc) return rc;

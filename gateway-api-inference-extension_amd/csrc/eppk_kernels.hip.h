@@ -2091,7 +2091,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     bool tok = tpv && !((bits[tq >> 5] >> (tq & 31u)) & 1u);         // entry k exists and is not listed
     if (MASKED) tok = tok && ((s_cn[tq >> 6] >> (tq & 63u)) & 1ull);  // ... and is a candidate of this request
     wave_lds_fence();
-    if (!TOPK) {                                                      // (TOPK keeps the bitmap until its rounds are over: refills look entries up)
+    if (!TOPK && !MASKED) {                                           // (TOPK, and MASKED single picks, keep the bitmap a little longer: refills look entries up)
       if (lsA) bits[pA >> 5] = 0u;
       if (anyB && lsB) bits[pB >> 5] = 0u;
     }
@@ -2164,9 +2164,34 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     widx = dpp_min_u32<0x141, 0xf>(widx);
     widx = dpp_min_u32<0x140, 0xf>(widx);
     // ---- best pod outside the list: the first table entry that is not listed
-    const uint32_t okr = row16(__ballot(tok));
-    const uint32_t e = (uint32_t)__builtin_ctz(okr | 0x10000u);       // 16: none among the 16 entries
-    badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand);         // all 16 exist and are listed (or no candidates): the rest of the table is needed
+    uint32_t okr = row16(__ballot(tok));
+    uint32_t e = (uint32_t)__builtin_ctz(okr | 0x10000u);             // 16: none among the 16 entries
+    if constexpr (MASKED) {
+      // With candidate masks the first 16 entries of the adapter's table often hold no candidate at all (a 1/8-density mask: one request
+      // in eight; they used to be deferred to the work-list pass, whose slowest request -- 20-odd us -- then ended the launch): the
+      // row walks on through the table's 64 entries, 16 at a time, as the fallback rounds above do (round 5).
+      uint32_t tbase = 0u;
+      for (int refill = 0; refill < 3; ++refill) {
+        const bool dry = e == 16u && tvr == 0xFFFFu && !no_cand && tbase < 48u;
+        if (!__any(dry)) break;
+        if (dry) {
+          tbase += 16u;
+          top_t = __longlong_as_double((long long)buffer_load_u64(rsn, (tbase + k) * 8u, SnapOff<LW>::topv + arow * 512u));
+          top_p = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsn, (int)((tbase + k) * 4u), (int)(SnapOff<LW>::topi + arow * 256u), 0);
+          const bool ex = top_p != kNoPod;
+          const uint32_t tq2 = ex ? top_p : 0u;
+          tok = ex && !((bits[tq2 >> 5] >> (tq2 & 31u)) & 1u) && ((s_cn[tq2 >> 6] >> (tq2 & 63u)) & 1ull);
+        }
+        const uint32_t tv2 = row16(__ballot(top_p != kNoPod)), ok2 = row16(__ballot(tok));
+        if (dry) { tvr = tv2; okr = ok2; e = (uint32_t)__builtin_ctz(okr | 0x10000u); }
+      }
+      wave_lds_fence();
+      if (lsA) bits[pA >> 5] = 0u;
+      if (anyB && lsB) bits[pB >> 5] = 0u;
+      badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
+    } else {
+      badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand);       // all 16 exist and are listed (or no candidates): the rest of the table is needed
+    }
     const uint32_t src = gsh + (e & 15u);
     double cand_t = __hiloint2double(__shfl(__double2hiint(top_t), (int)src), __shfl(__double2loint(top_t), (int)src));
     uint32_t cand_p = (uint32_t)__shfl((int)top_p, (int)src);
@@ -2411,6 +2436,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
         __syncthreads();
         rb.reqs = a->rows_copy;
+#ifdef EPPK_RESIDENT_STAMPS
+        if (bell_wave && lane0) ctl->pad1[3] = (uint32_t)(wall_clock64() - ts0);      // bell seen -> rows copied
+#endif
       }
       const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN, /*RESIDENT*/ true>(
           0u, 1u, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, rb.out_pick, rb.out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
@@ -4210,8 +4238,7 @@ __device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const 
       s_il.safe = (live >= 0 && (unsigned long long)live + total < (unsigned long long)a->limit && (unsigned long long)words + total < (unsigned long long)(slots / 4u * 3u)) ? 1u : 0u;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (the zeroed booking words, before any lane books)
-  __syncthreads();
+  __syncthreads();                                         // (the booking words were zeroed with agent-scope atomic stores, acknowledged at the barrier)
   // (2) a thread per (request, block) pair, in rounds of the workgroup's size (index_insert_picks_kernel)
   SortWl sw;
   sw.wl = a->sort_wl; sw.cap = a->sort_cap; sw.which = 0u;
@@ -4236,8 +4263,8 @@ __device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const 
     index_insert_one<LW>(a->keys_w, a->bitmaps_w, a->lists_w, a->rstamps, slots, a->ix.shift, a->limit, a->epoch, ixc, &s_il, s_tmp, h, (uint32_t)pick, active, act, sw,
                          a->status, known_only);
   }
-  // (3) the lists that got an id appended behind others go back to ascending order (index_lists_sort_kernel)
-  __threadfence();
+  // (3) the lists that got an id appended behind others go back to ascending order (index_lists_sort_kernel).  The work-list entries were
+  // plain stores of this workgroup's lanes: acknowledged at the barrier, read below past the vector cache (agent-scope loads)
   __syncthreads();
   uint32_t* wl = a->sort_wl;
   const uint32_t n_listed_raw = __hip_atomic_load(&wl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -227,19 +227,31 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
 
 /* The latency path of SMALL batches (opt-in: EPPK_RESIDENT=1 in the environment when the context is created).  What a per-request
  * caller hands over (pkg/lwepp/handlers/request.go:141-163; design point 10-1000 QPS, docs/proposals/006-scheduler/README.md:133) is
- * batches of a few dozen requests at most, and such a batch is all launch and completion latency.  With the switch on, eppk_pick_batch and
- * eppk_pick_batch_staged hand an unmasked batch of at most EPPK_RESIDENT_MAX requests (default 64; 32 where the four-requests-per-
- * wavefront kernel does not apply) to a RESIDENT workgroup instead of launching a kernel: it polls a doorbell in pinned host memory,
- * scores the batch with the same code as the launched kernels (pick_fast_kernel's body below EPPK_RESIDENT_QUAD_FROM = 8 requests,
- * pick_quad_kernel's from there on: one resident workgroup of each form, same picks, same scores), writes the pinned result buffers
- * and raises a completion word the call is polling (host-observed: 1 request 11 us, 16 requests 12 us, 32: 13.4, 64: 17-19, against
- * 19-21 us through a launch: profiles/r04_resident_latency.txt).  Costs: a CU per form in use (the persistent pick kernels of the
- * context are sized for two fewer), and a polling host thread for the duration of the call.  A workgroup leaves by itself after
- * ~20-50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next batch of its kind; the library parks
- * both in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel does not serve,
- * masked batches, fallbacks and assumed load take the launched path as before.
- * eppk_resident_stats: returns 1 when the switch is on (0 otherwise); batches = small batches answered by the resident workgroup,
- * starts = times it was (re)started. */
+ * batches of a few dozen requests at most, and such a batch is all launch and completion latency.  With the switch on, a batch of at
+ * most EPPK_RESIDENT_MAX requests (default 64; 32 where the four-requests-per-wavefront kernel does not apply) is handed to a RESIDENT
+ * workgroup instead of a kernel launch: it polls a doorbell in pinned host memory, scores the batch with the same code as the launched
+ * kernels (same picks, same scores), writes the pinned result buffers and raises a completion word the call is polling.  Every call
+ * shape a dispatcher issues has its workgroup, started by the first batch that needs it:
+ *     eppk_pick_batch / eppk_pick_batch_staged                 plain and MASKED single picks
+ *     eppk_pick_topk                                          ordered fallbacks (k <= 8), with or without masks
+ *     eppk_pick_stage_begin / _end                            both staging sets, plain and masked (begin rings, end polls), and with
+ *                                                             EPPK_PICK_LEARN: the workgroup copies the rows, answers, and then applies
+ *                                                             the post-route index update ITSELF (no launch); the next batch of the
+ *                                                             context -- resident or launched -- is ordered behind that update
+ * Host-observed, 16 requests, C5 snapshot (profiles/r05_resident_latency.txt): plain 12 us, masked 14-15, top-4 13, pick + LEARN 12
+ * (23 back to back, the previous update included) against 20 / 28 / 22 / 30-40 us through launches.
+ * Costs: a CU per workgroup alive (at most four: each runs on a high-priority stream, i.e. a hardware queue, of its own -- a kernel
+ * that never ends would otherwise block whatever shares its queue -- and the least recently rung one leaves when a fifth shape shows
+ * up; the persistent pick kernels of the context are sized for four CUs fewer), and a polling host thread for the duration of a call.
+ * A workgroup leaves by itself after ~20-50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next batch of
+ * its kind; the library parks all of them in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel
+ * does not serve, the random-top-k picker and assumed load take the launched path as before.
+ * Streams: the resident workgroups are OUTSIDE stream order.  The library orders them against everything it has queued itself (the
+ * context's own stream, the staging sets, LEARN updates, evictions); index or snapshot work a caller has queued on a stream of ITS OWN
+ * (eppk_index_insert_picks_device / eppk_pick_learn_device / eppk_index_evict_older_device with a non-NULL stream) must have finished
+ * before a small batch is handed over.
+ * eppk_resident_stats: returns 1 when the switch is on (0 otherwise); batches = small batches answered by resident workgroups,
+ * starts = times one was (re)started. */
 int eppk_resident_stats(const eppk_ctx* ctx, uint64_t* batches, uint64_t* starts);
 
 /* The PIPELINED host path: EPPK_STAGE_SETS staging sets, each with its own pinned rows / masks / results, device buffers and
@@ -287,6 +299,8 @@ int eppk_pick_batch_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs,
  * blocks of the shared prefix with the picked pod on their list: half of a 64k x 32-block batch's 2 Mi pairs -- and the update only
  * refreshes their stamps.  (Batches that do not take the four-requests-per-wavefront kernel get the plain update.)  The closed loop a
  * router runs: pick -> the index learns the pick -> next batch.  EPPK_PICK_LEARN of the staged host path does the same. */
+/* (The learn words live in one buffer per context: calls on DIFFERENT streams are ordered by the library -- the later pick waits, on the
+ * device, for the earlier call's update.) */
 int eppk_pick_learn_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, int32_t* d_out_pick,
                            double* d_out_score, void* stream);
 /* Trust contract of the *_device entry points.  The host-buffer entry points check every request row and fail the call with
