@@ -4093,7 +4093,7 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
   const uint32_t total = slots + 2u;
   const uint32_t cur_tag = tag_of_epoch(epoch);
   const long long keep = (long long)epoch - (long long)min_epoch;
-  uint32_t gone = 0, freed_words = 0;
+  uint32_t gone = 0;
   for (uint32_t base0 = wave * 64u * kEvictChunks; base0 < total; base0 += nwaves * 64u * kEvictChunks) {
     uint64_t kk[kEvictChunks];
 #pragma unroll
@@ -4129,23 +4129,6 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
         }
         slot_bury(keys, slots, row, fat && row < slots);
       }
-      // The TAIL of a bucket goes back to EMPTY (round 5).  A closed loop turns every word it ever used into a tombstone: after a few
-      // hundred steps most buckets are full of them, chains grow (the overflow bit, a second bucket per look-up of an absent key -- the
-      // miss that ends every request's walk) and the update slows by a fifth.  Words behind the LAST live key of a bucket that never
-      // overflowed (header bit 0 clear: no key that hashed here lives further on) can be empty again without breaking "nothing lives
-      // behind an empty word": a tombstone or a victim there becomes 0, and is no longer counted as a non-empty word.  Their list
-      // lines keep the tombstone's state (count <= 1, positions 1.. at 0xFFFF: all a claimer of an empty word relies on as well).
-      {
-        const bool in_table = row < slots && !header;
-        const bool live = in_table && k != 0ull && k != kTomb && !victim;
-        const bool dead = in_table && (victim || k == kTomb);
-        const unsigned long long livem = __ballot(live);
-        const uint32_t in_bucket = (uint32_t)(livem >> (lane & ~(kBucket - 1u))) & 0xFFu;      // live keys of this lane's bucket, bit = position
-        const bool tail = (in_bucket >> ((lane & (kBucket - 1u)) + 1u)) == 0u;               // none behind this word
-        const bool freed = dead && tail && !(hdr & 1ull);
-        if (freed) keys[row] = 0ull;
-        freed_words += (uint32_t)__builtin_popcountll(__ballot(freed));
-      }
       unsigned long long vm = __ballot(whole);          // dense sets: the whole row, by the wavefront
       while (vm) {
         const uint32_t v = base + (uint32_t)__builtin_ctzll(vm);
@@ -4159,7 +4142,6 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
     atomicAdd(&ixc[shard + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
     atomicAdd(&ixc[shard + kIxEvicted], (unsigned long long)gone);   // evicted by this launch (the synchronous entry point zeroes it first)
   }
-  if (lane == 0 && freed_words) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxWords], (unsigned long long)(0ull - (unsigned long long)freed_words));
 }
 
 // Diagnostic (eppk_index_selfcheck): counts the slots that break an invariant of the index (the list at the head of this section, and
@@ -4194,7 +4176,7 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     const uint32_t id = ((const uint16_t*)L)[list_pos(j)], prev = j ? ((const uint16_t*)L)[list_pos(j - 1u)] : 0u;
     bool ok = true;
     if (lane < kListCap) {
-      if (tomb || (!present && row < slots)) ok = lane == 0u || id == kListNone;   // positions 1.. (position 0: whatever the previous occupant left)
+      if (tomb) ok = lane == 0u || id == kListNone;                        // positions 1.. (position 0: whatever the previous occupant left)
       else if (count <= kListCap) {
         if (lane < count) ok = id != kListNone && (id >> 6) < 8u * (uint32_t)sizeof(LW) && (lane == 0u || prev < id);   // valid, strictly ascending
         else ok = id == kListNone;
@@ -4205,8 +4187,7 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     const unsigned long long notok = __ballot(!ok);
     uint32_t why = notok ? 1u : 0u;                                        // bit 0: a list entry (ballot in the record), then per state
     if (tomb) why |= (count > 1u ? 2u : 0u) | (members != 0u ? 4u : 0u);                 // tombstone: a plain line at most, all-zero row
-    else if (!present) why |= ((row < slots ? count > 1u : count != 0u) ? 2u : 0u) | (members != 0u ? 4u : 0u);   // empty word: a reset list line or what a tombstone leaves (round 5: the
-                                                                                                                  // eviction frees bucket tails); absent reserved row: reset list; all-zero row
+    else if (!present) why |= (count != 0u ? 2u : 0u) | (members != 0u ? 4u : 0u);       // empty / absent reserved row: reset list, all-zero row
     else if (count <= kListCap) why |= (count == 0u ? 8u : 0u) | (members != 0u ? 16u : 0u);   // listed: non-empty, all-zero row
     else why |= members <= kListCap ? 32u : 0u;                            // dense: more than kListCap members in the row
     if (row < slots) {
