@@ -281,6 +281,10 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     assert st["requests_per_gpu"] == 32 and st["requests_per_step"] == 64 and abs(st["value"] - 64 * 10 / (st["ms_per_step"] * 1e-3 * 10)) < 1e-6 * st["value"]
     assert ("ONE launch" in st["note"]) == grouped and st["requests_per_launch"] == (4 * 32 if grouped else 32)
     assert st["completion_latency_p50_ms"] <= st["completion_latency_p99_ms"]
+    # BASELINE.json configs[4] first class in `config` (the driver's stored record keeps `config` in full): the strong-scaled single batch
+    c = d["config"]
+    assert c["strong_value"] == st["value"] and c["strong_ms_per_step"] == st["ms_per_step"]
+    assert c["strong_completion_latency_p99_ms"] == st["completion_latency_p99_ms"] and c["completion_latency_p99_ms"] == cl["p99_ms"]
 
 
 def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
