@@ -376,3 +376,74 @@ def test_ordered_fallbacks_with_candidate_masks(pkg, orc, R, P, k, density):
         assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64))
         assert (got_p[3] == -1).all()
         assert (ql, qd < R) == ((1, True) if on else (0, True))
+
+
+@pytest.mark.parametrize("P,B", [(4096, 32), (1000, 16), (2000, 8)])
+def test_requests_that_come_back(pkg, orc, P, B):
+    """A request that RETURNS after the index learned its pick: the tail blocks are listed on that one pod, the prefix blocks on the
+    group's pods and that pod (differing lists: pick_quad_kernel hands such a request to the work-list pass) -- against the oracle over
+    several generations of pick + LEARN on the SAME and on half-new batches, with candidate masks, as ordered fallbacks, and for the
+    shapes next to it (fewer than four prefix hits, a tail pod outside the prefix list, tail blocks on two pods).  (Round 5 built a
+    two-list route for the shape inside pick_quad_kernel and took it out again: the returning batch did not get faster -- it is bound by
+    the 32 index lines a returning request touches, 72 us per 64k against 65 through the work-list pass -- and the headline lost 5 %:
+    profiles/r05_revisit_probe.txt.)"""
+    with quad_env(True):
+        import torch
+        R = 1024
+        wl = pkg.workload.make_workload(5, R=R, P=P, B=B, n_groups=12, masked=True)
+        other = pkg.workload.make_requests(wl, 4242)
+        half = wl.reqs.copy(); half[::2] = other[::2]
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.Stream()
+        d_pick = torch.empty(R * 4, dtype=torch.int32, device=dev); d_score = torch.empty(R * 4, dtype=torch.float64, device=dev)
+        with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=B, max_batch=R, index_slots=1 << 18) as pk:
+            pk.publish(wl.pods)
+            pk.index_insert(wl.index_hashes, wl.index_pods)
+            oix = orc.OracleIndex()
+            oix.insert(wl.index_hashes, wl.index_pods)
+            q0 = pk.quad_stats()
+            deferred = []
+            for gen, reqs in enumerate([wl.reqs, wl.reqs, half, wl.reqs, half, other, wl.reqs]):
+                d_reqs = torch.from_numpy(reqs.view(np.int64)).to(dev)
+                l0, d0 = pk.quad_stats()
+                pk.pick_learn_device(d_reqs.data_ptr(), R, None, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream)
+                torch.cuda.synchronize()
+                l1, d1 = pk.quad_stats()
+                deferred.append(d1 - d0)
+                op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, B)
+                assert_same(d_pick[:R].cpu().numpy(), d_score[:R].cpu().numpy(), op, osc)
+                oix.insert_picks(reqs, B, op)
+                assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0, gen
+            assert deferred[0] == 0, deferred               # (generation 1 re-sends generation 0's batch: every request is a returning one)
+            # the same index through masks and ordered fallbacks (returning requests again)
+            d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
+            d_mask = torch.from_numpy(wl.mask.view(np.int64)).to(dev)
+            pk.pick_device(d_reqs.data_ptr(), R, d_mask.data_ptr(), d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, B, wl.mask)
+            assert_same(d_pick[:R].cpu().numpy(), d_score[:R].cpu().numpy(), op, osc)
+            for mask, dm in ((None, None), (wl.mask, d_mask.data_ptr())):
+                pk._check(pk._lib.eppk_pick_topk_device(pk._ctx, d_reqs.data_ptr(), R, dm, 4, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream), "topk")
+                torch.cuda.synchronize()
+                tp, ts = orc.pick_topk_batch(wl.chain, wl.pods, oix, wl.reqs, B, 4, mask)
+                assert np.array_equal(d_pick.cpu().numpy().reshape(R, 4), tp)
+                assert np.array_equal(d_score.cpu().numpy().view(np.uint64).reshape(R, 4), ts.view(np.uint64))
+            # neighbouring shapes (hand-made): tail pod outside A; tail on two pods; fewer than four prefix hits; one-pod lists throughout
+            odd = wl.reqs[:64].copy()
+            hs = odd[:, 1:1 + B]
+            extra_h, extra_p = [], []
+            for r in range(64):
+                tail = hs[r, B // 2:]
+                if r % 4 == 0:                       # a second pod on the tail blocks
+                    extra_h += list(tail); extra_p += [(7 * r + 3) % P] * tail.size
+                elif r % 4 == 1:                     # ... on the LAST block only (three lists)
+                    extra_h.append(tail[-1]); extra_p.append((5 * r + 1) % P)
+            pk.index_insert(np.array(extra_h, dtype=np.uint64), np.array(extra_p, dtype=np.uint32))
+            oix.insert(np.array(extra_h, dtype=np.uint64), np.array(extra_p, dtype=np.uint32))
+            short = odd.copy()
+            short[:, 1:1 + B] = np.roll(hs, -(B // 2 - 2), axis=1)   # two prefix hits, then the tail, then misses
+            for reqs in (odd, short):
+                picks, scores = pk.pick(reqs)
+                op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, B)
+                assert_same(picks, scores, op, osc)
+            assert pk.launch_status() == 0
