@@ -385,8 +385,7 @@ def test_requests_that_come_back(pkg, orc, P, B):
     several generations of pick + LEARN on the SAME and on half-new batches, with candidate masks, as ordered fallbacks, and for the
     shapes next to it (fewer than four prefix hits, a tail pod outside the prefix list, tail blocks on two pods).  (Round 5 built a
     two-list route for the shape inside pick_quad_kernel and took it out again: the returning batch did not get faster -- it is bound by
-    the 32 index lines a returning request touches, 72 us per 64k against 65 through the work-list pass -- and the headline lost 5 %:
-    profiles/r05_revisit_probe.txt.)"""
+    the 32 index lines a returning request touches, 72 us per 64k against 65 through the work-list pass: profiles/r05_revisit_probe.txt.)"""
     with quad_env(True):
         import torch
         R = 1024
