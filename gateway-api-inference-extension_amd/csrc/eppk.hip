@@ -161,6 +161,7 @@ struct eppk_ctx {
     bool pending = false; uint32_t pending_seq = 0;   // a doorbell rung (eppk_pick_stage_begin) and not collected yet
     bool updating = false; uint32_t update_seq = 0;   // LEARN units: the index update behind that doorbell has not been seen finished yet
     int32_t slot = -1; uint64_t last_rung = 0;        // the stream slot it runs on; when it was last rung (the slots are handed out LRU)
+    uint32_t misses = 0;                              // calls in a row that wanted this unit while every slot was taken (resident_admit)
   } res[kResUnits];
   eppk::ResidentArgs* d_res_args = nullptr;
   uint32_t* d_res_wl = nullptr; uint32_t res_wl_cap = 0;     // the resident workgroup's work list (its pick_quad_kernel form): total[32] | cnt[16] | list[16][cap]
@@ -670,6 +671,12 @@ bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t
   if (learn && (k != 1u || !c->slots || !c->have_snapshot)) return false;
   return k <= EPPK_MAX_TOPK && n_reqs <= 255u && resident_quad(c);     // the variants exist for the quad form
 }
+uint32_t resident_unit_of(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, bool learn);
+bool resident_admit(eppk_ctx* c, uint32_t unit);
+// what the entry points ask: may this batch take the latency path NOW?
+bool resident_takes(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k = 1u, bool learn = false) {
+  return resident_eligible(c, n_reqs, masked, k, learn) && resident_admit(c, resident_unit_of(c, n_reqs, masked, k, learn));
+}
 int resident_ensure(eppk_ctx* c) {            // control blocks, argument block, streams (each made once: a call that failed half-way is resumed)
   if (c->d_res_args) return EPPK_OK;
   if (!c->d_res_wl) {   // the work list of the quad forms: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
@@ -820,6 +827,28 @@ int resident_drain(eppk_ctx* c) {
   }
   return EPPK_OK;
 }
+// The unit a call shape rings.
+uint32_t resident_unit_of(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, bool learn) {
+  if (learn) return masked ? kResLearnMasked : kResLearn;
+  if (!masked && k == 1u) return (n_reqs >= c->resident_quad_from && resident_quad(c)) ? kResQuad : kResFast;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
+  return k > 1u ? (masked ? kResTopkMasked : kResTopk) : kResMasked;
+}
+// More call shapes than stream slots: a shape whose unit is not resident while every slot is taken by units in use takes the LAUNCHED path
+// (false) until it has been asked for kResAdmitAfter times in a row -- only then does the least recently rung unit make room.  (Five
+// shapes in rotation over four slots parked and started a unit per call: ~35 us each, worse than a launch; profiles/r05_resident_latency.txt.)
+constexpr uint32_t kResAdmitAfter = 8u;
+bool resident_admit(eppk_ctx* c, uint32_t unit) {
+  eppk_ctx::ResidentUnit& u = c->res[unit];
+  if (u.running || u.slot >= 0) { u.misses = 0u; return true; }
+  for (uint32_t sl = 0; sl < eppk_ctx::kResSlots; ++sl) {
+    const int32_t other = c->res_slot_unit[sl];
+    if (other < 0) { u.misses = 0u; return true; }                                  // a free slot
+    const eppk_ctx::ResidentUnit& o = c->res[other];
+    if (o.h_ctl && !o.pending && __atomic_load_n(&o.h_ctl->state, __ATOMIC_ACQUIRE) == eppk::kResExited) { u.misses = 0u; return true; }   // ... or one whose unit has left by itself
+  }
+  if (++u.misses >= kResAdmitAfter) { u.misses = 0u; return true; }                 // asked for often enough: the LRU unit goes
+  return false;
+}
 // Ring a small batch in: its rows (and mask rows) are in buffer set `bufset` (0 = the context's pinned staging buffers, 1 + s = staging
 // set s) already and have been validated; the results land in that set's pinned result buffers.  *unit_out / *seq_out: what to wait for.
 int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_t bufset, uint32_t* unit_out, uint32_t* seq_out, bool learn = false) {
@@ -870,10 +899,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
     HIPCHK(c, hipMemcpy(c->d_res_args, all, sizeof all, hipMemcpyHostToDevice));
     c->res_args_dirty = false;
   }
-  uint32_t unit;
-  if (learn) unit = masked ? kResLearnMasked : kResLearn;
-  else if (!masked && k == 1u) unit = (n_reqs >= c->resident_quad_from && resident_quad(c)) ? kResQuad : kResFast;   // (EPPK_RESIDENT_QUAD_FROM; measured crossover: see eppk_ctx)
-  else unit = k > 1u ? (masked ? kResTopkMasked : kResTopk) : kResMasked;
+  const uint32_t unit = resident_unit_of(c, n_reqs, masked, k, learn);
   eppk_ctx::ResidentUnit& u = c->res[unit];
   if (u.pending) {                  // one doorbell per unit at a time (the other staging set's batch of the same kind): answered first
     rc = resident_wait(c, unit, u.pending_seq, "resident path");
@@ -1960,7 +1986,7 @@ int eppk_pick_batch(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64
   if (!c->have_snapshot) return fail(c, EPPK_ERR_NO_SNAPSHOT, "eppk_pick_batch: no snapshot published");
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch: n_reqs > max_batch");
   if (n_reqs == 0) return EPPK_OK;
-  if (c->n_pods != 0u && resident_eligible(c, n_reqs, cand_mask != nullptr)) {      // the latency path of a small batch: a resident workgroup, no launch
+  if (c->n_pods != 0u && resident_takes(c, n_reqs, cand_mask != nullptr)) {      // the latency path of a small batch: a resident workgroup, no launch
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rcr = ensure_host_staging(c, cand_mask != nullptr);
     if (rcr) return rcr;
@@ -1990,7 +2016,7 @@ int eppk_pick_batch_staged(eppk_ctx* c, uint32_t n_reqs, int use_mask, int32_t* 
   if (n_reqs > c->cfg.max_batch) return fail(c, EPPK_ERR_LIMIT, "eppk_pick_batch_staged: n_reqs > max_batch");
   if (!c->h_reqs || (use_mask && !c->h_mask)) return fail(c, EPPK_ERR_ARG, "eppk_pick_batch_staged: eppk_host_staging was not called for these buffers");
   if (n_reqs == 0) return EPPK_OK;
-  if (c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0)) {
+  if (c->n_pods != 0u && resident_takes(c, n_reqs, use_mask != 0)) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_batch_staged", use_mask != 0);
   }
@@ -2065,7 +2091,7 @@ int eppk_pick_stage_begin(eppk_ctx* c, uint32_t set, uint32_t n_reqs, int use_ma
   const bool learn = (flags & EPPK_PICK_LEARN) != 0u;
   const bool zero_copy = n_reqs <= c->zero_copy_max;
   int rc;
-  if (c->n_pods != 0u && resident_eligible(c, n_reqs, use_mask != 0, 1u, learn)) {
+  if (c->n_pods != 0u && resident_takes(c, n_reqs, use_mask != 0, 1u, learn)) {
     // the latency path of a small batch (EPPK_RESIDENT=1): rung into a resident workgroup, which reads the set's pinned rows (and mask
     // rows) and writes its pinned results; end() polls the completion word -- no launch, no event.  With LEARN the workgroup applies
     // the post-route index update itself, right behind the answer (it has copied the rows: the caller may refill the set after end()).
@@ -2417,7 +2443,7 @@ int eppk_pick_topk(eppk_ctx* c, const void* reqs, uint32_t n_reqs, const uint64_
     if (reqs != c->h_reqs) std::memcpy(c->h_reqs, reqs, (size_t)n_reqs * c->stride);
     if (cand_mask && cand_mask != c->h_mask) std::memcpy(c->h_mask, cand_mask, (size_t)n_reqs * J * 8u);
     // the latency path of a dispatcher that asks for fallback lists (every one of its batches comes through here): a resident workgroup
-    if (resident_eligible(c, n_reqs, cand_mask != nullptr, k)) return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_topk", cand_mask != nullptr, k);
+    if (resident_takes(c, n_reqs, cand_mask != nullptr, k)) return resident_pick(c, n_reqs, out_pick, out_score, "eppk_pick_topk", cand_mask != nullptr, k);
     rc = run_pick(c, (const uint8_t*)c->h_reqs_dev, n_reqs, cand_mask ? c->h_mask_dev : nullptr, c->h_pick_dev, c->h_score_dev, c->stream, k, false, 0ull, 0u);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

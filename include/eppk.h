@@ -241,8 +241,9 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
  * Host-observed, 16 requests, C5 snapshot (profiles/r05_resident_latency.txt): plain 12 us, masked 14-15, top-4 13, pick + LEARN 12
  * (23 back to back, the previous update included) against 20 / 28 / 22 / 30-40 us through launches.
  * Costs: a CU per workgroup alive (at most four: each runs on a high-priority stream, i.e. a hardware queue, of its own -- a kernel
- * that never ends would otherwise block whatever shares its queue -- and the least recently rung one leaves when a fifth shape shows
- * up; the persistent pick kernels of the context are sized for four CUs fewer), and a polling host thread for the duration of a call.
+ * that never ends would otherwise block whatever shares its queue; a fifth shape takes the launched path until it has been asked for
+ * eight times, then the least recently rung workgroup makes room; the persistent pick kernels of the context are sized for four CUs
+ * fewer), and a polling host thread for the duration of a call.
  * A workgroup leaves by itself after ~20-50 ms without a doorbell (EPPK_RESIDENT_IDLE_POLLS) and is started again by the next batch of
  * its kind; the library parks all of them in front of every device-wide wait of its own and in eppk_destroy.  Chains the fused kernel
  * does not serve, the random-top-k picker and assumed load take the launched path as before.
