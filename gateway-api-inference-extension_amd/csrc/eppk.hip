@@ -641,7 +641,10 @@ int resident_park(eppk_ctx* c) {
 // ONE unit leaves (its slot goes to another): answered and updated first, then "quit".
 int resident_park_one(eppk_ctx* c, uint32_t unit) {
   eppk_ctx::ResidentUnit& u = c->res[unit];
-  if (!u.running) return EPPK_OK;
+  if (!u.running) {          // (a unit whose restart failed keeps no slot: two units on one stream is the 38 ms queue blocking the slots exist to avoid)
+    if (u.slot >= 0) { c->res_slot_unit[u.slot] = -1; u.slot = -1; }
+    return EPPK_OK;
+  }
   { const int rcd = resident_drain(c); if (rcd) return rcd; }
   __atomic_store_n(&u.h_ctl->bell, eppk::kResQuit, __ATOMIC_RELEASE);
   HIPCHK(c, hipStreamSynchronize(u.stream));
@@ -665,11 +668,12 @@ bool resident_quad(const eppk_ctx* c) {
 }
 // k = entries per request (1: the pick); learn: the post-route index update chained behind the pick (single picks)
 bool resident_eligible(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k = 1u, bool learn = false) {
-  if (!(c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
+  // (n_reqs <= 255 for EVERY shape: the doorbell's upper half carries n in eight bits -- res_bell_hi)
+  if (!(c->resident_on && n_reqs != 0 && n_reqs <= c->resident_max && n_reqs <= 255u && c->canonical && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
         c->assumed_epochs == 0 && c->cfg.max_blocks >= 1)) return false;
   if (!masked && k == 1u && !learn) return true;
   if (learn && (k != 1u || !c->slots || !c->have_snapshot)) return false;
-  return k <= EPPK_MAX_TOPK && n_reqs <= 255u && resident_quad(c);     // the variants exist for the quad form
+  return k <= EPPK_MAX_TOPK && resident_quad(c);     // the variants exist for the quad form
 }
 uint32_t resident_unit_of(const eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, bool learn);
 bool resident_admit(eppk_ctx* c, uint32_t unit);
@@ -1154,6 +1158,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (const char* qf = getenv("EPPK_RESIDENT_QUAD_FROM")) c->resident_quad_from = atoi(qf) > 0 ? (uint32_t)atoi(qf) : 1u;
   bool resident_max_set = false;
   if (const char* rm = getenv("EPPK_RESIDENT_MAX")) { c->resident_max = atoi(rm) > 0 ? (uint32_t)atoi(rm) : 0u; resident_max_set = true; }
+  if (c->resident_max > 255u) c->resident_max = 255u;      // (the doorbell carries the request count in eight bits: res_bell_hi)
   if (c->resident_on && c->num_cu > (int)eppk_ctx::kResSlots) c->num_cu -= (int)eppk_ctx::kResSlots;    // a resident workgroup holds one CU (kResSlots of them at most): the persistent pick kernels are sized for the rest
   if (const char* qd = getenv("EPPK_QUAD")) c->quad_on = atoi(qd) != 0;
   if (const char* qm = getenv("EPPK_QUAD_MIN")) c->quad_min = atoi(qm) >= 4 ? (uint32_t)atoi(qm) : 4u;
@@ -3296,8 +3301,14 @@ int eppk_group_pick_stage_end(eppk_group* g, uint32_t set, int32_t* out_pick, do
       if (*s.h_bad != 0xFFFFFFFFu && s.row_base + *s.h_bad < bad) bad = s.row_base + *s.h_bad;
     }
   }
-  if (dev_failed) return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_end: a member's stream failed");
-  if (bad != 0xFFFFFFFFu) return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: request row " + std::to_string(bad) + " out of range");
+  // (EPPK_GATHER_HOST + LEARN: the owed update of a batch whose end fails.  A bad row: applied right here, as PEER / RCCL applied it in the
+  //  begin and the single-context path behind the pick -- out-of-range rows are skipped by the update kernel itself.  A failed stream:
+  //  there are no picks to learn from; the batch is not learned, whatever is called next.)
+  if (dev_failed) { gs.host_learn = false; return gfail(g, EPPK_ERR_DEVICE, "eppk_group_pick_stage_end: a member's stream failed"); }
+  if (bad != 0xFFFFFFFFu) {
+    group_host_learn_flush(g, set);
+    return gfail(g, EPPK_ERR_ARG, "eppk_group_pick_stage_end: request row " + std::to_string(bad) + " out of range");
+  }
   eppk_ctx* c0 = g->ctx[0];
   const size_t J = (c0->n_pods + 63u) / 64u;
   std::memcpy(out_pick, gs.h_pick, (size_t)gs.n * 4u);

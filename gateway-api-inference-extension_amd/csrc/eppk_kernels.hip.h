@@ -1967,11 +1967,16 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     for (int i = 0; i < 4; ++i) { L[i].x = 0x00020001u + (sl0 & 1u); L[i].y = 0x00040003u; L[i].z = 0xFFFFFFFFu; L[i].w = 8u; }
 #else
     L[0] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sl0 * 64u + j16), 0, 0);
+#ifdef EPPK_DBGQ_ONE_LIST   // timing experiment only (wrong results for differing lists): ONE list line per request, as if the bucket lines decided "all lists identical"
+#pragma unroll
+    for (int i = 1; i < 4; ++i) L[i] = L[0];
+#else
 #pragma unroll
     for (int i = 1; i < 4; ++i) {
       const uint32_t s = (4u * (uint32_t)i + q < m) ? slot[i] : sl0;
       L[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(s * 64u + j16), 0, 0);
     }
+#endif
 #endif
 #ifdef EPPK_DBGQ_NO_TOP     // timing experiment only (wrong results): no top-table loads
     const double top_t = -1.0 - (double)arow;
@@ -2006,7 +2011,11 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
 #pragma unroll
     for (int i = 1; i < 4; ++i) diff |= (L[i].x ^ L[0].x) | (L[i].y ^ L[0].y) | (L[i].z ^ L[0].z) | (L[i].w ^ L[0].w);
     if (j == 0u && L[0].w > kListCap) diff = 1u;                      // an overflowed list (count > capacity): the dense rows
+#ifdef EPPK_DBGQ_ONE_LIST
+    if (false) {
+#else
     if (__any(m > 16u)) {                                             // hits 16..31: loaded and consumed here
+#endif
 #pragma unroll
       for (int i2 = 0; i2 < 4; i2 += 2) {                              // (two at a time: the registers of four more lists would spill)
         u32x4_t M[2];

@@ -193,9 +193,30 @@ def make_workload(config: int, R: Optional[int] = None, P: Optional[int] = None,
                                          group_bytes=gbytes if B > 0 else None))
 
 
-def make_requests(wl: Workload, req_seed: int) -> np.ndarray:
+def returning_rows(fresh: np.ndarray, earlier: np.ndarray, revisit_frac: float, seed: int) -> np.ndarray:
+    """A batch in which a fraction `revisit_frac` of the rows are RETURNING requests: row r of `earlier` -- a batch that has been routed
+    and whose picks the index has learned -- takes the place of row r of `fresh` wherever a splitmix64 draw falls below the fraction
+    (positions scattered over the batch, so that returning and new requests share wavefronts).  What the prefix scorer exists for
+    (docs/proposals/0602-prefix-cache-aware-routing-proposal/README.md:101-112): such a request finds its whole prompt in the index --
+    the group's shared blocks on the group's pods, its own tail blocks on the ONE pod it was routed to."""
+    assert fresh.shape == earlier.shape
+    if revisit_frac <= 0.0:
+        return fresh.copy()
+    R = fresh.shape[0]
+    u = (splitmix64(_sub(seed, 16), R) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    back = u < revisit_frac
+    out = fresh.copy()
+    out[back] = earlier[back]
+    return out
+
+
+def make_requests(wl: Workload, req_seed: int, revisit_of: Optional[np.ndarray] = None, revisit_frac: float = 0.0) -> np.ndarray:
     """Another batch of request rows against the SAME snapshot, prefix groups and index as `wl` (bench.py rotates through several
-    distinct batches): exactly the rows make_workload(..., req_seed=req_seed) would produce, without rebuilding pods and index."""
+    distinct batches): exactly the rows make_workload(..., req_seed=req_seed) would produce, without rebuilding pods and index.
+    `revisit_of` / `revisit_frac`: that fraction of the rows are returning requests out of the earlier batch `revisit_of`
+    (returning_rows above)."""
+    if revisit_of is not None and revisit_frac > 0.0:
+        return returning_rows(make_requests(wl, req_seed), revisit_of, revisit_frac, req_seed)
     m = wl.meta
     R, B, n_groups = wl.R, wl.B, m["n_groups"]
     lib = _lib.load_library()

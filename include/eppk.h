@@ -237,7 +237,12 @@ int eppk_pick_batch_staged(eppk_ctx* ctx, uint32_t n_reqs, int use_mask, int32_t
  *     eppk_pick_stage_begin / _end                            both staging sets, plain and masked (begin rings, end polls), and with
  *                                                             EPPK_PICK_LEARN: the workgroup copies the rows, answers, and then applies
  *                                                             the post-route index update ITSELF (no launch); the next batch of the
- *                                                             context -- resident or launched -- is ordered behind that update
+ *                                                             context -- resident or launched -- is ordered behind that update.
+ *                                                             On this path the two sets do NOT overlap: a begin first waits (spinning)
+ *                                                             until the other set's batch is answered and, with LEARN, updated; and a
+ *                                                             bad request row is reported by the BEGIN (host-side row check; the set
+ *                                                             stays idle and must not be ended), where the launched path reports it
+ *                                                             from the end with the row named
  * Host-observed, 16 requests, C5 snapshot (profiles/r05_resident_latency.txt): plain 12 us, masked 14-15, top-4 13, pick + LEARN 12
  * (23 back to back, the previous update included) against 20 / 28 / 22 / 30-40 us through launches.
  * Costs: a CU per workgroup alive (at most four: each runs on a high-priority stream, i.e. a hardware queue, of its own -- a kernel

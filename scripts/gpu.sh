@@ -43,6 +43,11 @@ if h:
     s += "\n   host_path " + str({k: (round(v.get('decisions_per_s', v.get('decisions_per_s_p50', 0)) / 1e6, 1) if isinstance(v, dict) else v) for k, v in h.items() if k in ('staged', 'pipelined', 'pipelined_learn', 'decisions_per_s_p50')})
     lb = (h.get("latency_by_batch") or {}).get("requests")
     if lb: s += "\n   latency_by_batch " + str({n: {k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items() if not k.startswith("resident_")} for n, e in lb.items()})
+rv = (d.get("revisit") or {}).get("by_fraction") or {}
+if rv: s += "\n   revisit " + str({f: (round(v.get("kernel_us_per_batch") or 0, 1), round(v.get("deferred_per_launch") or 0), v.get("picks_and_scores_equal_oracle")) for f, v in rv.items()})
+rcold = d.get("roofline_cold") or {}
+if rcold: s += f"\n   cold {rcold.get('value', 0) / 1e6:.0f} M/s kernel {1e3 * (rcold.get('kernel_avg_ms') or 0):.1f} us frac {rcold.get('frac') or 0:.3f} strict {rcold.get('frac_strict') or 0:.3f}"
+s += f"\n   config keys {len(d.get('config') or {})}"
 print(s)
 EOF
 }
@@ -57,15 +62,15 @@ for stage in "$@"; do
     quick) timeout 200 python scripts/dump_workload.py --config 5 --out /tmp/c5 > /dev/null 2>&1; timeout 120 ./tests/cpp/parity_quick /tmp/c5 4 2>&1 | tail -4 ;;
     bench20)  timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; digest $OUT/bench_steps20.json ;;
     bench200) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; digest $OUT/bench.json ;;
-    benchq20)  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/benchq20.json 2> $OUT/benchq20.err; digest $OUT/benchq20.json ;;
-    benchq200) timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref > $OUT/benchq200.json 2> $OUT/benchq200.err; digest $OUT/benchq200.json ;;
+    benchq20)  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 > $OUT/benchq20.json 2> $OUT/benchq20.err; digest $OUT/benchq20.json ;;
+    benchq200) timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg > $OUT/benchq200.json 2> $OUT/benchq200.err; digest $OUT/benchq200.json ;;
     closed)  timeout 600 python bench.py --closed-loop > $OUT/bench_closed_loop.json 2> $OUT/bench_closed_loop.err; digest $OUT/bench_closed_loop.json ;;
     closedq) f=$OUT/closedq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --closed-loop --cl-verify 0 $arg > $f.json 2> $f.err; digest $f.json ;;
-    configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
+    configs) for c in 2 3 4; do timeout 300 python bench.py --config $c --no-cold-ref --no-revisit-leg > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "config $c:"; digest $OUT/bench_c$c.json; done ;;
     routes) timeout 300 python scripts/gpu_route_times.py > $OUT/route_times.json 2> $OUT/route_times.err; tail -c 1500 $OUT/route_times.json ;;
     routes_nopause) EPPK_QUAD_PAUSE=0 timeout 300 python scripts/gpu_route_times.py > $OUT/route_times_nopause.json 2> $OUT/route_times_nopause.err; tail -c 1500 $OUT/route_times_nopause.json ;;
-    benchq) f=$OUT/benchq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --no-closed-loop-leg $arg > $f.json 2> $f.err; digest $f.json; grep "host time" $f.err ;;
-    trace20) ( cd /tmp; EPPK_BENCH_HOSTTIME=1 timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace20 -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --no-closed-loop-leg $arg > $OUT/trace20_bench.json 2> $OUT/trace20.err )
+    benchq) f=$OUT/benchq${arg//[^a-zA-Z0-9]/_}; timeout 300 python bench.py --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 --no-closed-loop-leg $arg > $f.json 2> $f.err; digest $f.json; grep "host time" $f.err ;;
+    trace20) ( cd /tmp; EPPK_BENCH_HOSTTIME=1 timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace20 -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 --no-closed-loop-leg $arg > $OUT/trace20_bench.json 2> $OUT/trace20.err )
            digest $OUT/trace20_bench.json; grep "host time" $OUT/trace20.err
            python - $OUT/trace20 <<'EOF3' | tee $OUT/trace20_timeline.txt
 import csv, glob, sys
@@ -90,13 +95,13 @@ EOF3
       python scripts/pmc_summary.py $OUT/lg2 gather2 --by-kernel | tee $OUT/micro_linegather2_pmc.csv | cut -c1-160
       rm -f $(find $OUT/lg2 -name "*agent_info.csv") $(find $OUT/lg2 -name "*kernel_trace.csv") ;;
     dist1) # the N > 1 code path of bench.py on ONE GPU: RCCL at world size 1, through torch.distributed.run as the driver launches it
-      timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref $arg > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
+      timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg $arg > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
       digest $OUT/bench_force_dist.json; tail -3 $OUT/bench_force_dist.err | cut -c1-300
       python - $OUT/bench_force_dist.json <<'EOF4'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("   metric:", d["metric"]); print("   scaling_note:", d.get("scaling_note")); c = d["config"]
+    print("   metric:", d["metric"]); print("   scaling_note:", d.get("scaling_note")); c = d["config_detail"]
     print("   ", {k: c.get(k) for k in ("ranks_seen", "per_rank_kernel_us", "collective_us", "sharding")}); print("   strong:", {k: (d.get("strong") or {}).get(k) for k in ("value", "ms_per_step")}, " completion_latency:", d.get("completion_latency"))
 except Exception as e:
     print("   (", e, ")")
@@ -106,7 +111,7 @@ EOF4
     doorbell|claim|claim2|evictloop|insertbreak)
       bin=$name; [ $name = claim ] && bin=claimcost; [ $name = claim2 ] && bin=claimcost2
       timeout 60 ./scripts/micro/_bin/$bin $arg 2>&1 | tee $OUT/micro_$name.txt | tail -40 ;;
-    stats) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 > $OUT/prof_bench_under_rocprof.json 2> $OUT/prof.err )
+    stats) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 > $OUT/prof_bench_under_rocprof.json 2> $OUT/prof.err )
            head -6 $OUT/prof/*kernel_stats.csv 2>/dev/null | cut -c1-200; rm -f $(find $OUT/prof -name "*agent_info.csv") $(find $OUT/prof -name "*kernel_trace.csv") ;;
     stats_cl) ( cd /tmp; timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cl -o trace -- python $GRAFT_REPO_ROOT/bench.py --closed-loop --steps 60 --warmup 10 --no-cpu-baseline --cl-verify 0 > $OUT/prof_cl_bench_under_rocprof.json 2> $OUT/prof_cl.err )
            head -8 $OUT/prof_cl/*kernel_stats.csv 2>/dev/null | cut -c1-200
@@ -124,9 +129,9 @@ for f in glob.glob(sys.argv[1] + "/*kernel_trace.csv"):
 EOF2
            rm -f $(find $OUT/prof_cl -name "*agent_info.csv") $(find $OUT/prof_cl -name "*kernel_trace.csv") ;;
     pmc|pmc_cold)
-      if [ $name = pmc ]; then ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --inflight 1"
+      if [ $name = pmc ]; then ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 --inflight 1"
         CTRS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TA_BUSY_avr TA_TA_BUSY_sum TCC_BUSY_avr")
-      else ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --p99-samples 0 --groups 262144 --zipf 0 --pods-per-group 4 --batches 4 --inflight 1"
+      else ARGS="--steps 6 --warmup 10 --no-cpu-baseline --host-path 0 --no-cold-ref --no-revisit-leg --p99-samples 0 --groups 262144 --zipf 0 --pods-per-group 4 --batches 4 --inflight 1"
         CTRS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum"); fi
       mkdir -p $OUT/$name; i=0
       for ctrs in "${CTRS[@]}"; do i=$((i+1))     # (counters in passes of their own, with --kernel-trace only: /opt/skills/guides/MI355X_MICROARCH.md)

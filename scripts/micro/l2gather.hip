@@ -7,6 +7,8 @@
 //   C  pair per line, 2 x 16 B     lanes 2p, 2p+1 read one half line each, two instructions     (32 lines per 2 instructions)
 //   D  lane per line, 1 x 8 B      one 8-byte word of 64 different lines                        (64 lines per instruction)
 //   E  row  per line, 1 x 4 B      16 lanes read 64 contiguous bytes                            (4 lines per instruction)
+//   F  octet per 128-byte line     lanes 8o..8o+7 read the eight pieces of ONE 128-byte-aligned line (8 double lines per instruction):
+//                                  does a 128-byte bucket cost one line or two?  (round 6: pricing a bucket that carries its pod-set ids)
 // Prints ns per line and lines per clock per CU (2.0 GHz assumed) at 4 wavefronts per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -51,6 +53,12 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ tab, u
     } else if constexpr (MODE == 3) {   // D: one instruction, 64 lines
       const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((mix(seed + lane) & line_mask) * 64u + (lane & 7u) * 8u), 0, 0);
       acc ^= v.x ^ v.y;
+    } else if constexpr (MODE == 5) {   // F: 4 instructions x 8 double lines
+      u32x4_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((mix(seed + i * 8u + (lane >> 3)) & (line_mask >> 1)) * 128u + (lane & 7u) * 16u), 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
     } else {                            // E: 4 instructions x 4 lines
       uint32_t v[4];
 #pragma unroll
@@ -91,6 +99,7 @@ int main() {
     run<2>("C pair/line 2x16B (x2)", tab, mask, out, 64);
     run<3>("D lane/line 1x8B", tab, mask, out, 64);
     run<4>("E row/line 1x4B (x4)", tab, mask, out, 16);
+    run<5>("F octet/128-B line (x4)", tab, mask, out, 32);     // (counted in 128-byte lines)
   }
   return 0;
 }

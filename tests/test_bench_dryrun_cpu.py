@@ -180,6 +180,10 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
     d = json.loads(lines[-1])                                           # the JSON line is the last thing on stdout
     closed = "--closed-loop" in argv
+    # `config`: at most 20 scalar keys (what the driver's stored record keeps), the workload first; the rest is in `config_detail`
+    assert 5 <= len(d["config"]) <= 20 and all(not isinstance(v, (dict, list)) for v in d["config"].values()), d["config"]
+    assert list(d["config"])[:5] == ["workload", "requests_per_step", "pods", "blocks_per_request", "chain"]
+    assert d["config_detail"]["workload"] == d["config"]["workload"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline") + (() if closed else ("cpu_baseline",)):
         assert key in d, key
@@ -191,7 +195,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     n_picks = sum(1 for e in log if e[0] == "pick")
     if closed:
         assert d["closed_loop"]["picks_equal_oracle"] and d["closed_loop"]["scores_bitwise_equal_oracle"]
-        assert d["closed_loop"]["generations_verified"] == 3 and d["config"]["closed_loop"] is True
+        assert d["closed_loop"]["generations_verified"] == 3 and d["config_detail"]["closed_loop"] is True
         rc = d["roofline_closed_loop"]
         assert rc["bound"] == "hbm-random-lines" and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-12
         assert set(rc["step_parts_ms"]) >= {"pick", "index_update", "ageing_per_step"} and rc["per_step"]["new_keys"] >= 0
@@ -203,14 +207,14 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     assert d["parity"]["picks_equal_oracle"] and d["parity"]["scores_bitwise_equal_oracle"]
     if "--force-dist" in argv:
         both = "--scaling" not in argv
-        assert d["scaling"] == "weak" and d["config"]["ranks_seen"] == 1          # N > 1: weak scaling is the headline, strong beside it
+        assert d["scaling"] == "weak" and d["config_detail"]["ranks_seen"] == 1          # N > 1: weak scaling is the headline, strong beside it
         assert ("strong" in d) == both and "weak" not in d
         extra = max(0, 40 - d["steps"]) if "--p99-samples" in argv else 0
         steps = d["steps"] + d["warmup"]
         if both:
             # strong scaling scores the shards of a whole gather bucket (16 batches) with ONE launch; weak scaling one launch per batch
-            assert "ONE launch" in d["strong"]["note"] and d["strong"]["requests_per_launch"] == 16 * 96 and d["config"]["requests_per_launch"] == 96
-            assert "int16" not in d["config"]["sharding"]                                   # (--pack16 is opt-in)
+            assert "ONE launch" in d["strong"]["note"] and d["strong"]["requests_per_launch"] == 16 * 96 and d["config_detail"]["requests_per_launch"] == 96
+            assert "int16" not in d["config_detail"]["sharding"]                                   # (--pack16 is opt-in)
             assert n_picks >= (steps + 15) // 16 + steps + extra                              # (extra = launches beyond the timed region: samples)
         else:
             assert n_picks >= steps + extra
@@ -222,7 +226,7 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     else:
         assert d["scaling"] == "weak" and n_picks >= d["steps"] + d["warmup"]
         if "--batches" in argv:
-            assert d["config"]["distinct_batches"] == 3
+            assert d["config_detail"]["distinct_batches"] == 3
 
 
 def _bench_worker(rank, world, port, outdir, extra_args=("--batches", "5"), requests=64):
@@ -265,13 +269,13 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3
     # headline = weak scaling: a whole 64-request batch per rank and step, the aggregate counts BOTH ranks; every rank ends up with the
     # picks of both (rank 0 checks each rank's part against the oracle on the batch that rank scored)
-    assert d["scaling"] == "weak" and d["config"]["requests_per_gpu"] == 64 and d["config"]["requests_per_step"] == 128
-    assert "cpu_baseline" not in d and "one whole batch per rank" in d["config"]["sharding"] and d["config"]["ranks_seen"] == 2
-    assert ("int16" in d["config"]["sharding"]) == ("--pack16" in extra) and d["config"]["requests_per_launch"] == 64
+    assert d["scaling"] == "weak" and d["config_detail"]["requests_per_gpu"] == 64 and d["config_detail"]["requests_per_step"] == 128
+    assert "cpu_baseline" not in d and "one whole batch per rank" in d["config_detail"]["sharding"] and d["config_detail"]["ranks_seen"] == 2
+    assert ("int16" in d["config_detail"]["sharding"]) == ("--pack16" in extra) and d["config_detail"]["requests_per_launch"] == 64
     # what `value` is: the metric names the scaling, the note quotes north_star with rank 0's measured launch time, the communicator is asked
     assert "closed loop" not in d["metric"]        # (a reduced workload here: the headline's names are checked in test_metric_names_say_which_scaling)
     assert "outgrows one device" in d["scaling_note"] and "weak" in d["scaling_note"]
-    assert d["config"]["per_rank_kernel_us"] > 0 and d["config"]["collective_us"]["collectives"] >= 1 and d["config"]["collective_us"]["p50"] >= 0
+    assert d["config_detail"]["per_rank_kernel_us"] > 0 and d["config_detail"]["collective_us"]["collectives"] >= 1 and d["config_detail"]["collective_us"]["p50"] >= 0
     cl = d["completion_latency"]                  # N > 1: when a batch's picks exist on every rank (per gather bucket)
     assert cl["buckets"] >= 1 and cl["p50_ms"] <= cl["p99_ms"] <= cl["max_ms"] and cl["batches_per_bucket"] >= 1
     assert d["parity"] == {"gathered_picks_equal_oracle": True, "ranks_checked": 2}
@@ -285,6 +289,9 @@ def test_bench_two_ranks_on_cpu(tmp_path, extra, grouped):
     c = d["config"]
     assert c["strong_value"] == st["value"] and c["strong_ms_per_step"] == st["ms_per_step"]
     assert c["strong_completion_latency_p99_ms"] == st["completion_latency_p99_ms"] and c["completion_latency_p99_ms"] == cl["p99_ms"]
+    # ... and `config` is what the driver's record can hold: a handful of scalars, the N > 1 figures among them
+    assert len(c) <= 20 and all(not isinstance(v, (dict, list)) for v in c.values())
+    assert c["ranks_seen"] == 2 and c["collective_us"] >= 0 and c["per_rank_kernel_us"] > 0 and c["requests_per_step"] == 128
 
 
 def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
@@ -294,9 +301,9 @@ def test_bench_two_ranks_ragged_shards_grouped(tmp_path):
     mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), ("--batches", "8", "--gather-every", "4", "--scaling", "strong"), 71), nprocs=world, join=True)
     out0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
     d = json.loads(out0[-1])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["requests_per_gpu"] == 36 and d["config"]["requests_per_step"] == 71
-    assert "ONE launch" in d["config"]["sharding"] and d["config"]["requests_per_launch"] == 4 * 36
-    assert "strong" in d["scaling_note"] and d["config"]["ranks_seen"] == 2 and d["config"]["per_rank_kernel_us"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config_detail"]["requests_per_gpu"] == 36 and d["config_detail"]["requests_per_step"] == 71
+    assert "ONE launch" in d["config_detail"]["sharding"] and d["config_detail"]["requests_per_launch"] == 4 * 36
+    assert "strong" in d["scaling_note"] and d["config_detail"]["ranks_seen"] == 2 and d["config_detail"]["per_rank_kernel_us"] > 0
     assert d["completion_latency"]["p50_ms"] <= d["completion_latency"]["p99_ms"]
     assert d["parity"]["gathered_picks_equal_oracle"] is True
 

@@ -40,3 +40,21 @@ def test_request_seed_changes_only_requests(pkg):
 def test_masked_workload(pkg):
     w = pkg.workload.make_workload(2, R=50, P=100, masked=True)
     assert w.mask.shape == (50, 2) and (w.mask[:, 1] >> np.uint64(36) == 0).all()
+
+
+def test_returning_rows_bring_back_rows_of_an_earlier_batch(pkg):
+    """workload.returning_rows / make_requests(revisit_of=, revisit_frac=): the declared returning-request workload (a returning request = a
+    row of an earlier batch, whole -- shared blocks AND its own tail -- at a scattered position of an otherwise new batch)."""
+    w = pkg.workload.make_workload(5, R=512)
+    earlier = w.reqs
+    fresh = pkg.workload.make_requests(w, 777)
+    assert not (fresh[:, 17:] == earlier[:, 17:]).any()
+    for f in (0.0, 0.25, 0.5, 1.0):
+        rows = pkg.workload.returning_rows(fresh, earlier, f, 42)
+        back = (rows == earlier).all(axis=1)
+        assert ((rows == fresh).all(axis=1) | back).all() and rows.shape == fresh.shape
+        assert abs(back.mean() - f) < 0.08, (f, back.mean())
+        if 0.0 < f < 1.0:      # scattered, not a block at the front
+            assert back[: 256].any() and back[256:].any() and not back[: 64].all()
+    assert np.array_equal(pkg.workload.returning_rows(fresh, earlier, 0.5, 42), pkg.workload.returning_rows(fresh, earlier, 0.5, 42))
+    assert np.array_equal(pkg.workload.make_requests(w, 777, revisit_of=earlier, revisit_frac=0.5), pkg.workload.returning_rows(fresh, earlier, 0.5, 777))
