@@ -1341,7 +1341,7 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     `keep_epochs` epochs go, stream-ordered on the device (eppk_index_evict_older_device between two begins: behind the picks and updates
     begun before it, ahead of those begun after; the pipeline is not drained).
     The batches ROTATE: batch i is the ring's batch i mod NB (>= 16 distinct batches), copied into the pinned set right before its begin
-    -- INSIDE the timed loop (a multi-threaded memcpy: the stand-in for a dispatcher writing its request rows; `fill_ms_per_batch`) --
+    -- INSIDE the timed loop (a thread pool of slice copies: the stand-in for a dispatcher's request threads writing their rows; `fill_ms_per_batch`) --
     so that every batch brings a tail of hashes the index has not learned, or has aged out again: with a ring of NB batches and hashes
     that live `age_every x keep_epochs` (+ up to age_every) batches, a batch that comes round again after NB others finds only its
     group's shared blocks (`returning_fraction` = share of the requests that found more than that, from the probe statistics).  Round 5
@@ -1350,10 +1350,14 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     pk, torch = run.pk, run.torch
     NB = len(batches)
     sb = [pk.stage_buffers(0)[0], pk.stage_buffers(1)[0]]
-    t_sb = [torch.from_numpy(x[:R].view(np.int64)) for x in sb]
-    t_b = [torch.from_numpy(b.view(np.int64)) for b in batches]
     every = args.age_every                  # (the closed loop's own policy: the index holds the same ~4 Mi hashes in both legs)
     lat, t_begin, fill = [], [0.0, 0.0], []
+    # the caller's row construction, as a dispatcher's request threads would do it: FILL_THREADS threads, each writing its slice of the
+    # rows into the pinned set (numpy releases the GIL inside a large copy)
+    from concurrent.futures import ThreadPoolExecutor
+    n_thr = max(1, min(32, (os.cpu_count() or 1) // 2))
+    pool = ThreadPoolExecutor(max_workers=n_thr)
+    cuts = [(R * k) // n_thr for k in range(n_thr + 1)]
 
     def tick():
         state["epoch"] = pk.index_advance_epoch()
@@ -1362,7 +1366,8 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
 
     def put(which, i):                      # the caller's row construction: batch i of the ring into pinned set `which`
         t0 = time.perf_counter()
-        t_sb[which].copy_(t_b[i % NB])
+        dst, src = sb[which], batches[i % NB]
+        list(pool.map(lambda k: np.copyto(dst[cuts[k]:cuts[k + 1]], src[cuts[k]:cuts[k + 1]]), range(n_thr)))
         fill.append(time.perf_counter() - t0)
 
     # warm-up: two batches through each set (ring positions behind the timed ones: the timed loop's first batches are new to the index)
@@ -1395,6 +1400,7 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     lat = np.asarray(lat) * 1e3
     abytes, lookups, launches = pk.profile_bytes()
     pk.profile(False)
+    pool.shutdown()
     # hits per request from the device-counted probe statistics (byte_models' arithmetic): shared blocks only = B/2 per request
     lw_bytes = 2 if wl.P <= 1024 else 4 if wl.P <= 2048 else 8
     launches = max(int(launches), 1)
@@ -1403,11 +1409,11 @@ def pipelined_learn_leg(run, wl, args, batches, state, n_batches: int = 512):
     returning = max(0.0, (hits / R - shared) / max(1, wl.B - shared)) if wl.B else 0.0
     return {"batches": int(n_batches), "distinct_batches": NB, "decisions_per_s": R * n_batches / t_all, "ms_per_batch": 1e3 * t_all / n_batches,
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "pcie_floor_ms": R * run.stride / 55e9 * 1e3,
-            "fill_ms_per_batch": 1e3 * float(np.mean(fill)) if fill else None, "hits_per_request": hits / R, "returning_fraction": returning,
+            "fill_ms_per_batch": 1e3 * float(np.mean(fill)) if fill else None, "fill_threads": n_thr, "hits_per_request": hits / R, "returning_fraction": returning,
             "ageing_every_batches": every, "index_dropped": int(pk.index_dropped()), "launch_status": int(pk.launch_status()),
             "index_size_before": size0, "index_size_after": int(pk.index_size()),
             "what": f"eppk_pick_stage_begin(EPPK_PICK_LEARN) / _end over two staging sets, a ring of {NB} distinct batches copied into the pinned sets inside the timed loop "
-                    "(torch CPU copy, the stand-in for the caller's row construction): the post-route index update chained on the device behind every pick; epoch tick + "
+                    "(a thread pool of numpy slice copies, the stand-in for the caller's request threads writing their rows): the post-route index update chained on the device behind every pick; epoch tick + "
                     f"eviction every {every} batches, stream-ordered on the device between two begins (no drain); {args.cl_slots} index slots; wall time of the whole loop, "
                     "fills included; latency = begin -> end of a batch"}
 

@@ -101,9 +101,16 @@ struct eppk_ctx {
   uint32_t* rstamps = nullptr;              // [2] exact stamps of the two reserved rows (hashes 0 / ~0: no bucket header); every other key's stamp is
                                             // a TAG in its bucket header (eppk_kernels.hip.h: "stamps as tags")
   uint32_t min_live = 0;                    // no live key is stamped before this epoch (the largest eviction horizon so far): the tags' window
-  uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists: where a set with at most kListCap members lives (always maintained)
+  uint32_t* lists = nullptr;                // [slots + 4][16] short pod lists: where a set with at most kListCap members lives (always maintained),
+                                            // then the SET TABLE [sets_cap][16]: interned copies of the listed sets, named by the set ids in the bucket lines
+  uint32_t sets_cap = 0;                    // lines of the set table (a power of two)
+  uint32_t* set_ctl = nullptr;              // device [2]: set-table lines in use, sets that found no line
+  uint32_t* h_set_report = nullptr;         // pinned [2]: the same two, as index_canon_kernel last left them (read without synchronising)
+  uint32_t* h_set_report_dev = nullptr;
+  uint32_t set_fail_seen = 0;               // sets without a line as of the last rebuild
+  uint32_t set_passes = 0;                  // canon passes since the last rebuild (a table whose LIVE sets fill half of it is not rebuilt on every update)
   bool list_routes = true;                  // EPPK_LISTS=0: the pick kernels' list routes are off (every request takes the dense route)
-  uint32_t* sortwl = nullptr;               // work list of index_lists_sort_kernel: cursors[2] | lost | arrived | slots[sortwl_cap]
+  uint32_t* sortwl = nullptr;               // work list of index_canon_kernel: cursors[2] | lost | arrived | slots[sortwl_cap]
   uint32_t sortwl_cap = 0, sort_uses = 0;
   eppk::IxLaunch* d_ixl = nullptr;          // the capacity verdict of the insert launch in flight (index_budget_kernel)
   uint32_t index_epoch = 1;
@@ -320,8 +327,9 @@ KIndex make_kindex(const eppk_ctx* c) {
   k.small = (c->slots && c->index_bytes < (1ull << 32)) ? 1u : 0u;
   k.table_bytes = k.small ? (uint32_t)c->index_bytes : 0u;
   k.keys_off = k.small ? (uint32_t)c->rows_bytes : 0u;
-  // the pick reads the lists through one raw buffer descriptor: only while the list table is below 4 GiB (slots < 2^26)
-  k.lists = (c->lists && c->list_routes && ((size_t)c->slots + 4u) * 64u < (1ull << 32)) ? c->lists : nullptr;
+  // the pick reads the lists (and the set table behind them) through one raw buffer descriptor: only while that is below 4 GiB
+  k.sets_mask = c->sets_cap ? c->sets_cap - 1u : 0u;
+  k.lists = (c->lists && c->list_routes && ((size_t)c->slots + 4u + c->sets_cap) * 64u < (1ull << 32)) ? c->lists : nullptr;
   k.lists_all = c->lists;
   return k;
 }
@@ -886,6 +894,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
       a.keys_w = c->keys; a.bitmaps_w = c->bitmaps; a.lists_w = c->lists; a.rstamps = c->rstamps; a.ixc = c->ixc; a.status = c->d_status + 1;   // (rows are validated on the host: the quiet word)
       a.act = c->have_snapshot ? c->snap[c->cur].act_t : nullptr;
       a.limit = c->limit; a.epoch = c->index_epoch; a.max_blocks = c->cfg.max_blocks; a.max_pods = c->cfg.max_pods;
+      a.set_ctl = c->set_ctl;
     }
     eppk::ResidentArgs all[eppk_ctx::kResUnits];
     const size_t wl_words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
@@ -1016,10 +1025,31 @@ int sortwl_begin(eppk_ctx* c, uint64_t n_pairs, eppk::SortWl* sw) {
   ++c->sort_uses;
   return EPPK_OK;
 }
-// ... and the sort pass behind the insert launch, on its stream.  The host does not know how many lists the launch touched: a
-// grid of 64 workgroups walks whatever the cursor says (a closed-loop step of a 64k batch re-sorts a few thousand lists at most).
+eppk::SetTab make_settab(const eppk_ctx* c) {
+  eppk::SetTab st{};
+  st.lines = c->lists + ((size_t)c->slots + 4u) * eppk::kListDwords; st.mask = c->sets_cap - 1u; st.ctl = c->set_ctl;
+  return st;
+}
+// ... and the canon pass behind the update launch, on its stream: the lists it changed go back to ascending order and get their set ids
+// again (eppk_kernels.hip.h: index_canon_kernel).  The host does not know how many lists the launch touched: a grid of 64 workgroups
+// walks whatever the cursor says (a closed-loop step of a 64k batch touches a few thousand lists at most).
+// The set table fills with the lines of sets that no key names any more (a prefix whose pod set grew leaves its earlier sets behind, an
+// evicted key its own): when the pass last reported it half full -- or a set that found no line since the last rebuild -- the table is
+// cleared and the pass walks the whole index instead, interning every listed set again (`force_all`).  The report is a pinned word the
+// pass before this one wrote: read without synchronising, late by one launch at most; a set without a line is only slower to pick from.
 int sortwl_finish(eppk_ctx* c, const eppk::SortWl& sw, hipStream_t st) {
-  hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, st, c->lists, c->slots, sw.wl, sw.cap, sw.which);
+  const uint32_t used = __atomic_load_n(&c->h_set_report[0], __ATOMIC_RELAXED), failed = __atomic_load_n(&c->h_set_report[1], __ATOMIC_RELAXED);
+  const bool rebuild = (used > c->sets_cap / 2u || failed != c->set_fail_seen) && ++c->set_passes >= 16u;
+  if (rebuild) {
+    c->set_passes = 0u;
+    HIPCHK(c, hipMemsetAsync(c->lists + ((size_t)c->slots + 4u) * eppk::kListDwords, 0, (size_t)c->sets_cap * eppk::kListDwords * 4u, st));
+    HIPCHK(c, hipMemsetAsync(c->set_ctl, 0, 4u, st));          // (lines in use; the failure count keeps counting)
+    c->h_set_report[0] = 0u;
+    c->set_fail_seen = failed;
+  }
+  const uint32_t grid = rebuild ? (uint32_t)std::min<size_t>(((size_t)c->slots + 2u + 255u) / 256u, 4096u) : 64u;
+  hipLaunchKernelGGL(eppk::index_canon_kernel, dim3(grid), dim3(256), 0, st, c->keys, c->lists, c->slots, make_settab(c), sw.wl, sw.cap, sw.which, rebuild ? 1u : 0u,
+                     c->h_set_report_dev);
   HIPCHK(c, hipGetLastError());
   return EPPK_OK;
 }
@@ -1037,13 +1067,17 @@ int index_scrub(eppk_ctx* c, const uint64_t* holes) {
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
-  int rc = by_lane_word(c, [&](auto tag) {
+  eppk::SortWl sw{};
+  int rc = sortwl_begin(c, 1u << 16, &sw);        // (the sets the pass edits lose their ids: the canon pass behind it gives them new ones)
+  if (rc) return rc;
+  rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, 0u, c->ixc,
-                       (const LW*)c->d_rm);
+                       (const LW*)c->d_rm, sw);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  if (rc == EPPK_OK) rc = sortwl_finish(c, sw, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));    // (`packed` is a stack buffer)
   return rc;
 }
@@ -1126,7 +1160,7 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   if (cfg->max_blocks > EPPK_MAX_BLOCKS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: max_blocks > 256");
   if (cfg->n_scorers > EPPK_MAX_SCORERS) return fail(nullptr, EPPK_ERR_LIMIT, "eppk_create: n_scorers > 8");
   if (cfg->index_slots && ((cfg->index_slots & (cfg->index_slots - 1)) || cfg->index_slots < 64u || cfg->index_slots > (1u << 28)))
-    return fail(nullptr, EPPK_ERR_ARG, "eppk_create: index_slots must be a power of two in [64, 2^28]");
+    return fail(nullptr, EPPK_ERR_ARG, "eppk_create: index_slots must be a power of two in [64, 2^28]");      // (2^29 physical slots: 32-bit slot numbers to spare)
   for (uint32_t k = 0; k < cfg->n_scorers; ++k)
     if (cfg->chain[k].kind < EPPK_SCORER_QUEUE || cfg->chain[k].kind > EPPK_SCORER_PREFIX)
       return fail(nullptr, EPPK_ERR_ARG, "eppk_create: unknown scorer kind");
@@ -1269,11 +1303,14 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
   CHK(hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t)));
   CHK(hipMemset(c->d_status, 0, 2 * sizeof(uint32_t)));
   if (cfg->index_slots) {
-    c->slots = cfg->index_slots;
+    // PHYSICAL slots = words of the key table: twice the API's index_slots, because five of a bucket's eight words hold keys (the other
+    // three: flags and the keys' meta dwords -- tag + set id, eppk_kernels.hip.h: kBucket).  The capacity the API promises stays
+    // index_slots / 2 live hashes: 40 % of the key words, about one key per bucket at the recommended sizing (a quarter of index_slots).
+    c->slots = cfg->index_slots * 2u;
     uint32_t lg = 0;
     while ((1u << lg) < c->slots / kBucket) ++lg;   // 8-word buckets (eppk_kernels.hip.h: KIndex)
     c->shift = 32u - lg;
-    c->limit = c->slots / 2u;  // load factor <= 0.5
+    c->limit = cfg->index_slots / 2u;  // load factor <= 0.5 of the API's slots
     // ONE allocation: pod-set rows first, the key table behind them (the fast kernel reads both through one descriptor)
     c->rows_bytes = (((size_t)c->slots + 3u) * 64u * (size_t)c->lw_bytes + 255u) & ~(size_t)255u;
     c->index_bytes = c->rows_bytes + ((size_t)c->slots + 2u) * 8u;
@@ -1285,10 +1322,19 @@ int eppk_create(const eppk_cfg* cfg, eppk_ctx** out) {
     const char* le = getenv("EPPK_LISTS");
     c->list_routes = !(le && atoi(le) == 0);
     {
-      const size_t nd = ((size_t)c->slots + 4u) * eppk::kListDwords;
-      CHK(hipMalloc((void**)&c->lists, nd * 4u));
+      // the set table: one line per 16 physical slots, 1024 at least (a line per distinct listed pod SET, not per key: the blocks of a
+      // prefix share one); all-zero = every line free
+      c->sets_cap = c->slots / 16u < 1024u ? 1024u : c->slots / 16u;
+      const size_t nd = ((size_t)c->slots + 4u) * eppk::kListDwords, ns = (size_t)c->sets_cap * eppk::kListDwords;
+      CHK(hipMalloc((void**)&c->lists, (nd + ns) * 4u));
       hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, nd);
       CHK(hipGetLastError());
+      CHK(hipMemsetAsync(c->lists + nd, 0, ns * 4u, c->stream));
+      CHK(hipMalloc((void**)&c->set_ctl, 2u * 4u));
+      CHK(hipMemsetAsync(c->set_ctl, 0, 2u * 4u, c->stream));
+      CHK(hipHostMalloc((void**)&c->h_set_report, 2u * 4u, hipHostMallocDefault));
+      c->h_set_report[0] = c->h_set_report[1] = 0u;
+      CHK(hipHostGetDevicePointer((void**)&c->h_set_report_dev, c->h_set_report, 0));
       CHK(hipStreamSynchronize(c->stream));
     }
   }
@@ -1321,7 +1367,7 @@ void eppk_destroy(eppk_ctx* c) {
   (void)hipFree(c->d_res_rows); (void)hipFree(c->d_res_learn); (void)hipFree(c->d_res_sortwl);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int b = 0; b < 2; ++b) (void)hipFree(c->snap[b].blob);
-  (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
+  (void)hipFree(c->bitmaps); (void)hipFree(c->rstamps); (void)hipFree(c->lists); (void)hipFree(c->set_ctl); (void)hipHostFree(c->h_set_report); (void)hipFree(c->sortwl); (void)hipFree(c->d_ixl);
   (void)hipFree(c->d_at); (void)hipFree(c->d_av); (void)hipFree(c->d_sk); (void)hipFree(c->d_so);
   if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
   (void)hipFree(c->stats); (void)hipFree(c->pterm); (void)hipFree(c->d_status); (void)hipFree(c->ixc);
@@ -1422,6 +1468,9 @@ int eppk_index_clear(eppk_ctx* c) {
   c->min_live = c->index_epoch;            // (nothing is left that could be older)
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->lists, ((size_t)c->slots + 4u) * eppk::kListDwords);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->lists + ((size_t)c->slots + 4u) * eppk::kListDwords, 0, (size_t)c->sets_cap * eppk::kListDwords * 4u, c->stream));   // the set table
+  HIPCHK(c, hipMemsetAsync(c->set_ctl, 0, 2u * 4u, c->stream));
+  c->h_set_report[0] = c->h_set_report[1] = 0u; c->set_fail_seen = 0u;
   HIPCHK(c, hipMemsetAsync(c->ixc, 0, eppk::kIxShards * 8u * sizeof(unsigned long long), c->stream));  // key / drop counters
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return EPPK_OK;
@@ -1509,13 +1558,17 @@ int eppk_index_remove_pod(eppk_ctx* c, uint32_t pod) {
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
-  int rc = by_lane_word(c, [&](auto tag) {
+  eppk::SortWl sw{};
+  int rc = sortwl_begin(c, 1u << 16, &sw);
+  if (rc) return rc;
+  rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_remove_pod_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, c->slots, pod, c->ixc,
-                       (const LW*)nullptr);
+                       (const LW*)nullptr, sw);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  if (rc == EPPK_OK) rc = sortwl_finish(c, sw, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return rc;
 }
@@ -1558,7 +1611,7 @@ int eppk_index_selfcheck(eppk_ctx* c, uint64_t* n_bad) {
   int rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_selfcheck_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
-                       (const uint32_t*)c->lists, c->slots, d_bad);
+                       (const uint32_t*)c->lists, c->slots, c->sets_cap - 1u, d_bad);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
@@ -1644,16 +1697,20 @@ int eppk_index_trim_pods(eppk_ctx* c, uint32_t cap, uint64_t* n_removed) {
   const uint32_t rows = c->slots + 2u, threads = 256;
   uint32_t grid = (rows * 64u + threads - 1) / threads;
   if (grid > 4096u) grid = 4096u;
+  eppk::SortWl sw{};
+  rc = sortwl_begin(c, 1u << 16, &sw);
+  if (rc) return rc;
   rc = by_lane_word(c, [&](auto tag) {
     using LW = decltype(tag);
     hipLaunchKernelGGL((index_pod_hist_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, (const uint64_t*)c->keys, (const void*)c->bitmaps,
                        (const uint32_t*)c->lists, (const uint32_t*)c->rstamps, c->slots, c->index_epoch, hist);
     hipLaunchKernelGGL(index_pod_cut_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, c->cfg.max_pods, cap, cutage, over_t);
     hipLaunchKernelGGL((index_pod_trim_kernel<LW>), dim3(grid), dim3(threads), 0, c->stream, c->keys, c->bitmaps, c->lists, (const uint32_t*)c->rstamps,
-                       c->slots, c->index_epoch, (const uint32_t*)cutage, (const uint64_t*)over_t, c->ixc, removed);
+                       c->slots, c->index_epoch, (const uint32_t*)cutage, (const uint64_t*)over_t, c->ixc, removed, sw);
     return EPPK_OK;
   });
   HIPCHK(c, hipGetLastError());
+  if (rc == EPPK_OK) rc = sortwl_finish(c, sw, c->stream);
   unsigned long long rm = 0;
   HIPCHK(c, hipMemcpyAsync(&rm, removed, sizeof rm, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -62,7 +62,27 @@ constexpr uint32_t kNotFound = 0xFFFFFFFFu;
 constexpr uint32_t kNoPod = 0xFFFFFFFFu;
 constexpr uint32_t kHomeMul = 0x9E3779B1u;    // 2^32 / golden ratio (odd): multiplicative hashing of the folded key
 constexpr uint64_t kTomb = ~0ull;           // key of a slot whose pod set became empty (never matches, never reused)
-constexpr uint32_t kBucket = 8u;            // u64 words per bucket = half a 128-byte line: word 0 is the bucket header, words 1..7 hold keys
+constexpr uint32_t kBucket = 8u;            // u64 words per bucket = half a 128-byte line (protocol v5, round 6):
+                                            //   dword 0      flags (bit 0: "a key that hashed here lives in a later bucket")
+                                            //   dwords 1..5  META of the keys in words 3..7: {tag : 8 (top byte), set id : 24}
+                                            //   words 3..7   keys, filled front to back (0 = empty, ~0 = tombstone)
+constexpr uint32_t kKeySub0 = 3u;           // first key word of a bucket; slot = bucket * 8 + word (3..7), as before the index of the key word
+constexpr uint32_t kKeysPerBucket = kBucket - kKeySub0;
+// The META dword of a key: its stamp TAG (0 = no valid pod set behind this word: empty, tombstone, or a claim in progress; else
+// 1 + (stamp - 1) mod 255) and the SET ID of its pod set:
+//   sid <  kSidSets   the set is exactly ONE pod, sid = its id: no list line is needed to know the set
+//   sid >= kSidSets   line sid - kSidSets of the SET TABLE holds an immutable, interned copy of the slot's sorted pod list (2..24 ids): two
+//                     keys with the same sid have the same pod set, exactly (the reverse need not hold: an interning race or a full
+//                     table may give equal sets different ids or none)
+//   kSidNone          no id: the set lives in its dense row (> 24 pods), or it has changed since it was last canonicalised (only between
+//                     an update launch and the index_canon_kernel behind it), or the set table was full
+// The slot's own list line stays the source of truth for every reader but pick_quad_kernel, which decides "all hits of this request list
+// the same pods" from the bucket lines it has gathered anyway and fetches ONE set line per request (one line per hit before: 16 of the 36
+// L2 requests per decision of the headline, half of the HBM requests of a cold index, and what made a returning request the slow path).
+constexpr uint32_t kSidMask = 0x00FFFFFFu, kSidNone = 0x00FFFFFFu, kSidSets = 0x00010000u;
+__host__ __device__ __forceinline__ constexpr uint32_t words_cap(uint32_t slots) { return slots / 32u * 15u; }   // 3/4 of the key words (5 of every 8 words) may be non-empty
+__host__ __device__ __forceinline__ constexpr bool is_key_word(uint32_t row) { return (row & (kBucket - 1u)) >= kKeySub0; }
+__host__ __device__ __forceinline__ constexpr uint32_t meta_dword(uint32_t slot) { return (slot & ~(kBucket - 1u)) * 2u + (slot & (kBucket - 1u)) - 2u; }   // dword index into keys[]
 constexpr uint32_t kStatSlots = 32768u;  // per-wavefront probe-statistics slots: stats[4 + 2*wave + {0,1}]
 
 // ---- kernel argument blocks (plain structs, passed by value) --------------------------------
@@ -105,23 +125,26 @@ constexpr uint32_t kStatusBadRow = 1u;      // eppk.h: EPPK_LAUNCH_BAD_REQUEST_R
 constexpr uint32_t kStatusBadPick = 2u;     // eppk.h: EPPK_LAUNCH_BAD_PICK
 constexpr uint32_t kStatusIndexStall = 4u;  // eppk.h: EPPK_LAUNCH_INDEX_STALL
 
-// Prefix index: a BUCKETED open-addressing table.  A key lives in the first free word of its home bucket (8 u64 words =
-// 64 bytes: word 0 = header, bit 0 "a key that hashed here was placed in a later bucket"; words 1..7 = keys, filled front
-// to back, 0 = empty, ~0 = tombstone).  A look-up therefore reads ONE 64-byte bucket and is finished unless the key is
-// absent from an overflowed bucket (0.03 % of buckets at load 0.25, the recommended sizing; 2.7 % at the hard limit 0.5)
-// -- no data-dependent probe chain on the hot path.  (With per-slot linear probing the 32 parallel look-ups of a request
+// Prefix index: a BUCKETED open-addressing table.  A key lives in the first free key word of its home bucket (8 u64 words =
+// 64 bytes: flags + five meta dwords, then five keys in words 3..7, filled front to back, 0 = empty, ~0 = tombstone; kBucket above).
+// A look-up therefore reads ONE 64-byte bucket -- the key AND the identity of its pod set -- and is finished unless the key is
+// absent from an overflowed bucket (the library allocates one bucket per four API slots: 0.06 % of the buckets at the recommended
+// load of a quarter of the API slots, 1.7 % at the hard limit of a half) -- no data-dependent probe chain on the hot path.  (With per-slot linear probing the 32 parallel look-ups of a request
 // needed max-over-lanes dependent round trips: 3-6 at load 0.5; measured 31 of 95 us per batch.)
-// Slot = bucket * 8 + word; the pod-set row of a key has its slot's index (rows of header words are unused).
+// Slot = bucket * 8 + word; the pod-set row of a key has its slot's index (rows of the three meta words are unused).
 struct KIndex {
   const uint64_t* keys;    // [slots+2]; keys[slots], keys[slots+1] = presence of the reserved hashes 0 / ~0.
                            // Invariant: a key that is present has a NON-EMPTY row.
   const void*     bitmaps; // [slots+3][64] LW: rows slots / slots+1 hold hashes 0 / ~0, row slots+2 is all-zero
-  uint32_t slots;          // power of two >= 64 (0 = no index); slots / 8 buckets
+  uint32_t slots;          // PHYSICAL slots (words of the table): power of two >= 128 (0 = no index); slots / 8 buckets.  Twice the API's
+                           // index_slots: five of a bucket's eight words hold keys
   uint32_t shift;          // 32 - log2(slots / 8)
   uint32_t small;          // rows + keys (ONE allocation, rows first) are < 4 GiB: both are read through one buffer descriptor
   uint32_t table_bytes;    // bytes of that allocation when small
   uint32_t keys_off;       // byte offset of keys inside it
-  const uint32_t* lists;   // [slots+4][16] short pod lists (kListCap ids of 16 bits + count) for the pick kernels' LIST ROUTES: nullptr when
+  uint32_t sets_mask;      // the SET TABLE (kSidSets above): sets_mask + 1 lines of 64 bytes (a power of two) right behind the slots' lists
+                           // in the same allocation -- line slots + 4 + i of `lists_all` -- so that pick_quad_kernel reads both through one descriptor
+  const uint32_t* lists;   // [slots+4 (+ set table)][16] short pod lists (kListCap ids of 16 bits + count) for the pick kernels' LIST ROUTES: nullptr when
                            // those are off (EPPK_LISTS=0) or the table is beyond a 32-bit buffer descriptor (4 GiB: slots >= 2^26)
   const uint32_t* lists_all;   // the same table, always: a set with at most kListCap members lives ONLY in its list (its dense row is
                                // all-zero; "lists first", index maintenance section), so every reader of pod sets starts here
@@ -196,7 +219,7 @@ __device__ __forceinline__ uint32_t probe(const KIndex& ix, uint64_t h, bool act
   for (uint32_t n = 0; n <= bmask; ++n) {
     const uint64_t* kb = ix.keys + (size_t)b * kBucket;
 #pragma unroll 1
-    for (uint32_t i = 1; i < kBucket; ++i) {
+    for (uint32_t i = kKeySub0; i < kBucket; ++i) {
       const uint64_t k = kb[i];
       if (k == h) return b * kBucket + i;
       if (k == 0) return kNotFound;                 // buckets fill front to back and never shrink: an empty word ends the search
@@ -629,12 +652,13 @@ __device__ __forceinline__ void pair_probe_issue(__amdgpu_buffer_rsrc_t rk, uint
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// Position (0..3) of h among this lane's 4 bucket words, 4 if absent.  Word 0 of the even lane is the header, not a key.
+// Position (0..3) of h among this lane's 4 bucket words, 4 if absent.  Words 0..2 of a bucket -- the even lane's first three -- are
+// flags and meta dwords, not keys (kBucket).
 __device__ __forceinline__ uint32_t match4(const uint4 (&kw)[2], uint64_t h, bool even) {
   uint32_t pos = 4u;
   if (u64_of(kw[1].z, kw[1].w) == h) pos = 3u;
-  if (u64_of(kw[1].x, kw[1].y) == h) pos = 2u;
-  if (u64_of(kw[0].z, kw[0].w) == h) pos = 1u;
+  if (!even && u64_of(kw[1].x, kw[1].y) == h) pos = 2u;
+  if (!even && u64_of(kw[0].z, kw[0].w) == h) pos = 1u;
   if (!even && u64_of(kw[0].x, kw[0].y) == h) pos = 0u;
   return pos;
 }
@@ -648,7 +672,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
   const uint64_t h = q.h;
   uint32_t slot;
 #ifdef EPPK_DBG_SKIP_KEYS   // timing experiment only (wrong results): 16 pseudo-hits
-  slot = (ki < 16u && act) ? q.bkt * kBucket + 1u : kNotFound;
+  slot = (ki < 16u && act) ? q.bkt * kBucket + kKeySub0 : kNotFound;
 #else
   if (__builtin_expect(__any(act && (h + 1ull) <= 1ull), 0)) {             // h == 0 or h == ~0 somewhere in the request (rare)
     slot = probe(ix, h, act);
@@ -671,7 +695,7 @@ __device__ __forceinline__ uint32_t pair_probe_finish(const KIndex& ix, const Re
           uint32_t s2 = kNotFound;
 #pragma unroll 1
           for (uint32_t i = 0; i < 4u; ++i)
-            if (kb[i] == h && (sub | i) != 0u) s2 = b * kBucket + sub * 4u + i;
+            if (kb[i] == h && sub * 4u + i >= kKeySub0) s2 = b * kBucket + sub * 4u + i;
           uint32_t o2 = sub == 0u ? (uint32_t)(kb[0] & 1ull) : 0u;
           const uint32_t s2o = dpp_xor1(s2);
           s2 = s2o < s2 ? s2o : s2;
@@ -1747,7 +1771,10 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)ix.keys, 0, (int)((ix.slots + 2u) * 8u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)sn.blob, 0, (int)sn.blob_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)reqs, 0, (int)(n_reqs * stride), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)ix.lists, 0, (int)((ix.slots + 4u) * 64u), 0x00020000);
+  // (the set table sits right behind the slots' lists: line ix.slots + 4 + i; the kernel reads ONLY set lines -- the identity of a hit's pod
+  // set comes with its bucket line, kSidSets)
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)ix.lists, 0, (int)((ix.slots + 4u + ix.sets_mask + 1u) * 64u), 0x00020000);
+  const uint32_t set_line0 = ix.slots + 4u;
   const uint32_t hwords = (stride - 8u) / 8u;                        // hash words per request row (>= 1: the host checks)
   const uint32_t hw0 = hwords < kKeysPerProbe ? hwords : kKeysPerProbe;
   // byte offsets inside a row of the two hashes this lane loads (clamped into the row; unused keys are masked by nb)
@@ -1810,7 +1837,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       b = (b + 1u) & bmask;
       const uint64_t* kb = ix.keys + (size_t)b * kBucket;
 #pragma unroll 1
-      for (uint32_t i = 1; i < kBucket; ++i)
+      for (uint32_t i = kKeySub0; i < kBucket; ++i)
         if (kb[i] == h) return b * kBucket + i;
       if (!(kb[0] & 1ull)) break;
     }
@@ -1833,12 +1860,6 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
   auto row16 = [&](unsigned long long m_) -> uint32_t { return (uint32_t)(m_ >> gsh) & 0xFFFFu; };   // this row's slice of a wavefront mask
   // v | (v of another lane): DPP controls quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_ror:4 = 0x124, row_ror:8 = 0x128
   auto or_dpp = [](uint32_t v, auto ctrl) { return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true); };
-  // (inline asm: written with the builtin, the compiler turns "(a ^ a') | (b ^ b') | ... != 0" into a chain of v_mov_dpp + v_cmp + s_or)
-  auto xshr4 = [](uint32_t v) {   // v ^ (v of the lane 4 below in the row); the first quad gets v ^ 0 (its result is not used)
-    uint32_t x;
-    asm("v_xor_b32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(x) : "v"(v));
-    return x;
-  };
 
   // Block `blk`: its rows in `cur`, its key gather in `pb`; issues the key gather of blk + nwaves (rows in `nxt`, into `pb`) and
   // the rows of blk + 2 nwaves (into `cur`).
@@ -1856,29 +1877,35 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
 #if !EPPK_QUAD_PIPE_KEYS
     issue_keys(cur, pb);      // (not pipelined: gathered and consumed right here; fewer live registers, more wavefronts per SIMD)
 #endif
-    // ---- finish the probe: slot of key 4i + q (0 = absent) in all four lanes of its quad
-    // Per step a lane produces a 4-bit CODE: 0 = its piece does not hold the key, else the key's word index in the bucket (2j or
-    // 2j + 1: 1..7).  The codes of all steps are packed into one register and OR-reduced over the quad ONCE (two DPP ops for the
-    // whole probe instead of two per step); slot = bucket * 8 + code, found = code != 0.
-    uint32_t slot[8];
+    // ---- finish the probe: found / absent and the SET ID of key 4i + q in all four lanes of its quad
+    // The pieces of a bucket (kBucket): j = 0 {flags, meta 3, meta 4, meta 5}, j = 1 {meta 6, meta 7, key 3}, j = 2 {key 4, key 5},
+    // j = 3 {key 6, key 7}.  Per step a lane produces a 4-bit CODE: 0 = its piece does not hold the key, else the key's word index in
+    // the bucket (2j or 2j + 1: 3..7).  The codes of all steps are packed into one register and OR-reduced over the quad ONCE (two
+    // DPP ops for the whole probe instead of two per step); found = code != 0.  The key's meta dword sits in the piece of lane j = 0
+    // (words 3..5) or j = 1 (words 6, 7): that lane selects it by the code, one more quad OR hands its low 24 bits -- the set id -- round.
+    uint32_t sid[8];
     uint32_t codes = 0u, hdr = 0u;
     const uint32_t j2 = 2u * j;
     auto match_step = [&](auto ic, uint32_t& cd) {
       constexpr int i = decltype(ic)::value;
       const uint64_t h = u64_of(pb.hlo[i], pb.hhi[i]);
-      const bool c0 = j != 0u && u64_of(pb.w[i].x, pb.w[i].y) == h;  // (word 0 of a bucket is its header)
-      const bool c1 = u64_of(pb.w[i].z, pb.w[i].w) == h;
+      const bool c0 = j >= 2u && u64_of(pb.w[i].x, pb.w[i].y) == h;  // (words 0..2 of a bucket are flags and meta dwords)
+      const bool c1 = j >= 1u && u64_of(pb.w[i].z, pb.w[i].w) == h;
       const uint32_t code = c1 ? j2 + 1u : (c0 ? j2 : 0u);
       cd |= code << (4 * i);
-      hdr |= pb.w[i].x;                                               // header bit 0 ("a key of this bucket lives further on"): lanes j == 0
+      hdr |= pb.w[i].x;                                               // flags bit 0 ("a key of this bucket lives further on"): lanes j == 0
     };
     auto quad_or = [&](uint32_t v) {
       v = or_dpp(v, std::integral_constant<int, 0xB1>{});
       return or_dpp(v, std::integral_constant<int, 0x4E>{});
     };
-    auto slot_of = [&](auto ic) {                                     // (unspecified where the key is absent: only hits are used)
+    auto sid_of = [&](auto ic) {                                      // (unspecified where the key is absent: only hits are used)
       constexpr int i = decltype(ic)::value;
-      slot[i] = pb.bkt[i] * kBucket + ((codes >> (4 * i)) & 15u);
+      const uint32_t c = (codes >> (4 * i)) & 15u;
+      const uint32_t a = c == 3u ? pb.w[i].y : (c == 4u ? pb.w[i].z : pb.w[i].w);     // lane j = 0: meta of words 3 / 4 / 5
+      const uint32_t b_ = c == 6u ? pb.w[i].x : pb.w[i].y;                             // lane j = 1: meta of words 6 / 7
+      const uint32_t mine = j == 0u ? (c <= 5u ? a : 0u) : (j == 1u && c >= 6u ? b_ : 0u);
+      sid[i] = quad_or(mine) & kSidMask;
     };
     // found bits of this quad's keys (bit 4i = step i) -> bit 4i + q = key 4i + q -> the whole row's keys in every lane
     auto row_found = [&](uint32_t cd) {
@@ -1894,12 +1921,12 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     match_step(std::integral_constant<int, 3>{}, codes);
     match_step(std::integral_constant<int, 4>{}, codes);
     codes = quad_or(codes);
-    slot_of(std::integral_constant<int, 0>{});
-    slot_of(std::integral_constant<int, 1>{});
-    slot_of(std::integral_constant<int, 2>{});
-    slot_of(std::integral_constant<int, 3>{});
-    slot_of(std::integral_constant<int, 4>{});
-    slot[5] = slot[6] = slot[7] = 0u;
+    sid_of(std::integral_constant<int, 0>{});
+    sid_of(std::integral_constant<int, 1>{});
+    sid_of(std::integral_constant<int, 2>{});
+    sid_of(std::integral_constant<int, 3>{});
+    sid_of(std::integral_constant<int, 4>{});
+    sid[5] = sid[6] = sid[7] = 0u;
     uint32_t W = row_found(codes);
     uint32_t m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);   // leading hits of this row's request (<= nbc)
     bool all8 = false;
@@ -1915,9 +1942,9 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       match_step(std::integral_constant<int, 6>{}, cd2);
       match_step(std::integral_constant<int, 7>{}, cd2);
       codes |= quad_or(cd2);
-      slot_of(std::integral_constant<int, 5>{});
-      slot_of(std::integral_constant<int, 6>{});
-      slot_of(std::integral_constant<int, 7>{});
+      sid_of(std::integral_constant<int, 5>{});
+      sid_of(std::integral_constant<int, 6>{});
+      sid_of(std::integral_constant<int, 7>{});
       W = row_found(codes);
       m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
       all8 = true;
@@ -1933,16 +1960,16 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
         if (i < kAhead || all8) ovf |= (pb.w[i].x & 1u) << i;
       bool pend = m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
       while (__any(pend)) {
-        uint32_t sf = 0u;
+        uint32_t sf = 0u;                                                // 0 = absent, else 0x80000000 | the set id of the key found further on
         if (pend) {
           const uint64_t hh = *(const uint64_t*)(reqs + (size_t)(r < n_reqs ? r : n_reqs - 1u) * stride + 8u + (size_t)m * 8u);
           const uint32_t s = walk(hh, home_bucket(hh, ix.shift));
-          sf = s != kNotFound ? s : 0u;
+          if (s != kNotFound) sf = 0x80000000u | (((const uint32_t*)ix.keys)[meta_dword(s)] & kSidMask);
         }
         sf = quad_or(sf);                                               // to the four lanes of the key's quad
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (sf != 0u && (m >> 2) == (uint32_t)i) slot[i] = sf;
+          if (sf != 0u && (m >> 2) == (uint32_t)i) sid[i] = sf & kSidMask;
         uint32_t add = sf != 0u ? 1u << (m & 31u) : 0u;                  // to the whole row
         add = or_dpp(add, std::integral_constant<int, 0x124>{});
         add = or_dpp(add, std::integral_constant<int, 0x128>{});
@@ -1952,31 +1979,60 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       }
     }
     unsigned long long badm = __ballot(badh || rsv || (m == kKeysPerProbe && nb > kKeysPerProbe));
-    // ---- lists of the hits: step i = piece j of the list of hit 4i + q (lanes without that hit: the list of step 0 again)
+    // ---- the pod sets of the hits, from their SET IDS (no line is fetched to compare them)
+    // Common case: every hit carries the same id -- the blocks of a shared prefix are cached together -- and ONE set line serves the
+    // request.  Second case, the prefix scorer's own (0602-.../README.md:101-112): a request that COMES BACK finds its shared blocks on
+    // the group's pods (id A) and its own tail blocks on the one pod it was routed to (a single-pod id b): two ids, the second of which
+    // needs no line at all.  matched[p] = cA [p in A] + cb [p == b].  Anything else -- three sets, two lists, an id-less hit -- is deferred.
     const bool any_hit = m > 0u;
-    uint32_t sl0 = slot[0];
-    {   // quads whose step-0 key is no hit (m < 4): the list of hit 0 -- quad 0's slot, broadcast along the row
-      uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)sl0, (int)sl0, 0x114, 0xf, 0xE, false);   // row_shr:4 into quads 1..3
-      t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x118, 0xf, 0xC, false);               // row_shr:8 into quads 2..3
-      sl0 = q < m ? sl0 : t;
+    uint32_t sid0 = sid[0];
+    {   // the id of hit 0: quad 0's step 0, broadcast along the row
+      uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)sid0, (int)sid0, 0x114, 0xf, 0xE, false);   // row_shr:4 into quads 1..3
+      t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x118, 0xf, 0xC, false);                 // row_shr:8 into quads 2..3
+      sid0 = q == 0u ? sid0 : t;
     }
-    if (!any_hit) sl0 = 0u;
-    u32x4_t L[4];
+    if (!any_hit) sid0 = 0u;
+    // (integer arithmetic in vector registers throughout: booleans here would live in scalar register pairs, of which the kernel has none to spare)
+    uint32_t dif = 0u, mx = sid0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t x = 4u * (uint32_t)i + q < m ? sid[i] : sid0;   // step i's key of this quad is one of the m leading hits, else: no opinion
+      dif |= x ^ sid0;
+      mx = x > mx ? x : mx;
+    }
+    uint32_t sidA = sid0, pod_b = kNoPod, cb = 0u;                    // the listed set; the single pod of the second set and how many hits name it
+    uint32_t bad2 = mx == kSidNone ? 1u : 0u;                         // a hit without an id (kSidNone is the largest 24-bit value)
+    if (__builtin_expect(__any(dif != 0u), 0)) {
+      // the second id of the row: every differing id must be the same one (row minimum == row maximum)
+      uint32_t lmin = 0xFFFFFFFFu, lmax = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t x = 4u * (uint32_t)i + q < m ? sid[i] : sid0;
+        lmin = (x != sid0 && x < lmin) ? x : lmin;
+        lmax = (x != sid0 && x > lmax) ? x : lmax;
+      }
+      lmin = dpp_min_u32<0xB1, 0xf>(lmin); lmin = dpp_min_u32<0x4E, 0xf>(lmin); lmin = dpp_min_u32<0x141, 0xf>(lmin); lmin = dpp_min_u32<0x140, 0xf>(lmin);
+      lmax = ~lmax;                                                    // (maximum = complement of the minimum of the complements)
+      lmax = dpp_min_u32<0xB1, 0xf>(lmax); lmax = dpp_min_u32<0x4E, 0xf>(lmax); lmax = dpp_min_u32<0x141, 0xf>(lmax); lmax = dpp_min_u32<0x140, 0xf>(lmax);
+      lmax = ~lmax;
+      uint32_t cx = 0u;                                                // hits of the row that carry the second id
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cx += (uint32_t)__builtin_popcount(row16(__ballot(j == 0u && 4u * (uint32_t)i + q < m && sid[i] == lmin)));
+      if (lmin != 0xFFFFFFFFu) {                                       // this row has a second id
+        bad2 |= (lmin != lmax || (sid0 >= kSidSets && lmin >= kSidSets)) ? 1u : 0u;      // three sets, or two lists
+        if (lmin < kSidSets) { pod_b = lmin; cb = cx; }                         // {A or a single pod} + single pod b
+        else { sidA = lmin; pod_b = sid0; cb = m - cx; }                        // hit 0 names the single pod, the others the list
+      }
+    }
+    badm |= __ballot(any_hit && bad2 != 0u);
+    const uint32_t cA = m - cb;
+    // ---- the ONE set line of the request (a single-pod id needs none: the line is made up in registers)
+    const bool lineA = sidA >= kSidSets && sidA != kSidNone;
+    u32x4_t L0;
 #ifdef EPPK_DBGQ_NO_LISTS   // timing experiment only (wrong results): no list loads, six pseudo pods per piece
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { L[i].x = 0x00020001u + (sl0 & 1u); L[i].y = 0x00040003u; L[i].z = 0xFFFFFFFFu; L[i].w = 8u; }
+    L0.x = 0x00020001u + (sidA & 1u); L0.y = 0x00040003u; L0.z = 0xFFFFFFFFu; L0.w = 8u;
 #else
-    L[0] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(sl0 * 64u + j16), 0, 0);
-#ifdef EPPK_DBGQ_ONE_LIST   // timing experiment only (wrong results for differing lists): ONE list line per request, as if the bucket lines decided "all lists identical"
-#pragma unroll
-    for (int i = 1; i < 4; ++i) L[i] = L[0];
-#else
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-      const uint32_t s = (4u * (uint32_t)i + q < m) ? slot[i] : sl0;
-      L[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(s * 64u + j16), 0, 0);
-    }
-#endif
+    L0 = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)((set_line0 + (lineA ? sidA - kSidSets : 0u)) * 64u + j16), 0, 0);
 #endif
 #ifdef EPPK_DBGQ_NO_TOP     // timing experiment only (wrong results): no top-table loads
     const double top_t = -1.0 - (double)arow;
@@ -1993,42 +2049,24 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the listed pods (as soon as step 0's list is there): lane (q, j) takes id 4q + j, and id 16 + 4q + j when the list is
-    //      that long; the LoRA tier words of pod A are requested before the other steps' lists are compared
+    // ---- the listed pods (as soon as the set line is there): lane (q, j) takes id 4q + j, and id 16 + 4q + j when the list is that long
+    if (!lineA) { L0.x = k == 0u ? (0xFFFF0000u | (sidA & 0xFFFFu)) : 0xFFFFFFFFu; L0.y = 0xFFFFFFFFu; L0.z = 0xFFFFFFFFu; }    // {the one pod}: id 0 = piece 0, low half of dword 0
     const uint32_t idsh = 16u * (q & 1u);
-    const uint32_t idA = (((q & 2u) ? L[0].y : L[0].x) >> idsh) & 0xFFFFu;
-    const uint32_t idB = q < 2u ? (L[0].z >> idsh) & 0xFFFFu : kListNone;
+    const uint32_t idA = (((q & 2u) ? L0.y : L0.x) >> idsh) & 0xFFFFu;
+    uint32_t idB = q < 2u ? (L0.z >> idsh) & 0xFFFFu : kListNone;
+    // the single pod b of a second set: where it is on the list its lane counts cA + cb hits, else the row's last lane takes it as a
+    // candidate of its own (ids 16 + 4q + j exist for q < 2 only: lane 15's second id is free)
+    const bool b_listed = row16(__ballot(idA == pod_b || idB == pod_b)) != 0u;      // (pod_b = kNoPod: never)
+    if (k == 15u && pod_b != kNoPod && !b_listed) idB = pod_b;
     bool lsA = any_hit && idA < sn.n_pods, lsB = any_hit && idB < sn.n_pods;
     const uint32_t pA = lsA ? idA : 0u, pB = lsB ? idB : 0u;
+    const uint32_t cntA = idA == pod_b ? cA + cb : cA;
+    const uint32_t cntB = idB == pod_b ? (b_listed ? cA + cb : cb) : cA;
     LW thA = 0, tlA = 0;
 #ifndef EPPK_DBGQ_NO_TIER   // (defined: timing experiment only, wrong results: no tier-word loads)
     if (HAS_L && lsA) load_tier_pair(arow, pA, thA, tlA);             // (lanes without a listed pod stay out of the gather)
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    // ---- all hits list the same pods?  every step against step 0, every quad against its neighbour quad
-    uint32_t diff = xshr4(L[0].x) | xshr4(L[0].y) | xshr4(L[0].z) | xshr4(L[0].w);
-    if (q == 0u) diff = 0u;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) diff |= (L[i].x ^ L[0].x) | (L[i].y ^ L[0].y) | (L[i].z ^ L[0].z) | (L[i].w ^ L[0].w);
-    if (j == 0u && L[0].w > kListCap) diff = 1u;                      // an overflowed list (count > capacity): the dense rows
-#ifdef EPPK_DBGQ_ONE_LIST
-    if (false) {
-#else
-    if (__any(m > 16u)) {                                             // hits 16..31: loaded and consumed here
-#endif
-#pragma unroll
-      for (int i2 = 0; i2 < 4; i2 += 2) {                              // (two at a time: the registers of four more lists would spill)
-        u32x4_t M[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint32_t s = (16u + 4u * (uint32_t)(i2 + i) + q < m) ? slot[4 + i2 + i] : sl0;
-          M[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(s * 64u + j16), 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) diff |= (M[i].x ^ L[0].x) | (M[i].y ^ L[0].y) | (M[i].z ^ L[0].z) | (M[i].w ^ L[0].w);
-      }
-    }
-    badm |= __ballot(any_hit && diff != 0u);
     // ---- next stages, queued BEHIND everything this block still waits for: key gather of the next block, rows of the one
     //      after, L2 prefetch of a later one
 #if EPPK_QUAD_PIPE_KEYS
@@ -2070,16 +2108,18 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       lsB = lsB && is_cand(pB);
     }
     // ---- evaluate: binary64 adds in chain order (pick_fast_kernel: pod_total)
-    const double pterm = s_pterm[(size_t)nb * sn.pterm_ld + m];
-    auto total_of = [&](uint32_t p, LW th, LW tl_) -> double {
+    // (the prefix term of a listed pod: clamp01(matched / n) * w for matched = the hits whose set holds it -- m for every listed pod of the
+    //  common case; cA, cb or cA + cb where a second, single-pod set is in play)
+    const uint32_t prow = nb * sn.pterm_ld;
+    auto total_of = [&](uint32_t p, LW th, LW tl_, uint32_t cnt) -> double {
       double lterm = 0.0;
       if (HAS_L) {
         const uint32_t jb = p >> 6;
         lterm = s_lw[(uint32_t)(((th >> jb) & 1) << 1) | (uint32_t)((tl_ >> jb) & 1)];
       }
-      return eval_total<HAS_L, true, P_FIRST>(s_base[p], lterm, pterm);
+      return eval_total<HAS_L, true, P_FIRST>(s_base[p], lterm, s_pterm[prow + cnt]);
     };
-    const double tA = total_of(pA, thA, tlA);
+    const double tA = total_of(pA, thA, tlA, cntA);
     double best = lsA ? tA : -__builtin_inf();
     uint32_t bidx = lsA ? pA : kNoPod;
     double tB_keep = -__builtin_inf();                                // (TOPK: the second listed pod of the lane stays a candidate of its own)
@@ -2087,7 +2127,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     if (anyB) {                                                       // a list of more than 16 pods
       LW thB = 0, tlB = 0;
       if (HAS_L) load_tier_pair(arow, pB, thB, tlB);
-      const double tB = total_of(pB, thB, tlB);
+      const double tB = total_of(pB, thB, tlB, cntB);
       tB_keep = tB;
       if (lsB && (tB > best || (tB == best && pB < bidx))) { best = tB; bidx = pB; }
     }
@@ -2217,7 +2257,9 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
           const bool none = widx == kNoPod || no_cand;
           out_pick[r] = none ? -1 : (int32_t)widx;
           if (out_score) out_score[r] = none ? 0.0 : wmax;
-          if constexpr (LEARN) learn_out[r] = none ? 0u : (((from_table || m == 0u) ? 0u : 0x80000000u) | ((widx + 1u) << 8) | m);
+          // (bit 31: the pick is in the set of ALL m hits -- every listed pod of the common case; with a second, single-pod set only that
+          //  pod, and only where the list holds it too)
+          if constexpr (LEARN) learn_out[r] = none ? 0u : (((from_table || m == 0u || (pod_b != kNoPod && !(widx == pod_b && b_listed))) ? 0u : 0x80000000u) | ((widx + 1u) << 8) | m);
         }
         if (!no_cand) {                                                 // (like pick_fast_kernel: a request without candidates is not counted)
           acc_hits += m;
@@ -2348,8 +2390,9 @@ struct ResidentArgs {           // device memory; rewritten by the host only bet
   uint8_t* rows_copy;             // device copy of the batch's request rows (the caller may refill the pinned rows as soon as it has the picks)
   uint32_t* learn;                // learn words of the batch (pick_quad_kernel<..., LEARN>)
   uint64_t* keys_w; void* bitmaps_w; uint32_t* lists_w; uint32_t* rstamps; unsigned long long* ixc; uint32_t* status; const void* act;
-  uint32_t* sort_wl; uint32_t sort_cap;      // a work list of the unit's own for the lists to re-sort (SortWl layout)
+  uint32_t* sort_wl; uint32_t sort_cap;      // a work list of the unit's own for the lists to canonicalise (SortWl layout)
   uint32_t limit, epoch, max_blocks, max_pods, pad2;
+  uint32_t* set_ctl;              // the set table's counters (SetTab::ctl); the table itself: ix.sets_mask + 1 lines behind the slots' lists (lists_w)
 };
 
 // MASKED / TOPK (QUAD form only): the variants a dispatcher issues beside plain picks -- a batch with candidate masks (the subset filter,
@@ -3309,7 +3352,6 @@ template <typename LW>
 __device__ __forceinline__ void list_overflow(uint64_t* keys, uint32_t slots, void* bitmaps, uint32_t* L, uint32_t slot, uint32_t pod) {
   const uint32_t old = atomicMax(&L[3], kListCap + 1u);
   if (old <= kListCap) {
-    if (slot < slots) atomicOr((unsigned long long*)&keys[slot & ~(kBucket - 1u)], 1ull << (slot & (kBucket - 1u)));   // bucket header: "slot overflowed"
     uint32_t d[16];
     load_line16(L, d);
 #pragma unroll
@@ -3387,33 +3429,42 @@ __global__ void lists_fill_kernel(uint32_t* lists, size_t n_dwords) {
 }
 #endif
 
-// ---- stamps as TAGS in the bucket header (round 4) -------------------------------------------------------------------
-// A key's stamp (SEMANTICS.md 6a: the index epoch of its last insert) lives in the header word of its bucket -- the line every look-up
-// of the key loads anyway -- instead of a u32 array of its own (one more random 64-byte line per new key and per known pair: 24 us of a
-// 121 us update per Mi new keys, scripts/micro/claimcost2.hip -> profiles/r04_micro_claimcost2.txt):
-//   header word = keys[bucket * 8]:  bit 0      "a key that hashed here lives in a later bucket"
-//                                    bits 1..7  FAT flag of word i: its pod set is (or was, since the flag was last cleared) more than a
-//                                               single listed pod -- two or more list entries, or the dense row
-//                                    byte i     TAG of word i, i = 1..7:  0 = no valid pod list behind this word (empty, tombstone, or a
-//                                               claim in progress), else 1 + (stamp - 1) % 255
-// A tag is written with a plain BYTE store (every writer of a launch writes the same value), never with a read-modify-write of the
-// word: the atomics that set the flag bits of byte 0 and the byte stores of the tags do not disturb each other.
+// ---- stamps as TAGS, set ids beside them: the META dword of a key (round 4: tags in a header word; round 6: protocol v5) ------------
+// A key's stamp (SEMANTICS.md 6a: the index epoch of its last insert) lives in the bucket line every look-up of the key loads anyway,
+// as the top byte of the key's meta dword (kBucket): 0 = no valid pod list behind this word (empty, tombstone, or a claim in progress),
+// else 1 + (stamp - 1) % 255.  The low 24 bits are the key's SET ID (kSidSets).
+//   * The claimer of a new key writes {tag, pod} with ONE 4-byte store, once its list store has been acknowledged: tag != 0 stays the
+//     "ready" signal of the insert protocol, and a single-pod set is known from the bucket line alone.
+//   * A restamp is a plain BYTE store of the top byte (every writer of a launch writes the same value); a set that changes gets its
+//     id bits raised to kSidNone by an atomic OR and its slot onto the work list of index_canon_kernel, which runs behind every update
+//     launch and gives the set its id again: byte stores and the 32-bit atomics do not disturb each other.
 // Ages: age = (tag(epoch) - tag) mod 255 is the true age of a live key as long as that is at most 254 epochs, which
 // eppk_index_advance_epoch enforces (SEMANTICS.md 6a "window": a hash stamped 255 epochs ago or more is evicted by the tick).
-// What the tags buy beyond the line: TAG 0 IS THE "NOT READY" SIGNAL of the insert protocol (it was "count == 0" in the list line), so
-// an eviction victim's list line no longer has to be reset: a plain single-pod victim keeps its stale line -- {old pod, count 1},
-// every other position 0xFFFF -- and the next claimer's ONE 16-byte store of {pod, count 1} makes it a canonical line again; only FAT
-// victims (rare: the hot prefixes) are reset in full.  Eviction: 68 -> 40 us per Mi victims (same micro-benchmark).
-// The two reserved rows (hashes 0 / ~0: no bucket, no header) keep exact u32 stamps (rstamps[2]) and the round-3 list protocol.
+// TAG 0 IS THE "NOT READY" SIGNAL, so an eviction victim's list line does not have to be reset: a plain single-pod victim keeps its
+// stale line -- {old pod, count 1}, every other position 0xFFFF -- and the next claimer's ONE 16-byte store of {pod, count 1} makes
+// it a canonical line again; only victims with a set id >= kSidSets (two pods or more, or the dense row: rare, the hot prefixes) are
+// reset in full.  Eviction: 68 -> 40 us per Mi victims (scripts/micro/claimcost2.hip).
+// The two reserved rows (hashes 0 / ~0: no bucket, no meta) keep exact u32 stamps (rstamps[2]) and the round-3 list protocol.
 constexpr uint32_t kTagMod = 255u;
 __host__ __device__ __forceinline__ constexpr uint32_t tag_of_epoch(uint32_t epoch) { return 1u + (epoch - 1u) % kTagMod; }     // epoch >= 1
 __device__ __forceinline__ uint32_t tag_age(uint32_t cur_tag, uint32_t tag) { return (cur_tag + kTagMod - tag) % kTagMod; }    // both in 1..255
-__device__ __forceinline__ uint32_t hdr_tag(unsigned long long hdr, uint32_t i) { return (uint32_t)(hdr >> (8u * i)) & 0xFFu; }   // i = 1..7
+__device__ __forceinline__ uint32_t* meta_ptr(uint64_t* keys, uint32_t slot) { return (uint32_t*)keys + meta_dword(slot); }
+__device__ __forceinline__ uint32_t meta_tag(uint32_t meta) { return meta >> 24; }
+__device__ __forceinline__ bool meta_fat(uint32_t meta) { return (meta & kSidMask) >= kSidSets; }      // more than one listed pod (or: was, until index_canon_kernel has looked)
 __device__ __forceinline__ void tag_store(uint64_t* keys, uint32_t slot, uint32_t tag) {       // (agent scope, like the atomics around it)
-  __hip_atomic_store((uint8_t*)&keys[slot & ~(kBucket - 1u)] + (slot & (kBucket - 1u)), (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((uint8_t*)meta_ptr(keys, slot) + 3, (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned long long hdr_load_coherent(const uint64_t* keys, uint32_t slot) {
-  return __hip_atomic_load((const unsigned long long*)&keys[slot & ~(kBucket - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ uint32_t meta_load_coherent(const uint64_t* keys, uint32_t slot) {
+  return __hip_atomic_load((const uint32_t*)keys + meta_dword(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the meta dword of the slot a scanning lane looks at (lane = word of the table, 64 per step: the three meta words of a bucket sit in
+// the first three lanes of its group of eight): k = the word this lane loaded
+__device__ __forceinline__ uint32_t meta_of_lane(unsigned long long k, uint32_t lane) {
+  const uint32_t sub = lane & (kBucket - 1u);
+  const uint32_t d = sub >= kKeySub0 ? sub - 2u : 1u;                  // dword of the bucket (1..5); lanes of meta words: any
+  const int src = (int)((lane & ~(kBucket - 1u)) + (d >> 1));
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)k, src), hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), src);
+  return (d & 1u) ? hi : lo;
 }
 
 // ---- index counters ------------------------------------------------------------------------------------------------
@@ -3472,22 +3523,137 @@ __global__ void index_budget_kernel(unsigned long long* ixc, uint32_t limit, uin
   if (l == 0u) {
     const long long live = (long long)lv, words = (long long)wd;     // (sums over the shards: a single shard may read "negative", removals land anywhere)
     long long left = (long long)limit - live;
-    const long long left_w = (long long)(slots / 4u * 3u) - words;
+    const long long left_w = (long long)words_cap(slots) - words;
     if (left_w < left) left = left_w;
     out->left = left;
-    out->safe = (live >= 0 && (unsigned long long)live + n_items < (unsigned long long)limit && (unsigned long long)words + n_items < (unsigned long long)(slots / 4u * 3u)) ? 1u : 0u;
+    out->safe = (live >= 0 && (unsigned long long)live + n_items < (unsigned long long)limit && (unsigned long long)words + n_items < (unsigned long long)words_cap(slots)) ? 1u : 0u;
   }
 }
 #endif
 
-// Work list of the lists that index_lists_sort_kernel has to bring back into ascending order after an insert launch:
-// wl[0] / wl[1] = two alternating cursors (a launch appends through one; its sort pass zeroes the other for the next launch),
-// wl[2] = "entries were lost" (the sort pass then walks the whole table), wl[4 ..] = slots.
+// Work list of the slots whose pod list an update launch has changed: index_canon_kernel, behind the launch, brings each list back into
+// ascending order and gives the set its id again (kSidSets).
+// wl[0] / wl[1] = two alternating cursors (a launch appends through one; its canon pass zeroes the other for the next launch),
+// wl[2] = "entries were lost" (the pass then walks the whole table), wl[4 ..] = slots.
 struct SortWl {
   uint32_t* wl;
   uint32_t cap;       // entries
   uint32_t which;     // cursor of this launch (0 / 1)
 };
+
+// ---- the SET TABLE: interned, immutable copies of sorted pod lists (kSidSets) ---------------------------------------------------------
+// An open-addressing table of 64-byte lines in the format of a list line (ids ascending, count in dword 3, unused positions 0xFFFF),
+// keyed by content: the set id of a list is kSidSets + the line that holds its copy.  A line is written once -- claimed by a
+// compare-and-swap on its count dword (0 -> kListBusy), filled, published by storing the count -- and never changes afterwards, so
+// whoever holds an id may read its line with ordinary cached loads, in any later launch.  Lines are never freed one by one: when the
+// table is half full of (mostly dead) sets the library clears it and has index_canon_kernel intern every listed set again
+// (eppk.hip: sets_rebuild).  A set that finds no free line within kSetProbes gets no id (kSidNone): correct, only slower to pick from.
+struct SetTab {
+  uint32_t* lines;    // [mask + 1][16]
+  uint32_t mask;
+  uint32_t* ctl;      // [0] lines claimed so far, [1] sets that found no line (device memory)
+};
+constexpr uint32_t kSetProbes = 32u;
+__device__ __forceinline__ uint32_t set_hash(const uint32_t (&d)[16]) {
+  uint32_t h = d[3] * kHomeMul;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if ((t & 3) != 3) { h = (h ^ d[t]) * 0x85EBCA6Bu; h ^= h >> 13; }
+  return h;
+}
+// The id of the canonical list line d (2 .. kListCap ids ascending, count in d[3]).  MUST BE CALLED BY EVERY LANE OF THE WAVEFRONT (`want`
+// = this lane has a list): lanes of one wavefront often bring the SAME new set (the blocks of a prefix, listed one after the other), one
+// of them claims the line and the others must find it there -- they wait for its count in the loop's own trip structure (the claimer
+// fills and publishes inside the trip in which it won, ahead of everybody's next look; a lane spinning in a loop of its own would keep
+// its wave-mate from ever getting there: NEXT.md "rules learnt"), and the loop's condition is wave-uniform.
+__device__ __forceinline__ uint32_t set_intern(const SetTab& st, const uint32_t (&d)[16], bool want) {
+  const uint32_t c = d[3];
+  uint32_t pos = set_hash(d) & st.mask, n = 0u, spins = 0u, result = kSidNone;
+  bool done = !want;
+  while (__any(!done)) {
+    uint32_t* S = st.lines + (size_t)pos * kListDwords;
+    uint32_t cnt = 1u;
+    if (!done) cnt = __hip_atomic_load(&S[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool won = false;
+    if (!done && cnt == 0u) {
+      const uint32_t old = atomicCAS(&S[3], 0u, kListBusy);
+      won = old == 0u;
+      cnt = won ? kListBusy : old;
+    }
+    if (won) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t != 3) __hip_atomic_store(&S[t], (t & 3) == 3 ? 0xFFFFFFFFu : d[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ids have reached memory before the count says so
+    if (won) {
+      __hip_atomic_store(&S[3], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&st.ctl[0], 1u);
+      result = kSidSets + pos;
+      done = true;
+    }
+    if (!done) {
+      if (cnt & kListBusy) {                                // somebody is filling this line: look again in the next trip
+        if (++spins > (1u << 16)) { done = true; atomicAdd(&st.ctl[1], 1u); }
+      } else {
+        bool eq = cnt == c;
+        if (eq) {
+          uint32_t e[16];
+          load_line16<true>(S, e);
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if ((t & 3) != 3) eq = eq && e[t] == d[t];
+        }
+        if (eq) { result = kSidSets + pos; done = true; }
+        else {
+          pos = (pos + 1u) & st.mask;
+          if (++n >= kSetProbes) { done = true; atomicAdd(&st.ctl[1], 1u); }
+        }
+      }
+    }
+  }
+  return result;
+}
+// One slot whose list has changed: lock (count dword: compare-and-swap count -> count | kListBusy), sort, intern, unlock, and the id into
+// the slot's meta dword.  EVERY LANE OF THE WAVEFRONT calls (set_intern); `active` = this lane has a slot.  A slot can be on the work list
+// several times (several appends in one launch): a lane that finds the lock taken leaves the list to its owner; one that comes after the
+// owner has finished does it all again, harmlessly (the same line of the set table answers).  Reserved rows (no meta): sorted only.
+// `all` = the pass walks the whole table (lost work-list entries, or a rebuild of the set table): `slot` is any word -- meta words,
+// empty words and tombstones are skipped, and so are single-pod sets (their id never needs a line).
+__device__ __forceinline__ void canon_slot(uint64_t* keys, uint32_t* lists, uint32_t slots, const SetTab& st, uint32_t slot, bool active, bool all) {
+  bool act = active;
+  if (act && all && slot < slots) {
+    const uint64_t k = is_key_word(slot) ? keys[slot] : 0ull;
+    act = k != 0ull && k != kTomb && meta_fat(meta_load_coherent(keys, slot));
+  }
+  uint32_t* L = lists + (size_t)slot * kListDwords;
+  uint32_t cnt = act ? __hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  bool mine = act && cnt >= 1u && cnt <= kListCap;          // (0: emptied meanwhile; > kListCap: the dense row, no id; busy bit: another lane is on it)
+  if (mine) mine = atomicCAS(&L[3], cnt, cnt | kListBusy) == cnt;
+  uint32_t d[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) d[t] = 0u;
+  if (mine) {
+    load_line16(L, d);
+    if (cnt >= 2u) {
+      list_sort_line(d);
+      d[3] = cnt | kListBusy;
+      store_line16(L, d);
+    }
+    d[3] = cnt;
+  }
+  const uint32_t sid_set = set_intern(st, d, mine && cnt >= 2u && slot < slots);
+  if (mine) {
+    __threadfence();
+    __hip_atomic_store(&L[3], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot < slots) {
+      const uint32_t sid = cnt == 1u ? (d[0] & 0xFFFFu) : sid_set;
+      uint32_t* mp = meta_ptr(keys, slot);
+      const uint32_t m = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mp, (m & ~kSidMask) | sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (nothing else writes the index while a canon pass runs)
+    }
+  }
+}
 
 // Must be called by EVERY lane of the wavefront (`active` = this lane has a pair): the counters are bumped once per wavefront
 // (ballot + popcount).  Capacity: at most `limit` (= slots/2) live keys and 3/4 of the words non-empty.  A launch whose pairs all
@@ -3527,18 +3693,18 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     for (uint32_t n = 0; n <= bmask && slot == kNotFound && !chain_end; ++n) {
       unsigned long long* kb = K + (size_t)bkt * kBucket;
       unsigned long long w[kBucket];
+      uint32_t q[16];
       {
-        uint32_t q[16];
         if (coherent) load_line16<true>((const uint32_t*)kb, q);
         else load_line16<false>((const uint32_t*)kb, q);
 #pragma unroll
         for (int i = 0; i < (int)kBucket; ++i) w[i] = ((unsigned long long)q[2 * i + 1] << 32) | q[2 * i];
       }
 #pragma unroll
-      for (uint32_t i = 1; i < kBucket; ++i) {
+      for (uint32_t i = kKeySub0; i < kBucket; ++i) {
         if (slot != kNotFound || chain_end) continue;
         const unsigned long long k = w[i];
-        if (k == (unsigned long long)h) { slot = bkt * kBucket + i; found_tag = hdr_tag(w[0], i); continue; }
+        if (k == (unsigned long long)h) { slot = bkt * kBucket + i; found_tag = meta_tag(q[i - 2u]); continue; }
         if ((k == 0ull || k == (unsigned long long)kTomb) && free_slot == kNotFound) { free_slot = bkt * kBucket + i; free_val = k; }
         if (k == 0ull) chain_end = true;                      // buckets fill front to back: nothing lives behind an empty word
       }
@@ -3671,7 +3837,8 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
   // maintenance -- a __threadfence here, buffer_wbl2 + buffer_inv per wavefront, made the kernel four times slower)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef EPPK_DBG_NO_STAMP
-  if (have && newkey && slot < slots) tag_store(keys, slot, cur_tag);       // (every insert of a launch carries the same epoch)
+  // tag AND set id -- the one pod -- with one 4-byte store (every insert of a launch carries the same epoch)
+  if (have && newkey && slot < slots) __hip_atomic_store(meta_ptr(keys, slot), (cur_tag << 24) | pod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   // (2) A key that was there.  Its tag first -- from the bucket line the search loaded; 0 = its claimer has not finished (or the
   // search never saw the line: the slot came out of a lost compare-and-swap): look again, coherently, until the tag is there -- the
@@ -3683,14 +3850,14 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
     bool ready = true;
     if (slot < slots) {
       uint32_t tag = found_tag, spins = 0;
-      while (tag == 0u && spins < (1u << 20)) { tag = hdr_tag(hdr_load_coherent(keys, slot), slot & (kBucket - 1u)); ++spins; }
+      while (tag == 0u && spins < (1u << 20)) { tag = meta_tag(meta_load_coherent(keys, slot)); ++spins; }
       ready = tag != 0u;
 #ifndef EPPK_DBG_NO_STAMP
       // An older tag: look again, COHERENTLY, before storing.  The first look was an ordinary cached load, and the copy of a hot bucket in
       // this XCD's L2 keeps showing the old tag to every later thread of the launch: in the first update after an epoch tick all
       // 256 pairs of every hot key stored the byte (1 Mi stores into 4096 lines: that update took 190 us instead of 106,
       // profiles/r04_closed_loop_kernel_stats_before_recheck.csv).  The coherent load sees the first store that has landed.
-      if (ready && tag != cur_tag && hdr_tag(hdr_load_coherent(keys, slot), slot & (kBucket - 1u)) != cur_tag) tag_store(keys, slot, cur_tag);
+      if (ready && tag != cur_tag && meta_tag(meta_load_coherent(keys, slot)) != cur_tag) tag_store(keys, slot, cur_tag);
 #endif
     }
     if (!ready) atomicOr(status, kStatusIndexStall);
@@ -3713,9 +3880,11 @@ __device__ __forceinline__ void index_insert_one(uint64_t* keys, void* bitmaps, 
       else if (d[3] > kListCap) bitmap_set<LW>(bitmaps, slot, pod);         // overflowed: the row is the set
       else res = list_add<false>(L, d, pod, pos);
       if (res == 2u) list_overflow<LW>(keys, slots, bitmaps, L, slot, pod);
-      unsorted = res == 1u && pos != 0u;
-      // the second member of a set: from here on its list line is more than {one pod, count 1} -- the eviction has to reset it in full
-      if (res == 1u && pos == 1u && slot < slots) atomicOr((unsigned long long*)&keys[slot & ~(kBucket - 1u)], 1ull << (slot & (kBucket - 1u)));
+      // The set has changed: its id no longer names it.  kSidNone until index_canon_kernel -- behind this launch -- has put the list
+      // back in order and interned it (the id is >= kSidSets from here on: the eviction resets such a list line in full).  Reserved
+      // rows have no meta: their lists are only re-sorted.
+      unsorted = res == 1u;
+      if (res != 0u && slot < slots) atomicOr(meta_ptr(keys, slot), kSidMask);
     }
   }
   // the lists to re-sort, appended to the work list once per wavefront
@@ -3778,32 +3947,24 @@ __global__ void index_insert_picks_kernel(uint64_t* keys, void* bitmaps, uint32_
 }
 
 #ifdef EPPK_MAIN_UNIT
-// Behind every insert launch (same stream): the lists that got an id appended behind others go back to ascending order, so that
-// equal SETS are equal LINES again -- pick_quad_kernel and the fast kernel's uniform route compare the lists of a request's hits
-// bit for bit (the blocks of a shared prefix are cached on the same pods; after a post-route update they must still look alike).
-// A lane per work-list entry.  A slot can be listed several times (several appends in one launch): the count dword is the lock
-// (compare-and-swap count -> count | kListBusy), a lane that finds it taken leaves the list to its owner; one that comes after the
-// owner has finished sorts a sorted list again, harmlessly.  Lost entries (work list full): the whole table is walked.
-__global__ void index_lists_sort_kernel(uint32_t* lists, uint32_t slots, uint32_t* wl, uint32_t cap, uint32_t which) {
+// Behind every launch that changes pod lists (same stream): the lists on the work list go back to ascending order and get their set
+// ids again (canon_slot) -- equal SETS are equal IDS (pick_quad_kernel) and equal LINES (the fast kernel's uniform route compares the
+// slots' own lists bit for bit).  A lane per work-list entry; lost entries (work list full) or `force_all` (a rebuild of the set table:
+// the library has just cleared it): the whole table is walked.  The last workgroup to arrive leaves the set table's counters in pinned
+// host memory (`report`: lines in use, sets without a line), where the library reads them before the next update -- no synchronisation.
+__global__ void index_canon_kernel(uint64_t* keys, uint32_t* lists, uint32_t slots, SetTab st, uint32_t* wl, uint32_t cap, uint32_t which, uint32_t force_all,
+                                   uint32_t* report) {
   const uint32_t n_listed = wl[which] < cap ? wl[which] : cap;
-  const bool lost = wl[2] != 0u;
+  const bool lost = wl[2] != 0u || force_all != 0u;
   const uint32_t total = lost ? slots + 2u : n_listed;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const uint32_t slot = lost ? i : wl[4u + i];
-    uint32_t* L = lists + (size_t)slot * kListDwords;
-    const uint32_t cnt = __hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cnt < 2u || cnt > kListCap) continue;              // nothing to order / overflowed / another lane is on it
-    if (atomicCAS(&L[3], cnt, cnt | kListBusy) != cnt) continue;
-    uint32_t d[16];
-    load_line16(L, d);
-    list_sort_line(d);
-    d[3] = cnt | kListBusy;
-    store_line16(L, d);
-    __threadfence();
-    __hip_atomic_store(&L[3], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {      // (uniform per wavefront: canon_slot is called by every lane)
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < total;
+    const uint32_t slot = !active ? 0u : (lost ? i : wl[4u + i]);
+    canon_slot(keys, lists, slots, st, slot, active, lost);
   }
   // the next launch's cursor (nobody reads it before that launch), and the lost flag once every thread of this grid has read it:
-  // the flag is only ever set by an insert launch, so clearing it from the LAST workgroup to arrive is safe
+  // the flag is only ever set by an update launch, so clearing it from the LAST workgroup to arrive is safe
   __shared__ uint32_t s_last;
   __syncthreads();
   if (threadIdx.x == 0u) {
@@ -3812,26 +3973,37 @@ __global__ void index_lists_sort_kernel(uint32_t* lists, uint32_t slots, uint32_
     s_last = atomicAdd(&wl[3], 1u) == gridDim.x - 1u ? 1u : 0u;
   }
   __syncthreads();
-  if (s_last && threadIdx.x == 0u) { wl[2] = 0u; wl[3] = 0u; }
+  if (s_last && threadIdx.x == 0u) {
+    wl[2] = 0u; wl[3] = 0u;
+    if (report) {
+      report[0] = __hip_atomic_load(&st.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      report[1] = __hip_atomic_load(&st.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 #endif
 
-// The scanning maintenance kernels below (removal, trim, ageing) walk the table with lane = slot, 64 slots per step and chunk: the
-// header word of a slot's bucket sits in the first lane of its group of eight.
-__device__ __forceinline__ unsigned long long bucket_hdr_of_lane(unsigned long long k, uint32_t lane) {
-  const int src = (int)(lane & ~(kBucket - 1u));
-  return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(k >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)k, src);
-}
+// The scanning maintenance kernels below (removal, trim, ageing) walk the table with lane = word, 64 words per step and chunk: the
+// three meta words of a bucket sit in the first three lanes of its group of eight (meta_of_lane).
 // A slot whose pod set has become empty: the key word turns into a tombstone (reusable by later inserts; reserved rows: presence
-// cleared), its tag into 0 ("no valid list behind this word") and its FAT flag is cleared -- the caller has left the list line with
+// cleared) and its meta dword into 0 (tag 0: "no valid list behind this word") -- the caller has left the list line with
 // every position from 1 on at 0xFFFF (reset, or a plain single-pod line), which is all the next claimer relies on.  These kernels run
-// alone (no insert in flight): plain stores, an atomic only for the flag bit that neighbouring lanes may clear as well.
-__device__ __forceinline__ void slot_bury(uint64_t* keys, uint32_t slots, uint32_t row, bool fat) {
+// alone (no insert in flight): plain stores (neighbouring lanes write other dwords).
+__device__ __forceinline__ void slot_bury(uint64_t* keys, uint32_t slots, uint32_t row) {
   keys[row] = row < slots ? kTomb : 0ull;
-  if (row < slots) {
-    *((uint8_t*)&keys[row & ~(kBucket - 1u)] + (row & (kBucket - 1u))) = (uint8_t)0;
-    if (fat) atomicAnd((unsigned long long*)&keys[row & ~(kBucket - 1u)], ~(1ull << (row & (kBucket - 1u))));
-  }
+  if (row < slots) *meta_ptr(keys, row) = 0u;
+}
+// A listed set that a removal pass has edited (d: the line it stored, count in d[3] >= 1): a single pod is its own id; a longer list loses
+// its id and goes onto the work list of the index_canon_kernel that follows the pass.
+__device__ __forceinline__ void slot_reid(uint64_t* keys, uint32_t slots, uint32_t row, uint32_t count, uint32_t first_id, const SortWl& sw) {
+  if (row >= slots) return;
+  uint32_t* mp = meta_ptr(keys, row);
+  const uint32_t m = *mp;
+  if (count == 1u) { *mp = (m & ~kSidMask) | first_id; return; }
+  *mp = m | kSidMask;
+  const uint32_t at = atomicAdd(&sw.wl[sw.which], 1u);
+  if (at < sw.cap) sw.wl[4u + at] = row;
+  else sw.wl[2] = 1u;
 }
 
 // Remove pods from every set; a set that becomes empty gets its key tombstoned so that the hot path never meets a present key
@@ -3842,7 +4014,7 @@ __device__ __forceinline__ void slot_bury(uint64_t* keys, uint32_t slots, uint32
 // one after the other: bits cleared, and a row that is back at kListCap members or fewer returns to its list.
 template <typename LW>
 __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, uint32_t slots, uint32_t pod, unsigned long long* ixc,
-                                        const LW* rm) {
+                                        const LW* rm, SortWl sw) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t total = slots + 2u;
@@ -3857,9 +4029,8 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
     const uint32_t row = base + lane;
     bool present = false;
     const uint64_t k = row < total ? keys[row] : 0ull;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))       // (bucket header words are not keys)
+    if (row < total && !(row < slots && !is_key_word(row)))       // (the meta words of a bucket are not keys)
       present = k != 0ull && !(row < slots && k == kTomb);
-    const bool fat = row < slots && ((bucket_hdr_of_lane(k, lane) >> (row & (kBucket - 1u))) & 1ull) != 0ull;
     bool over = false, emptied = false;
     if (present) {
       uint32_t* L = lists + (size_t)row * kListDwords;
@@ -3880,6 +4051,7 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
           d[3] -= nrm;
           store_line16(L, d);
           emptied = d[3] == 0u;
+          if (!emptied) slot_reid(keys, slots, row, d[3], d[0] & 0xFFFFu, sw);     // the set has changed: its id with it
         }
       }
     }
@@ -3893,16 +4065,18 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
       if (!__any(nv != v)) continue;
       uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)nv);
       for (uint32_t dd = 32; dd; dd >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)dd);
-      if (members <= kListCap) {                       // back to the list (or gone): the row returns to all-zero; the slot stays FAT
-        list_rebuild<LW>(lists, v_row, nv, lane);      // unless the set is down to one pod (or gone: slot_bury)
+      if (members <= kListCap) {                       // back to the list (or gone: slot_bury): the row returns to all-zero, the set gets an id again
+        list_rebuild<LW>(lists, v_row, nv, lane);
         *w = 0;
-        if (lane == 0 && v_row < slots && members == 1u) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
+        const unsigned long long hm = __ballot(nv != 0);
+        const uint32_t first = (uint32_t)__shfl((int)(nv != 0 ? ctz_lw<LW>(nv) * 64u + lane : 0u), hm ? __builtin_ctzll(hm) : 0);   // (the ONE pod when members == 1)
+        if (lane == 0 && members >= 1u) slot_reid(keys, slots, v_row, members, first, sw);
         if (members == 0u && v_row == row) emptied = true;
       } else if (nv != v) {
         *w = nv;
       }
     }
-    if (emptied) slot_bury(keys, slots, row, fat);
+    if (emptied) slot_bury(keys, slots, row);
     gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   if (lane == 0 && gone) atomicAdd(&ixc[(wave & (kIxShards - 1u)) * 8u + kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
@@ -3918,11 +4092,11 @@ __global__ void index_remove_pod_kernel(uint64_t* keys, void* bitmaps, uint32_t*
 constexpr uint32_t kTrimBins = 64u;
 constexpr uint32_t kNoCut = 0xFFFFFFFFu;
 
-// age (in epochs, capped at kTrimBins - 1) of the present key in `row`: from its tag in the bucket header, the reserved rows from their exact stamps
-__device__ __forceinline__ uint32_t slot_age(unsigned long long hdr, const uint32_t* rstamps, uint32_t slots, uint32_t row, uint32_t epoch) {
+// age (in epochs, capped at kTrimBins - 1) of the present key in `row`: from the tag in its meta dword, the reserved rows from their exact stamps
+__device__ __forceinline__ uint32_t slot_age(uint32_t meta, const uint32_t* rstamps, uint32_t slots, uint32_t row, uint32_t epoch) {
   uint32_t age;
   if (row < slots) {
-    const uint32_t tag = hdr_tag(hdr, row & (kBucket - 1u));
+    const uint32_t tag = meta_tag(meta);
     age = tag ? tag_age(tag_of_epoch(epoch), tag) : 0u;
   } else {
     age = epoch - rstamps[row - slots];
@@ -3940,13 +4114,13 @@ __global__ void index_pod_hist_kernel(const uint64_t* keys, const void* bitmaps,
     const uint32_t row = base + lane;
     bool present = false;
     const uint64_t k = row < total ? keys[row] : 0ull;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))
+    if (row < total && !(row < slots && !is_key_word(row)))
       present = k != 0ull && !(row < slots && k == kTomb);
-    const unsigned long long hdr = bucket_hdr_of_lane(k, lane);
+    const uint32_t meta = meta_of_lane(k, lane);
     bool over = false;
     uint32_t age = 0;
     if (present) {
-      age = slot_age(hdr, rstamps, slots, row, epoch);
+      age = slot_age(meta, rstamps, slots, row, epoch);
       uint32_t d[16];
       load_line16<false>(lists + (size_t)row * kListDwords, d);
       if (d[3] > kListCap) over = true;
@@ -3999,7 +4173,7 @@ __global__ __launch_bounds__(1024) void index_pod_cut_kernel(const uint32_t* his
 
 template <typename LW>
 __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* lists, const uint32_t* rstamps, uint32_t slots, uint32_t epoch,
-                                      const uint32_t* cutage, const uint64_t* over_t, unsigned long long* ixc, unsigned long long* removed) {
+                                      const uint32_t* cutage, const uint64_t* over_t, unsigned long long* ixc, unsigned long long* removed, SortWl sw) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t total = slots + 2u;
@@ -4009,14 +4183,13 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
     const uint32_t row = base + lane;
     bool present = false;
     const uint64_t k = row < total ? keys[row] : 0ull;
-    if (row < total && !(row < slots && (row & (kBucket - 1u)) == 0u))
+    if (row < total && !(row < slots && !is_key_word(row)))
       present = k != 0ull && !(row < slots && k == kTomb);
-    const unsigned long long hdr = bucket_hdr_of_lane(k, lane);
-    const bool fat = row < slots && ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
+    const uint32_t meta = meta_of_lane(k, lane);
     bool over = false, emptied = false;
     uint32_t age = 0;
     if (present) {
-      age = slot_age(hdr, rstamps, slots, row, epoch);
+      age = slot_age(meta, rstamps, slots, row, epoch);
       uint32_t* L = lists + (size_t)row * kListDwords;
       uint32_t d[16];
       load_line16<false>(L, d);                         // (a launch of its own: nothing else writes the index meanwhile)
@@ -4037,6 +4210,7 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
           store_line16(L, d);
           emptied = d[3] == 0u;
           pairs += nrm;
+          if (!emptied) slot_reid(keys, slots, row, d[3], d[0] & 0xFFFFu, sw);
         }
       }
     }
@@ -4061,13 +4235,15 @@ __global__ void index_pod_trim_kernel(uint64_t* keys, void* bitmaps, uint32_t* l
       if (members <= kListCap) {
         list_rebuild<LW>(lists, v_row, nv, lane);
         *w = 0;
-        if (lane == 0 && v_row < slots && members == 1u) atomicAnd((unsigned long long*)&keys[v_row & ~(kBucket - 1u)], ~(1ull << (v_row & (kBucket - 1u))));
+        const unsigned long long hm = __ballot(nv != 0);
+        const uint32_t first = (uint32_t)__shfl((int)(nv != 0 ? ctz_lw<LW>(nv) * 64u + lane : 0u), hm ? __builtin_ctzll(hm) : 0);
+        if (lane == 0 && members >= 1u) slot_reid(keys, slots, v_row, members, first, sw);
         if (members == 0u && lane == src) emptied = true;
       } else if (rmw != 0) {
         *w = nv;
       }
     }
-    if (emptied) slot_bury(keys, slots, row, fat);
+    if (emptied) slot_bury(keys, slots, row);
     gone += (uint32_t)__builtin_popcountll(__ballot(emptied));
   }
   for (int off = 32; off >= 1; off >>= 1) pairs += (uint32_t)__shfl_xor((int)pairs, off);
@@ -4115,14 +4291,14 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
       const uint32_t base = base0 + u * 64u;
       if (base >= total) break;                       // (uniform)
       const uint32_t row = base + lane;
-      const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
+      const bool header = row < slots && !is_key_word(row);
       const uint64_t k = kk[u];
-      const unsigned long long hdr = bucket_hdr_of_lane(k, lane);       // this slot's bucket header (rows < slots)
+      const uint32_t meta = meta_of_lane(k, lane);                      // this slot's meta dword (rows < slots)
       bool victim = false, fat = false;
       if (row < slots) {
-        const uint32_t tag = hdr_tag(hdr, row & (kBucket - 1u));
+        const uint32_t tag = meta_tag(meta);
         victim = !header && k != 0ull && k != kTomb && tag != 0u && (long long)tag_age(cur_tag, tag) > keep;
-        fat = ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
+        fat = meta_fat(meta);
       } else if (row < total) {
         victim = k != 0ull && rstamps[row - slots] < min_epoch;
         fat = true;                                   // (reserved rows: always the full reset)
@@ -4136,7 +4312,7 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
           const u32x4_t e0 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}, e1 = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
           Lp[0] = e0; Lp[1] = e1; Lp[2] = e1; Lp[3] = e1;
         }
-        slot_bury(keys, slots, row, fat && row < slots);
+        slot_bury(keys, slots, row);
       }
       unsigned long long vm = __ballot(whole);          // dense sets: the whole row, by the wavefront
       while (vm) {
@@ -4154,27 +4330,29 @@ __global__ void index_evict_kernel(uint64_t* keys, void* bitmaps, uint32_t* list
 }
 
 // Diagnostic (eppk_index_selfcheck): counts the slots that break an invariant of the index (the list at the head of this section, and
-// "stamps as tags").  A wavefront per slot: its row word per lane, its list dwords in lanes 0..15.  By state of the key word:
-//   empty          tag 0, not FAT, list line in the reset state (count 0, every id 0xFFFF), row all-zero
-//   tombstone      tag 0, not FAT, row all-zero; of the list line only what the next claimer relies on: count <= 1 and every position
+// "stamps as tags, set ids beside them").  A wavefront per slot: its row word per lane, its list dwords in lanes 0..15.  By state of the key word:
+//   empty          meta 0 (no tag, no id), list line in the reset state (count 0, every id 0xFFFF), row all-zero
+//   tombstone      meta 0, row all-zero; of the list line only what the next claimer relies on: count <= 1 and every position
 //                  from 1 on 0xFFFF (position 0 may still hold the previous occupant's pod)
 //   present        tag != 0; a non-empty set: listed (count <= 24: ids valid, unique, strictly ascending, nothing behind the count,
-//                  row all-zero) or dense (count > 24: more than 24 members in the row); two members or more => FAT
-//   reserved rows  (no header) absent: list reset, row zero; present: as above without tag / flag
+//                  row all-zero) or dense (count > 24: more than 24 members in the row).  Its SET ID: one member => the id IS that pod;
+//                  2..24 members => kSidNone or the id of a published line of the set table that equals the list dword for dword;
+//                  dense => kSidNone
+//   reserved rows  (no meta) absent: list reset, row zero; present: as above without tag / id
 template <typename LW>
-__global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, uint32_t slots, unsigned long long* bad) {
+__global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps, const uint32_t* lists, uint32_t slots, uint32_t sets_mask, unsigned long long* bad) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   uint32_t nbad = 0;
   for (uint32_t row = wave; row < slots + 3u; row += nwaves) {
-    const bool header = row < slots && (row & (kBucket - 1u)) == 0u;
-    if (header) continue;                                                  // (wave-uniform: the header words are checked through their slots)
+    const bool header = row < slots && !is_key_word(row);
+    if (header) continue;                                                  // (wave-uniform: the meta words are checked through their slots)
     const uint64_t k = row < slots + 2u ? keys[row] : 0ull;
     const bool tomb = row < slots && k == kTomb;
     const bool present = row < slots + 2u && k != 0ull && !tomb;
-    const unsigned long long hdr = row < slots ? keys[row & ~(kBucket - 1u)] : 0ull;
-    const uint32_t tag = row < slots ? hdr_tag(hdr, row & (kBucket - 1u)) : 0u;
-    const bool fat = row < slots && ((hdr >> (row & (kBucket - 1u))) & 1ull) != 0ull;
+    const uint32_t meta = row < slots ? ((const uint32_t*)keys)[meta_dword(row)] : 0u;
+    const uint32_t tag = meta_tag(meta), sid = meta & kSidMask;
+    const bool fat = row < slots && meta_fat(meta);
     const LW v = ((const LW*)bitmaps)[(size_t)row * 64u + lane];
     uint32_t members = (uint32_t)__builtin_popcountll((unsigned long long)v);
     for (uint32_t d = 32; d; d >>= 1) members += (uint32_t)__shfl_xor((int)members, (int)d);
@@ -4200,8 +4378,18 @@ __global__ void index_selfcheck_kernel(const uint64_t* keys, const void* bitmaps
     else if (count <= kListCap) why |= (count == 0u ? 8u : 0u) | (members != 0u ? 16u : 0u);   // listed: non-empty, all-zero row
     else why |= members <= kListCap ? 32u : 0u;                            // dense: more than kListCap members in the row
     if (row < slots) {
-      if (!present) why |= (tag != 0u ? 128u : 0u) | (fat ? 64u : 0u);                   // no key: no tag, no flag
-      else why |= (tag == 0u ? 128u : 0u) | ((count >= 2u && !fat) ? 64u : 0u);           // a key: a tag; two members or more => FAT
+      if (!present) why |= meta != 0u ? 128u : 0u;                                       // no key: no tag, no id
+      else {
+        why |= tag == 0u ? 128u : 0u;                                                     // a key: a tag
+        if (count == 1u) why |= sid != (L[0] & 0xFFFFu) ? 64u : 0u;                       // one pod: the id is that pod
+        else if (count > kListCap) why |= sid != kSidNone ? 64u : 0u;                     // dense: no id
+        else if (sid != kSidNone) {                                                       // a list: no id, or a line of the set table that equals it
+          bool same = sid >= kSidSets && sid - kSidSets <= sets_mask;
+          if (same && lane < kListDwords && (lane & 3u) != 3u) same = lists[((size_t)slots + 4u + (sid - kSidSets)) * kListDwords + lane] == L[lane];
+          if (same && lane == 3u) same = lists[((size_t)slots + 4u + (sid - kSidSets)) * kListDwords + 3u] == count;
+          why |= __ballot(!same) ? 64u : 0u;
+        }
+      }
     }
     if (why) {
       ++nbad;
@@ -4241,10 +4429,10 @@ __device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const 
     if (l == 0u) {
       const long long live = (long long)lv, words = (long long)wd;
       long long left = (long long)a->limit - live;
-      const long long left_w = (long long)(slots / 4u * 3u) - words;
+      const long long left_w = (long long)words_cap(slots) - words;
       if (left_w < left) left = left_w;
       s_il.left = left;
-      s_il.safe = (live >= 0 && (unsigned long long)live + total < (unsigned long long)a->limit && (unsigned long long)words + total < (unsigned long long)(slots / 4u * 3u)) ? 1u : 0u;
+      s_il.safe = (live >= 0 && (unsigned long long)live + total < (unsigned long long)a->limit && (unsigned long long)words + total < (unsigned long long)words_cap(slots)) ? 1u : 0u;
     }
   }
   __syncthreads();                                         // (the booking words were zeroed with agent-scope atomic stores, acknowledged at the barrier)
@@ -4272,25 +4460,19 @@ __device__ __noinline__ void resident_learn_update(const ResidentArgs* a, const 
     index_insert_one<LW>(a->keys_w, a->bitmaps_w, a->lists_w, a->rstamps, slots, a->ix.shift, a->limit, a->epoch, ixc, &s_il, s_tmp, h, (uint32_t)pick, active, act, sw,
                          a->status, known_only);
   }
-  // (3) the lists that got an id appended behind others go back to ascending order (index_lists_sort_kernel).  The work-list entries were
+  // (3) the lists that changed go back to ascending order and get their set ids again (index_canon_kernel).  The work-list entries were
   // plain stores of this workgroup's lanes: acknowledged at the barrier, read below past the vector cache (agent-scope loads)
   __syncthreads();
   uint32_t* wl = a->sort_wl;
   const uint32_t n_listed_raw = __hip_atomic_load(&wl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t n_listed = n_listed_raw < a->sort_cap ? n_listed_raw : a->sort_cap;
-  for (uint32_t i = threadIdx.x; i < n_listed; i += blockDim.x) {
-    const uint32_t slot = __hip_atomic_load(&wl[4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t* L = a->lists_w + (size_t)slot * kListDwords;
-    const uint32_t cnt = __hip_atomic_load(&L[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cnt < 2u || cnt > kListCap) continue;
-    if (atomicCAS(&L[3], cnt, cnt | kListBusy) != cnt) continue;
-    uint32_t d[16];
-    load_line16(L, d);
-    list_sort_line(d);
-    d[3] = cnt | kListBusy;
-    store_line16(L, d);
-    __threadfence();
-    __hip_atomic_store(&L[3], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  SetTab st;
+  st.lines = a->lists_w + ((size_t)slots + 4u) * kListDwords; st.mask = a->ix.sets_mask; st.ctl = a->set_ctl;
+  for (uint32_t base = 0; base < n_listed; base += blockDim.x) {        // (uniform: canon_slot is called by every lane of a wavefront)
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < n_listed;
+    const uint32_t slot = active ? __hip_atomic_load(&wl[4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    canon_slot(a->keys_w, a->lists_w, slots, st, slot, active, false);
   }
   __syncthreads();
   if (threadIdx.x == 0u) __hip_atomic_store(&wl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the cursor, for the next batch)

@@ -18,21 +18,25 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 int main(int argc, char** argv) {
   using LW = uint64_t;
-  const uint32_t slots = 16u << 20, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
+  const uint32_t api_slots = 16u << 20, slots = 2u * api_slots /* physical words: five of a bucket's eight hold keys (protocol v5) */, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
   const int steps = argc > 1 ? atoi(argv[1]) : 16;
   const bool use_learn = argc > 2 && atoi(argv[2]) != 0;
   uint32_t* d_learn; CK(hipMalloc((void**)&d_learn, 65536 * 4));
   { std::vector<uint32_t> lw(65536, 0x80000000u | 16u); CK(hipMemcpy(d_learn, lw.data(), 65536 * 4, hipMemcpyHostToDevice)); }
   uint32_t lg = 0; while ((1u << lg) < slots / eppk::kBucket) ++lg;
-  const uint32_t shift = 32u - lg, limit = slots / 2u;
+  const uint32_t shift = 32u - lg, limit = api_slots / 2u;
   const size_t rows_bytes = (((size_t)slots + 3u) * 64u * sizeof(LW) + 255u) & ~(size_t)255u, index_bytes = rows_bytes + ((size_t)slots + 2u) * 8u;
   void* bitmaps; uint32_t *stamps, *lists, *status; unsigned long long* ixc;
   CK(hipMalloc(&bitmaps, index_bytes)); CK(hipMemset(bitmaps, 0, index_bytes));
   uint64_t* keys = (uint64_t*)((uint8_t*)bitmaps + rows_bytes);
   CK(hipMalloc((void**)&stamps, 2u * 4u)); CK(hipMemset(stamps, 0, 2u * 4u));          // (the reserved rows' exact stamps; every other stamp is a header tag)
   const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
-  CK(hipMalloc((void**)&lists, nd * 4u));
+  const uint32_t sets_cap = slots / 16u;                      // the set table behind the lists (eppk.hip: eppk_create)
+  CK(hipMalloc((void**)&lists, (nd + (size_t)sets_cap * eppk::kListDwords) * 4u));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
+  CK(hipMemset(lists + nd, 0, (size_t)sets_cap * eppk::kListDwords * 4u));
+  uint32_t* set_ctl; CK(hipMalloc((void**)&set_ctl, 8)); CK(hipMemset(set_ctl, 0, 8));
+  const eppk::SetTab settab{lists + nd, sets_cap - 1u, set_ctl};
   CK(hipMalloc((void**)&ixc, 64 * 64)); CK(hipMemset(ixc, 0, 64 * 64));
   CK(hipMalloc((void**)&status, 8)); CK(hipMemset(status, 0, 8));
   eppk::IxLaunch* d_ixl; CK(hipMalloc((void**)&d_ixl, sizeof(eppk::IxLaunch)));
@@ -61,7 +65,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((eppk::index_insert_picks_kernel<LW>), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
                        epoch, ixc, d_rows[b], stride, B, d_picks[b], R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl,
                        (const uint32_t*)(use_learn && g >= 4 ? d_learn : nullptr));       // (the hot prefixes' pods are listed after a few steps)
-    hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
+    hipLaunchKernelGGL(eppk::index_canon_kernel, dim3(64), dim3(256), 0, 0, keys, lists, slots, settab, sw.wl, sw.cap, sw.which, 0u, (uint32_t*)nullptr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("step %2d epoch %u: update %7.1f us", g, epoch, ms * 1e3);

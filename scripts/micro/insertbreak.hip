@@ -21,7 +21,7 @@ static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)
 __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const uint32_t* lists, uint32_t slots, unsigned long long* out) {
   unsigned long long acc = 0;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
-    if ((s & (eppk::kBucket - 1u)) == 0u) continue;
+    if (!eppk::is_key_word(s)) continue;
     const uint64_t k = keys[s];
     if (k == 0ull || k == eppk::kTomb) continue;
     unsigned long long pc = 0, ids = 0;
@@ -30,7 +30,7 @@ __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const 
     if (cnt > eppk::kListCap) { for (uint32_t i = 0; i < 64; ++i) pc += __popcll(rows[(size_t)s * 64u + i]); } else pc = cnt;   // (a listed set's row is all-zero)
     for (uint32_t q = 0; q < (cnt < eppk::kListCap ? cnt : eppk::kListCap); ++q) { const unsigned long long id = ((const uint16_t*)L)[eppk::list_pos(q)]; ids += (id + 1) * (id + 1); }
     unsigned long long z = k + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
-    const unsigned long long tag = (keys[s & ~(eppk::kBucket - 1u)] >> (8u * (s & (eppk::kBucket - 1u)))) & 0xFFull;       // the stamp: a tag in the bucket header
+    const unsigned long long tag = ((const uint32_t*)keys)[eppk::meta_dword(s)] >> 24;       // the stamp: the tag in the key's meta dword
     acc += z * (1ull + pc + 7ull * tag + 13ull * cnt + 31ull * ids);
   }
   atomicAdd(out, acc);
@@ -38,17 +38,21 @@ __global__ void digest_kernel(const uint64_t* keys, const uint64_t* rows, const 
 
 int main(int argc, char** argv) {
   using LW = uint64_t;
-  const uint32_t slots = 8u << 20, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
+  const uint32_t api_slots = 8u << 20, slots = 2u * api_slots /* physical words: five of a bucket's eight hold keys (protocol v5) */, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
   uint32_t lg = 0; while ((1u << lg) < slots / eppk::kBucket) ++lg;
-  const uint32_t shift = 32u - lg, limit = slots / 2u;
+  const uint32_t shift = 32u - lg, limit = api_slots / 2u;
   const size_t rows_bytes = (((size_t)slots + 3u) * 64u * sizeof(LW) + 255u) & ~(size_t)255u, index_bytes = rows_bytes + ((size_t)slots + 2u) * 8u;
   void* bitmaps; uint32_t *stamps, *lists, *status; unsigned long long* ixc;
   CK(hipMalloc(&bitmaps, index_bytes)); CK(hipMemset(bitmaps, 0, index_bytes));
   uint64_t* keys = (uint64_t*)((uint8_t*)bitmaps + rows_bytes);
   CK(hipMalloc((void**)&stamps, 2u * 4u)); CK(hipMemset(stamps, 0, 2u * 4u));          // (exact stamps of the two reserved rows only)
   const size_t nd = ((size_t)slots + 4u) * eppk::kListDwords;
-  CK(hipMalloc((void**)&lists, nd * 4u));
+  const uint32_t sets_cap = slots / 16u;                      // the set table behind the lists (eppk.hip: eppk_create)
+  CK(hipMalloc((void**)&lists, (nd + (size_t)sets_cap * eppk::kListDwords) * 4u));
   hipLaunchKernelGGL(eppk::lists_fill_kernel, dim3(1024), dim3(256), 0, 0, lists, nd);
+  CK(hipMemset(lists + nd, 0, (size_t)sets_cap * eppk::kListDwords * 4u));
+  uint32_t* set_ctl; CK(hipMalloc((void**)&set_ctl, 8)); CK(hipMemset(set_ctl, 0, 8));
+  const eppk::SetTab settab{lists + nd, sets_cap - 1u, set_ctl};
   CK(hipMalloc((void**)&ixc, 256 * 64)); CK(hipMemset(ixc, 0, 256 * 64));   // (room for the 256-shard variant)
   CK(hipMalloc((void**)&status, 8)); CK(hipMemset(status, 0, 8));
 
@@ -87,7 +91,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(kern, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, keys, bitmaps, lists, stamps, slots, shift, limit,
                        epoch, ixc, d_rows, stride, B, d_picks, R, P, status, (const LW*)nullptr, sw, (const eppk::IxLaunch*)d_ixl, (const uint32_t*)nullptr);
     CK(hipEventRecord(e1));
-    hipLaunchKernelGGL(eppk::index_lists_sort_kernel, dim3(64), dim3(256), 0, 0, lists, slots, sw.wl, sw.cap, sw.which);
+    hipLaunchKernelGGL(eppk::index_canon_kernel, dim3(64), dim3(256), 0, 0, keys, lists, slots, settab, sw.wl, sw.cap, sw.which, 0u, (uint32_t*)nullptr);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
     float ms, ms2; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
     if (print) printf("%-8s epoch %u: %8.1f us  (+ sort pass %5.1f us)\n", what, epoch, ms * 1e3, ms2 * 1e3);

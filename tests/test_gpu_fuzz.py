@@ -335,3 +335,59 @@ def test_many_requests_teach_the_same_new_keys_the_same_pod(pkg, orc):
                 e = pk.index_advance_epoch()
                 assert e == oix.advance_epoch()
                 assert pk.index_evict_older(e) == oix.evict_older(e)
+
+
+def test_set_table_fills_with_dead_sets_and_is_rebuilt(pkg, orc):
+    """Protocol v5 (round 6): a key's pod set is named by a SET ID in its bucket line -- a line of the interned set table -- and
+    pick_quad_kernel decides "all hits list the same pods" from those ids.  Lines are never freed one by one: generations of keys with
+    ever new pod sets (inserted, aged out, inserted again) fill the 1024-line table of a small index with dead sets; sets then get no id
+    (still exact: such requests are deferred to the work-list pass) until the library clears the table and interns the live sets again.
+    Picks and scores against the oracle in every generation, on the quad route (EPPK_QUAD_MIN=4), and the index's invariants -- which
+    include "a set id names a line that equals the slot's list" -- after every step."""
+    import os
+    old = os.environ.get("EPPK_QUAD_MIN")
+    os.environ["EPPK_QUAD_MIN"] = "4"
+    try:
+        rng = np.random.default_rng(20260930)
+        P, B, R = 700, 8, 256
+        chain = [(Q, 1), (KV, 1), (PF, 3)]
+        pods = pkg.workload.make_pods(11, P, 128)
+        with pkg.BatchedPicker(chain, max_pods=1024, max_blocks=B, max_batch=R, index_slots=2048) as pk:
+            pk.publish(pods)
+            oix = orc.OracleIndex()
+            deferred_seen, launches0 = 0, pk.quad_stats()[0]
+            for gen in range(40):
+                # 40 chains of 8 blocks; every chain's blocks on the same random 2..6 pods (one set per chain, new in every generation)
+                chains = rng.integers(1, 2**63, (40, B), dtype=np.uint64)
+                ih, ip = [], []
+                for ci in range(40):
+                    members = rng.choice(P, int(rng.integers(2, 7)), replace=False)
+                    for b in range(B):
+                        for pod in members:
+                            ih.append(chains[ci, b]); ip.append(pod)
+                ih = np.asarray(ih, dtype=np.uint64); ip = np.asarray(ip, dtype=np.uint32)
+                pk.index_insert(ih, ip)
+                oix.insert(ih, ip, snapshot=pods)
+                assert pk.index_selfcheck() == 0, gen
+                hs = chains[rng.integers(0, 40, R)].copy()
+                hs[::3, 5:] = rng.integers(1, 2**63, (hs[::3].shape[0], B - 5), dtype=np.uint64)       # some requests leave their chain early
+                reqs = pkg.picker.make_req_rows(np.full(R, -1), np.full(R, B), hs, B)
+                d0 = pk.quad_stats()[1]
+                picks, scores = pk.pick(reqs)
+                deferred_seen += pk.quad_stats()[1] - d0
+                op, osc, _ = orc.pick_batch(chain, pods, oix, reqs, B)
+                assert np.array_equal(picks, op) and np.array_equal(scores.view(np.uint64), osc.view(np.uint64)), gen
+                # age everything out: the keys go, their sets stay behind in the set table
+                e = pk.index_advance_epoch(); assert oix.advance_epoch() == e
+                assert pk.index_evict_older(e) == oix.evict_older(e)
+                assert pk.index_size() == oix.size() == 0 and pk.index_selfcheck() == 0, gen
+            if os.environ.get("EPPK_QUAD") != "0" and os.environ.get("EPPK_LISTS") != "0":
+                assert pk.quad_stats()[0] > launches0           # the quad route was taken (not in the library modes that switch it off)
+            # 40 generations x 40 new sets = 1600 sets through a 1024-line table that is cleared when half full: requests were deferred for
+            # lack of an id at most in the generations right before a rebuild -- far fewer than all of them
+            assert deferred_seen < 40 * R // 2, deferred_seen
+    finally:
+        if old is None:
+            os.environ.pop("EPPK_QUAD_MIN", None)
+        else:
+            os.environ["EPPK_QUAD_MIN"] = old
