@@ -1879,19 +1879,20 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
 #endif
     // ---- finish the probe: found / absent and the SET ID of key 4i + q in all four lanes of its quad
     // The pieces of a bucket (kBucket): j = 0 {flags, meta 3, meta 4, meta 5}, j = 1 {meta 6, meta 7, key 3}, j = 2 {key 4, key 5},
-    // j = 3 {key 6, key 7}.  Per step a lane produces a 4-bit CODE: 0 = its piece does not hold the key, else the key's word index in
-    // the bucket (2j or 2j + 1: 3..7).  The codes of all steps are packed into one register and OR-reduced over the quad ONCE (two
-    // DPP ops for the whole probe instead of two per step); found = code != 0.  The key's meta dword sits in the piece of lane j = 0
-    // (words 3..5) or j = 1 (words 6, 7): that lane selects it by the code, one more quad OR hands its low 24 bits -- the set id -- round.
+    // j = 3 {key 6, key 7}.  Per step a lane produces a 4-bit CODE: 0 = its piece does not hold the key, else 8 | u, u = the key's word
+    // index in the bucket - 2 (1..5) = the DWORD of the bucket that holds its meta: bits 0..1 of u = the component of that dword in its
+    // lane's piece, bit 2 = the lane (j = 0 / 1).  The codes of all steps are packed into one register and OR-reduced over the quad ONCE
+    // (two DPP ops for the whole probe instead of two per step); found = bit 3.
     uint32_t sid[8];
     uint32_t codes = 0u, hdr = 0u;
-    const uint32_t j2 = 2u * j;
+    const uint32_t k_sel_hi = 0x04040404u, k_sel_lo = 0x03020100u;   // v_perm_b32 selectors: 0x03020100 = the second operand, | 0x04040404 = the first
+    const uint32_t codeA = 8u | (2u * j - 2u), codeB = 8u | (2u * j - 1u);   // the codes of this lane's first / second word (j >= 2 / j >= 1)
     auto match_step = [&](auto ic, uint32_t& cd) {
       constexpr int i = decltype(ic)::value;
       const uint64_t h = u64_of(pb.hlo[i], pb.hhi[i]);
       const bool c0 = j >= 2u && u64_of(pb.w[i].x, pb.w[i].y) == h;  // (words 0..2 of a bucket are flags and meta dwords)
       const bool c1 = j >= 1u && u64_of(pb.w[i].z, pb.w[i].w) == h;
-      const uint32_t code = c1 ? j2 + 1u : (c0 ? j2 : 0u);
+      const uint32_t code = c1 ? codeB : (c0 ? codeA : 0u);
       cd |= code << (4 * i);
       hdr |= pb.w[i].x;                                               // flags bit 0 ("a key of this bucket lives further on"): lanes j == 0
     };
@@ -1901,15 +1902,27 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     };
     auto sid_of = [&](auto ic) {                                      // (unspecified where the key is absent: only hits are used)
       constexpr int i = decltype(ic)::value;
-      const uint32_t c = (codes >> (4 * i)) & 15u;
-      const uint32_t a = c == 3u ? pb.w[i].y : (c == 4u ? pb.w[i].z : pb.w[i].w);     // lane j = 0: meta of words 3 / 4 / 5
-      const uint32_t b_ = c == 6u ? pb.w[i].x : pb.w[i].y;                             // lane j = 1: meta of words 6 / 7
-      const uint32_t mine = j == 0u ? (c <= 5u ? a : 0u) : (j == 1u && c >= 6u ? b_ : 0u);
-      sid[i] = quad_or(mine) & kSidMask;
+      // Which dword: BYTE PERMUTES whose selectors come straight out of the code's bits (v_perm_b32: selector bytes 0..3 = the second
+      // operand, 4..7 = the first; a bit sign-extended to a mask, then 0x03020100 | mask & 0x04040404) -- no compare, no condition mask in
+      // scalar registers (a v_cmp + v_cndmask pair per choice, with the wait states between them, was the most expensive line of the kernel).
+      // (inline asm: written in C the compiler turns "sign-extend a bit, AND, OR" back into test + v_cmp + v_cndmask with two wait states)
+      auto sel = [&](auto bit) {
+        uint32_t r_;
+        asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r_) : "v"(codes), "n"(4 * i + decltype(bit)::value), "v"(k_sel_hi), "v"(k_sel_lo));
+        return r_;
+      };
+      const uint32_t s0 = sel(std::integral_constant<int, 0>{}), s1 = sel(std::integral_constant<int, 1>{}), s2 = sel(std::integral_constant<int, 2>{});
+      // lane j = 0 holds components 1 / 2 / 3 = y / z / w: odd components by bit 1 (y | w), then bit 0 against z; lane j = 1: 0 / 1 = x / y
+      const uint32_t a = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pb.w[i].w, pb.w[i].y, s1), pb.w[i].z, s0);
+      const uint32_t b_ = __builtin_amdgcn_perm(pb.w[i].y, pb.w[i].x, s0);
+      // lane 0's candidate to the whole quad (quad_perm [0,0,0,0]), lane 1's ([1,1,1,1]); bit 2 takes the second
+      const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x00, 0xf, 0xf, true);
+      const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b_, 0x55, 0xf, 0xf, true);
+      sid[i] = __builtin_amdgcn_perm(tb, ta, s2);                     // (the whole meta dword: its top byte -- the stamp tag -- is masked off where the ids are compared)
     };
     // found bits of this quad's keys (bit 4i = step i) -> bit 4i + q = key 4i + q -> the whole row's keys in every lane
     auto row_found = [&](uint32_t cd) {
-      uint32_t w_ = (cd | (cd >> 1) | (cd >> 2)) & 0x11111111u;
+      uint32_t w_ = (cd >> 3) & 0x11111111u;
       w_ <<= q;
       w_ = or_dpp(w_, std::integral_constant<int, 0x124>{});
       w_ = or_dpp(w_, std::integral_constant<int, 0x128>{});
@@ -1925,58 +1938,78 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     sid_of(std::integral_constant<int, 1>{});
     sid_of(std::integral_constant<int, 2>{});
     sid_of(std::integral_constant<int, 3>{});
-    sid_of(std::integral_constant<int, 4>{});
-    sid[5] = sid[6] = sid[7] = 0u;
+    sid[4] = sid[5] = sid[6] = sid[7] = 0u;
     uint32_t W = row_found(codes);
     uint32_t m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);   // leading hits of this row's request (<= nbc)
+    // (step 4 -- keys 16..19 -- gives its ids only where some row of the wavefront has more than 16 hits: not in a batch of new requests
+    //  behind a 16-block prefix, the BASELINE workload)
+    bool have4 = __any(m > 16u);
+    if (have4) sid_of(std::integral_constant<int, 4>{});
     bool all8 = false;
-    if (__builtin_expect(__any(m == 4u * (uint32_t)kAhead && nbc > 4u * (uint32_t)kAhead), 0)) {   // steps 5..7 on demand
-      const uint32_t b1 = home_bucket(cur.h1, ix.shift);
-      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 5>{});
-      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 6>{});
-      fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 7>{});
+    uint32_t Wx = 0u;                                                 // hits found further on in a bucket chain (walk below): not in `codes`
+    // Two rare steps, in a loop because either can make the other necessary: (1) a row whose first 20 keys are all hits needs steps 5..7;
+    // (2) a row whose first missing key sits in an overflowed bucket follows the chain -- and may arrive at 20 hits that way.  (Until round 6
+    // step (1) ran once, ahead of (2): a returning request with a displaced key among its first 20, in a wavefront whose other rows
+    // stopped short of 20, was scored with 20 matched blocks instead of 32 -- right pick, low score; found by the `revisit` bench leg.)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool more = !all8 && __any(m == 4u * (uint32_t)kAhead && nbc > 4u * (uint32_t)kAhead);
+      if (pass == 1 && !more) break;
+      if (__builtin_expect(more, 0)) {   // steps 5..7 on demand
+        const uint32_t b1 = home_bucket(cur.h1, ix.shift);
+        fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 5>{});
+        fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 6>{});
+        fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 7>{});
 #pragma unroll
-      for (int i = kAhead; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
-      uint32_t cd2 = 0u;
-      match_step(std::integral_constant<int, 5>{}, cd2);
-      match_step(std::integral_constant<int, 6>{}, cd2);
-      match_step(std::integral_constant<int, 7>{}, cd2);
-      codes |= quad_or(cd2);
-      sid_of(std::integral_constant<int, 5>{});
-      sid_of(std::integral_constant<int, 6>{});
-      sid_of(std::integral_constant<int, 7>{});
-      W = row_found(codes);
-      m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
-      all8 = true;
-    }
-    if (__builtin_expect(__any(j == 0u && (hdr & 1u)), 0)) {
-      // The first missing key sits in an OVERFLOWED bucket: it may live in a later bucket (rare: 0.03 % of the buckets at load
-      // 1/4, but a displaced key of a popular prefix is looked up by every request of its group).  Lane (q = m & 3, j = 0) walks
-      // the chain; a key found there is a hit like any other: its slot goes to its quad, its bit into W, and the next first
-      // miss is examined in turn.
-      uint32_t ovf = 0u;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < kAhead || all8) ovf |= (pb.w[i].x & 1u) << i;
-      bool pend = m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
-      while (__any(pend)) {
-        uint32_t sf = 0u;                                                // 0 = absent, else 0x80000000 | the set id of the key found further on
-        if (pend) {
-          const uint64_t hh = *(const uint64_t*)(reqs + (size_t)(r < n_reqs ? r : n_reqs - 1u) * stride + 8u + (size_t)m * 8u);
-          const uint32_t s = walk(hh, home_bucket(hh, ix.shift));
-          if (s != kNotFound) sf = 0x80000000u | (((const uint32_t*)ix.keys)[meta_dword(s)] & kSidMask);
-        }
-        sf = quad_or(sf);                                               // to the four lanes of the key's quad
+        for (int i = kAhead; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
+        uint32_t cd2 = 0u;
+        match_step(std::integral_constant<int, 5>{}, cd2);
+        match_step(std::integral_constant<int, 6>{}, cd2);
+        match_step(std::integral_constant<int, 7>{}, cd2);
+        codes |= quad_or(cd2);
+        sid_of(std::integral_constant<int, 5>{});
+        sid_of(std::integral_constant<int, 6>{});
+        sid_of(std::integral_constant<int, 7>{});
+        W = row_found(codes) | Wx;
+        m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
+        all8 = true;
+      }
+      if (__builtin_expect(__any(j == 0u && (hdr & 1u)), 0)) {
+        // The first missing key sits in an OVERFLOWED bucket: it may live in a later bucket (rare: 0.06 % of the buckets at the
+        // recommended sizing, but a displaced key of a popular prefix is looked up by every request of its group).  Lane (q = m & 3,
+        // j = 0) walks the chain; a key found there is a hit like any other: its set id goes to its quad, its bit into W, and the
+        // next first miss is examined in turn.
+        uint32_t ovf = 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (sf != 0u && (m >> 2) == (uint32_t)i) sid[i] = sf & kSidMask;
-        uint32_t add = sf != 0u ? 1u << (m & 31u) : 0u;                  // to the whole row
-        add = or_dpp(add, std::integral_constant<int, 0x124>{});
-        add = or_dpp(add, std::integral_constant<int, 0x128>{});
-        W |= add;
-        m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
-        pend = add != 0u && m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
+          if (i < kAhead || all8) ovf |= (pb.w[i].x & 1u) << i;
+        bool pend = m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
+        while (__any(pend)) {
+          uint32_t sf = 0u;                                                // 0 = absent, else 0x80000000 | the set id of the key found further on
+          if (pend) {
+            const uint64_t hh = *(const uint64_t*)(reqs + (size_t)(r < n_reqs ? r : n_reqs - 1u) * stride + 8u + (size_t)m * 8u);
+            const uint32_t s = walk(hh, home_bucket(hh, ix.shift));
+            if (s != kNotFound) sf = 0x80000000u | (((const uint32_t*)ix.keys)[meta_dword(s)] & kSidMask);
+          }
+          sf = quad_or(sf);                                               // to the four lanes of the key's quad
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (sf != 0u && (m >> 2) == (uint32_t)i) sid[i] = sf & kSidMask;
+          uint32_t add = sf != 0u ? 1u << (m & 31u) : 0u;                  // to the whole row
+          add = or_dpp(add, std::integral_constant<int, 0x124>{});
+          add = or_dpp(add, std::integral_constant<int, 0x128>{});
+          Wx |= add;
+          W |= add;
+          m = (uint32_t)__builtin_ctzll(~(unsigned long long)W);
+          pend = add != 0u && m < nbc && q == (m & 3u) && j == 0u && ((ovf >> (m >> 2)) & 1u);
+        }
       }
+    }
+    if (__builtin_expect(!have4 && __any(m > 16u), 0)) {             // a chain walk took a row past 16 hits: step 4's ids after all (not over the walk's own)
+      const uint32_t keep = sid[4];
+      sid_of(std::integral_constant<int, 4>{});
+      if ((Wx >> (16u + q)) & 1u) sid[4] = keep;
+      have4 = true;
     }
     unsigned long long badm = __ballot(badh || rsv || (m == kKeysPerProbe && nb > kKeysPerProbe));
     // ---- the pod sets of the hits, from their SET IDS (no line is fetched to compare them)
@@ -1991,23 +2024,25 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x118, 0xf, 0xC, false);                 // row_shr:8 into quads 2..3
       sid0 = q == 0u ? sid0 : t;
     }
-    if (!any_hit) sid0 = 0u;
+    sid0 = any_hit ? sid0 & kSidMask : 0u;
     // (integer arithmetic in vector registers throughout: booleans here would live in scalar register pairs, of which the kernel has none to spare)
-    uint32_t dif = 0u, mx = sid0;
+    uint32_t dif = 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t x = 4u * (uint32_t)i + q < m ? sid[i] : sid0;   // step i's key of this quad is one of the m leading hits, else: no opinion
-      dif |= x ^ sid0;
-      mx = x > mx ? x : mx;
+    for (int i = 0; i < 4; ++i) dif |= 4u * (uint32_t)i + q < m ? sid[i] ^ sid0 : 0u;   // step i's key of this quad is one of the m leading hits, else: no opinion
+    if (have4) dif |= 16u + q < m ? sid[4] ^ sid0 : 0u;               // (wave-uniform)
+    if (all8) {                                                       // (wave-uniform: steps 5..7 were fetched)
+#pragma unroll
+      for (int i = kAhead; i < 8; ++i) dif |= 4u * (uint32_t)i + q < m ? sid[i] ^ sid0 : 0u;
     }
+    dif &= kSidMask;                                                  // (the top byte of a meta dword is its stamp tag)
     uint32_t sidA = sid0, pod_b = kNoPod, cb = 0u;                    // the listed set; the single pod of the second set and how many hits name it
-    uint32_t bad2 = mx == kSidNone ? 1u : 0u;                         // a hit without an id (kSidNone is the largest 24-bit value)
+    uint32_t bad2 = sid0 == kSidNone ? 1u : 0u;                       // hit 0 without an id (a later one: the second id below, kSidNone among them)
     if (__builtin_expect(__any(dif != 0u), 0)) {
       // the second id of the row: every differing id must be the same one (row minimum == row maximum)
       uint32_t lmin = 0xFFFFFFFFu, lmax = 0u;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint32_t x = 4u * (uint32_t)i + q < m ? sid[i] : sid0;
+        const uint32_t x = 4u * (uint32_t)i + q < m ? sid[i] & kSidMask : sid0;
         lmin = (x != sid0 && x < lmin) ? x : lmin;
         lmax = (x != sid0 && x > lmax) ? x : lmax;
       }
@@ -2017,9 +2052,9 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       lmax = ~lmax;
       uint32_t cx = 0u;                                                // hits of the row that carry the second id
 #pragma unroll
-      for (int i = 0; i < 8; ++i) cx += (uint32_t)__builtin_popcount(row16(__ballot(j == 0u && 4u * (uint32_t)i + q < m && sid[i] == lmin)));
+      for (int i = 0; i < 8; ++i) cx += (uint32_t)__builtin_popcount(row16(__ballot(j == 0u && 4u * (uint32_t)i + q < m && (sid[i] & kSidMask) == lmin)));
       if (lmin != 0xFFFFFFFFu) {                                       // this row has a second id
-        bad2 |= (lmin != lmax || (sid0 >= kSidSets && lmin >= kSidSets)) ? 1u : 0u;      // three sets, or two lists
+        bad2 |= (lmin != lmax || lmin == kSidNone || (sid0 >= kSidSets && lmin >= kSidSets)) ? 1u : 0u;      // three sets, a hit without an id, or two lists
         if (lmin < kSidSets) { pod_b = lmin; cb = cx; }                         // {A or a single pod} + single pod b
         else { sidA = lmin; pod_b = sid0; cb = m - cx; }                        // hit 0 names the single pod, the others the list
       }
