@@ -171,8 +171,9 @@ int eppk_index_size(eppk_ctx* ctx, uint32_t* n_entries);
 int eppk_index_dropped(eppk_ctx* ctx, uint64_t* n_dropped);
 /* Diagnostic: number of index slots that violate an internal invariant: a present hash with an empty pod set, a pod set left behind
  * a removed hash, a pod list that is not strictly ascending / holds an id twice / has entries behind its count, a set of at most
- * 24 pods that is not in its list (or whose dense row is not all-zero), a dense row with fewer than 25 pods, a bucket header whose
- * "moved to its dense row" bit disagrees with the list.  0 on a healthy index; synchronous full scan.  EPPK_SELFCHECK_VERBOSE in
+ * 24 pods that is not in its list (or whose dense row is not all-zero), a dense row with fewer than 25 pods, a key whose SET ID (the
+ * name of its pod set in its bucket line: the pod itself for a single pod, else a line of the interned set table) disagrees with its
+ * list.  0 on a healthy index; synchronous full scan.  EPPK_SELFCHECK_VERBOSE in
  * the environment prints the first eight offenders to stderr. */
 int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
 /* Ageing -- "mimicking a similar cache eviction strategy of the model server (e.g., LRU)", 0602-…/README.md:82.
@@ -181,7 +182,7 @@ int eppk_index_selfcheck(eppk_ctx* ctx, uint64_t* n_bad);
  * < min_epoch (for all pods) and makes its table word reusable.  A shim ticks the epoch once per interval and evicts
  * `epoch - keep` to bound the index like the model servers' own LRU bounds their caches.
  * Window (SEMANTICS.md 6a): a hash may be at most EPPK_INDEX_EPOCH_WINDOW = 254 epochs old -- the tick to epoch e first evicts every
- * hash stamped before e - 254 (the device keeps a stamp as an 8-bit tag in the hash's bucket header); a caller that never evicts,
+ * hash stamped before e - 254 (the device keeps a stamp as an 8-bit tag beside the hash, in its bucket line); a caller that never evicts,
  * or whose keep is 254 epochs and more, pays a table scan per tick from the 255th on (a shim clamps its keep to the window). */
 int eppk_index_advance_epoch(eppk_ctx* ctx, uint32_t* new_epoch);
 int eppk_index_evict_older(eppk_ctx* ctx, uint32_t min_epoch, uint32_t* n_evicted);

@@ -161,7 +161,7 @@ def test_fuzz_index_maintenance(pkg, orc, seed):
 
 
 def test_stamp_window_wraps_like_the_oracle(pkg, orc):
-    """Stamps live on the device as 8-bit tags in the bucket headers (1 + (epoch - 1) % 255): ages are exact up to 254 epochs, and a hash
+    """Stamps live on the device as 8-bit tags in the bucket lines (1 + (epoch - 1) % 255): ages are exact up to 254 epochs, and a hash
     that would be 255 epochs old is evicted by the tick itself (SEMANTICS.md 6a "window"; the oracle does the same).  600 ticks across two
     wrap-arounds of the tag, hashes stamped at all sorts of epochs (some re-stamped again and again so that they survive), evictions with
     horizons on either side of the wrap: live hashes, evicted counts and picks must agree throughout."""

@@ -304,7 +304,7 @@ def test_ordered_fallbacks(pkg, orc, R, P, k):
 
 
 def test_unordered_and_learned_lists_stay_on_the_quad_route(pkg, orc):
-    """The library keeps every list in ascending order itself (index_lists_sort_kernel behind every insert launch), so equal pod SETS
+    """The library keeps every list in ascending order itself (index_canon_kernel behind every update launch), so equal pod SETS
     are equal list LINES whatever order the pairs arrived in: ONE insert call with the pairs shuffled, then two generations of a closed
     loop whose chain pushes the picks AWAY from the cached pods (negative prefix weight: every learn appends new pods to all 16 blocks
     of a group, in device order) -- the quad kernel still scores every request itself, bit-exact against the oracle."""
@@ -381,11 +381,11 @@ def test_ordered_fallbacks_with_candidate_masks(pkg, orc, R, P, k, density):
 @pytest.mark.parametrize("P,B", [(4096, 32), (1000, 16), (2000, 8)])
 def test_requests_that_come_back(pkg, orc, P, B):
     """A request that RETURNS after the index learned its pick: the tail blocks are listed on that one pod, the prefix blocks on the
-    group's pods and that pod (differing lists: pick_quad_kernel hands such a request to the work-list pass) -- against the oracle over
-    several generations of pick + LEARN on the SAME and on half-new batches, with candidate masks, as ordered fallbacks, and for the
-    shapes next to it (fewer than four prefix hits, a tail pod outside the prefix list, tail blocks on two pods).  (Round 5 built a
-    two-list route for the shape inside pick_quad_kernel and took it out again: the returning batch did not get faster -- it is bound by
-    the 32 index lines a returning request touches, 72 us per 64k against 65 through the work-list pass: profiles/r05_revisit_probe.txt.)"""
+    group's pods and that pod -- two pod sets, the second a single pod: since protocol v5 (round 6) pick_quad_kernel reads both from the
+    set ids in the bucket lines and scores the request in place (rounds 2-5 deferred it to the work-list pass: 64 us per 64k returning
+    batch against 23 for new requests; now 33) -- against the oracle over several generations of pick + LEARN on the SAME and on half-new
+    batches, with candidate masks, as ordered fallbacks, and for the shapes next to it (fewer than four prefix hits, a tail pod outside
+    the prefix list, tail blocks on two pods: three sets, deferred)."""
     with quad_env(True):
         import torch
         R = 1024
@@ -413,7 +413,8 @@ def test_requests_that_come_back(pkg, orc, P, B):
                 assert_same(d_pick[:R].cpu().numpy(), d_score[:R].cpu().numpy(), op, osc)
                 oix.insert_picks(reqs, B, op)
                 assert pk.index_size() == oix.size() and pk.index_selfcheck() == 0, gen
-            assert deferred[0] == 0, deferred               # (generation 1 re-sends generation 0's batch: every request is a returning one)
+            assert deferred[0] == 0, deferred               # (generation 1 re-sends generation 0's batch: every request is a returning one ...
+            assert deferred[1] <= R // 16, deferred         #  ... and the quad kernel scores it itself: prefix set + the one pod of its tail)
             # the same index through masks and ordered fallbacks (returning requests again)
             d_reqs = torch.from_numpy(wl.reqs.view(np.int64)).to(dev)
             d_mask = torch.from_numpy(wl.mask.view(np.int64)).to(dev)
