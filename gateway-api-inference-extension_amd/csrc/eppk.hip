@@ -469,7 +469,8 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
                                                                                                             : eppk::pick_quad_u64(c->has_l, c->p_first, masked, tkq);
     // LDS: base[] | lw[4] | pterm | one "listed" bit per pod for each of the 4 rows of each wavefront
     //      (masked: + the snapshot's three natural-layout sets + the candidate words of each row)
-    quad_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 4u * sn.J * 8u + (masked ? 192u * 8u + (size_t)qwpb * 4u * sn.J * 8u : 0u);
+    //      then the crossbar scratch of the set-id look-up: 512 bytes per wavefront (eppk_kernels.hip.h: quad_xbar_off)
+    quad_lds = (size_t)eppk::quad_xbar_off(sn.J, pwn, qwpb, masked) + (size_t)qwpb * 512u;
     if (tail) {     // ... or the fast kernel's layout for a workgroup of this size, whichever is larger: base | lw | pterm | scratch | histogram
       const size_t fast_lds = (size_t)sn.J * 64u * 8u + 32u + (size_t)pwn * 8u + (size_t)qwpb * 64u * (size_t)c->lw_bytes + (size_t)qwpb * sn.J * 64u;
       if (fast_lds > quad_lds) quad_lds = fast_lds;
@@ -618,6 +619,10 @@ size_t resident_lds(const eppk_ctx* c, bool* hist_fits) {
   if (*hist_fits) lds += hist;
   const size_t quad_masked = front + (size_t)wpb * 4u * J * 8u + 192u * 8u + (size_t)wpb * 4u * J * 8u;     // | listed bits | natural sets | candidate words
   if (*hist_fits && quad_masked > lds && quad_masked <= c->max_lds) lds = quad_masked;
+  // the quad body's crossbar scratch (512 bytes per wavefront) at the END of the allocation: behind everything either body keeps all-zero
+  lds = (lds + 15u) & ~(size_t)15u;
+  if (*hist_fits && lds + (size_t)wpb * 512u <= c->max_lds) lds += (size_t)wpb * 512u;
+  else *hist_fits = false;                      // (no room: the resident units run pick_fast_kernel's body alone)
   return lds;
 }
 // Park them: ring "quit" and wait for the workgroups to leave.  In front of every device-wide wait of the library's own (a

@@ -1688,6 +1688,12 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 // beyond the LDS base: handed the kernel's argument structs -- by reference or by value -- the compiler copies them to the stack in
 // the kernel's prologue (every wavefront pays) and, by reference, re-reads them from there inside the hot loop.  It reads the
 // kernel's arguments itself, from the kernarg segment, through a struct that mirrors pick_quad_kernel's parameter list.
+// Byte offset of the crossbar scratch of pick_quad_body (wpb x 512 bytes) in a LAUNCHED workgroup's LDS: right behind the quad layout --
+// base | lw | pterm | "listed" bits (| natural sets | candidate words) -- rounded up to 16 bytes.  (The resident kernels keep it at the
+// end of their allocation: the fast body's histogram, which must stay all-zero between two doorbells, overlaps the quad layout's tail.)
+__host__ __device__ __forceinline__ constexpr uint32_t quad_xbar_off(uint32_t J, uint32_t pwn, uint32_t wpb, bool masked) {
+  return ((J * 64u * 8u + 32u + pwn * 8u + wpb * 4u * J * 8u + (masked ? 192u * 8u + wpb * 4u * J * 8u : 0u)) + 15u) & ~15u;
+}
 struct QuadKernArgs {
   KSnap sn; KIndex ix; KTail tl; const uint8_t* reqs; uint32_t stride, n_reqs, pwn; const uint64_t* cand_mask; int32_t* out_pick; double* out_score;
   unsigned long long* stats; uint32_t* defer_cnt; uint32_t* defer_list; uint32_t defer_cap; uint32_t* defer_total; uint32_t* defer_total_next; uint32_t topk;
@@ -1746,7 +1752,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
                                                    const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                    int32_t* __restrict__ out_pick, double* __restrict__ out_score, unsigned long long* __restrict__ stats,
                                                    uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                   uint32_t* __restrict__ defer_total, uint32_t topk, uint32_t* __restrict__ learn_out) {
+                                                   uint32_t* __restrict__ defer_total, uint32_t topk, uint32_t* __restrict__ learn_out, const uint32_t xbar_off) {
   static_assert(!(LEARN && TOPK), "learn words go with single picks");
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -1757,6 +1763,10 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
   // per row, the request's candidates (mask & active: [J] u64)
   uint64_t* s_nat = (uint64_t*)(s_bits_all + (blockDim.x >> 4) * bits_dw);
   uint64_t* s_cn_all = s_nat + 192;
+  // The wavefront's CROSSBAR scratch (512 bytes at byte offset xbar_off of the workgroup's LDS, 16-byte aligned: quad_xbar_off): the two
+  // pieces of a bucket that hold meta dwords -- 32 bytes per quad -- written by lanes j = 0, 1 and read back by all four lanes at the
+  // dword the match code names.  One region serves every probe step: LDS operations of one wavefront execute in order.
+  unsigned char* s_xbar = smem + xbar_off + (threadIdx.x >> 6) * 512u + (((uint32_t)threadIdx.x & 63u) >> 2) * 32u;     // this quad's 32 bytes
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t k = (uint32_t)lane & 15u, g = (uint32_t)lane >> 4, gsh = (uint32_t)lane & 48u;
   const uint32_t q = ((uint32_t)lane >> 2) & 3u, j = (uint32_t)lane & 3u, j16 = j * 16u;
@@ -1885,7 +1895,6 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     // (two DPP ops for the whole probe instead of two per step); found = bit 3.
     uint32_t sid[8];
     uint32_t codes = 0u, hdr = 0u;
-    const uint32_t k_sel_hi = 0x04040404u, k_sel_lo = 0x03020100u;   // v_perm_b32 selectors: 0x03020100 = the second operand, | 0x04040404 = the first
     const uint32_t codeA = 8u | (2u * j - 2u), codeB = 8u | (2u * j - 1u);   // the codes of this lane's first / second word (j >= 2 / j >= 1)
     auto match_step = [&](auto ic, uint32_t& cd) {
       constexpr int i = decltype(ic)::value;
@@ -1902,23 +1911,15 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     };
     auto sid_of = [&](auto ic) {                                      // (unspecified where the key is absent: only hits are used)
       constexpr int i = decltype(ic)::value;
-      // Which dword: BYTE PERMUTES whose selectors come straight out of the code's bits (v_perm_b32: selector bytes 0..3 = the second
-      // operand, 4..7 = the first; a bit sign-extended to a mask, then 0x03020100 | mask & 0x04040404) -- no compare, no condition mask in
-      // scalar registers (a v_cmp + v_cndmask pair per choice, with the wait states between them, was the most expensive line of the kernel).
-      // (inline asm: written in C the compiler turns "sign-extend a bit, AND, OR" back into test + v_cmp + v_cndmask with two wait states)
-      auto sel = [&](auto bit) {
-        uint32_t r_;
-        asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r_) : "v"(codes), "n"(4 * i + decltype(bit)::value), "v"(k_sel_hi), "v"(k_sel_lo));
-        return r_;
-      };
-      const uint32_t s0 = sel(std::integral_constant<int, 0>{}), s1 = sel(std::integral_constant<int, 1>{}), s2 = sel(std::integral_constant<int, 2>{});
-      // lane j = 0 holds components 1 / 2 / 3 = y / z / w: odd components by bit 1 (y | w), then bit 0 against z; lane j = 1: 0 / 1 = x / y
-      const uint32_t a = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pb.w[i].w, pb.w[i].y, s1), pb.w[i].z, s0);
-      const uint32_t b_ = __builtin_amdgcn_perm(pb.w[i].y, pb.w[i].x, s0);
-      // lane 0's candidate to the whole quad (quad_perm [0,0,0,0]), lane 1's ([1,1,1,1]); bit 2 takes the second
-      const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x00, 0xf, 0xf, true);
-      const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b_, 0x55, 0xf, 0xf, true);
-      sid[i] = __builtin_amdgcn_perm(tb, ta, s2);                     // (the whole meta dword: its top byte -- the stamp tag -- is masked off where the ids are compared)
+      // The key's meta dword sits in the piece of lane j = 0 (bucket dwords 1..3) or j = 1 (dwords 4, 5): dword u of the bucket, u = the low
+      // three bits of the code.  Through the LDS: lanes 0 and 1 park their pieces, every lane of the quad reads dword u back -- two LDS
+      // operations and two vector instructions per step.  (In registers it took a tree of byte permutes with selectors made from the
+      // code's bits, two quad broadcasts and a final select: 14 vector instructions per step, the largest single item of a kernel that is
+      // bound by vector issue: profiles/r06_quad_valu.txt.)
+      // (no fence between them: the LDS operations of ONE wavefront execute in issue order, the compiler keeps accesses that may alias in
+      //  program order, and nobody else touches this wavefront's 512 bytes; the read's result is waited for where it is first used)
+      if (j < 2u) *(u32x4_t*)(s_xbar + j16) = pb.w[i];
+      sid[i] = *(const uint32_t*)(s_xbar + ((codes >> (4 * i)) & 7u) * 4u);   // (the whole meta dword: its top byte -- the stamp tag -- is masked off where ids are compared)
     };
     // found bits of this quad's keys (bit 4i = step i) -> bit 4i + q = key 4i + q -> the whole row's keys in every lane
     auto row_found = [&](uint32_t cd) {
@@ -2367,7 +2368,8 @@ __global__ __launch_bounds__(EPPK_QUAD_MAX_THREADS, EPPK_QUAD_WAVES) void pick_q
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.x == 0 && threadIdx.x == 0) *defer_total_next = 0u;   // the counter of this buffer set's NEXT launch (nobody reads it before)
   const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN>(blockIdx.x, gridDim.x, smem, sn, ix, tl, reqs, stride, n_reqs, pwn, cand_mask, out_pick, out_score,
-                                                                                 stats, defer_cnt, defer_list, defer_cap, defer_total, topk, learn_out);
+                                                                                 stats, defer_cnt, defer_list, defer_cap, defer_total, topk, learn_out,
+                                                                                 quad_xbar_off(sn.J, pwn, blockDim.x >> 6, MASKED));
   (void)tail_chain; (void)done_ctr; (void)report; (void)n_def;
   if constexpr (TAIL) {
     // the end of the one-launch form -- the work-list pass over what THIS workgroup deferred (rarely anything), the arrival counters and
@@ -2529,7 +2531,7 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
       }
       const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN, /*RESIDENT*/ true>(
           0u, 1u, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, rb.out_pick, rb.out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
-          a->defer_total, TOPK ? kk : 1u, LEARN ? a->learn : nullptr);
+          a->defer_total, TOPK ? kk : 1u, LEARN ? a->learn : nullptr, a->lds_bytes - (blockDim.x >> 6) * 512u);      // (crossbar scratch: the last 512 bytes per wavefront of the allocation)
       // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
       // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also
       // asks "did anybody defer?".  Only then the work-list pass, and a second release + barrier behind it.

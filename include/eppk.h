@@ -85,7 +85,11 @@ typedef struct eppk_cfg {
   uint32_t index_slots;   /* prefix table capacity: power of two in [64, 2^28], 0 = no prefix index.  Holds at most
                            * index_slots/2 live hashes (EPPK_ERR_INDEX_FULL beyond; the two reserved hash values 0 and ~0 have
                            * rows of their own behind the table and are always admitted); size it at >= 4x the expected
-                           * number (load <= 0.25).  Memory: index_slots * (64 * lane-word bytes + 12) */
+                           * number (load <= 0.25: about one hash per 64-byte bucket).  Memory: the library allocates TWO physical
+                           * slots per index_slot (five of a bucket's eight words hold hashes, the other three their stamps and
+                           * pod-set ids): index_slots * 2 * (8 + 64 + 64 * lane-word bytes) + a pod-set table of index_slots * 8
+                           * bytes -- 1.2 KiB per index_slot at max_pods = 4096, almost all of it dense pod-set rows that are
+                           * touched only by hashes cached on more than 24 pods */
   uint32_t n_scorers;     /* <= EPPK_MAX_SCORERS; order fixes the fp summation order */
   uint32_t reserved;
   eppk_weighted_scorer chain[EPPK_MAX_SCORERS];

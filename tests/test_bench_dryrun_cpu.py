@@ -89,6 +89,10 @@ def _fake_picker_class(pkg, orc, log):
             self.last_stream = stream
             log.append(("pick", p_pick, stream))
 
+        def pick_learn_device(self, p_reqs, n, mask, p_pick, p_score, stream=0):
+            self.pick_device(p_reqs, n, mask, p_pick, p_score, stream)
+            self.index_insert_picks_device(p_reqs, p_pick, n, stream)
+
         def index_insert_picks_device(self, p_reqs, p_picks, n, stream=0):
             raw = (ctypes.c_uint8 * (n * self.stride)).from_address(p_reqs)
             reqs = np.frombuffer(raw, dtype=np.uint64).reshape(n, 1 + self.B).copy()
@@ -143,6 +147,7 @@ def _fake_picker_class(pkg, orc, log):
 @pytest.mark.parametrize("argv", [["--force-dist", "--steps", "11", "--warmup", "3", "--p99-samples", "40"],
                                   ["--force-dist", "--steps", "8", "--warmup", "8", "--gather-every", "1", "--inflight", "1", "--scaling", "weak"],
                                   ["--steps", "5", "--warmup", "2", "--batches", "3"],
+                                  ["--steps", "4", "--warmup", "1", "--batches", "2", "--revisit-leg"],
                                   ["--steps", "6", "--warmup", "2", "--batches", "4", "--closed-loop", "--cl-slots", "4096", "--cl-verify", "3"]])
 def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
     import torch
@@ -225,7 +230,15 @@ def test_bench_control_flow_on_cpu(pkg, orc, monkeypatch, argv):
             assert d["roofline"]["kernel_samples"] >= 40
     else:
         assert d["scaling"] == "weak" and n_picks >= d["steps"] + d["warmup"]
-        if "--batches" in argv:
+        if "--revisit-leg" in argv:
+            # the returning-requests leg: batch 0 learned, then batches with 0 / 25 / 50 / 100 % of its rows coming back, each against the oracle
+            rv = d["revisit"]
+            assert rv["learned_batch_picks_equal_oracle"] and rv["index_size_equal_oracle"]
+            assert list(rv["by_fraction"]) == ["0.0", "0.25", "0.5", "1.0"]
+            assert all(v["picks_and_scores_equal_oracle"] for v in rv["by_fraction"].values())
+            assert rv["by_fraction"]["1.0"]["returning_requests"] == 96 and rv["by_fraction"]["0.0"]["returning_requests"] == 0
+            assert d["config"]["revisit_50_equal_oracle"] is True and d["config"]["revisit_50_value"] > 0
+        elif "--batches" in argv:
             assert d["config_detail"]["distinct_batches"] == 3
 
 

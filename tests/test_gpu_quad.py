@@ -447,3 +447,65 @@ def test_requests_that_come_back(pkg, orc, P, B):
                 op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, reqs, B)
                 assert_same(picks, scores, op, osc)
             assert pk.launch_status() == 0
+
+
+def test_two_pod_sets_per_request_are_scored_in_place(pkg, orc):
+    """Protocol v5 (round 6): pick_quad_kernel reads the identity of a hit's pod set from its bucket line.  A request whose hits name TWO
+    sets, at most one of them a list and the other a single pod, is scored in place -- matched[p] = cA [p in A] + cb [p == b] -- in every
+    arrangement: list then pod (a returning request), pod then list (hit 0 names the single pod), pod then another pod, the single pod on
+    the list or not, the single pod beyond the snapshot's pods; three sets, two lists and a dense set among the hits are deferred.  Every
+    variant against the oracle, masked as well, with the route on and off (run())."""
+    wl = pkg.workload.make_workload(5, R=320, P=4096, n_groups=8)
+    base = group_sets(wl)
+    hs = hashes_of(wl)
+    sets = dict(base)
+    rng = np.random.default_rng(5)
+    kinds = 10
+    expect_deferred = 0
+    for r in range(wl.R):
+        A = base[int(hs[r, 0])]                              # the group's pods (blocks 0..15 of the row)
+        kind = r % kinds
+        tail = [int(h) for h in hs[r, 16:]]                  # the row's own 16 blocks: nobody else asks for them
+        on = int(A[r % len(A)]); off = int((A[0] + 1 + r) % wl.P)
+        while off in A:
+            off = (off + 1) % wl.P
+        if kind == 0:                                        # returning: tail on one pod of the list
+            for h in tail: sets[h] = (on,)
+        elif kind == 1:                                      # ... on a pod that is NOT on the list
+            for h in tail: sets[h] = (off,)
+        elif kind == 2:                                      # only 5 tail blocks learned (m = 21: steps 5..7 on demand)
+            for h in tail[:5]: sets[h] = (on,)
+        elif kind == 3:                                      # tail on TWO different single pods: three sets -> deferred
+            for h in tail[:8]: sets[h] = (on,)
+            for h in tail[8:]: sets[h] = (off,)
+            expect_deferred += 1
+        elif kind == 4:                                      # tail on a second LIST: two lists -> deferred
+            for h in tail: sets[h] = tuple(sorted({on, off}))
+            expect_deferred += 1
+        elif kind == 5:                                      # tail on a dense set (more than 24 pods): no id -> deferred
+            big = tuple(sorted(set(rng.choice(wl.P, 30, replace=False).tolist())))
+            for h in tail[:4]: sets[h] = big
+            expect_deferred += 1
+        # kinds 6..9: new requests (one set), the common shape
+    # rows whose FIRST hit names a single pod and the rest a list / another pod: private copies of the shared blocks
+    reqs = wl.reqs.copy()
+    for r in range(0, wl.R, 16):
+        priv = rng.integers(1, 2**63, 6, dtype=np.uint64)
+        reqs[r, 1:7] = priv
+        reqs[r, 7:] ^= np.uint64(0x5DEECE66D)                # the rest of the row: misses
+        A = base[int(hs[r, 0])]
+        sets[int(priv[0])] = (int(A[1]),) if (r // 16) % 2 == 0 else ((int(A[0]) + 3) % wl.P,)     # the single pod: on the list / not on it
+        for h in priv[1:4]: sets[int(h)] = A                 # then the list
+        for h in priv[4:]: sets[int(h)] = A
+    for r in range(8, wl.R, 32):                             # pod then ANOTHER pod
+        priv = rng.integers(1, 2**63, 5, dtype=np.uint64)
+        reqs[r, 1:6] = priv
+        reqs[r, 6:] ^= np.uint64(0x5DEECE66D)
+        sets[int(priv[0])] = (11,)
+        for h in priv[1:]: sets[int(h)] = (4000,)
+    ql, qd = run(pkg, orc, wl, sets, reqs=reqs)
+    assert ql == 1
+    # exactly the three-set / two-list / dense rows are deferred (rows rewritten above may have replaced a few of them)
+    assert 0 < qd <= expect_deferred, (qd, expect_deferred)
+    mask = pkg.workload.make_workload(5, R=wl.R, P=wl.P, n_groups=8, masked=True).mask
+    run(pkg, orc, wl, sets, reqs=reqs, mask=mask)
