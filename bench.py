@@ -505,9 +505,9 @@ def byte_models(wl, R, kern_stats, khash, lists_on=True, quad=False):
     per_hit = 64 if lists_on else 64 * lw_bytes
     n_sets = int((wl.meta or {}).get("n_groups", 0)) or 1          # distinct pod sets of the pre-populated index: one per prefix group
     with_hits = R if hits > 0 else 0                              # (every request of the bench workloads finds its group's shared blocks)
-    if quad:      # pick_quad_kernel (protocol v5): 20 key buckets gathered ahead (the rest only behind 20 hits) -- a hit's set id comes with its
+    if quad:      # pick_quad_kernel (protocol v5): 17 key buckets gathered ahead (the rest only behind 17 hits) -- a hit's set id comes with its
         # bucket line -- ONE 64-byte set line per request, one 64-byte line of interleaved tier planes per listed pod (~8), 16 table entries
-        probed = min(wl.B, 20) if hits <= 20 * R else min(wl.B, 32)
+        probed = min(wl.B, 17) if hits < 17 * R else min(wl.B, 32)
         l2_side = R * stride + out_bytes + (R * probed * 64 + with_hits * 64 if wl.B else 0) + R * (16 * 12 + 8 * 64)
     else:
         l2_side = R * stride + out_bytes + (R * min(wl.B, 32) * 64 + hits * per_hit if wl.B else 0) + R * (16 * 12 + 2 * 64 * lw_bytes)
@@ -518,7 +518,7 @@ def byte_models(wl, R, kern_stats, khash, lists_on=True, quad=False):
     compulsory = R * stride + out_bytes + distinct_buckets * 64 + distinct_sets * per_hit + tables
     # an index far beyond the caches: every gathered bucket comes from HBM (and, counted here although a 16 MiB set table mostly stays in
     # the Infinity Cache, the request's one set line); the adapter tables do not
-    probed_cold = (min(wl.B, 20) if hits <= 20 * R else min(wl.B, 32)) if quad else min(wl.B, 32)
+    probed_cold = (min(wl.B, 17) if hits < 17 * R else min(wl.B, 32)) if quad else min(wl.B, 32)
     cold_hbm = R * stride + out_bytes + (R * probed_cold * 64 + (with_hits * 64 if quad else hits * per_hit) if wl.B else 0)
     # SURVEY 8(d) strictly: only the probes the sequential walk needs (matched + 1 per request, device-counted) and the pod-set lines the
     # layout needs for them (v5: one per request; the fast kernel: one per hit)
@@ -1637,7 +1637,7 @@ def closed_loop_roofline(run, wl, args, state, ms_per_step, steps: int = 24):
 
 def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
     """The pick kernel where HBM IS the bound: 262 144 prefix groups, uniform -> 4.2 M distinct hashes in 268 MB of key buckets (16.8 M API
-    slots = 4.2 M buckets of 64 bytes), far beyond the 32 MB of L2 and the 256 MB Infinity Cache; every request gathers 20 random 64-byte
+    slots = 4.2 M buckets of 64 bytes), far beyond the 32 MB of L2 and the 256 MB Infinity Cache; every request gathers 17 random 64-byte
     buckets and ONE line of the 16 MiB set table (protocol v5; round 5: 20 buckets + 16 random 64-byte lists).  One batch at a time (the
     kernel has the GPU to itself: its duration is the launch duration)."""
     import copy
@@ -1667,7 +1667,7 @@ def cold_reference(pkg, torch, args, khash, steps: int = 60, warmup: int = 10):
                                  "gathers ahead of knowing where the walk ends.  Every 64-byte line costs HBM a 128-byte request: `frac_hbm_granular` prices the same lines at 128 bytes",
             "kernel": "pick_quad_kernel" if quad else "pick_fast_kernel",
             "bytes_definition": ("what the layout reads from HBM per launch: request rows + outputs + one 64-byte key bucket per gathered hash (" +
-                                 ("20 per request: pick_quad_kernel gathers the first 20 ahead, the rest only behind 20 hits" if quad else "32 per request") +
+                                 ("17 per request: pick_quad_kernel gathers the first 17 ahead, the rest only behind 17 hits" if quad else "32 per request") +
                                  ") + " + ("one 64-byte set line per request" if quad else "one 64-byte pod list per hit") + " (adapter tables stay in L2)"),
             "launches_in_flight": len(run.streams), "steps": steps, "generate_seconds": gen_s, "kernel_src_sha16": khash}
     tj = stamped_json("pmc_traffic_cold.json", khash)

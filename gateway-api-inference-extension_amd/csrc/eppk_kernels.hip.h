@@ -1814,24 +1814,27 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     r_.h1 = buffer_load_u64(rq, roff + hoff1, 0u);
   };
   // hash + home bucket of step i's key from the lanes that loaded them, then the 16-byte piece of that bucket
-  auto fetch_step = [&](const Row& r_, uint32_t b0, uint32_t b1, Probe& pb, auto ic) {
+  // (`first_only`: every quad of the row fetches the step's FIRST key -- key 4i, quad 0's -- instead of its own: the same line four times, one L2 request)
+  auto fetch_step = [&](const Row& r_, uint32_t b0, uint32_t b1, Probe& pb, auto ic, bool first_only = false) {
     constexpr int i = decltype(ic)::value;
-    const int a = (int)(bp_addr + 16u * (uint32_t)(i & 3));
+    const int a = (int)((first_only ? gsh * 4u : bp_addr) + 16u * (uint32_t)(i & 3));
     pb.hlo[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(i < 4 ? r_.h0 : r_.h1));
     pb.hhi[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)((i < 4 ? r_.h0 : r_.h1) >> 32));
     pb.bkt[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(i < 4 ? b0 : b1));
   };
-  // The pipelined gather covers the first kAhead steps (20 keys): the walk ends at the first miss, and a request whose first 20
-  // blocks are all cached is the exception -- it fetches steps 5..7 on demand (one more round trip) instead of every request
-  // paying 12 bucket lines it never looks at.
+  // The pipelined gather covers the first 17 keys -- steps 0..3 in full, of step 4 only key 16 (quad 0's) -- : the walk ends at the first
+  // miss, and a request whose first 17 blocks are all cached is the exception: it fetches keys 17..31 on demand (one more round trip)
+  // instead of every request paying bucket lines it never looks at.  (Rounds 2-5 gathered 20 ahead: three lines per request of a
+  // workload whose shared prefixes are 16 blocks long, 13 % of a cold index's HBM traffic.)
   constexpr int kAhead = 5;
+  constexpr uint32_t kAheadKeys = 17u;
   auto issue_keys = [&](const Row& r_, Probe& pb) {
     const uint32_t b0 = home_bucket(r_.h0, ix.shift), b1 = home_bucket(r_.h1, ix.shift);
     fetch_step(r_, b0, b1, pb, std::integral_constant<int, 0>{});
     fetch_step(r_, b0, b1, pb, std::integral_constant<int, 1>{});
     fetch_step(r_, b0, b1, pb, std::integral_constant<int, 2>{});
     fetch_step(r_, b0, b1, pb, std::integral_constant<int, 3>{});
-    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 4>{});
+    fetch_step(r_, b0, b1, pb, std::integral_constant<int, 4>{}, /*first_only*/ true);
 #ifdef EPPK_DBGQ_NO_BKT     // timing experiment only (wrong results): no key-bucket loads, every key a miss
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) pb.w[i] = (u32x4_t)(0u);
@@ -1934,6 +1937,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     match_step(std::integral_constant<int, 2>{}, codes);
     match_step(std::integral_constant<int, 3>{}, codes);
     match_step(std::integral_constant<int, 4>{}, codes);
+    codes &= q == 0u ? 0xFFFFFFFFu : 0xFFF0FFFFu;                     // (step 4 was gathered for key 16 alone: the other quads looked at ITS bucket)
     codes = quad_or(codes);
     sid_of(std::integral_constant<int, 0>{});
     sid_of(std::integral_constant<int, 1>{});
@@ -1954,20 +1958,26 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     // stopped short of 20, was scored with 20 matched blocks instead of 32 -- right pick, low score; found by the `revisit` bench leg.)
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      const bool more = !all8 && __any(m == 4u * (uint32_t)kAhead && nbc > 4u * (uint32_t)kAhead);
+      const bool more = !all8 && __any(m == kAheadKeys && nbc > kAheadKeys);
       if (pass == 1 && !more) break;
-      if (__builtin_expect(more, 0)) {   // steps 5..7 on demand
+      if (__builtin_expect(more, 0)) {   // keys 17..31 on demand: step 4 once more, for every quad's own key, and steps 5..7
         const uint32_t b1 = home_bucket(cur.h1, ix.shift);
+        fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 4>{});
         fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 5>{});
         fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 6>{});
         fetch_step(cur, 0u, b1, pb, std::integral_constant<int, 7>{});
 #pragma unroll
-        for (int i = kAhead; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
+        for (int i = kAhead - 1; i < 8; ++i) pb.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(pb.bkt[i] * (kBucket * 8u) + j16), 0, 0);
         uint32_t cd2 = 0u;
+        match_step(std::integral_constant<int, 4>{}, cd2);
         match_step(std::integral_constant<int, 5>{}, cd2);
         match_step(std::integral_constant<int, 6>{}, cd2);
         match_step(std::integral_constant<int, 7>{}, cd2);
-        codes |= quad_or(cd2);
+        codes = (codes & 0x0000FFFFu) | quad_or(cd2);
+        const uint32_t keep4 = sid[4];                                // (key 16 may be a hit the chain walk of the first pass found: not in `codes`)
+        sid_of(std::integral_constant<int, 4>{});
+        if ((Wx >> (16u + q)) & 1u) sid[4] = keep4;
+        have4 = true;
         sid_of(std::integral_constant<int, 5>{});
         sid_of(std::integral_constant<int, 6>{});
         sid_of(std::integral_constant<int, 7>{});
