@@ -16,8 +16,41 @@
 static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// EXPERIMENT (round 6, not in the library): the eviction scan with lane = BUCKET, reading only the 24 bytes of a bucket that hold its flags and
+// meta dwords (a key is present iff its tag is non-zero: the key words need not be read to find the victims).  mode 1 = with the victims'
+// stores, mode 2 = the scan alone.  Listed sets of more than one pod are left to the library's kernel (none in this workload's victims).
+__global__ void evict_meta_scan(uint64_t* keys, uint32_t slots, uint32_t epoch, uint32_t min_epoch, unsigned long long* ixc, int store) {
+  const uint32_t nb = slots / eppk::kBucket, cur_tag = eppk::tag_of_epoch(epoch);
+  const long long keep = (long long)epoch - (long long)min_epoch;
+  uint32_t gone = 0;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    const u32x4* P = (const u32x4*)(keys + (size_t)b * eppk::kBucket);
+    const u32x4 m0 = P[0];
+    const uint2 m1 = *(const uint2*)(P + 1);
+    const uint32_t meta[5] = {m0.y, m0.z, m0.w, m1.x, m1.y};
+#pragma unroll
+    for (uint32_t i = 0; i < 5u; ++i) {
+      const uint32_t tag = meta[i] >> 24;
+      if (tag != 0u && (long long)eppk::tag_age(cur_tag, tag) > keep) {
+        ++gone;
+        if (store) {
+          keys[(size_t)b * eppk::kBucket + eppk::kKeySub0 + i] = eppk::kTomb;
+          ((uint32_t*)(keys + (size_t)b * eppk::kBucket))[1u + i] = 0u;
+        }
+      }
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) gone += (uint32_t)__shfl_xor((int)gone, off);
+  if ((threadIdx.x & 63u) == 0u && gone && store) {
+    const uint32_t shard = (blockIdx.x & 63u) * 8u;
+    atomicAdd(&ixc[shard + eppk::kIxLive], (unsigned long long)(0ull - (unsigned long long)gone));
+    atomicAdd(&ixc[shard + eppk::kIxEvicted], (unsigned long long)gone);
+  }
+}
+
 int main(int argc, char** argv) {
   using LW = uint64_t;
+  const int evict_mode = argc > 3 ? atoi(argv[3]) : 0;
   const uint32_t api_slots = 16u << 20, slots = 2u * api_slots /* physical words: five of a bucket's eight hold keys (protocol v5) */, R = 65536, B = 32, P = 4096, stride = 8 + 8 * B;
   const int steps = argc > 1 ? atoi(argv[1]) : 16;
   const bool use_learn = argc > 2 && atoi(argv[2]) != 0;
@@ -73,7 +106,16 @@ int main(int argc, char** argv) {
       ++epoch;
       if (epoch > 2) {
         CK(hipEventRecord(e2));
-        hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch, epoch - 1u, ixc);
+        if (evict_mode == 2) {      // the two scans alone (no victims: min_epoch 0 keeps everything), one after the other
+          hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch, 0u, ixc);
+          CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3)); CK(hipEventElapsedTime(&ms, e2, e3)); printf("   [library scan alone %6.1f us]", ms * 1e3);
+          CK(hipEventRecord(e2));
+          hipLaunchKernelGGL(evict_meta_scan, dim3(4096), dim3(256), 0, 0, keys, slots, epoch, 0u, ixc, 0);
+          CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3)); CK(hipEventElapsedTime(&ms, e2, e3)); printf(" [meta scan alone %6.1f us]", ms * 1e3);
+          CK(hipEventRecord(e2));
+        }
+        if (evict_mode == 1) hipLaunchKernelGGL(evict_meta_scan, dim3(4096), dim3(256), 0, 0, keys, slots, epoch, epoch - 1u, ixc, 1);
+        else hipLaunchKernelGGL((eppk::index_evict_kernel<LW>), dim3(4096), dim3(256), 0, 0, keys, bitmaps, lists, (const uint32_t*)stamps, slots, epoch, epoch - 1u, ixc);
         CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
         CK(hipEventElapsedTime(&ms, e2, e3));
         unsigned long long h[64 * 8]; CK(hipMemcpy(h, ixc, sizeof h, hipMemcpyDeviceToHost));
