@@ -357,6 +357,18 @@ __device__ __forceinline__ void half_add(LW a, LW b, LW& sum, LW& carry) {
 }
 
 // Transpose one natural-layout candidate mask row ([J] u64, bit p%64 of word p/64) into a lane word.
+// `mine` = natural word `lane` of a pod set (lanes >= J: anything) -> the set's lane word (bit j = pod j*64 + lane)
+template <typename LW>
+__device__ __forceinline__ LW transpose_words(const uint64_t mine, uint32_t J, int lane) {
+  LW out = 0;
+  for (uint32_t j = 0; j < J; ++j) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, j);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), j);
+    const uint64_t mj = ((uint64_t)hi << 32) | lo;
+    out |= (LW)((LW)((mj >> lane) & 1ull) << j);
+  }
+  return out;
+}
 template <typename LW>
 __device__ __forceinline__ LW transpose_mask(const uint64_t* row, uint32_t J, int lane) {
   const uint64_t mine = ((uint32_t)lane < J) ? row[lane] : 0ull;
@@ -793,6 +805,155 @@ template <typename LW>
 __device__ __forceinline__ uint32_t ctz_lw(LW x) {
   if constexpr (sizeof(LW) == 8) return (uint32_t)__builtin_ctzll((unsigned long long)x);
   else return (uint32_t)__builtin_ctz((uint32_t)x);
+}
+
+// masked_exact for the LIST routes (fast kernel) and for pick_quad_kernel: the same expressions in the same order (every scorer of the
+// chain, binary64, the request's own QUEUE normalisers), without dense rows, carry-save counters or one-candidate trips: the set bits of a
+// lane word are taken FOUR at a time, so the gauges of four candidates are in flight together (masked_exact walks one candidate per
+// trip behind two dependent L2 round trips).  matched[p] comes from the caller's LDS: a byte histogram (the lists of the request's hits
+// counted into it: fast kernel, exact_sweep) or a "listed" bitmap -- a listed candidate is then left out (the caller scores those
+// itself: pick_quad_kernel, whose lanes hold the listed pods and their counts) and everybody else has matched 0 (exact_sweep_nat).
+struct ExactChain {            // the chain in scalar registers (read once per request: no indexed access to the argument struct in the loops)
+  uint32_t n, kinds;           // four bits per scorer
+  double w[8];
+  bool has_q;
+};
+__device__ __forceinline__ ExactChain exact_chain(const KChain& ch) {
+  ExactChain ec;
+  ec.n = ch.n; ec.kinds = 0u; ec.has_q = false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ec.w[k] = 0.0;
+    if ((uint32_t)k < ec.n) { ec.kinds |= (ch.kind[k] & 15u) << (4 * k); ec.w[k] = ch.w[k]; ec.has_q |= ch.kind[k] == 1u; }
+  }
+  return ec;
+}
+// minimum / maximum queue depth over the request's candidates (wave-uniform result)
+// (NAT: `cand` is natural word `lane` of the set -- pod lane * 64 + j -- instead of the lane word -- pod j * 64 + lane)
+template <typename LW, bool NAT = false>
+__device__ __forceinline__ void exact_qrange(const uint32_t* __restrict__ queue, const LW cand, const int lane, uint32_t& qmin, uint32_t& qmax) {
+  constexpr int U = 4;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  LW rem = cand;
+  while (__any(rem != 0)) {
+    uint32_t q[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = rem != 0;
+      const uint32_t j = v[u] ? ctz_lw<LW>(rem) : 0u;
+      rem = (LW)(rem & (LW)(rem - 1));
+      q[u] = queue[NAT ? (v[u] ? (uint32_t)lane * 64u + j : 0u) : j * 64u + (uint32_t)lane];   // (a lane that has run out re-reads pod 0 / pod `lane`: in bounds, never used)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mn = (v[u] && q[u] < mn) ? q[u] : mn;
+      mx = (v[u] && q[u] > mx) ? q[u] : mx;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t omn = (uint32_t)__shfl_xor((int)mn, off), omx = (uint32_t)__shfl_xor((int)mx, off);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  qmin = mn; qmax = mx;
+}
+// one candidate's total: masked_exact's loop body (`sp` = its clamped PREFIX score, computed by the caller)
+__device__ __forceinline__ double exact_total(const ExactChain& ec, const uint32_t qmin, const uint32_t qmax, const double qden, const uint32_t q, const double kv,
+                                              const uint32_t tier, const double sp) {
+  const double sq = clamp01((qmax == qmin) ? 1.0 : (double)(qmax - q) / qden);
+  const double skv = clamp01(1.0 - kv);
+  const double sl = tier == 3u ? 1.0 : tier == 2u ? 0.8 : tier == 1u ? 0.6 : 0.0;
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if ((uint32_t)k < ec.n) {                           // (wave-uniform: scalar branches)
+      const uint32_t kd = (ec.kinds >> (4 * k)) & 15u;
+      const double sc = kd == 1u ? sq : kd == 2u ? skv : kd == 3u ? sl : sp;
+      t = t + sc * ec.w[k];
+    }
+  }
+  return t;
+}
+template <typename LW>
+__device__ __forceinline__ void exact_sweep(const KSnap& sn, const ExactChain& ec, const uint32_t qmin, const uint32_t qmax, const LW cand, const LW thi, const LW tlo,
+                                            const uint32_t nb, const int lane, const uint32_t* s_cnt, double& best, uint32_t& bidx) {
+  constexpr int U = 4;
+  const double qden = (double)(qmax - qmin), nbd = (double)nb;
+  LW rem = cand;
+  while (__any(rem != 0)) {
+    uint32_t q[U], hw[U], jj[U];
+    double kv[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = rem != 0;
+      jj[u] = v[u] ? ctz_lw<LW>(rem) : 0u;
+      rem = (LW)(rem & (LW)(rem - 1));
+      const uint32_t p = jj[u] * 64u + (uint32_t)lane;
+      q[u] = sn.queue[p];
+      kv[u] = sn.kv[p];
+      hw[u] = s_cnt[p >> 2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = jj[u], p = j * 64u + (uint32_t)lane;
+      const bool take = v[u];
+      const uint32_t cnt = (hw[u] >> ((p & 3u) * 8u)) & 0xFFu;
+      const uint32_t tier = (uint32_t)(((thi >> j) & 1) << 1) | (uint32_t)((tlo >> j) & 1);
+      double sp = 0.0;                                  // (0 / nb == +0.0: the division is skipped where no lane's candidate is listed)
+      if (nb != 0u && __any(take && cnt != 0u)) sp = clamp01((double)cnt / nbd);
+      const double t = exact_total(ec, qmin, qmax, qden, q[u], kv[u], tier, sp);
+      if (take && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
+    }
+  }
+}
+// The sweep of pick_quad_kernel's rows: the candidate words as they lie in LDS (natural layout: lane w holds pods 64 w .. 64 w + 63, no
+// transposition), a listed candidate (bit in `bits`) left to the caller, matched = 0 for everybody else; the LoRA tier of a candidate
+// from the interleaved {hi, lo} table (one more load beside the two gauges: twelve loads of four candidates in flight per trip).
+template <typename LW, bool HAS_L>
+__device__ __forceinline__ void exact_sweep_nat(const KSnap& sn, const ExactChain& ec, const uint32_t qmin, const uint32_t qmax, const uint64_t cand, const uint32_t arow,
+                                                const int lane, const uint32_t* bits, double& best, uint32_t& bidx) {
+  constexpr int U = 4;
+  const double qden = (double)(qmax - qmin);
+  const LW* thl = (const LW*)((const uint8_t*)sn.blob + SnapOff<LW>::thl) + (size_t)arow * 128u;
+  uint64_t rem = cand;
+  while (__any(rem != 0ull)) {
+    uint32_t q[U], hw[U], jj[U];
+    double kv[U];
+    LW th[U], tl_[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = rem != 0ull;
+      jj[u] = v[u] ? (uint32_t)__builtin_ctzll(rem) : 0u;
+      rem &= rem - 1ull;
+      const uint32_t p = v[u] ? (uint32_t)lane * 64u + jj[u] : 0u;                // (a lane that has run out, or beyond the last word: pod 0, never used)
+      jj[u] = p;
+      q[u] = sn.queue[p];
+      kv[u] = sn.kv[p];
+      hw[u] = bits[p >> 5];
+      if (HAS_L) { th[u] = thl[(p & 63u) * 2u]; tl_[u] = thl[(p & 63u) * 2u + 1u]; }   // (pod p: lane word p & 63, bit p >> 6)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = jj[u];
+      const bool take = v[u] && !((hw[u] >> (p & 31u)) & 1u);
+      uint32_t tier = 0u;
+      if (HAS_L) tier = (uint32_t)((((uint64_t)th[u] >> (p >> 6)) & 1ull) << 1) | (uint32_t)(((uint64_t)tl_[u] >> (p >> 6)) & 1ull);
+      const double t = exact_total(ec, qmin, qmax, qden, q[u], kv[u], tier, 0.0);
+      if (take && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
+    }
+  }
+}
+template <typename LW>
+__device__ __forceinline__ void masked_exact_hist(const KSnap& sn, const KChain& ch, const LW cand, const LW thi, const LW tlo, const uint32_t nb,
+                                                  const int lane, const uint32_t* s_hist, double& best, uint32_t& bidx) {
+  const ExactChain ec = exact_chain(ch);
+  uint32_t qmin = 0u, qmax = 0u;
+  if (ec.has_q) exact_qrange<LW>(sn.queue, cand, lane, qmin, qmax);
+  exact_sweep<LW>(sn, ec, qmin, qmax, cand, thi, tlo, nb, lane, s_hist, best, bidx);
 }
 
 // LDS of the fast kernel: base[J*64] f64 | pterm[(B+1)*ld] f64 (when the host built the table).
@@ -1337,6 +1498,47 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
     }
   };
 
+  // MASKED single picks whose candidates miss a snapshot-wide QUEUE extreme (base[] and the top tables do not apply: the request's own
+  // normalisers), from the lists: matched[] into the byte histogram as stage_sparse does, the candidate row transposed in registers,
+  // every candidate evaluated in full (masked_exact_hist), histogram cleared.  The dense route (16 rows built from the lists, the
+  // carry-save tree, masked_exact's one-candidate trips) cost such a request 30-odd us at 1/8 density -- and it ends its workgroup.
+  auto stage_exact_lists = [&](const ReqS& s, u32x4_t la, u32x4_t lb, Tabs& tb) {
+    const uint32_t r = s.r, m0 = s.m0;
+    const uint32_t k = (uint32_t)lane & 15u, cch = (uint32_t)lane >> 4;
+    if (cch == 0u) { la.w = 0xFFFFFFFFu; lb.w = 0xFFFFFFFFu; }            // (the count)
+    if (k >= m0) la = (u32x4_t)(0xFFFFFFFFu);
+    if (16u + k >= m0) lb = (u32x4_t)(0xFFFFFFFFu);
+    const uint32_t d[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t id = (d[half * 4 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+        if (!__any(id != kListNone)) break;
+        if (id < sn.n_pods) atomicAdd(&s_hist[id >> 2], 1u << ((id & 3u) * 8u));
+      }
+    }
+    const LW cand = (LW)(valid & transpose_words<LW>(tb.cn, sn.J, lane));
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
+    masked_exact_hist<LW>(sn, ch, cand, tb.thi, tb.tlo, s.nb, lane, s_hist, best, bidx);
+    wave_argmax_dpp(best, bidx);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t id = (d[half * 4 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+        if (!__any(id != kListNone)) break;
+        if (id < sn.n_pods) s_hist[id >> 2] = 0u;
+      }
+    }
+    const bool none = bidx == kNoPod;
+    if (lane == 0) {
+      out_pick[r] = (none ? -1 : (int32_t)bidx) | (int32_t)s.badm;
+      if (out_score) out_score[r] = __longlong_as_double(__double_as_longlong(none ? 0.0 : best) & ~(long long)(int32_t)s.badm);
+    }
+  };
+
   // evaluate, select, store
   auto stage_eval = [&](const ReqS& s, const LW (&c)[NPL], Tabs& tb) {
     const uint32_t r = s.r, nb = s.nb, hits = s.hits, arow = s.arow, m0 = s.m0;
@@ -1517,6 +1719,7 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
+    bool exact_lists = false;
     if (MASKED && SPARSE && sp) {
       // no candidate at all: fail closed right here; candidates that miss the snapshot-wide QUEUE extremes need the request's own
       // normalisers: the exact evaluation of the dense route
@@ -1527,8 +1730,12 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
         return;
       }
       if (sn.lead_queue && !(__any((tb.cn & sn.nat[64 + lane]) != 0ull) && __any((tb.cn & sn.nat[128 + lane]) != 0ull))) {
-        sp = false;
-        stage_rows(s, slot0, w);
+        if constexpr (!TOPK) {
+          exact_lists = true;                      // (single picks: every candidate in full, matched[] from the lists)
+        } else {
+          sp = false;
+          stage_rows(s, slot0, w);
+        }
       }
     }
     if (SPARSE && sp && __builtin_expect(lists_overflowed(s, la, lb), 0)) {
@@ -1537,6 +1744,10 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
     }
     bool done = false;
     if (SPARSE && sp) {
+      if (MASKED && !TOPK && exact_lists) {
+        stage_exact_lists(s, la, lb, tb);
+        done = true;
+      } else {
 #ifndef EPPK_DBG_NO_UNIFORM
       done = stage_uniform(s, la, lb, tb);
 #endif
@@ -1544,6 +1755,7 @@ __device__ __forceinline__ void pick_fast_body(const uint32_t vblock, const uint
         if (!done) { stage_sparse(s, la, lb, tb); done = true; }
       } else {
         if (!done) stage_rows(s, slot0, w);        // fallback lists from differing pod lists: the dense rows after all
+      }
       }
       if (done && stats) { w_hits += s.hits; w_lookups += (s.hits + 1u < s.nb) ? s.hits + 1u : s.nb; }
     }
@@ -1736,6 +1948,73 @@ __device__ __attribute__((noinline)) void quad_tail_report() {
   }
 }
 
+// (3) MASKED single picks whose candidates miss a snapshot-wide QUEUE extreme -- base[] and the top tables embed the snapshot-wide
+//     normalisers, the request needs its own (request.go:104-133 + the queue scorer's min / max over the CANDIDATES) -- scored where
+//     pick_quad_kernel finds them, by the whole wavefront, one row after the other.  Until round 6 such a request was deferred, and the
+//     work-list pass spent ~25 us on it (tail function entered 2.9 us after the wavefront left the loop, LDS re-staged 6.4, keys landed
+//     10.7, lists 12+, pick stored 26.6: one request behind a chain of cold round trips, profiles/r06_masked_tail_stamps.txt) -- at 1/8
+//     density one request in 1200 misses an extreme, and each of them ended its workgroup, i.e. the launch.  Here the row's state is
+//     at hand: the candidates in LDS, the listed pods and their matched counts in the row's lanes.  Every candidate that is not listed
+//     is evaluated with matched = 0 (exact_sweep_nat over the candidate words as they lie in LDS, four candidates per trip), the listed candidates
+//     by the lanes that hold them; same expressions, same order as masked_exact.  Never inlined (the hot loop is compiled as if it
+//     were not there: the loop only PARKS such a row -- index, listed pods, counts -- and the wavefront comes here when its loop is over);
+//     reads the kernel's arguments itself (quad_kernargs: launched kernels only -- the resident kernels keep deferring).
+//     `rows`: bit g = row g of the wavefront wants it (wave-uniform).  ls: bit 0 = pA, bit 1 = pB is a listed CANDIDATE of this lane's row.
+template <typename LW, bool HAS_L>
+__device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                          const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w) {
+  const QuadKernArgs* a = quad_kernargs();
+  const KSnap& sn = a->sn;
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t J = sn.J, g_mine = (uint32_t)lane >> 4;
+  const ExactChain ec = exact_chain(a->chain);
+  for (uint32_t g = 0; g < 4u; ++g) {
+    if (!((rows >> g) & 1u)) continue;
+    const uint32_t rg = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(16u * g)), nbg = (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)(16u * g));
+    const uint32_t ag = (uint32_t)__builtin_amdgcn_readlane((int)arow, (int)(16u * g));
+    const uint64_t cand = (uint32_t)lane < J ? s_cn_w[g * J + (uint32_t)lane] : 0ull;     // (mask & existing, active pods: pick_quad_body)
+    uint32_t* bits = s_bits_w + g * (2u * J);
+    const bool mine = g_mine == g;
+    const bool hasA = mine && (ls & 1u), hasB = mine && (ls & 2u);
+    if (hasA) atomicOr(&bits[pA >> 5], 1u << (pA & 31u));
+    if (hasB) atomicOr(&bits[pB >> 5], 1u << (pB & 31u));
+    uint32_t qmin = 0u, qmax = 0u;
+    if (ec.has_q) exact_qrange<uint64_t, true>(sn.queue, cand, lane, qmin, qmax);
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
+    exact_sweep_nat<LW, HAS_L>(sn, ec, qmin, qmax, cand, ag, lane, bits, best, bidx);
+    // the listed candidates, by the lanes that hold them
+    const double qden = (double)(qmax - qmin), nbd = (double)nbg;
+    const LW* thl = (const LW*)((const uint8_t*)sn.blob + SnapOff<LW>::thl) + (size_t)ag * 128u;
+    if (__any(hasA || hasB)) {
+      const uint32_t p0 = hasA ? pA : 0u, p1 = hasB ? pB : 0u;
+      const uint32_t q0 = sn.queue[p0], q1 = sn.queue[p1];
+      const double kv0 = sn.kv[p0], kv1 = sn.kv[p1];
+      uint32_t tier0 = 0u, tier1 = 0u;
+      if (HAS_L) {
+        const LW h0 = thl[(p0 & 63u) * 2u], l0 = thl[(p0 & 63u) * 2u + 1u], h1 = thl[(p1 & 63u) * 2u], l1 = thl[(p1 & 63u) * 2u + 1u];
+        tier0 = (uint32_t)((((uint64_t)h0 >> (p0 >> 6)) & 1ull) << 1) | (uint32_t)(((uint64_t)l0 >> (p0 >> 6)) & 1ull);
+        tier1 = (uint32_t)((((uint64_t)h1 >> (p1 >> 6)) & 1ull) << 1) | (uint32_t)(((uint64_t)l1 >> (p1 >> 6)) & 1ull);
+      }
+      const double sp0 = nbg != 0u ? clamp01((double)cntA / nbd) : 0.0, sp1 = nbg != 0u ? clamp01((double)cntB / nbd) : 0.0;
+      const double t0 = exact_total(ec, qmin, qmax, qden, q0, kv0, tier0, sp0);
+      if (hasA && (t0 > best || (t0 == best && p0 < bidx))) { best = t0; bidx = p0; }
+      if (__any(hasB)) {
+        const double t1 = exact_total(ec, qmin, qmax, qden, q1, kv1, tier1, sp1);
+        if (hasB && (t1 > best || (t1 == best && p1 < bidx))) { best = t1; bidx = p1; }
+      }
+    }
+    wave_argmax_dpp(best, bidx);
+    if (hasA) bits[pA >> 5] = 0u;
+    if (hasB) bits[pB >> 5] = 0u;
+    const bool none = bidx == kNoPod;
+    if (lane == 0) {
+      a->out_pick[rg] = none ? -1 : (int32_t)bidx;
+      if (a->out_score) a->out_score[rg] = none ? 0.0 : best;
+    }
+  }
+}
+
 // LEARN (single picks only): the kernel also leaves one word per request for the post-route index update that follows the pick
 // (index_insert_picks_kernel: `learn`) -- bits 0..7 = m, the leading blocks of the request it found in the index; bits 8..23 = pick + 1
 // (so that the update does not have to fetch the pick from wherever the caller wanted it: pinned host memory on the staged paths);
@@ -1794,6 +2073,13 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
   uint32_t n_def = 0;                                                // requests this wavefront deferred (wave-uniform)
   uint32_t acc_hits = 0, acc_look = 0;                               // probe statistics (lane 0 of each row)
   uint32_t* my_list = defer_list + (size_t)gwave * defer_cap;
+  // MASKED single picks of a launched kernel: the rows that need their own QUEUE normalisers are scored by this wavefront when its loop is
+  // over (quad_exact_rows) -- their request indices and, per lane of the row, the listed pods and matched counts are parked behind the work
+  // lists: [n_segs][cap] indices, then [n_segs][cap][16] lanes x 8 bytes {pA | pB << 16, cntA | cntB << 8 | listed-candidate bits << 16}
+  uint32_t n_x = 0;                                                  // rows parked (wave-uniform)
+  // (computed where they are needed -- rarely -- from my_list: two pointers less to keep through the loop)
+  auto my_xr = [&]() -> uint32_t* { return my_list + (size_t)nwaves * defer_cap; };
+  auto my_xs = [&]() -> uint32_t* { return my_list + (size_t)defer_cap * (2u * (size_t)nwaves + 31u * (size_t)gwave); };
 #if EPPK_QUAD_PREFETCH > 0
   uint32_t pf_sink = 0, pf_prev = 0;                                 // landing registers of the row prefetches (never read)
   const uint32_t pf_lim = n_reqs * stride - 4u;
@@ -2131,6 +2417,12 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
 #endif
     __builtin_amdgcn_sched_barrier(0);
     bool no_cand = false;
+    // PARK (MASKED single picks of a launched kernel): a row that cannot be scored from base[] and the top table ALONE -- its candidates miss
+    // a snapshot-wide QUEUE extreme, or none of the table's 64 entries is a candidate outside its list -- is not deferred: every
+    // candidate is evaluated in full by quad_exact_rows when the loop is over.  softm = those rows.
+    constexpr bool PARK = MASKED && !TOPK && !RESIDENT;
+    unsigned long long softm = 0ull;
+    uint32_t xe1 = 0u;                                                // this lane's matched counts and listed-candidate bits, for quad_exact_rows
     if (MASKED) {
       // this lane's four candidate words: mask & active (words beyond J are no pods)
       uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
@@ -2147,11 +2439,15 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       no_cand = row16(__ballot(anyc)) == 0u;                          // fail closed: EPPK_NO_PICK (stored below)
       // base[] and the top tables embed the snapshot-wide QUEUE normalisers: they apply iff the candidates contain a pod at the
       // minimum and one at the maximum queue depth; otherwise the request's own normalisers are needed (exact evaluation: deferred)
-      if (sn.lead_queue) badm |= __ballot(!no_cand && (row16(__ballot(hmin)) == 0u || row16(__ballot(hmax)) == 0u));
+      unsigned long long exm = 0ull;
+      if (sn.lead_queue) exm = __ballot(!no_cand && (row16(__ballot(hmin)) == 0u || row16(__ballot(hmax)) == 0u));
+      if constexpr (PARK) softm = exm; else badm |= exm;
       wave_lds_fence();
       auto is_cand = [&](uint32_t p_) -> bool { return (s_cn[p_ >> 6] >> (p_ & 63u)) & 1ull; };
       lsA = lsA && is_cand(pA);
       lsB = lsB && is_cand(pB);
+      // (one register to the end of the block; parked in the wavefront's LDS scratch instead it cost the loop 1 us per 64k batch more)
+      if constexpr (PARK) xe1 = cntA | (cntB << 8) | ((lsA ? 1u : 0u) << 16) | ((lsB ? 1u : 0u) << 17);
     }
     // ---- evaluate: binary64 adds in chain order (pick_fast_kernel: pod_total)
     // (the prefix term of a listed pod: clamp01(matched / n) * w for matched = the hits whose set holds it -- m for every listed pod of the
@@ -2283,7 +2579,8 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       wave_lds_fence();
       if (lsA) bits[pA >> 5] = 0u;
       if (anyB && lsB) bits[pB >> 5] = 0u;
-      badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
+      const unsigned long long drym = __ballot(e == 16u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
+      if constexpr (PARK) softm |= drym; else badm |= drym;
     } else {
       badm |= __ballot(e == 16u && tvr == 0xFFFFu && !no_cand);       // all 16 exist and are listed (or no candidates): the rest of the table is needed
     }
@@ -2294,11 +2591,33 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     if (cand_t > wmax || (cand_t == wmax && cand_p < widx)) { wmax = cand_t; widx = cand_p; from_table = true; }
     }
     // ---- store, or defer
+    bool xdone = false;                                               // PARK: the row's pick will be stored by quad_exact_rows
+    if constexpr (PARK) {
+      if (__builtin_expect(softm != 0ull, 0)) {
+        const bool want = row16(softm) != 0u && row16(badm) == 0u;    // (a row that is deferred for another reason anyway: the work-list pass sorts it all out)
+        const unsigned long long wm = __ballot(want);
+        const uint32_t rows = (uint32_t)(wm & 1ull) | (uint32_t)((wm >> 15) & 2ull) | (uint32_t)((wm >> 30) & 4ull) | (uint32_t)((wm >> 45) & 8ull);
+        if (want) {
+          const uint32_t xi = n_x + (uint32_t)__builtin_popcount(rows & ((1u << g) - 1u));
+          uint32_t* e_ = my_xs() + (size_t)xi * 32u + k * 2u;
+          e_[0] = pA | (pB << 16);
+          e_[1] = xe1;
+          if (k == 0u) my_xr()[xi] = r;
+        }
+        n_x += (uint32_t)__builtin_popcount(rows);
+        xdone = want;
+        badm |= softm;
+      }
+    }
     const bool gbad = row16(badm) != 0u;
     const bool lead = k == 0u && live;
-    const unsigned long long dm = __ballot(lead && gbad);
+    const unsigned long long dm = __ballot(lead && gbad && !xdone);
     if (lead) {      // (one store instruction for pick and score -- lanes 0 / 1 / 2 of a row writing pick / score halves -- was measured: no gain)
-      if (!gbad) {
+      if (MASKED && xdone) {                                          // (stored already; the update that follows a LEARN pick takes the whole path)
+        if constexpr (LEARN) learn_out[r] = 0u;
+        acc_hits += m;
+        acc_look += (m + 1u < nb) ? m + 1u : nb;
+      } else if (!gbad) {
         if constexpr (!TOPK) {
           const bool none = widx == kNoPod || no_cand;
           out_pick[r] = none ? -1 : (int32_t)widx;
@@ -2347,6 +2666,35 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       process(blk, qa, qb, pb);
       if (blk + nwaves >= nblk) break;
       process(blk + nwaves, qb, qa, pb);
+    }
+    if constexpr (MASKED && !TOPK && !RESIDENT) {
+      if (__builtin_expect(n_x != 0u, 0)) {                            // the parked rows, four at a time: row g of the wavefront takes entry base + g
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (this wavefront's own stores have reached the L2)
+        for (uint32_t base = 0; base < n_x; base += 4u) {
+          const bool have = base + g < n_x;
+          const uint32_t xi = have ? base + g : base;
+          const uint32_t rr = __hip_atomic_load(&my_xr()[xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t e0 = __hip_atomic_load(&my_xs()[(size_t)xi * 32u + k * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t e1 = __hip_atomic_load(&my_xs()[(size_t)xi * 32u + k * 2u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t hdr = *(const uint64_t*)(reqs + (size_t)rr * stride);     // (a row the loop has validated)
+          const int32_t adapter = (int32_t)(uint32_t)hdr;
+          const uint32_t xarow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+          // the row's candidate words back into its LDS area: mask & active, as in the loop
+          const uint32_t mo = (rr * sn.J + 4u * k) * 8u;
+          const u32x4_t mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0), mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
+          const uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t w = 4u * k + (uint32_t)i;
+            if (w < sn.J) s_cn[w] = cw[i] & s_nat[w];
+          }
+          wave_lds_fence();
+          const unsigned long long hm = __ballot(have);
+          const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
+          quad_exact_rows<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
+                                     s_cn_all + (size_t)(threadIdx.x >> 6) * 4u * sn.J, s_bits_all + (threadIdx.x >> 6) * 4u * bits_dw);
+        }
+      }
     }
 #if EPPK_QUAD_PREFETCH > 0
     asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)

@@ -8,7 +8,7 @@ CS=gateway-api-inference-extension_amd/csrc
 UNIT=${UNIT:-eppk_pick_quad}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function"
 mkdir -p ab/base; rm -f ab/*.so
-python -c "import __graft_entry__ as g; g.build()" 2>/dev/null >/dev/null
+[ -n "$NOBUILD" ] || python -c "import __graft_entry__ as g; g.build()" 2>/dev/null >/dev/null   # (NOBUILD=1: the other units as they were last built)
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc $FLAGS $flags -c -o ab/base/quad_$name.o $CS/$UNIT.hip 2>/dev/null

@@ -19,7 +19,7 @@ m50 = wl.mask
 m25 = m50 & r(); m12 = m25 & r(); m6 = m12 & r(); m3 = m6 & r()
 with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots) as pk:
     pk.publish(wl.pods); pk.index_insert(wl.index_hashes, wl.index_pods)
-    for name, m in (("50%", m50), ("25%", m25), ("12%", m12), ("6%", m6), ("3%", m3)):
+    for name, m in [x for x in (("50%", m50), ("25%", m25), ("12%", m12), ("6%", m6), ("3%", m3)) if not os.environ.get("MASK_ONLY") or x[0] in os.environ["MASK_ONLY"].split(",")]:
         d_mask = torch.from_numpy(m.view(np.int64)).to(dev)
         l0, d0 = pk.quad_stats()
         for _ in range(3):

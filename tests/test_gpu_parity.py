@@ -4,6 +4,8 @@ Bar: picks identical, scores BITWISE identical (binary64), for every BASELINE.js
 with and without candidate masks, canonical and non-canonical chain orders.
 """
 import os
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -226,6 +228,39 @@ def test_masked_fast_path_corner_cases(pkg, orc):
     # chains without a QUEUE scorer never need the exact path
     assert_same(*run_both(pkg, orc, wl, chain=[(2, 3), (3, 2), (4, 5)], mask=mask, max_pods=4096))
     assert_same(*run_both(pkg, orc, wl, chain=[(4, 5), (3, 2)], mask=mask, max_pods=4096))
+
+
+@pytest.mark.parametrize("P,max_pods", [(3000, 4096), (1500, 2048), (700, 1024), (50, 64)])
+@pytest.mark.parametrize("chain", [None, [(KV, 1), (Q, 3), (PF, 2), (Q, 1)], [(PF, 4), (L, 2), (Q, 2)]], ids=["c5", "queue_twice", "prefix_first"])
+def test_masked_requests_with_their_own_queue_normalisers_from_the_lists(pkg, orc, P, max_pods, chain):
+    """Single picks whose candidates miss a snapshot-wide QUEUE extreme are evaluated candidate by candidate with the request's own
+    normalisers (request.go:104-133 + the queue scorer's min / max over the CANDIDATES).  The fast kernel's list route does that from
+    the hits' pod lists (matched[] in a byte histogram, masked_exact_hist) in every lane-word width: sparse and dense masks, hits
+    whose lists DIFFER (a second, third ... pod learned for some blocks only), listed pods inside and outside the candidates."""
+    wl = pkg.workload.make_workload(5, R=256, P=P, masked=True)
+    W = (P + 63) // 64
+    q = wl.pods["queue"]
+    rng = np.random.default_rng(P)
+    bits = np.zeros((wl.R, W * 64), dtype=bool)
+    dens = np.where(np.arange(wl.R) % 3 == 0, 0.6, np.where(np.arange(wl.R) % 3 == 1, 0.125, 0.03))
+    bits[:, :P] = rng.random((wl.R, P)) < dens[:, None]
+    bits[: wl.R // 2, :P] &= (q != q.min())[None, :]
+    bits[wl.R // 2 :, :P] &= (q != q.max())[None, :]
+    bits[::16, :P] &= ((q != q.max()) & (q != q.min()))[None, :]
+    # more pods for SOME blocks of the indexed prefixes: the lists of a request's hits differ, matched[] varies per pod; every second
+    # request is sure to have one of its listed pods among its candidates
+    ih, ip = wl.index_hashes, wl.index_pods
+    sel = rng.random(ih.size) < 0.3
+    ih2 = np.concatenate([ih, ih[sel], ih[sel][::2]])
+    ip2 = np.concatenate([ip, (ip[sel].astype(np.int64) * 7 + 3) % P, (ip[sel][::2].astype(np.int64) * 11 + 5) % P]).astype(ip.dtype)
+    first = {int(h): int(p_) for h, p_ in zip(ih[::-1], ip[::-1])}
+    for r in range(0, wl.R, 2):
+        h0 = int(wl.reqs[r, 1])
+        if h0 in first:
+            bits[r, first[h0]] = True
+    mask = np.packbits(bits.reshape(wl.R, W, 64), axis=2, bitorder="little").view(np.uint64).reshape(wl.R, W)
+    wl2 = dataclasses.replace(wl, index_hashes=ih2, index_pods=ip2)
+    assert_same(*run_both(pkg, orc, wl2, chain=chain, mask=mask, max_pods=max_pods))
 
 
 def _home_bucket(h: np.ndarray, n_buckets: int) -> np.ndarray:

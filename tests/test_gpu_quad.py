@@ -250,7 +250,8 @@ def test_many_launches_in_flight_on_several_streams(pkg, orc, n_streams):
 @pytest.mark.parametrize("R,P,density", [(1024, 4096, 0.5), (1000, 4096, 0.12), (640, 1000, 0.5), (512, 777, 0.3), (256, 2048, 0.5), (96, 64, 0.5)])
 def test_candidate_masks(pkg, orc, R, P, density):
     """Masked batches on the quad route: random subsets, rows without any candidate, rows whose candidates miss the snapshot-wide QUEUE
-    extremes (deferred: the request's own normalisers), rows whose listed pods are no candidates."""
+    extremes (the request's own normalisers: every candidate in full, by the wavefront that found the row -- quad_exact_rows -- not
+    deferred since round 6), rows whose listed pods are no candidates."""
     wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=24, masked=True)
     rng = np.random.default_rng(R + P)
     W = (P + 63) // 64
@@ -270,7 +271,7 @@ def test_candidate_masks(pkg, orc, R, P, density):
             mask[r, p // 64] |= np.uint64(1) << np.uint64(p % 64)
     ql, qd = run(pkg, orc, wl, group_sets(wl), mask=mask)
     assert ql == 1
-    assert 0 < qd < (R // 4 if density >= 0.5 and P >= 1000 else R), f"{qd} of {R} masked requests deferred"
+    assert qd <= R // 16, f"{qd} of {R} masked requests deferred"
 
 
 @pytest.mark.parametrize("R,P,k", [(512, 4096, 2), (777, 4096, 8), (300, 1000, 3), (256, 64, 8), (128, 12, 8)])
