@@ -2015,6 +2015,121 @@ __device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, c
   }
 }
 
+// (3b) The same for FOUR parked rows at once, each scored by its own 16 lanes (lane k: words 4k .. 4k+3 of the row's candidates, handed
+//      over in registers): the form for batches in which every row is parked -- a subset filter that leaves a handful of endpoints
+//      (request.go:104-133: the realistic mask) misses a QUEUE extreme in nearly every request.  One trip serves four candidates of
+//      every lane of every row; row-wide reductions by DPP.  (One row at a time with 64 lanes is the better form where parked rows are
+//      rare and their candidates many -- a 1/8-density mask: (3) above; the caller chooses by the number of rows it has.)
+template <typename LW, bool HAS_L>
+__device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                              const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
+                                                              const uint64_t c3, uint32_t* s_bits_w) {
+  const QuadKernArgs* a = quad_kernargs();
+  const KSnap& sn = a->sn;
+  const uint32_t lane = threadIdx.x & 63u, k = lane & 15u, g = lane >> 4;
+  const bool on = (rows >> g) & 1u;
+  const ExactChain ec = exact_chain(a->chain);
+  uint32_t* bits = s_bits_w + g * (2u * sn.J);
+  const bool hasA = on && (ls & 1u), hasB = on && (ls & 2u);
+  if (hasA) atomicOr(&bits[pA >> 5], 1u << (pA & 31u));
+  if (hasB) atomicOr(&bits[pB >> 5], 1u << (pB & 31u));
+  // the next candidate of this lane, over its four words in ascending order (0 with v = false when it has none left)
+  auto next = [&](uint64_t (&c)[4], bool& v) -> uint32_t {
+    const uint32_t ws = c[0] ? 0u : c[1] ? 1u : c[2] ? 2u : 3u;
+    const uint64_t cur = ws == 0u ? c[0] : ws == 1u ? c[1] : ws == 2u ? c[2] : c[3];
+    v = cur != 0ull;
+    const uint32_t j = v ? (uint32_t)__builtin_ctzll(cur) : 0u;
+    const uint64_t rest = cur & (cur - 1ull);
+    c[0] = ws == 0u ? rest : c[0]; c[1] = ws == 1u ? rest : c[1]; c[2] = ws == 2u ? rest : c[2]; c[3] = ws == 3u ? rest : c[3];
+    return v ? (4u * k + ws) * 64u + j : 0u;
+  };
+  constexpr int U = 4;
+  uint32_t qmin = 0u, qmax = 0u;
+  if (ec.has_q) {
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    uint64_t c[4] = {on ? c0 : 0ull, on ? c1 : 0ull, on ? c2 : 0ull, on ? c3 : 0ull};
+    while (__any((c[0] | c[1] | c[2] | c[3]) != 0ull)) {
+      uint32_t q[U];
+      bool v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) q[u] = sn.queue[next(c, v[u])];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        mn = (v[u] && q[u] < mn) ? q[u] : mn;
+        mx = (v[u] && q[u] > mx) ? q[u] : mx;
+      }
+    }
+    mn = dpp_min_u32<0xB1, 0xf>(mn); mn = dpp_min_u32<0x4E, 0xf>(mn); mn = dpp_min_u32<0x141, 0xf>(mn); mn = dpp_min_u32<0x140, 0xf>(mn);
+    mx = ~mx;                                                         // (maximum = complement of the minimum of the complements)
+    mx = dpp_min_u32<0xB1, 0xf>(mx); mx = dpp_min_u32<0x4E, 0xf>(mx); mx = dpp_min_u32<0x141, 0xf>(mx); mx = dpp_min_u32<0x140, 0xf>(mx);
+    qmin = mn; qmax = ~mx;
+  }
+  const double qden = (double)(qmax - qmin), nbd = (double)nb;
+  const LW* thl = (const LW*)((const uint8_t*)sn.blob + SnapOff<LW>::thl) + (size_t)(on ? arow : 128u) * 128u;
+  auto tier_of = [&](LW th, LW tl_, uint32_t p) -> uint32_t {
+    return (uint32_t)((((uint64_t)th >> (p >> 6)) & 1ull) << 1) | (uint32_t)(((uint64_t)tl_ >> (p >> 6)) & 1ull);
+  };
+  double best = -__builtin_inf();
+  uint32_t bidx = kNoPod;
+  {
+    uint64_t c[4] = {on ? c0 : 0ull, on ? c1 : 0ull, on ? c2 : 0ull, on ? c3 : 0ull};
+    while (__any((c[0] | c[1] | c[2] | c[3]) != 0ull)) {
+      uint32_t q[U], hw[U], pp[U];
+      double kv[U];
+      LW th[U], tl_[U];
+      bool v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = next(c, v[u]);
+        pp[u] = p;
+        q[u] = sn.queue[p];
+        kv[u] = sn.kv[p];
+        hw[u] = bits[p >> 5];
+        if (HAS_L) { th[u] = thl[(p & 63u) * 2u]; tl_[u] = thl[(p & 63u) * 2u + 1u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = pp[u];
+        const bool take = v[u] && !((hw[u] >> (p & 31u)) & 1u);
+        const double t = exact_total(ec, qmin, qmax, qden, q[u], kv[u], HAS_L ? tier_of(th[u], tl_[u], p) : 0u, 0.0);
+        if (take && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
+      }
+    }
+  }
+  if (__any(hasA || hasB)) {                                          // the listed candidates, by the lanes that hold them
+    const uint32_t p0 = hasA ? pA : 0u, p1 = hasB ? pB : 0u;
+    const uint32_t q0 = sn.queue[p0], q1 = sn.queue[p1];
+    const double kv0 = sn.kv[p0], kv1 = sn.kv[p1];
+    uint32_t tier0 = 0u, tier1 = 0u;
+    if (HAS_L) {
+      tier0 = tier_of(thl[(p0 & 63u) * 2u], thl[(p0 & 63u) * 2u + 1u], p0);
+      tier1 = tier_of(thl[(p1 & 63u) * 2u], thl[(p1 & 63u) * 2u + 1u], p1);
+    }
+    const double sp0 = nb != 0u ? clamp01((double)cntA / nbd) : 0.0, sp1 = nb != 0u ? clamp01((double)cntB / nbd) : 0.0;
+    const double t0 = exact_total(ec, qmin, qmax, qden, q0, kv0, tier0, sp0);
+    if (hasA && (t0 > best || (t0 == best && p0 < bidx))) { best = t0; bidx = p0; }
+    if (__any(hasB)) {
+      const double t1 = exact_total(ec, qmin, qmax, qden, q1, kv1, tier1, sp1);
+      if (hasB && (t1 > best || (t1 == best && p1 < bidx))) { best = t1; bidx = p1; }
+    }
+  }
+  // argmax over the row: (total desc, pod asc)
+  double wmax = best;
+  wmax = vmax_f64(wmax, dpp_f64<0xB1, 0xf>(wmax));
+  wmax = vmax_f64(wmax, dpp_f64<0x4E, 0xf>(wmax));
+  wmax = vmax_f64(wmax, dpp_f64<0x141, 0xf>(wmax));
+  wmax = vmax_f64(wmax, dpp_f64<0x140, 0xf>(wmax));
+  uint32_t widx = best == wmax ? bidx : kNoPod;
+  widx = dpp_min_u32<0xB1, 0xf>(widx); widx = dpp_min_u32<0x4E, 0xf>(widx); widx = dpp_min_u32<0x141, 0xf>(widx); widx = dpp_min_u32<0x140, 0xf>(widx);
+  if (hasA) bits[pA >> 5] = 0u;
+  if (hasB) bits[pB >> 5] = 0u;
+  if (on && k == 0u) {
+    const bool none = widx == kNoPod;
+    a->out_pick[r] = none ? -1 : (int32_t)widx;
+    if (a->out_score) a->out_score[r] = none ? 0.0 : wmax;
+  }
+}
+
 // LEARN (single picks only): the kernel also leaves one word per request for the post-route index update that follows the pick
 // (index_insert_picks_kernel: `learn`) -- bits 0..7 = m, the leading blocks of the request it found in the index; bits 8..23 = pick + 1
 // (so that the update does not have to fetch the pick from wherever the caller wanted it: pinned host memory on the staged paths);
@@ -2682,15 +2797,25 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
           // the row's candidate words back into its LDS area: mask & active, as in the loop
           const uint32_t mo = (rr * sn.J + 4u * k) * 8u;
           const u32x4_t mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0), mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
-          const uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
+          uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const uint32_t w = 4u * k + (uint32_t)i;
-            if (w < sn.J) s_cn[w] = cw[i] & s_nat[w];
+            cw[i] = w < sn.J ? cw[i] & s_nat[w] : 0ull;
           }
-          wave_lds_fence();
           const unsigned long long hm = __ballot(have);
           const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
+          if (rows & (rows - 1u)) {                                    // two rows or more: each by its own 16 lanes, side by side
+            quad_exact_rows_par<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
+                                           cw[0], cw[1], cw[2], cw[3], s_bits_all + (threadIdx.x >> 6) * 4u * bits_dw);
+            continue;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {                                // one row: the whole wavefront on it, its candidate words through LDS
+            const uint32_t w = 4u * k + (uint32_t)i;
+            if (w < sn.J) s_cn[w] = cw[i];
+          }
+          wave_lds_fence();
           quad_exact_rows<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
                                      s_cn_all + (size_t)(threadIdx.x >> 6) * 4u * sn.J, s_bits_all + (threadIdx.x >> 6) * 4u * bits_dw);
         }

@@ -274,6 +274,31 @@ def test_candidate_masks(pkg, orc, R, P, density):
     assert qd <= R // 16, f"{qd} of {R} masked requests deferred"
 
 
+@pytest.mark.parametrize("R,P", [(1024, 4096), (777, 3000), (500, 2048), (300, 1000), (128, 64), (61, 12)])
+def test_subset_filters_that_leave_a_handful_of_endpoints(pkg, orc, R, P):
+    """What the reference's subset filter produces (request.go:104-133: the endpoints named by the request's metadata): 1 .. 8 candidates
+    per request.  Nearly every such request misses a pod at the snapshot-wide minimum or maximum queue depth, so EVERY row of a wavefront
+    is scored in full with its own normalisers -- four rows side by side, each by its own 16 lanes (quad_exact_rows_par) -- and none is
+    deferred.  Half of the requests keep one of the pods their prefix is cached on among the candidates (a listed candidate)."""
+    wl = pkg.workload.make_workload(5, R=R, P=P, n_groups=24, masked=True)
+    rng = np.random.default_rng(3 * R + P)
+    W = (P + 63) // 64
+    sets = group_sets(wl)
+    mask = np.zeros((R, W), dtype=np.uint64)
+    for r in range(R):
+        n = int(rng.integers(1, min(8, P) + 1))
+        keep = list(rng.choice(P, size=n, replace=False))
+        pods = sets.get(int(wl.reqs[r, 1]), ())
+        if r % 2 == 0 and pods:
+            keep.append(pods[int(rng.integers(0, len(pods)))])
+        for p_ in keep:
+            mask[r, int(p_) // 64] |= np.uint64(1) << np.uint64(int(p_) % 64)
+    mask[3] = 0                                              # no candidate at all: EPPK_NO_PICK
+    ql, qd = run(pkg, orc, wl, sets, mask=mask)
+    assert ql == 1
+    assert qd <= R // 16, f"{qd} of {R} masked requests deferred"
+
+
 @pytest.mark.parametrize("R,P,k", [(512, 4096, 2), (777, 4096, 8), (300, 1000, 3), (256, 64, 8), (128, 12, 8)])
 def test_ordered_fallbacks(pkg, orc, R, P, k):
     """eppk_pick_topk on the quad route: the k best candidates in order (listed pods and top-table entries merged in the row); lists of
