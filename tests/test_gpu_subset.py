@@ -188,3 +188,36 @@ def test_candidate_major_kernel(pkg, orc, chain, P, B):
     assert np.array_equal(gp, op) and np.array_equal(gs.view(np.uint64), osc.view(np.uint64))
     otp, ots = orc.pick_topk(chain, pods, oix, wl.reqs, 3, mask)
     assert np.array_equal(tp, otp) and np.array_equal(ts.view(np.uint64), ots.view(np.uint64))
+
+
+def test_large_single_pick_batches_of_few_candidates_take_the_general_route(pkg, orc):
+    """eppk_pick_batch_candidates_device with k = 1 hands batches of 8192 requests or more to the general masked route where pick_quad_kernel
+    serves them (it parks every row whose candidates miss a QUEUE extreme and scores four at a time: 64k x 8 candidates 71 us against
+    210 through the candidate-major kernel): same picks, same scores, the oracle's; ordered fallbacks stay on the candidate-major kernel."""
+    R, P = 8192, 4096
+    wl = pkg.workload.make_workload(5, R=R, P=P, masked=True)
+    rng = np.random.default_rng(8)
+    J = (P + 63) // 64
+    mask = np.zeros((R, J), dtype=np.uint64)
+    pods = rng.integers(0, P, (R, 6))
+    for j in range(6):
+        np.bitwise_or.at(mask, (np.arange(R), pods[:, j] // 64), np.uint64(1) << (pods[:, j] % 64).astype(np.uint64))
+    mask[11] = 0
+    with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=wl.B, max_batch=R, index_slots=wl.index_slots) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        l0, _ = pk.quad_stats()
+        picks, scores = pk.pick_candidates(wl.reqs, mask)
+        l1, d1 = pk.quad_stats()
+        tp, ts = pk.pick_candidates(wl.reqs, mask, 2)
+        l2, _ = pk.quad_stats()
+    if os.environ.get("EPPK_QUAD", "1") != "0" and os.environ.get("EPPK_LISTS", "1") != "0" and int(os.environ.get("EPPK_QUAD_MIN", "4096")) <= R:
+        assert l1 == l0 + 1 and l2 == l1, "k = 1: one pick_quad_kernel launch; k = 2: the candidate-major kernel"
+        assert d1 <= R // 16
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, wl.reqs, wl.B, mask)
+    assert picks[11, 0] == -1
+    assert np.array_equal(picks[:, 0], op) and np.array_equal(scores[:, 0].view(np.uint64), osc.view(np.uint64))
+    otp, ots = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, 2, mask)
+    assert np.array_equal(tp, otp) and np.array_equal(ts.view(np.uint64), ots.view(np.uint64))
