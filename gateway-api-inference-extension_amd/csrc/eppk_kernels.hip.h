@@ -1873,6 +1873,9 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, EPPK_MIN_WAVES) void pick_fa
 #ifndef EPPK_QUAD_PIPE_KEYS
 #define EPPK_QUAD_PIPE_KEYS 1   // 1: the key gather of the next block is in flight while this one is evaluated
 #endif
+#ifndef EPPK_QUAD_PARK
+#define EPPK_QUAD_PARK 1        // 0: masked single picks defer the rows they cannot score from base[] and the top table (A/B runs)
+#endif
 #ifndef EPPK_QUAD_WAVES
 #define EPPK_QUAD_WAVES 4       // wavefronts per SIMD the register allocation aims at (<= 128 VGPRs)
 #endif
@@ -2127,6 +2130,59 @@ __device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t row
     const bool none = widx == kNoPod;
     a->out_pick[r] = none ? -1 : (int32_t)widx;
     if (a->out_score) a->out_score[r] = none ? 0.0 : wmax;
+  }
+}
+
+// (3c) The parked rows of one wavefront, four at a time: row g of the wavefront takes entry base + g.  LDS layout and work-list geometry
+//      as in pick_quad_body (launched kernel: vgrid = gridDim.x).
+template <typename LW, bool HAS_L>
+__device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, unsigned char* smem) {
+  const QuadKernArgs* a = quad_kernargs();
+  const KSnap& sn = a->sn;
+  const uint32_t lane = threadIdx.x & 63u, k = lane & 15u, g = lane >> 4, wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wave)), nwaves = gridDim.x * wpb;
+  const uint32_t J = sn.J, bits_dw = J * 2u, cap = a->defer_cap, stride = a->stride;
+  uint32_t* s_bits_all = (uint32_t*)((double*)smem + (size_t)J * 64u + 4u + a->pwn);
+  const uint64_t* s_nat = (const uint64_t*)(s_bits_all + (blockDim.x >> 4) * bits_dw);
+  uint64_t* s_cn_all = (uint64_t*)s_nat + 192;
+  uint64_t* s_cn = s_cn_all + (wave * 4u + g) * J;
+  const uint32_t* my_xr = a->defer_list + ((size_t)nwaves + gwave) * cap;
+  const uint32_t* my_xs = a->defer_list + (size_t)nwaves * cap * 2u + (size_t)gwave * cap * 32u;
+  const __amdgpu_buffer_rsrc_t rmk = __builtin_amdgcn_make_buffer_rsrc((void*)a->cand_mask, 0, (int)((size_t)a->n_reqs * J * 8u), 0x00020000);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (this wavefront's own stores have reached the L2)
+  for (uint32_t base = 0; base < n_x; base += 4u) {
+    const bool have = base + g < n_x;
+    const uint32_t xi = have ? base + g : base;
+    const uint32_t rr = __hip_atomic_load(&my_xr[xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t e0 = __hip_atomic_load(&my_xs[(size_t)xi * 32u + k * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t e1 = __hip_atomic_load(&my_xs[(size_t)xi * 32u + k * 2u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hdr = *(const uint64_t*)(a->reqs + (size_t)rr * stride);          // (a row the loop has validated)
+    const int32_t adapter = (int32_t)(uint32_t)hdr;
+    const uint32_t xarow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+    // the row's candidate words again: mask & active, as in the loop
+    const uint32_t mo = (rr * J + 4u * k) * 8u;
+    const u32x4_t mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0), mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
+    uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t w = 4u * k + (uint32_t)i;
+      cw[i] = w < J ? cw[i] & s_nat[w] : 0ull;
+    }
+    const unsigned long long hm = __ballot(have);
+    const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
+    if (rows & (rows - 1u)) {                                          // two rows or more: each by its own 16 lanes, side by side
+      quad_exact_rows_par<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
+                                     cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw);
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                      // one row: the whole wavefront on it, its candidate words through LDS
+      const uint32_t w = 4u * k + (uint32_t)i;
+      if (w < J) s_cn[w] = cw[i];
+    }
+    wave_lds_fence();
+    quad_exact_rows<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
+                               s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw);
   }
 }
 
@@ -2535,7 +2591,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     // PARK (MASKED single picks of a launched kernel): a row that cannot be scored from base[] and the top table ALONE -- its candidates miss
     // a snapshot-wide QUEUE extreme, or none of the table's 64 entries is a candidate outside its list -- is not deferred: every
     // candidate is evaluated in full by quad_exact_rows when the loop is over.  softm = those rows.
-    constexpr bool PARK = MASKED && !TOPK && !RESIDENT;
+    constexpr bool PARK = MASKED && !TOPK && !RESIDENT && EPPK_QUAD_PARK != 0;
     unsigned long long softm = 0ull;
     uint32_t xe1 = 0u;                                                // this lane's matched counts and listed-candidate bits, for quad_exact_rows
     if (MASKED) {
@@ -2782,44 +2838,10 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       if (blk + nwaves >= nblk) break;
       process(blk + nwaves, qb, qa, pb);
     }
-    if constexpr (MASKED && !TOPK && !RESIDENT) {
-      if (__builtin_expect(n_x != 0u, 0)) {                            // the parked rows, four at a time: row g of the wavefront takes entry base + g
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (this wavefront's own stores have reached the L2)
-        for (uint32_t base = 0; base < n_x; base += 4u) {
-          const bool have = base + g < n_x;
-          const uint32_t xi = have ? base + g : base;
-          const uint32_t rr = __hip_atomic_load(&my_xr()[xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t e0 = __hip_atomic_load(&my_xs()[(size_t)xi * 32u + k * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t e1 = __hip_atomic_load(&my_xs()[(size_t)xi * 32u + k * 2u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t hdr = *(const uint64_t*)(reqs + (size_t)rr * stride);     // (a row the loop has validated)
-          const int32_t adapter = (int32_t)(uint32_t)hdr;
-          const uint32_t xarow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
-          // the row's candidate words back into its LDS area: mask & active, as in the loop
-          const uint32_t mo = (rr * sn.J + 4u * k) * 8u;
-          const u32x4_t mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0), mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
-          uint64_t cw[4] = {u64_of(mk0.x, mk0.y), u64_of(mk0.z, mk0.w), u64_of(mk1.x, mk1.y), u64_of(mk1.z, mk1.w)};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t w = 4u * k + (uint32_t)i;
-            cw[i] = w < sn.J ? cw[i] & s_nat[w] : 0ull;
-          }
-          const unsigned long long hm = __ballot(have);
-          const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
-          if (rows & (rows - 1u)) {                                    // two rows or more: each by its own 16 lanes, side by side
-            quad_exact_rows_par<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
-                                           cw[0], cw[1], cw[2], cw[3], s_bits_all + (threadIdx.x >> 6) * 4u * bits_dw);
-            continue;
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {                                // one row: the whole wavefront on it, its candidate words through LDS
-            const uint32_t w = 4u * k + (uint32_t)i;
-            if (w < sn.J) s_cn[w] = cw[i];
-          }
-          wave_lds_fence();
-          quad_exact_rows<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
-                                     s_cn_all + (size_t)(threadIdx.x >> 6) * 4u * sn.J, s_bits_all + (threadIdx.x >> 6) * 4u * bits_dw);
-        }
-      }
+    if constexpr (MASKED && !TOPK && !RESIDENT && EPPK_QUAD_PARK != 0) {
+      // the parked rows: a function of its own that finds everything it needs in the kernel's arguments -- nothing is kept alive
+      // through the loop for it but the count
+      if (__builtin_expect(n_x != 0u, 0)) quad_park_drain<LW, HAS_L>(n_x, smem);
     }
 #if EPPK_QUAD_PREFETCH > 0
     asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
