@@ -1259,6 +1259,16 @@ def dispatcher_latency_leg(pkg, wl, batches, calls: int, n: int = 16):
             res["pick_masked"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: pk.pick_staged_into(n, a_p, a_s, use_mask=True))
             op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, mask)
             ok = ok and bool(np.array_equal(p[:n], op)) and bool(np.array_equal(sc[:n].view(np.uint64), osc.view(np.uint64)))
+            # what the reference's subset filter leaves (request.go:104-133): a handful of endpoints -- such a request nearly always needs its
+            # own QUEUE normalisers (its candidates miss a pod at the snapshot-wide minimum or maximum)
+            mask8 = np.zeros((n, W), dtype=np.uint64)
+            for r_ in range(n):
+                for p_ in rng.choice(P, size=min(8, P), replace=False):
+                    mask8[r_, int(p_) // 64] |= np.uint64(1) << np.uint64(int(p_) % 64)
+            stm[:n * W] = mask8.reshape(-1)
+            res["pick_subset_8_endpoints"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: pk.pick_staged_into(n, a_p, a_s, use_mask=True))
+            op, osc, _ = orc.pick_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, mask8)
+            ok = ok and bool(np.array_equal(p[:n], op)) and bool(np.array_equal(sc[:n].view(np.uint64), osc.view(np.uint64)))
             st_ptr = st.ctypes.data
             res["top4"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: lib.eppk_pick_topk(ctx, st_ptr, n, None, 4, a_p, a_s))
             op, osc = orc.pick_topk_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, 4)

@@ -701,7 +701,7 @@ int resident_ensure(eppk_ctx* c) {            // control blocks, argument block,
   if (!c->d_res_wl) {   // the work list of the quad forms: 16 wavefronts, each with room for every request it can meet (4 per block, its share of the blocks)
     const uint32_t nblk = (c->resident_max + 3u) / 4u, per_wave = (nblk + 15u) / 16u;
     c->res_wl_cap = 4u * (per_wave ? per_wave : 1u);
-    const size_t words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
+    const size_t words = 32u + 16u + 16u * (size_t)c->res_wl_cap * 34u;       // (... | masked single picks: the rows a wavefront parks, pick_quad_body my_xr / my_xs)
     uint32_t* wl = nullptr;
     HIPCHK(c, hipMalloc((void**)&wl, words * 4u * eppk_ctx::kResUnits));      // (one work list per unit: two units may be scoring at once)
     if (hipMemset(wl, 0, words * 4u * eppk_ctx::kResUnits) != hipSuccess) { (void)hipFree(wl); return fail(c, EPPK_ERR_DEVICE, "resident path: hipMemset of the work lists failed"); }
@@ -904,7 +904,7 @@ int resident_ring(eppk_ctx* c, uint32_t n_reqs, bool masked, uint32_t k, uint32_
       a.set_ctl = c->set_ctl;
     }
     eppk::ResidentArgs all[eppk_ctx::kResUnits];
-    const size_t wl_words = 32u + 16u + 16u * (size_t)c->res_wl_cap;
+    const size_t wl_words = 32u + 16u + 16u * (size_t)c->res_wl_cap * 34u;
     const size_t rm = c->resident_max ? c->resident_max : 1u, sort_words = 4u + rm * (c->cfg.max_blocks ? c->cfg.max_blocks : 1u);
     for (uint32_t unit = 0; unit < eppk_ctx::kResUnits; ++unit) {
       all[unit] = a;

@@ -1951,6 +1951,14 @@ __device__ __attribute__((noinline)) void quad_tail_report() {
   }
 }
 
+// What the functions that score PARKED rows read ((3), (3b), (3c) below): pointers into the launched kernel's kernarg segment, or into the
+// resident kernels' argument block.  Filled in by pick_quad_body where a wavefront has parked rows -- rarely -- and handed over by address.
+struct ParkArgs {
+  const KSnap* sn; const KChain* chain;
+  int32_t* out_pick; double* out_score;
+  const uint64_t* cand_mask; const uint32_t* defer_list;
+  uint32_t defer_cap, n_reqs, pwn, vblock, vgrid;
+};
 // (3) MASKED single picks whose candidates miss a snapshot-wide QUEUE extreme -- base[] and the top tables embed the snapshot-wide
 //     normalisers, the request needs its own (request.go:104-133 + the queue scorer's min / max over the CANDIDATES) -- scored where
 //     pick_quad_kernel finds them, by the whole wavefront, one row after the other.  Until round 6 such a request was deferred, and the
@@ -1961,16 +1969,16 @@ __device__ __attribute__((noinline)) void quad_tail_report() {
 //     is evaluated with matched = 0 (exact_sweep_nat over the candidate words as they lie in LDS, four candidates per trip), the listed candidates
 //     by the lanes that hold them; same expressions, same order as masked_exact.  Never inlined (the hot loop is compiled as if it
 //     were not there: the loop only PARKS such a row -- index, listed pods, counts -- and the wavefront comes here when its loop is over);
-//     reads the kernel's arguments itself (quad_kernargs: launched kernels only -- the resident kernels keep deferring).
+//     handed the kernel's arguments by address (ParkArgs: the kernarg segment of a launched kernel, the argument block of a resident one).
 //     `rows`: bit g = row g of the wavefront wants it (wave-uniform).  ls: bit 0 = pA, bit 1 = pB is a listed CANDIDATE of this lane's row.
 template <typename LW, bool HAS_L>
-__device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
-                                                          const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w) {
-  const QuadKernArgs* a = quad_kernargs();
-  const KSnap& sn = a->sn;
+__device__ __forceinline__ void quad_exact_rows_i(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                  const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w,
+                                                  const ParkArgs* a) {
+  const KSnap& sn = *a->sn;
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t J = sn.J, g_mine = (uint32_t)lane >> 4;
-  const ExactChain ec = exact_chain(a->chain);
+  const ExactChain ec = exact_chain(*a->chain);
   for (uint32_t g = 0; g < 4u; ++g) {
     if (!((rows >> g) & 1u)) continue;
     const uint32_t rg = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(16u * g)), nbg = (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)(16u * g));
@@ -2018,20 +2026,25 @@ __device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, c
   }
 }
 
+template <typename LW, bool HAS_L>
+__device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                          const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w,
+                                                          const ParkArgs* a) {
+  quad_exact_rows_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, s_cn_w, s_bits_w, a);
+}
 // (3b) The same for FOUR parked rows at once, each scored by its own 16 lanes (lane k: words 4k .. 4k+3 of the row's candidates, handed
 //      over in registers): the form for batches in which every row is parked -- a subset filter that leaves a handful of endpoints
 //      (request.go:104-133: the realistic mask) misses a QUEUE extreme in nearly every request.  One trip serves four candidates of
 //      every lane of every row; row-wide reductions by DPP.  (One row at a time with 64 lanes is the better form where parked rows are
 //      rare and their candidates many -- a 1/8-density mask: (3) above; the caller chooses by the number of rows it has.)
 template <typename LW, bool HAS_L>
-__device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
-                                                              const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
-                                                              const uint64_t c3, uint32_t* s_bits_w) {
-  const QuadKernArgs* a = quad_kernargs();
-  const KSnap& sn = a->sn;
+__device__ __forceinline__ void quad_exact_rows_par_i(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                      const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
+                                                      const uint64_t c3, uint32_t* s_bits_w, const ParkArgs* a) {
+  const KSnap& sn = *a->sn;
   const uint32_t lane = threadIdx.x & 63u, k = lane & 15u, g = lane >> 4;
   const bool on = (rows >> g) & 1u;
-  const ExactChain ec = exact_chain(a->chain);
+  const ExactChain ec = exact_chain(*a->chain);
   uint32_t* bits = s_bits_w + g * (2u * sn.J);
   const bool hasA = on && (ls & 1u), hasB = on && (ls & 2u);
   if (hasA) atomicOr(&bits[pA >> 5], 1u << (pA & 31u));
@@ -2133,15 +2146,21 @@ __device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t row
   }
 }
 
-// (3c) The parked rows of one wavefront, four at a time: row g of the wavefront takes entry base + g.  LDS layout and work-list geometry
-//      as in pick_quad_body (launched kernel: vgrid = gridDim.x).
 template <typename LW, bool HAS_L>
-__device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, unsigned char* smem) {
-  const QuadKernArgs* a = quad_kernargs();
-  const KSnap& sn = a->sn;
+__device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
+                                                              const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
+                                                              const uint64_t c3, uint32_t* s_bits_w, const ParkArgs* a) {
+  quad_exact_rows_par_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, c0, c1, c2, c3, s_bits_w, a);
+}
+// (3c) The parked rows of one wavefront, four at a time: row g of the wavefront takes entry base + g.  LDS layout and work-list geometry
+//      as in pick_quad_body.  INL: everything inlined into the caller -- the resident kernels, where ONE call inside the doorbell loop
+//      tripled the kernel's spill code (944 scratch loads against 353) and cost a 16-request batch of dense masks 5-7 us.
+template <typename LW, bool HAS_L, bool INL>
+__device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned char* smem, const ParkArgs* a) {
+  const KSnap& sn = *a->sn;
   const uint32_t lane = threadIdx.x & 63u, k = lane & 15u, g = lane >> 4, wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wave)), nwaves = gridDim.x * wpb;
-  const uint32_t J = sn.J, bits_dw = J * 2u, cap = a->defer_cap, stride = a->stride;
+  const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a->vblock * wpb + wave)), nwaves = a->vgrid * wpb;
+  const uint32_t J = sn.J, bits_dw = J * 2u, cap = a->defer_cap;
   uint32_t* s_bits_all = (uint32_t*)((double*)smem + (size_t)J * 64u + 4u + a->pwn);
   const uint64_t* s_nat = (const uint64_t*)(s_bits_all + (blockDim.x >> 4) * bits_dw);
   uint64_t* s_cn_all = (uint64_t*)s_nat + 192;
@@ -2156,9 +2175,7 @@ __device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, un
     const uint32_t rr = __hip_atomic_load(&my_xr[xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t e0 = __hip_atomic_load(&my_xs[(size_t)xi * 32u + k * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t e1 = __hip_atomic_load(&my_xs[(size_t)xi * 32u + k * 2u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t hdr = *(const uint64_t*)(a->reqs + (size_t)rr * stride);          // (a row the loop has validated)
-    const int32_t adapter = (int32_t)(uint32_t)hdr;
-    const uint32_t xarow = (HAS_L && adapter >= 0) ? (uint32_t)adapter : 128u;
+    const uint32_t xarow = (e1 >> 14) & 0xFFu, xnb = (e1 >> 22) & 0x7Fu;           // (the row's header, as the loop saw it)
     // the row's candidate words again: mask & active, as in the loop
     const uint32_t mo = (rr * J + 4u * k) * 8u;
     const u32x4_t mk0 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)mo, 0, 0), mk1 = __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)(mo + 16u), 0, 0);
@@ -2171,8 +2188,10 @@ __device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, un
     const unsigned long long hm = __ballot(have);
     const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
     if (rows & (rows - 1u)) {                                          // two rows or more: each by its own 16 lanes, side by side
-      quad_exact_rows_par<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
-                                     cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw);
+      if constexpr (INL) quad_exact_rows_par_i<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                                          cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
+      else quad_exact_rows_par<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                          cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
       continue;
     }
 #pragma unroll
@@ -2181,9 +2200,28 @@ __device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, un
       if (w < J) s_cn[w] = cw[i];
     }
     wave_lds_fence();
-    quad_exact_rows<LW, HAS_L>(rows, rr, (uint32_t)(hdr >> 32), xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFu, (e1 >> 8) & 0xFFu, (e1 >> 16) & 3u,
-                               s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw);
+    if constexpr (INL) quad_exact_rows_i<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                                    s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
+    else quad_exact_rows<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                    s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
   }
+}
+
+// (3d) ... behind ONE small call from the loop's kernel: the argument block is put together here, not in the caller's frame
+template <typename LW, bool HAS_L>
+__device__ __attribute__((noinline)) void quad_park_drain_launched(const uint32_t n_x, unsigned char* smem) {
+  const QuadKernArgs* a = quad_kernargs();
+  ParkArgs pa;
+  pa.sn = &a->sn; pa.chain = &a->chain; pa.out_pick = a->out_pick; pa.out_score = a->out_score; pa.cand_mask = a->cand_mask; pa.defer_list = a->defer_list;
+  pa.defer_cap = a->defer_cap; pa.n_reqs = a->n_reqs; pa.pwn = a->pwn; pa.vblock = blockIdx.x; pa.vgrid = gridDim.x;
+  quad_park_drain_i<LW, HAS_L, false>(n_x, smem, &pa);
+}
+template <typename LW, bool HAS_L, typename RA>
+__device__ __forceinline__ void quad_park_drain_resident(const uint32_t n_x, unsigned char* smem, const RA* ra, const uint32_t bufset, const uint32_t n_reqs) {
+  ParkArgs pa;
+  pa.sn = &ra->sn; pa.chain = &ra->chain; pa.out_pick = ra->buf[bufset].out_pick; pa.out_score = ra->buf[bufset].out_score; pa.cand_mask = ra->buf[bufset].mask;
+  pa.defer_list = ra->defer_list; pa.defer_cap = ra->defer_cap; pa.n_reqs = n_reqs; pa.pwn = ra->pwn; pa.vblock = 0u; pa.vgrid = 1u;
+  quad_park_drain_i<LW, HAS_L, true>(n_x, smem, &pa);
 }
 
 // LEARN (single picks only): the kernel also leaves one word per request for the post-route index update that follows the pick
@@ -2197,12 +2235,13 @@ __device__ __attribute__((noinline)) void quad_park_drain(const uint32_t n_x, un
 // RESIDENT small-batch kernel (pick_resident_kernel: one workgroup behind a doorbell, tables already in LDS, request rows in pinned
 // host memory) the other.  vblock / vgrid = this workgroup's place among the workgroups that share the batch.  Returns the number of
 // requests this WAVEFRONT deferred (wave-uniform): they are in its segment of the work list.
-template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED, bool TOPK, bool LEARN, bool RESIDENT = false>
+template <typename LW, bool HAS_L, bool P_FIRST, bool MASKED, bool TOPK, bool LEARN, bool RESIDENT = false, typename RA = void>
 __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const uint32_t vgrid, unsigned char* smem, const KSnap& sn, const KIndex& ix, const KTail& tl,
                                                    const uint8_t* __restrict__ reqs, uint32_t stride, uint32_t n_reqs, uint32_t pwn, const uint64_t* __restrict__ cand_mask,
                                                    int32_t* __restrict__ out_pick, double* __restrict__ out_score, unsigned long long* __restrict__ stats,
                                                    uint32_t* __restrict__ defer_cnt, uint32_t* __restrict__ defer_list, uint32_t defer_cap,
-                                                   uint32_t* __restrict__ defer_total, uint32_t topk, uint32_t* __restrict__ learn_out, const uint32_t xbar_off) {
+                                                   uint32_t* __restrict__ defer_total, uint32_t topk, uint32_t* __restrict__ learn_out, const uint32_t xbar_off,
+                                                   const RA* = nullptr) {
   static_assert(!(LEARN && TOPK), "learn words go with single picks");
   double* s_base = (double*)smem;
   double* s_lw = s_base + (size_t)sn.J * 64u;
@@ -2591,7 +2630,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
     // PARK (MASKED single picks of a launched kernel): a row that cannot be scored from base[] and the top table ALONE -- its candidates miss
     // a snapshot-wide QUEUE extreme, or none of the table's 64 entries is a candidate outside its list -- is not deferred: every
     // candidate is evaluated in full by quad_exact_rows when the loop is over.  softm = those rows.
-    constexpr bool PARK = MASKED && !TOPK && !RESIDENT && EPPK_QUAD_PARK != 0;
+    constexpr bool PARK = MASKED && !TOPK && EPPK_QUAD_PARK != 0;
     unsigned long long softm = 0ull;
     uint32_t xe1 = 0u;                                                // this lane's matched counts and listed-candidate bits, for quad_exact_rows
     if (MASKED) {
@@ -2618,7 +2657,8 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       lsA = lsA && is_cand(pA);
       lsB = lsB && is_cand(pB);
       // (one register to the end of the block; parked in the wavefront's LDS scratch instead it cost the loop 1 us per 64k batch more)
-      if constexpr (PARK) xe1 = cntA | (cntB << 8) | ((lsA ? 1u : 0u) << 16) | ((lsB ? 1u : 0u) << 17);
+      //  bits 0-5 / 6-11 matched counts (<= 32), 12 / 13 "is a listed candidate", 14-21 the adapter's table row, 22-28 the request's blocks (< 64)
+      if constexpr (PARK) xe1 = cntA | (cntB << 6) | ((lsA ? 1u : 0u) << 12) | ((lsB ? 1u : 0u) << 13) | (arow << 14) | (nb << 22);
     }
     // ---- evaluate: binary64 adds in chain order (pick_fast_kernel: pod_total)
     // (the prefix term of a listed pod: clamp01(matched / n) * w for matched = the hits whose set holds it -- m for every listed pod of the
@@ -2838,10 +2878,13 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       if (blk + nwaves >= nblk) break;
       process(blk + nwaves, qb, qa, pb);
     }
-    if constexpr (MASKED && !TOPK && !RESIDENT && EPPK_QUAD_PARK != 0) {
-      // the parked rows: a function of its own that finds everything it needs in the kernel's arguments -- nothing is kept alive
-      // through the loop for it but the count
-      if (__builtin_expect(n_x != 0u, 0)) quad_park_drain<LW, HAS_L>(n_x, smem);
+    if constexpr (MASKED && !TOPK && EPPK_QUAD_PARK != 0) {
+      // the parked rows: a function of its own that is handed the kernel's arguments by address (launched: where they lie in the kernarg
+      // segment, re-read from there) -- nothing is kept alive through the loop for it but the count
+      // (RESIDENT: the caller does that, where its work-list pass is -- the count comes back in the upper half of the result; a call in
+      //  here cost a 16-request batch of dense masks 7 us of spills through scratch that the doorbell's acquire had just invalidated)
+      if constexpr (!RESIDENT)
+        if (__builtin_expect(n_x != 0u, 0)) quad_park_drain_launched<LW, HAS_L>(n_x, smem);
     }
 #if EPPK_QUAD_PREFETCH > 0
     asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
@@ -2858,6 +2901,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
                         (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 48);
     if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
   }
+  if constexpr (RESIDENT && MASKED && !TOPK && EPPK_QUAD_PARK != 0) return n_def | (n_x << 16);    // (at most 64 requests per wavefront)
   return n_def;
 }
 
@@ -3034,9 +3078,17 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
         if (bell_wave && lane0) ctl->pad1[3] = (uint32_t)(wall_clock64() - ts0);      // bell seen -> rows copied
 #endif
       }
-      const uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN, /*RESIDENT*/ true>(
+      uint32_t n_def = pick_quad_body<LW, HAS_L, P_FIRST, MASKED, TOPK, LEARN, /*RESIDENT*/ true>(
           0u, 1u, smem, a->sn, a->ix, a->tl, rb.reqs, a->stride, n, a->pwn, MASKED ? rb.mask : nullptr, rb.out_pick, rb.out_score, nullptr, a->defer_cnt, a->defer_list, a->defer_cap,
-          a->defer_total, TOPK ? kk : 1u, LEARN ? a->learn : nullptr, a->lds_bytes - (blockDim.x >> 6) * 512u);      // (crossbar scratch: the last 512 bytes per wavefront of the allocation)
+          a->defer_total, TOPK ? kk : 1u, LEARN ? a->learn : nullptr, a->lds_bytes - (blockDim.x >> 6) * 512u,       // (crossbar scratch: the last 512 bytes per wavefront of the allocation)
+          (const void*)nullptr);
+      // MASKED single picks: the rows this wavefront PARKED (their candidates miss a QUEUE extreme -- what a subset filter of a few endpoints
+      // does to nearly every request --, or the adapter's table holds none of them) are scored by the wavefront now, every candidate in full
+      if constexpr (MASKED && !TOPK && EPPK_QUAD_PARK != 0) {
+        const uint32_t n_x = n_def >> 16;
+        n_def &= 0xFFFFu;
+        if (n_x != 0u) quad_park_drain_resident<LW, HAS_L, ResidentArgs>(n_x, smem, a, bufset, n);
+      }
       // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
       // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also
       // asks "did anybody defer?".  Only then the work-list pass, and a second release + barrier behind it.

@@ -234,6 +234,50 @@ def test_small_learn_batches_update_the_index_inside_the_resident_workgroup(pkg,
         _same(pk.pick(wl.reqs[:64]), orc.pick_batch(wl.chain, pods, oix, wl.reqs[:64], wl.B)[:2], "after the loop")
 
 
+@pytest.mark.parametrize("P,B", [(4096, 32), (1000, 8), (64, 4)])
+def test_subset_filters_through_the_masked_resident_workgroup(pkg, orc, resident, eppk_mode, P, B):
+    """What a per-request caller with a subset filter hands over (request.go:104-133, 141-163): a few requests, each with a handful of
+    candidate endpoints -- nearly every one needs its own QUEUE normalisers.  The masked resident workgroup PARKS such rows and scores them
+    itself, four side by side (pick_quad_body<RESIDENT> + quad_park_drain_i: 16 requests x 8 endpoints 79 -> 23 us host-observed), no
+    work-list pass; dense masks beside them in the same batches; every size on both sides of the body switch (8 requests)."""
+    wl = pkg.workload.make_workload(5, R=256, P=P, n_groups=16, B=B)
+    oix = orc.OracleIndex()
+    oix.insert(wl.index_hashes, wl.index_pods)
+    rng = np.random.default_rng(P + B)
+    W = (P + 63) // 64
+    sets = {}
+    for h, p_ in zip(wl.index_hashes.tolist(), wl.index_pods.tolist()):
+        sets.setdefault(h, p_)
+    with pkg.BatchedPicker(wl.chain, max_pods=P, max_blocks=wl.B, max_batch=256, index_slots=wl.index_slots * 4) as pk:
+        pk.publish(wl.pods)
+        pk.index_insert(wl.index_hashes, wl.index_pods)
+        _, b0, _ = pk.resident_stats()
+        served = 0
+        for rep in range(3):
+            for n in (1, 5, 8, 9, 16, 31, 32, 47, 64):
+                lo = (rep * 61) % 128
+                reqs = wl.reqs[lo:lo + n]
+                mask = np.zeros((n, W), dtype=np.uint64)
+                for r in range(n):
+                    if (r + rep) % 5 == 4:                                   # a dense row among them
+                        mask[r] = rng.integers(0, 2**63, W, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, W, dtype=np.uint64)
+                        if P % 64:
+                            mask[r, -1] &= np.uint64((1 << (P % 64)) - 1)
+                        continue
+                    keep = list(rng.choice(P, size=int(rng.integers(1, min(8, P) + 1)), replace=False))
+                    if r % 2 == 0 and int(reqs[r, 1]) in sets:                # a pod the request's prefix is cached on stays a candidate
+                        keep.append(sets[int(reqs[r, 1])])
+                    for p_ in keep:
+                        mask[r, int(p_) // 64] |= np.uint64(1) << np.uint64(int(p_) % 64)
+                if n > 2:
+                    mask[2] = 0                                              # no candidate at all
+                want = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B, mask)[:2]
+                _same(pk.pick(reqs, mask), want, f"subset masks n={n} rep={rep}")
+                served += 1
+        if eppk_mode in ("default", "quadmin4"):
+            assert pk.resident_stats()[1] - b0 == served, "every masked batch of at most 64 requests is answered by the masked resident workgroup"
+
+
 def test_the_resident_workgroup_leaves_when_idle_and_comes_back(pkg, orc, resident, monkeypatch):
     monkeypatch.setenv("EPPK_RESIDENT_IDLE_POLLS", "2000")                            # a few milliseconds of polls
     wl = pkg.workload.make_workload(5, R=32, P=700, n_groups=8)
