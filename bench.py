@@ -1273,6 +1273,12 @@ def dispatcher_latency_leg(pkg, wl, batches, calls: int, n: int = 16):
             res["top4"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: lib.eppk_pick_topk(ctx, st_ptr, n, None, 4, a_p, a_s))
             op, osc = orc.pick_topk_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, 4)
             ok = ok and bool(np.array_equal(p.reshape(n, 4), op)) and bool(np.array_equal(sc.view(np.uint64).reshape(n, 4), osc.view(np.uint64)))
+            # ... and PickResult.Fallbacks within a subset filter of 8 endpoints (server.go:72-77 behind request.go:104-133)
+            m8 = np.ascontiguousarray(mask8)
+            m8_ptr = m8.ctypes.data
+            res["top4_subset_8_endpoints"] = timed(lambda i: np.copyto(st[:n], rows(i)), lambda: lib.eppk_pick_topk(ctx, st_ptr, n, m8_ptr, 4, a_p, a_s))
+            op, osc = orc.pick_topk_batch(wl.chain, wl.pods, oix, st[:n].copy(), B, 4, m8)
+            ok = ok and bool(np.array_equal(p.reshape(n, 4), op)) and bool(np.array_equal(sc.view(np.uint64).reshape(n, 4), osc.view(np.uint64)))
             # pick + LEARN through a staging set: begin -> end is what the request waits for; the update runs on behind it, and the
             # next begin waits for it on the device (launched) / on the completion word of the resident update
             learned = []

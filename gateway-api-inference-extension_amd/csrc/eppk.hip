@@ -485,9 +485,9 @@ int launch_pick(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t
     if (quad_grid < 1) quad_grid = 1;
     quad_segs = quad_grid * qwpb;
     defer_cap = 4u * ((nblk + quad_segs - 1) / quad_segs);
-    // header: total[2] | done counters[17] (TAIL) | cnt | list | masked single picks: the rows a wavefront scores itself when its loop is over
+    // header: total[2] | done counters[17] (TAIL) | cnt | list | masked batches: the rows a wavefront scores itself when its loop is over
     // (pick_quad_body: my_xr / my_xs -- an index and 16 lanes x 8 bytes of state per request)
-    const size_t words = 32u + (size_t)quad_segs + (size_t)quad_segs * defer_cap * (masked && topk == 1 ? 34u : 1u);
+    const size_t words = 32u + (size_t)quad_segs + (size_t)quad_segs * defer_cap * (masked ? 34u : 1u);
     if (words > dset->words) {             // grow this stream's buffer (rare: its first launch, or a larger batch than ever before)
       { const int rcp = resident_park(c); if (rcp) return rcp; }      // (hipFree waits for the device)
       HIPCHK(c, hipStreamSynchronize(st));

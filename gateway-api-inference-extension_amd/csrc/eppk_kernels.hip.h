@@ -1957,7 +1957,7 @@ struct ParkArgs {
   const KSnap* sn; const KChain* chain;
   int32_t* out_pick; double* out_score;
   const uint64_t* cand_mask; const uint32_t* defer_list;
-  uint32_t defer_cap, n_reqs, pwn, vblock, vgrid;
+  uint32_t defer_cap, n_reqs, pwn, vblock, vgrid, topk;
 };
 // (3) MASKED single picks whose candidates miss a snapshot-wide QUEUE extreme -- base[] and the top tables embed the snapshot-wide
 //     normalisers, the request needs its own (request.go:104-133 + the queue scorer's min / max over the CANDIDATES) -- scored where
@@ -2032,12 +2032,16 @@ __device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, c
                                                           const ParkArgs* a) {
   quad_exact_rows_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, s_cn_w, s_bits_w, a);
 }
+__device__ __forceinline__ uint32_t row16_any(const bool b, const uint32_t lane) { return (uint32_t)(__ballot(b) >> (lane & 48u)) & 0xFFFFu; }
 // (3b) The same for FOUR parked rows at once, each scored by its own 16 lanes (lane k: words 4k .. 4k+3 of the row's candidates, handed
 //      over in registers): the form for batches in which every row is parked -- a subset filter that leaves a handful of endpoints
 //      (request.go:104-133: the realistic mask) misses a QUEUE extreme in nearly every request.  One trip serves four candidates of
 //      every lane of every row; row-wide reductions by DPP.  (One row at a time with 64 lanes is the better form where parked rows are
 //      rare and their candidates many -- a 1/8-density mask: (3) above; the caller chooses by the number of rows it has.)
-template <typename LW, bool HAS_L>
+//      TOPK (ordered fallbacks, eppk_pick_topk): a->topk rounds of the same sweep over the candidates not yet reported -- the QUEUE normalisers
+//      range over ALL candidates in every round (masked_exact: `cand` / `eval`); a reported pod joins the "listed" bits, which the sweep
+//      leaves out, or -- a listed candidate -- leaves its lane's pool.  Always this form for fallback lists, also for a single row.
+template <typename LW, bool HAS_L, bool TOPK = false>
 __device__ __forceinline__ void quad_exact_rows_par_i(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
                                                       const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
                                                       const uint64_t c3, uint32_t* s_bits_w, const ParkArgs* a) {
@@ -2085,9 +2089,27 @@ __device__ __forceinline__ void quad_exact_rows_par_i(const uint32_t rows, const
   auto tier_of = [&](LW th, LW tl_, uint32_t p) -> uint32_t {
     return (uint32_t)((((uint64_t)th >> (p >> 6)) & 1ull) << 1) | (uint32_t)(((uint64_t)tl_ >> (p >> 6)) & 1ull);
   };
-  double best = -__builtin_inf();
-  uint32_t bidx = kNoPod;
-  {
+  // the listed candidates' totals, by the lanes that hold them (once: the rounds only choose among them)
+  double t0 = -__builtin_inf(), t1 = -__builtin_inf();
+  bool vA = hasA, vB = hasB;
+  if (__any(hasA || hasB)) {
+    const uint32_t p0 = hasA ? pA : 0u, p1 = hasB ? pB : 0u;
+    const uint32_t q0 = sn.queue[p0], q1 = sn.queue[p1];
+    const double kv0 = sn.kv[p0], kv1 = sn.kv[p1];
+    uint32_t tier0 = 0u, tier1 = 0u;
+    if (HAS_L) {
+      tier0 = tier_of(thl[(p0 & 63u) * 2u], thl[(p0 & 63u) * 2u + 1u], p0);
+      tier1 = tier_of(thl[(p1 & 63u) * 2u], thl[(p1 & 63u) * 2u + 1u], p1);
+    }
+    const double sp0 = nb != 0u ? clamp01((double)cntA / nbd) : 0.0, sp1 = nb != 0u ? clamp01((double)cntB / nbd) : 0.0;
+    t0 = exact_total(ec, qmin, qmax, qden, q0, kv0, tier0, sp0);
+    if (__any(hasB)) t1 = exact_total(ec, qmin, qmax, qden, q1, kv1, tier1, sp1);
+  }
+  const uint32_t tk = TOPK ? a->topk : 1u;
+  uint32_t reported = kNoPod;                                         // TOPK: the unlisted pod this lane has added to the bits (lane k: round k's)
+  for (uint32_t round = 0; round < tk; ++round) {
+    double best = -__builtin_inf();
+    uint32_t bidx = kNoPod;
     uint64_t c[4] = {on ? c0 : 0ull, on ? c1 : 0ull, on ? c2 : 0ull, on ? c3 : 0ull};
     while (__any((c[0] | c[1] | c[2] | c[3]) != 0ull)) {
       uint32_t q[U], hw[U], pp[U];
@@ -2111,51 +2133,49 @@ __device__ __forceinline__ void quad_exact_rows_par_i(const uint32_t rows, const
         if (take && (t > best || (t == best && p < bidx))) { best = t; bidx = p; }
       }
     }
-  }
-  if (__any(hasA || hasB)) {                                          // the listed candidates, by the lanes that hold them
-    const uint32_t p0 = hasA ? pA : 0u, p1 = hasB ? pB : 0u;
-    const uint32_t q0 = sn.queue[p0], q1 = sn.queue[p1];
-    const double kv0 = sn.kv[p0], kv1 = sn.kv[p1];
-    uint32_t tier0 = 0u, tier1 = 0u;
-    if (HAS_L) {
-      tier0 = tier_of(thl[(p0 & 63u) * 2u], thl[(p0 & 63u) * 2u + 1u], p0);
-      tier1 = tier_of(thl[(p1 & 63u) * 2u], thl[(p1 & 63u) * 2u + 1u], p1);
+    if (vA && (t0 > best || (t0 == best && pA < bidx))) { best = t0; bidx = pA; }
+    if (vB && (t1 > best || (t1 == best && pB < bidx))) { best = t1; bidx = pB; }
+    // argmax over the row: (total desc, pod asc)
+    double wmax = best;
+    wmax = vmax_f64(wmax, dpp_f64<0xB1, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x4E, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x141, 0xf>(wmax));
+    wmax = vmax_f64(wmax, dpp_f64<0x140, 0xf>(wmax));
+    uint32_t widx = best == wmax ? bidx : kNoPod;
+    widx = dpp_min_u32<0xB1, 0xf>(widx); widx = dpp_min_u32<0x4E, 0xf>(widx); widx = dpp_min_u32<0x141, 0xf>(widx); widx = dpp_min_u32<0x140, 0xf>(widx);
+    if (on && k == 0u) {
+      const bool none = widx == kNoPod;
+      a->out_pick[(size_t)r * tk + round] = none ? -1 : (int32_t)widx;
+      if (a->out_score) a->out_score[(size_t)r * tk + round] = none ? 0.0 : wmax;
     }
-    const double sp0 = nb != 0u ? clamp01((double)cntA / nbd) : 0.0, sp1 = nb != 0u ? clamp01((double)cntB / nbd) : 0.0;
-    const double t0 = exact_total(ec, qmin, qmax, qden, q0, kv0, tier0, sp0);
-    if (hasA && (t0 > best || (t0 == best && p0 < bidx))) { best = t0; bidx = p0; }
-    if (__any(hasB)) {
-      const double t1 = exact_total(ec, qmin, qmax, qden, q1, kv1, tier1, sp1);
-      if (hasB && (t1 > best || (t1 == best && p1 < bidx))) { best = t1; bidx = p1; }
+    if constexpr (TOPK) {                                             // the winner leaves the pool
+      const bool listedA = vA && pA == widx, listedB = vB && pB == widx;
+      const uint32_t was_listed = row16_any(listedA || listedB, lane);
+      if (listedA) vA = false;
+      if (listedB) vB = false;
+      if (on && widx != kNoPod && was_listed == 0u && k == (round & 15u)) {
+        atomicOr(&bits[widx >> 5], 1u << (widx & 31u));
+        reported = widx;
+      }
+      wave_lds_fence();
     }
   }
-  // argmax over the row: (total desc, pod asc)
-  double wmax = best;
-  wmax = vmax_f64(wmax, dpp_f64<0xB1, 0xf>(wmax));
-  wmax = vmax_f64(wmax, dpp_f64<0x4E, 0xf>(wmax));
-  wmax = vmax_f64(wmax, dpp_f64<0x141, 0xf>(wmax));
-  wmax = vmax_f64(wmax, dpp_f64<0x140, 0xf>(wmax));
-  uint32_t widx = best == wmax ? bidx : kNoPod;
-  widx = dpp_min_u32<0xB1, 0xf>(widx); widx = dpp_min_u32<0x4E, 0xf>(widx); widx = dpp_min_u32<0x141, 0xf>(widx); widx = dpp_min_u32<0x140, 0xf>(widx);
+  wave_lds_fence();
   if (hasA) bits[pA >> 5] = 0u;
   if (hasB) bits[pB >> 5] = 0u;
-  if (on && k == 0u) {
-    const bool none = widx == kNoPod;
-    a->out_pick[r] = none ? -1 : (int32_t)widx;
-    if (a->out_score) a->out_score[r] = none ? 0.0 : wmax;
-  }
+  if (reported != kNoPod) bits[reported >> 5] = 0u;
 }
 
-template <typename LW, bool HAS_L>
+template <typename LW, bool HAS_L, bool TOPK = false>
 __device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
                                                               const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
                                                               const uint64_t c3, uint32_t* s_bits_w, const ParkArgs* a) {
-  quad_exact_rows_par_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, c0, c1, c2, c3, s_bits_w, a);
+  quad_exact_rows_par_i<LW, HAS_L, TOPK>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, c0, c1, c2, c3, s_bits_w, a);
 }
 // (3c) The parked rows of one wavefront, four at a time: row g of the wavefront takes entry base + g.  LDS layout and work-list geometry
 //      as in pick_quad_body.  INL: everything inlined into the caller -- the resident kernels, where ONE call inside the doorbell loop
 //      tripled the kernel's spill code (944 scratch loads against 353) and cost a 16-request batch of dense masks 5-7 us.
-template <typename LW, bool HAS_L, bool INL>
+template <typename LW, bool HAS_L, bool INL, bool TOPK = false>
 __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned char* smem, const ParkArgs* a) {
   const KSnap& sn = *a->sn;
   const uint32_t lane = threadIdx.x & 63u, k = lane & 15u, g = lane >> 4, wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -2187,13 +2207,14 @@ __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned c
     }
     const unsigned long long hm = __ballot(have);
     const uint32_t rows = (uint32_t)(hm & 1ull) | (uint32_t)((hm >> 15) & 2ull) | (uint32_t)((hm >> 30) & 4ull) | (uint32_t)((hm >> 45) & 8ull);
-    if (rows & (rows - 1u)) {                                          // two rows or more: each by its own 16 lanes, side by side
-      if constexpr (INL) quad_exact_rows_par_i<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
-                                                          cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
-      else quad_exact_rows_par<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
-                                          cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
+    if (TOPK || (rows & (rows - 1u))) {                                // two rows or more (fallback lists: always): each by its own 16 lanes, side by side
+      if constexpr (INL) quad_exact_rows_par_i<LW, HAS_L, TOPK>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                                                cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
+      else quad_exact_rows_par<LW, HAS_L, TOPK>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
+                                                cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
       continue;
     }
+    if constexpr (!TOPK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                      // one row: the whole wavefront on it, its candidate words through LDS
       const uint32_t w = 4u * k + (uint32_t)i;
@@ -2204,24 +2225,25 @@ __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned c
                                                     s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
     else quad_exact_rows<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
                                     s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
+    }
   }
 }
 
 // (3d) ... behind ONE small call from the loop's kernel: the argument block is put together here, not in the caller's frame
-template <typename LW, bool HAS_L>
+template <typename LW, bool HAS_L, bool TOPK>
 __device__ __attribute__((noinline)) void quad_park_drain_launched(const uint32_t n_x, unsigned char* smem) {
   const QuadKernArgs* a = quad_kernargs();
   ParkArgs pa;
   pa.sn = &a->sn; pa.chain = &a->chain; pa.out_pick = a->out_pick; pa.out_score = a->out_score; pa.cand_mask = a->cand_mask; pa.defer_list = a->defer_list;
-  pa.defer_cap = a->defer_cap; pa.n_reqs = a->n_reqs; pa.pwn = a->pwn; pa.vblock = blockIdx.x; pa.vgrid = gridDim.x;
-  quad_park_drain_i<LW, HAS_L, false>(n_x, smem, &pa);
+  pa.defer_cap = a->defer_cap; pa.n_reqs = a->n_reqs; pa.pwn = a->pwn; pa.vblock = blockIdx.x; pa.vgrid = gridDim.x; pa.topk = a->topk;
+  quad_park_drain_i<LW, HAS_L, false, TOPK>(n_x, smem, &pa);
 }
-template <typename LW, bool HAS_L, typename RA>
-__device__ __forceinline__ void quad_park_drain_resident(const uint32_t n_x, unsigned char* smem, const RA* ra, const uint32_t bufset, const uint32_t n_reqs) {
+template <typename LW, bool HAS_L, bool TOPK, typename RA>
+__device__ __forceinline__ void quad_park_drain_resident(const uint32_t n_x, unsigned char* smem, const RA* ra, const uint32_t bufset, const uint32_t n_reqs, const uint32_t topk) {
   ParkArgs pa;
   pa.sn = &ra->sn; pa.chain = &ra->chain; pa.out_pick = ra->buf[bufset].out_pick; pa.out_score = ra->buf[bufset].out_score; pa.cand_mask = ra->buf[bufset].mask;
-  pa.defer_list = ra->defer_list; pa.defer_cap = ra->defer_cap; pa.n_reqs = n_reqs; pa.pwn = ra->pwn; pa.vblock = 0u; pa.vgrid = 1u;
-  quad_park_drain_i<LW, HAS_L, true>(n_x, smem, &pa);
+  pa.defer_list = ra->defer_list; pa.defer_cap = ra->defer_cap; pa.n_reqs = n_reqs; pa.pwn = ra->pwn; pa.vblock = 0u; pa.vgrid = 1u; pa.topk = topk;
+  quad_park_drain_i<LW, HAS_L, true, TOPK>(n_x, smem, &pa);
 }
 
 // LEARN (single picks only): the kernel also leaves one word per request for the post-route index update that follows the pick
@@ -2627,10 +2649,10 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
 #endif
     __builtin_amdgcn_sched_barrier(0);
     bool no_cand = false;
-    // PARK (MASKED single picks of a launched kernel): a row that cannot be scored from base[] and the top table ALONE -- its candidates miss
+    // PARK (MASKED): a row that cannot be scored from base[] and the top table ALONE -- its candidates miss
     // a snapshot-wide QUEUE extreme, or none of the table's 64 entries is a candidate outside its list -- is not deferred: every
     // candidate is evaluated in full by quad_exact_rows when the loop is over.  softm = those rows.
-    constexpr bool PARK = MASKED && !TOPK && EPPK_QUAD_PARK != 0;
+    constexpr bool PARK = MASKED && EPPK_QUAD_PARK != 0;
     unsigned long long softm = 0ull;
     uint32_t xe1 = 0u;                                                // this lane's matched counts and listed-candidate bits, for quad_exact_rows
     if (MASKED) {
@@ -2722,7 +2744,10 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
           const uint32_t tv2 = row16(__ballot(top_p != kNoPod));
           if (dry) tvr = tv2;                                         // (a full window: the table may go on)
         }
-        badm |= __ballot(row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
+        {
+          const unsigned long long drym = __ballot(row16(__ballot(vT)) == 0u && tvr == 0xFFFFu && !no_cand && sn.n_pods > tbase + 16u);   // still dry and entries beyond the window exist
+          if constexpr (PARK) softm |= drym; else badm |= drym;
+        }
         double lb = vA ? tA : -__builtin_inf();
         uint32_t lp = vA ? pA : kNoPod;
         if (vB && (tB_keep > lb || (tB_keep == lb && pB < lp))) { lb = tB_keep; lp = pB; }
@@ -2878,13 +2903,13 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
       if (blk + nwaves >= nblk) break;
       process(blk + nwaves, qb, qa, pb);
     }
-    if constexpr (MASKED && !TOPK && EPPK_QUAD_PARK != 0) {
+    if constexpr (MASKED && EPPK_QUAD_PARK != 0) {
       // the parked rows: a function of its own that is handed the kernel's arguments by address (launched: where they lie in the kernarg
       // segment, re-read from there) -- nothing is kept alive through the loop for it but the count
       // (RESIDENT: the caller does that, where its work-list pass is -- the count comes back in the upper half of the result; a call in
       //  here cost a 16-request batch of dense masks 7 us of spills through scratch that the doorbell's acquire had just invalidated)
       if constexpr (!RESIDENT)
-        if (__builtin_expect(n_x != 0u, 0)) quad_park_drain_launched<LW, HAS_L>(n_x, smem);
+        if (__builtin_expect(n_x != 0u, 0)) quad_park_drain_launched<LW, HAS_L, TOPK>(n_x, smem);
     }
 #if EPPK_QUAD_PREFETCH > 0
     asm volatile("" ::"v"(pf_sink ^ pf_prev));     // (the prefetch loads must not be dead-code eliminated)
@@ -2901,7 +2926,7 @@ __device__ __forceinline__ uint32_t pick_quad_body(const uint32_t vblock, const 
                         (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 32) + (uint32_t)__builtin_amdgcn_readlane((int)acc_look, 48);
     if (lane == 0 && (hs | ls)) { stats[4 + 2 * gwave] += hs; stats[5 + 2 * gwave] += ls; }
   }
-  if constexpr (RESIDENT && MASKED && !TOPK && EPPK_QUAD_PARK != 0) return n_def | (n_x << 16);    // (at most 64 requests per wavefront)
+  if constexpr (RESIDENT && MASKED && EPPK_QUAD_PARK != 0) return n_def | (n_x << 16);    // (at most 64 requests per wavefront)
   return n_def;
 }
 
@@ -3084,10 +3109,10 @@ __global__ __launch_bounds__(EPPK_FAST_MAX_THREADS, 1) void pick_resident_kernel
           (const void*)nullptr);
       // MASKED single picks: the rows this wavefront PARKED (their candidates miss a QUEUE extreme -- what a subset filter of a few endpoints
       // does to nearly every request --, or the adapter's table holds none of them) are scored by the wavefront now, every candidate in full
-      if constexpr (MASKED && !TOPK && EPPK_QUAD_PARK != 0) {
+      if constexpr (MASKED && EPPK_QUAD_PARK != 0) {
         const uint32_t n_x = n_def >> 16;
         n_def &= 0xFFFFu;
-        if (n_x != 0u) quad_park_drain_resident<LW, HAS_L, ResidentArgs>(n_x, smem, a, bufset, n);
+        if (n_x != 0u) quad_park_drain_resident<LW, HAS_L, TOPK, ResidentArgs>(n_x, smem, a, bufset, n, TOPK ? kk : 1u);
       }
       // ONE barrier ends the common case: picks and scores released to host memory, this wavefront's segment of the work list in device
       // memory (the system-scope release covers both), and the barrier that tells the doorbell wavefront "everybody is through" also

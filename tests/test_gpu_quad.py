@@ -297,6 +297,27 @@ def test_subset_filters_that_leave_a_handful_of_endpoints(pkg, orc, R, P):
     ql, qd = run(pkg, orc, wl, sets, mask=mask)
     assert ql == 1
     assert qd <= R // 16, f"{qd} of {R} masked requests deferred"
+    # ordered fallbacks within the subset (PickResult.Fallbacks, server.go:72-77): the same rows, k rounds each -- more rounds than
+    # some requests have candidates (the lists end in EPPK_NO_PICK)
+    calls = pairs_by_pod(sets)
+    oix = orc.OracleIndex()
+    for h, p_ in calls:
+        oix.insert(h, p_)
+    for k in (2, 5):
+        want_p, want_s = orc.pick_topk(wl.chain, wl.pods, oix, wl.reqs, k, mask)
+        for on in (True, False):
+            with quad_env(on):
+                with pkg.BatchedPicker(wl.chain, max_pods=max(P, 64), max_blocks=wl.B, max_batch=R, index_slots=max(wl.index_slots, 1024)) as pk:
+                    pk.publish(wl.pods)
+                    for h, p_ in calls:
+                        pk.index_insert(h, p_)
+                    got_p, got_s = pk.pick_topk(wl.reqs, k, mask)
+                    ql, qd = pk.quad_stats()
+            assert np.array_equal(got_p, want_p), f"k {k}, quad {on}: {np.count_nonzero(got_p != want_p)} entries differ, first rows {np.nonzero((got_p != want_p).any(axis=1))[0][:5]}"
+            assert np.array_equal(got_s.view(np.uint64), want_s.view(np.uint64)), f"k {k}, quad {on}: scores differ"
+            assert (got_p[3] == -1).all()
+            if on:
+                assert qd <= R // 16, f"k {k}: {qd} of {R} masked requests deferred"
 
 
 @pytest.mark.parametrize("R,P,k", [(512, 4096, 2), (777, 4096, 8), (300, 1000, 3), (256, 64, 8), (128, 12, 8)])

@@ -274,6 +274,11 @@ def test_subset_filters_through_the_masked_resident_workgroup(pkg, orc, resident
                 want = orc.pick_batch(wl.chain, wl.pods, oix, reqs, wl.B, mask)[:2]
                 _same(pk.pick(reqs, mask), want, f"subset masks n={n} rep={rep}")
                 served += 1
+                if n in (9, 16, 47):                                         # ordered fallbacks within the subset: the top-k masked unit
+                    tw = orc.pick_topk(wl.chain, wl.pods, oix, reqs, 3, mask)
+                    tg = pk.pick_topk(reqs, 3, mask)
+                    assert np.array_equal(tg[0], tw[0]) and np.array_equal(tg[1].view(np.uint64), tw[1].view(np.uint64)), f"subset masks, top-3, n={n} rep={rep}"
+                    served += 1
         if eppk_mode in ("default", "quadmin4"):
             assert pk.resident_stats()[1] - b0 == served, "every masked batch of at most 64 requests is answered by the masked resident workgroup"
 
