@@ -2270,8 +2270,10 @@ namespace {
 // SINGLE picks on masks of a few candidates: from 8192 requests on the general masked route is the faster one wherever pick_quad_kernel
 // serves the batch -- it parks every such row and scores four at a time (quad_exact_rows_par): 16k x 8 candidates 27 us against 55,
 // 64k 71 against 210; below, the candidate-major kernel (4096: 18 against 20, 1024: 13 against 26; scripts/subset_route_probe.py).
-bool general_route_is_faster(eppk_ctx* c, uint32_t n_reqs) {
-  return n_reqs >= 8192u && n_reqs >= c->quad_min && c->canonical && c->quad_on && c->quad_backoff == 0u && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
+// Ordered fallbacks (k > 1, parked and scored in k rounds): from 4096 requests on -- top-3 of 8 candidates, 4096: 35 us against 43, 16k: 45
+// against 141, 64k: 122 against 559.
+bool general_route_is_faster(eppk_ctx* c, uint32_t n_reqs, uint32_t k = 1u) {
+  return n_reqs >= (k == 1u ? 8192u : 4096u) && n_reqs >= c->quad_min && c->canonical && c->quad_on && c->quad_backoff == 0u && c->has_p && c->npl == 6 && !c->gen && c->pterm &&
          c->slots != 0u && c->cfg.max_blocks >= 1 && make_kindex(c).lists != nullptr;
 }
 int launch_pick_cands(eppk_ctx* c, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_mask, uint32_t k, int32_t* d_pick, double* d_score, hipStream_t st) {
@@ -2322,7 +2324,9 @@ int eppk_pick_batch_candidates_device(eppk_ctx* c, const void* d_reqs, uint32_t 
   if (c->assumed_epochs)                                           // assumed load works in epochs of the general path (SEMANTICS.md §2b)
     return k == 1 ? eppk_pick_batch_device(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream)
                   : eppk_pick_topk_device(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, stream);
-  if (k == 1 && general_route_is_faster(c, n_reqs)) return eppk_pick_batch_device(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream);
+  if (general_route_is_faster(c, n_reqs, k))
+    return k == 1 ? eppk_pick_batch_device(c, d_reqs, n_reqs, d_cand_mask, d_out_pick, d_out_score, stream)
+                  : eppk_pick_topk_device(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, stream);
   return launch_pick_cands(c, d_reqs, n_reqs, d_cand_mask, k, d_out_pick, d_out_score, st);
 }
 

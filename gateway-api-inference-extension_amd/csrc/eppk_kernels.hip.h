@@ -2026,11 +2026,21 @@ __device__ __forceinline__ void quad_exact_rows_i(const uint32_t rows, const uin
   }
 }
 
+// The never-inlined forms of a LAUNCHED kernel put their ParkArgs together themselves, from the kernarg segment (scalar loads; the struct
+// dissolves into registers).  Handed over by address from the caller's frame it lived in scratch, and every function began with a chain of
+// scratch -> kernarg -> data loads: +5 us per call (1/8-density batch 43.8 -> 49.2 us, 64k x 8 endpoints 74 -> 92).
+__device__ __forceinline__ ParkArgs park_args_launched() {
+  const QuadKernArgs* a = quad_kernargs();
+  ParkArgs pa;
+  pa.sn = &a->sn; pa.chain = &a->chain; pa.out_pick = a->out_pick; pa.out_score = a->out_score; pa.cand_mask = a->cand_mask; pa.defer_list = a->defer_list;
+  pa.defer_cap = a->defer_cap; pa.n_reqs = a->n_reqs; pa.pwn = a->pwn; pa.vblock = blockIdx.x; pa.vgrid = gridDim.x; pa.topk = a->topk;
+  return pa;
+}
 template <typename LW, bool HAS_L>
 __device__ __attribute__((noinline)) void quad_exact_rows(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
-                                                          const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w,
-                                                          const ParkArgs* a) {
-  quad_exact_rows_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, s_cn_w, s_bits_w, a);
+                                                          const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t* s_cn_w, uint32_t* s_bits_w) {
+  const ParkArgs pa = park_args_launched();
+  quad_exact_rows_i<LW, HAS_L>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, s_cn_w, s_bits_w, &pa);
 }
 __device__ __forceinline__ uint32_t row16_any(const bool b, const uint32_t lane) { return (uint32_t)(__ballot(b) >> (lane & 48u)) & 0xFFFFu; }
 // (3b) The same for FOUR parked rows at once, each scored by its own 16 lanes (lane k: words 4k .. 4k+3 of the row's candidates, handed
@@ -2169,8 +2179,9 @@ __device__ __forceinline__ void quad_exact_rows_par_i(const uint32_t rows, const
 template <typename LW, bool HAS_L, bool TOPK = false>
 __device__ __attribute__((noinline)) void quad_exact_rows_par(const uint32_t rows, const uint32_t r, const uint32_t nb, const uint32_t arow, const uint32_t pA, const uint32_t pB,
                                                               const uint32_t cntA, const uint32_t cntB, const uint32_t ls, const uint64_t c0, const uint64_t c1, const uint64_t c2,
-                                                              const uint64_t c3, uint32_t* s_bits_w, const ParkArgs* a) {
-  quad_exact_rows_par_i<LW, HAS_L, TOPK>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, c0, c1, c2, c3, s_bits_w, a);
+                                                              const uint64_t c3, uint32_t* s_bits_w) {
+  const ParkArgs pa = park_args_launched();
+  quad_exact_rows_par_i<LW, HAS_L, TOPK>(rows, r, nb, arow, pA, pB, cntA, cntB, ls, c0, c1, c2, c3, s_bits_w, &pa);
 }
 // (3c) The parked rows of one wavefront, four at a time: row g of the wavefront takes entry base + g.  LDS layout and work-list geometry
 //      as in pick_quad_body.  INL: everything inlined into the caller -- the resident kernels, where ONE call inside the doorbell loop
@@ -2211,7 +2222,7 @@ __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned c
       if constexpr (INL) quad_exact_rows_par_i<LW, HAS_L, TOPK>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
                                                                 cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
       else quad_exact_rows_par<LW, HAS_L, TOPK>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
-                                                cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw, a);
+                                                cw[0], cw[1], cw[2], cw[3], s_bits_all + wave * 4u * bits_dw);
       continue;
     }
     if constexpr (!TOPK) {
@@ -2224,7 +2235,7 @@ __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned c
     if constexpr (INL) quad_exact_rows_i<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
                                                     s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
     else quad_exact_rows<LW, HAS_L>(rows, rr, xnb, xarow, e0 & 0xFFFFu, e0 >> 16, e1 & 0x3Fu, (e1 >> 6) & 0x3Fu, (e1 >> 12) & 3u,
-                                    s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw, a);
+                                    s_cn_all + (size_t)wave * 4u * J, s_bits_all + wave * 4u * bits_dw);
     }
   }
 }
@@ -2232,10 +2243,7 @@ __device__ __forceinline__ void quad_park_drain_i(const uint32_t n_x, unsigned c
 // (3d) ... behind ONE small call from the loop's kernel: the argument block is put together here, not in the caller's frame
 template <typename LW, bool HAS_L, bool TOPK>
 __device__ __attribute__((noinline)) void quad_park_drain_launched(const uint32_t n_x, unsigned char* smem) {
-  const QuadKernArgs* a = quad_kernargs();
-  ParkArgs pa;
-  pa.sn = &a->sn; pa.chain = &a->chain; pa.out_pick = a->out_pick; pa.out_score = a->out_score; pa.cand_mask = a->cand_mask; pa.defer_list = a->defer_list;
-  pa.defer_cap = a->defer_cap; pa.n_reqs = a->n_reqs; pa.pwn = a->pwn; pa.vblock = blockIdx.x; pa.vgrid = gridDim.x; pa.topk = a->topk;
+  const ParkArgs pa = park_args_launched();
   quad_park_drain_i<LW, HAS_L, false, TOPK>(n_x, smem, &pa);
 }
 template <typename LW, bool HAS_L, bool TOPK, typename RA>

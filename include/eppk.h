@@ -500,8 +500,9 @@ int eppk_subset_mask(const char* const* addrs, const char* const* ports, uint32_
  *                                batch, from a kernel whose cost grows with the number of CANDIDATES of a request instead of the
  *                                number of pods: the one to call when the masks leave a few dozen candidates (a subset hint);
  *                                the general entry points stay better for dense masks.  eppk_pick_batch_subset chooses by itself,
- *                                and single picks (k = 1) of 8192 requests or more are handed to eppk_pick_batch_device, whose
- *                                kernel scores such rows faster at that size (same picks, same scores).
+ *                                and batches of 8192 requests or more (k = 1; ordered fallbacks: 4096 or more) are handed to
+ *                                eppk_pick_batch_device / eppk_pick_topk_device, whose kernels score such rows faster at that size
+ *                                (same picks, same scores).
  * Two different addresses with the same 128-bit fingerprint would be confused (probability ~ 2^-100 per pair); the
  * string-exact eppk_subset_mask stays available. */
 int eppk_pick_batch_candidates_device(eppk_ctx* ctx, const void* d_reqs, uint32_t n_reqs, const uint64_t* d_cand_mask, uint32_t k,

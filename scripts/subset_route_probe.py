@@ -37,3 +37,10 @@ with pkg.BatchedPicker(wl.chain, max_pods=wl.P, max_blocks=wl.B, max_batch=RMAX,
             b = timed(pk, lambda: pk.pick_candidates_device(d_reqs.data_ptr(), R, d_mask.data_ptr(), 1, d_pick.data_ptr(), d_score.data_ptr(), st.cuda_stream))
             same = bool(torch.equal(ref, d_pick[:R])) and bool(torch.equal(refs, d_score[:R]))
             print(f"{ncand:3d} candidates  R = {R:6d}: general {a:7.1f} us   candidate-major {b:7.1f} us   same picks and scores: {same}", flush=True)
+            if ncand == 8:
+                d_p3 = torch.empty(R * 3, dtype=torch.int32, device=dev); d_s3 = torch.empty(R * 3, dtype=torch.float64, device=dev)
+                a3 = timed(pk, lambda: pk._check(pk._lib.eppk_pick_topk_device(pk._ctx, d_reqs.data_ptr(), R, d_mask.data_ptr(), 3, d_p3.data_ptr(), d_s3.data_ptr(), st.cuda_stream), 'topk'))
+                r3 = d_p3.clone(); rs3 = d_s3.clone()
+                b3 = timed(pk, lambda: pk.pick_candidates_device(d_reqs.data_ptr(), R, d_mask.data_ptr(), 3, d_p3.data_ptr(), d_s3.data_ptr(), st.cuda_stream))
+                same3 = bool(torch.equal(r3, d_p3)) and bool(torch.equal(rs3, d_s3))
+                print(f"      top-3           R = {R:6d}: general {a3:7.1f} us   candidate-major {b3:7.1f} us   same: {same3}", flush=True)
