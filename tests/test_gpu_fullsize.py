@@ -51,6 +51,16 @@ class Full:
             a = _splitmix(np.arange(R * W, dtype=np.uint64) + np.uint64(0xA11CE)).reshape(R, W)
             b = _splitmix(np.arange(R * W, dtype=np.uint64) + np.uint64(0xB0B0000)).reshape(R, W)
         self.masks = {"50": wl.mask, "12": (wl.mask & a & b)}        # ~2048 / ~512 candidates per request
+        # what a subset filter leaves (request.go:104-133): 1 .. 8 endpoints per request -- nearly every request needs its own QUEUE normalisers
+        sub = np.zeros((R, W), dtype=np.uint64)
+        rng = np.random.default_rng(0x5B5E7)
+        pods = rng.integers(0, P, (R, 8))
+        keep = rng.integers(1, 9, R)
+        for j in range(8):
+            on = j < keep
+            np.bitwise_or.at(sub, (np.arange(R)[on], pods[on, j] // 64), np.uint64(1) << (pods[on, j] % 64).astype(np.uint64))
+        sub[12345] = 0
+        self.masks["subset8"] = sub
         self.cache = {}
 
     def oracle_pick(self, mask_key):
@@ -120,6 +130,19 @@ def test_masked_picks_at_full_size(full, form, density):
         assert pk.launch_status() == 0
         # the same batch again (work-list buffers, counters and reports of the first launch are reused)
         _same(pk.pick(full.wl.reqs, full.masks[density]), full.oracle_pick(density), f"masked pick ({density} %), {form}, second launch")
+
+
+def test_subset_filters_at_full_size(full, form):
+    """64k requests, each with 1 .. 8 candidate endpoints: single picks and ordered fallbacks (more rounds than some requests have
+    candidates); on the quad route every row is parked and scored by its own wavefront -- nothing is deferred."""
+    with full.picker() as pk:
+        got = pk.pick(full.wl.reqs, full.masks["subset8"])
+        _same(got, full.oracle_pick("subset8"), f"subset filter, pick, {form}")
+        assert got[0][12345] == -1
+        assert _took_quad(pk) <= R // 64
+        gk = pk.pick_topk(full.wl.reqs, 4, full.masks["subset8"])
+        _same(gk, full.oracle_topk(4, "subset8"), f"subset filter, top-4, {form}")
+        assert pk.launch_status() == 0
 
 
 def test_masked_fallbacks_at_full_size(full, form):
